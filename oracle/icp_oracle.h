@@ -1,0 +1,113 @@
+/* icp_oracle.h — CPU ORACLE for the photogeometric ICP iteration path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is product code: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only
+ * as the checker.  The product path (icp_amd/csrc + include/icp_amd.h) never links,
+ * loads or calls it.
+ *
+ * It is a plain-C restatement of the reference's per-iteration algorithm
+ * (nlamprian/ICP, /root/reference): every function cites the reference file:line it
+ * follows.  Arithmetic is the canonical spec of DESIGN.md §3: fp32, round-to-nearest,
+ * NO fused multiply-add (build with -ffp-contract=off), IEEE divide and sqrt, reduction
+ * trees of the reference's shape for a 64-wide wavefront (W = 64).
+ *
+ * PINNING STATUS
+ *   - kernels a1,a3,a5..a9 (getReps, transform, weights, means, deviations, S matrix,
+ *     power method): pinned against the reference's own CPU twins
+ *     (include/ICP/tests/helper_funcs.hpp) compiled from /root/reference into
+ *     oracle/_ref/ (see oracle/Makefile), against the power-method known-answer test
+ *     (tests/testsICP.cpp:1008-1046) and the committed golden fixtures in tests/golden/.
+ *   - RBC construct/search (a2,a4): ** PARITY UNPINNED **.  The algorithm lives in
+ *     github.com/nlamprian/RandomBallCover (un-vendored, no pinned version:
+ *     external/RandomBallCover/CMakeLists.txt:5-12) and the reference holds no test or
+ *     golden vector at that boundary.  The restatement follows the published one-shot
+ *     Random Ball Cover algorithm (Cayton 2012) anchored on the reference's call sites
+ *     (src/ICP/algorithms.cpp:4503-4536, 4674) — see orc_rbc_construct/orc_rbc_search.
+ */
+#ifndef ICP_ORACLE_H
+#define ICP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors `rbc_dist_id` / `dist_id` (kernels/icp_kernels.cl:34-38). */
+typedef struct { float dist; uint32_t id; } orc_dist_id;
+
+enum { ORC_ROT_SVD = 0, ORC_ROT_POWER = 1 };          /* ICPStepConfigT  (algorithms.hpp:1544) */
+enum { ORC_W_REGULAR = 0, ORC_W_WEIGHTED = 1 };       /* ICPStepConfigW  (algorithms.hpp:1560) */
+
+/* ---- single kernels ------------------------------------------------------------------- */
+void     orc_get_lms (const float *cloud, float *lms);
+int      orc_reps_grid (uint32_t m, uint32_t nr, uint32_t *nrx, uint32_t *nry, uint32_t *side);
+int      orc_get_reps (const float *F, uint32_t m, uint32_t nr, float *R, uint32_t *rep_src);
+void     orc_transform_q (const float *M, float *tM, const float *T, uint32_t m);
+void     orc_transform_q2 (const float *M, float *tM, const float *T, uint32_t m);
+void     orc_transform_m (const float *M, float *tM, const float *T16, uint32_t m);
+float    orc_metric8 (const float *x, const float *y, float a);
+void     orc_rbc_construct (const float *F, uint32_t m, const float *R, uint32_t nr, float a,
+                            uint32_t *owner, uint32_t *N, uint32_t *O, uint32_t *perm, float *XP);
+void     orc_rbc_search (const float *Q, uint32_t nq, const float *R, uint32_t nr,
+                         const float *XP, const uint32_t *perm, const uint32_t *O,
+                         const uint32_t *N, const uint32_t *rep_src, float a,
+                         orc_dist_id *nn_id, float *NN, uint32_t *rid);
+void     orc_nn_brute (const float *Q, uint32_t nq, const float *F, uint32_t m, float a,
+                       orc_dist_id *nn_id);
+void     orc_weights (const orc_dist_id *D, uint32_t n, float *W, double *sum_w);
+void     orc_mean (const float *F, const float *M, uint32_t n, float *mean8);
+void     orc_mean_weighted (const float *F, const float *M, const float *W, double sum_w,
+                            uint32_t n, float *mean8);
+void     orc_devs (const float *F, const float *M, const float *mean8, uint32_t n,
+                   float *DF, float *DM);
+void     orc_sij (const float *DM, const float *DF, const float *W, uint32_t m, float c,
+                  float *S11);
+int      orc_power_method (const float *S11, const float *mean8, float *Tk8);
+int      orc_power_method_fast (const float *S11, const float *mean8, float *Tk8);
+void     orc_svd_rotation (const float *S11, const float *mean8, float *Rk9, float *Tk8);
+void     orc_quat_to_rot (const float *q4, float *R9);
+void     orc_rot_to_quat (const float *R9, float *q4);
+void     orc_reduce_sum_f (const float *in, uint32_t cols, uint32_t rows, float *out);
+void     orc_exscan_u32 (const uint32_t *in, uint32_t n, uint32_t *out);
+
+/* ---- pipeline object: mirrors cl_algo::ICP::ICPStep / ICP (algorithms.hpp:2234-2496) ---- */
+typedef struct orc_icp orc_icp;
+
+orc_icp *orc_icp_create (int rot, int weighted);
+void     orc_icp_destroy (orc_icp *h);
+int      orc_icp_init (orc_icp *h, uint32_t m, uint32_t nr, float a, float c,
+                       uint32_t max_iterations, double angle_threshold,
+                       double translation_threshold);
+void     orc_icp_set_power_fast (orc_icp *h, int fast);
+void     orc_icp_set_threads (orc_icp *h, int threads);
+void     orc_icp_write_f (orc_icp *h, const float *F);
+void     orc_icp_write_m (orc_icp *h, const float *M);
+void     orc_icp_write_t (orc_icp *h, const float *T8);
+void     orc_icp_build_rbc (orc_icp *h);
+void     orc_icp_step (orc_icp *h);
+uint32_t orc_icp_run (orc_icp *h);
+int      orc_icp_converged (const orc_icp *h);
+/* observers (pointers stay valid until the next call on the handle) */
+const float       *orc_icp_T (const orc_icp *h);       /* [q | t, s]  cumulative  */
+const float       *orc_icp_Tk (const orc_icp *h);      /* [qk | tk, sk] last step */
+const float       *orc_icp_R (const orc_icp *h);       /* 3x3 row-major cumulative */
+const float       *orc_icp_Rk (const orc_icp *h);
+const float       *orc_icp_S (const orc_icp *h);       /* 11 */
+const float       *orc_icp_means (const orc_icp *h);   /* 8  */
+const float       *orc_icp_W (const orc_icp *h);       /* m  */
+double             orc_icp_sum_w (const orc_icp *h);
+const orc_dist_id *orc_icp_nn_id (const orc_icp *h);   /* m, query order, id = fixed index */
+const uint32_t    *orc_icp_rid (const orc_icp *h);     /* m, nearest representative */
+const float       *orc_icp_reps (const orc_icp *h);    /* nr*8 */
+const uint32_t    *orc_icp_rbc_N (const orc_icp *h);
+const uint32_t    *orc_icp_rbc_O (const orc_icp *h);
+const uint32_t    *orc_icp_rbc_perm (const orc_icp *h);
+const uint32_t    *orc_icp_rbc_owner (const orc_icp *h);
+uint32_t           orc_icp_k (const orc_icp *h);
+int                orc_icp_last_power_iters (const orc_icp *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

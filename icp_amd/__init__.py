@@ -1,0 +1,346 @@
+"""icp_amd — MI355X-native photogeometric ICP iteration engine (host-side Python mirror).
+
+Thin ctypes binding of the C-ABI in include/icp_amd.h (icp_amd/libicp_amd.so, hand-written HIP
+for gfx950).  The classes keep the names and argument meaning of the reference's
+cl_algo::ICP::ICPStep<CR,CW> / ICP<CR,CW> (include/ICP/algorithms.hpp:2234-2496 of nlamprian/ICP).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device is visible,
+calls raise.  Nothing in this package imports oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = ["ICP", "ICPStep", "ICPError", "Memory", "ICPStepConfigT", "ICPStepConfigW",
+           "PowerMode", "lib", "lib_path", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libicp_amd.so")
+
+DIST_ID = np.dtype([("dist", np.float32), ("id", np.uint32)])
+
+
+class ICPError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("icp_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ICPStepConfigT:            # include/ICP/algorithms.hpp:1544
+    EIGEN = 0
+    POWER_METHOD = 1
+
+
+class ICPStepConfigW:            # include/ICP/algorithms.hpp:1560
+    REGULAR = 0
+    WEIGHTED = 1
+
+
+class PowerMode:
+    LITERAL = 0
+    SQUARED = 1
+
+
+class Memory:                    # icp_mem in include/icp_amd.h
+    F, M, T, TK, MEANS, S, NN_ID, W, SUM_W, REPS, RBC_N, RBC_O, RBC_PERM, RBC_OWNER, RBC_XP, RID, R, RK, NN, QT = range(20)
+    # reference spellings (ICPStep::Memory, include/ICP/algorithms.hpp:2241-2267)
+    D_IN_F, D_IN_M, D_IO_T, H_IO_T = F, M, T, T
+
+
+class _State(C.Structure):
+    _fields_ = [("R", C.c_float * 9), ("q", C.c_float * 4), ("t", C.c_float * 3), ("s", C.c_float),
+                ("Rk", C.c_float * 9), ("qk", C.c_float * 4), ("tk", C.c_float * 3), ("sk", C.c_float),
+                ("k", C.c_uint32), ("converged", C.c_uint32), ("power_iterations", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib_path():
+    return _SO
+
+
+def lib():
+    """Loads icp_amd/libicp_amd.so; raises if it has not been built (`make` or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ICPError(-1, "%s not found: build it with `make` (hipcc --offload-arch=gfx950); "
+                           "there is no CPU fallback" % _SO)
+    L = C.CDLL(_SO)
+    vp, u32, i32, f32, f64 = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_double
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("icp_create", i32, C.POINTER(vp), i32, i32, i32)
+    sig("icp_destroy", i32, vp)
+    sig("icp_init", i32, vp, u32, u32, f32, f32, u32, f64, f64)
+    sig("icp_init_batched", i32, vp, u32, u32, u32, f32, f32, u32, f64, f64)
+    sig("icp_write", i32, vp, i32, vp, i32)
+    sig("icp_write_b", i32, vp, u32, i32, vp, i32)
+    sig("icp_read", i32, vp, i32, vp, C.c_size_t)
+    sig("icp_read_b", i32, vp, u32, i32, vp, C.c_size_t)
+    sig("icp_mem_size", C.c_size_t, vp, i32)
+    sig("icp_device_ptr", i32, vp, i32, C.POINTER(vp))
+    sig("icp_adopt_device_buffer", i32, vp, i32, vp)
+    sig("icp_build_rbc", i32, vp)
+    sig("icp_step", i32, vp, i32)
+    sig("icp_run", i32, vp, C.POINTER(u32))
+    sig("icp_run_fixed", i32, vp, u32)
+    sig("icp_sync", i32, vp)
+    sig("icp_get_alpha", i32, vp, C.POINTER(f32))
+    sig("icp_set_alpha", i32, vp, f32)
+    sig("icp_get_scaling", i32, vp, C.POINTER(f32))
+    sig("icp_set_scaling", i32, vp, f32)
+    sig("icp_get_max_iterations", i32, vp, C.POINTER(u32))
+    sig("icp_set_max_iterations", i32, vp, u32)
+    sig("icp_get_angle_threshold", i32, vp, C.POINTER(f64))
+    sig("icp_set_angle_threshold", i32, vp, f64)
+    sig("icp_get_translation_threshold", i32, vp, C.POINTER(f64))
+    sig("icp_set_translation_threshold", i32, vp, f64)
+    sig("icp_set_power_mode", i32, vp, i32)
+    sig("icp_state", i32, vp, C.POINTER(_State))
+    sig("icp_state_b", i32, vp, u32, C.POINTER(_State))
+    sig("icp_write_cloud", i32, vp, i32, vp, i32)
+    sig("icp_transform_cloud", i32, vp, vp, vp, u32)
+    sig("icp_time_run_fixed", i32, vp, u32, u32, C.POINTER(f32))
+    sig("icp_time_kernels", i32, vp, u32, C.POINTER(f32))
+    sig("icp_last_error", C.c_char_p, vp)
+    sig("icp_version", C.c_char_p)
+    sig("icp_device_count", i32, C.POINTER(i32))
+    sig("icp_synth_pair", i32, C.c_uint64, u32, f32, vp, vp, f32, f32, f32, vp, vp)
+    sig("icp_synth_cloud_vga", i32, C.c_uint64, i32, vp)
+    _lib = L
+    return L
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().icp_device_count(C.byref(n))
+    return n.value
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def synth_pair(side, seed=0x1C9D5EED, rot_deg=3.0, axis=(0.3, 0.9, 0.1), t=(25.0, -10.0, 15.0),
+               noise_mm=1.0, noise_rgb=0.01, zero_fraction=0.0):
+    """Synthetic fixed/moving landmark pair (side*side points each), SURVEY.md §8d. Host only."""
+    F = np.empty((side * side, 8), np.float32)
+    M = np.empty((side * side, 8), np.float32)
+    ax = np.asarray(axis, np.float32)
+    tt = np.asarray(t, np.float32)
+    rc = lib().icp_synth_pair(seed, side, rot_deg, _p(ax), _p(tt), noise_mm, noise_rgb, zero_fraction, _p(F), _p(M))
+    if rc:
+        raise ICPError(rc, "icp_synth_pair")
+    return F, M
+
+
+def synth_cloud_vga(seed=0x1C9D5EED, moved=False):
+    cloud = np.empty((480 * 640, 8), np.float32)
+    rc = lib().icp_synth_cloud_vga(seed, int(moved), _p(cloud))
+    if rc:
+        raise ICPError(rc, "icp_synth_cloud_vga")
+    return cloud
+
+
+_MEM_DTYPE = {
+    Memory.F: (np.float32, 8), Memory.M: (np.float32, 8), Memory.RBC_XP: (np.float32, 8),
+    Memory.T: (np.float32, None), Memory.TK: (np.float32, None), Memory.MEANS: (np.float32, None),
+    Memory.S: (np.float32, None), Memory.NN_ID: (DIST_ID, None), Memory.W: (np.float32, None),
+    Memory.SUM_W: (np.float64, None), Memory.REPS: (np.float32, 8), Memory.RBC_N: (np.uint32, None),
+    Memory.RBC_O: (np.uint32, None), Memory.RBC_PERM: (np.uint32, None), Memory.RBC_OWNER: (np.uint32, None),
+    Memory.RID: (np.uint32, None), Memory.R: (np.float32, 3), Memory.RK: (np.float32, 3),
+    Memory.NN: (np.float32, 4), Memory.QT: (np.float32, 4),
+}
+
+
+class ICPStep:
+    """One ICP iteration engine — mirror of cl_algo::ICP::ICPStep<CR,CW>.
+
+    Reference                                   here
+    ICPStep(env, infoRBC, infoICP)              ICPStep(device=0, CR=POWER_METHOD, CW=WEIGHTED)
+    init(m, nr, a=1e2, c=1e-6, staging)         init(m, nr, a=1e2, c=1e-6, batch=1)
+    write(mem, ptr, block)                      write(mem, array, block=False, batch_index=0)
+    read(mem, block)                            read(mem, batch_index=0) -> numpy array
+    buildRBC() / run(config=False)              buildRBC() / run(config=False)
+    getAlpha/setAlpha/getScaling/setScaling     same names
+    members Rk qk tk sk R q t s                 properties of the same names (blocking read)
+    """
+
+    def __init__(self, device=0, CR=ICPStepConfigT.POWER_METHOD, CW=ICPStepConfigW.WEIGHTED):
+        self._L = lib()
+        self._h = C.c_void_p()
+        rc = self._L.icp_create(C.byref(self._h), device, CR, CW)
+        if rc:
+            msg = self._L.icp_last_error(None).decode()
+            self._h = None
+            raise ICPError(rc, msg)
+        self.m = self.nr = 0
+        self.batch = 1
+        self._max_it, self._ang, self._tra = 40, 0.001, 0.01
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.icp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise ICPError(rc, self._L.icp_last_error(self._h).decode())
+
+    # -- reference API ---------------------------------------------------------------------
+    def init(self, m, nr, a=1e2, c=1e-6, batch=1):
+        self._chk(self._L.icp_init_batched(self._h, batch, m, nr, a, c, self._max_it, self._ang, self._tra))
+        self.m, self.nr, self.batch = m, nr, batch
+
+    def write(self, mem=Memory.D_IN_F, ptr=None, block=False, batch_index=0):
+        arr = None
+        if ptr is not None:
+            arr = np.ascontiguousarray(ptr, dtype=np.float32)
+            want = 8 if mem == Memory.T else self.m * 8
+            if arr.size != want:
+                raise ValueError("write(%d): expected %d floats, got %d" % (mem, want, arr.size))
+        self._chk(self._L.icp_write_b(self._h, batch_index, mem, _p(arr) if arr is not None else None, int(block)))
+
+    def read(self, mem=Memory.H_IO_T, batch_index=0):
+        nbytes = self._L.icp_mem_size(self._h, mem)
+        if nbytes == 0:
+            raise ValueError("unknown memory object %r" % (mem,))
+        dt, cols = _MEM_DTYPE[mem]
+        out = np.empty(nbytes // np.dtype(dt).itemsize, dt)
+        self._chk(self._L.icp_read_b(self._h, batch_index, mem, _p(out), nbytes))
+        return out.reshape(-1, cols) if cols else out
+
+    def buildRBC(self):
+        self._chk(self._L.icp_build_rbc(self._h))
+
+    def run(self, config=False):
+        """ICPStep::run — one iteration (enqueue only)."""
+        self._chk(self._L.icp_step(self._h, int(config)))
+
+    def getAlpha(self):
+        v = C.c_float()
+        self._chk(self._L.icp_get_alpha(self._h, C.byref(v)))
+        return v.value
+
+    def setAlpha(self, a):
+        self._chk(self._L.icp_set_alpha(self._h, a))
+
+    def getScaling(self):
+        v = C.c_float()
+        self._chk(self._L.icp_get_scaling(self._h, C.byref(v)))
+        return v.value
+
+    def setScaling(self, c):
+        self._chk(self._L.icp_set_scaling(self._h, c))
+
+    # -- extensions ------------------------------------------------------------------------
+    def setPowerMode(self, mode):
+        self._chk(self._L.icp_set_power_mode(self._h, mode))
+
+    def sync(self):
+        self._chk(self._L.icp_sync(self._h))
+
+    def run_fixed(self, iterations):
+        """ICP::run(timer) — exactly `iterations` steps, no convergence test (enqueue only)."""
+        self._chk(self._L.icp_run_fixed(self._h, iterations))
+
+    def write_cloud(self, which, cloud):
+        cloud = np.ascontiguousarray(cloud, np.float32)
+        if cloud.size != 640 * 480 * 8:
+            raise ValueError("expected a 640x480 float8 cloud")
+        self._chk(self._L.icp_write_cloud(self._h, which, _p(cloud), 1))
+
+    def transform_cloud(self, cloud):
+        cloud = np.ascontiguousarray(cloud, np.float32).reshape(-1, 8)
+        out = np.empty_like(cloud)
+        self._chk(self._L.icp_transform_cloud(self._h, _p(cloud), _p(out), cloud.shape[0]))
+        return out
+
+    def time_run_fixed(self, iterations, reps):
+        ms = C.c_float()
+        self._chk(self._L.icp_time_run_fixed(self._h, iterations, reps, C.byref(ms)))
+        return ms.value
+
+    def time_kernels(self, reps):
+        out = (C.c_float * 4)()
+        self._chk(self._L.icp_time_kernels(self._h, reps, out))
+        return dict(zip(("search", "means", "sij", "finalize"), [float(v) for v in out]))
+
+    def state(self, batch_index=0):
+        st = _State()
+        self._chk(self._L.icp_state_b(self._h, batch_index, C.byref(st)))
+        return st
+
+    def _vec(self, name, shape=None):
+        a = np.array(getattr(self.state(), name), dtype=np.float32)
+        return a.reshape(shape) if shape else a
+
+    R = property(lambda s: s._vec("R", (3, 3)))
+    Rk = property(lambda s: s._vec("Rk", (3, 3)))
+    q = property(lambda s: s._vec("q"))
+    qk = property(lambda s: s._vec("qk"))
+    t = property(lambda s: s._vec("t"))
+    tk = property(lambda s: s._vec("tk"))
+    s = property(lambda s: float(s.state().s))
+    sk = property(lambda s: float(s.state().sk))
+    k = property(lambda s: int(s.state().k))
+
+
+class ICP(ICPStep):
+    """Full registration loop — mirror of cl_algo::ICP::ICP<CR,CW> (include/ICP/algorithms.hpp:2433-2496)."""
+
+    def init(self, m, nr, a=1e2, c=1e-6, max_iterations=40, angle_threshold=0.001,
+             translation_threshold=0.01, batch=1):
+        self._max_it, self._ang, self._tra = max_iterations, angle_threshold, translation_threshold
+        super().init(m, nr, a, c, batch)
+
+    def run(self):
+        """ICP::run — iterate until check() stops (blocking); returns k."""
+        k = C.c_uint32()
+        self._chk(self._L.icp_run(self._h, C.byref(k)))
+        return k.value
+
+    def step(self, config=False):
+        ICPStep.run(self, config)
+
+    def getMaxIterations(self):
+        v = C.c_uint32()
+        self._chk(self._L.icp_get_max_iterations(self._h, C.byref(v)))
+        return v.value
+
+    def setMaxIterations(self, n):
+        self._chk(self._L.icp_set_max_iterations(self._h, n))
+        self._max_it = n
+
+    def getAngleThreshold(self):
+        v = C.c_double()
+        self._chk(self._L.icp_get_angle_threshold(self._h, C.byref(v)))
+        return v.value
+
+    def setAngleThreshold(self, deg):
+        self._chk(self._L.icp_set_angle_threshold(self._h, deg))
+        self._ang = deg
+
+    def getTranslationThreshold(self):
+        v = C.c_double()
+        self._chk(self._L.icp_get_translation_threshold(self._h, C.byref(v)))
+        return v.value
+
+    def setTranslationThreshold(self, mm):
+        self._chk(self._L.icp_set_translation_threshold(self._h, mm))
+        self._tra = mm

@@ -1,0 +1,609 @@
+// icp_capi.hip — C-ABI (include/icp_amd.h) over the HIP kernels: handle, buffers, stream, hipGraphs.
+//
+// Host-side counterpart of ICPStep<CR,CW> / ICP<CR,CW> (include/ICP/algorithms.hpp:2234-2496,
+// src/ICP/algorithms.cpp:4348-4903).  The reference wires ten kernel-wrapper objects by sharing
+// cl::Buffer handles (:4499-4581) and syncs with the host every iteration (:4681-4697); here one
+// handle owns one stream, all device buffers of a batch of registrations and the device-resident
+// registration state, and an ICP run is a single hipGraph launch.
+//
+// There is NO CPU fallback: without a gfx950 device icp_create fails with ICP_ENODEVICE.
+#include "../../include/icp_amd.h"
+#include "icp_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct graph_entry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+
+}  // namespace
+
+struct icp_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool inited = false, built = false;
+    icp_params p {};
+    uint32_t max_iterations = 40;
+    double angle_threshold = 0.001, translation_threshold = 0.01;
+    std::string err;
+    // owned allocations
+    std::vector<void *> dev_allocs;
+    float *dF = nullptr, *dM = nullptr;          // may be adopted
+    bool ownF = true, ownM = true;
+    float *hF = nullptr, *hM = nullptr, *hT = nullptr;   // pinned staging (H_IN_F / H_IN_M / H_IO_T)
+    float *dTin = nullptr;                       // device scratch for write(T)
+    float *dCloud = nullptr, *dCloudOut = nullptr; uint32_t cloud_cap = 0;
+    std::map<uint64_t, graph_entry> graphs;      // key: iterations << 1 | check
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int fail (icp_context *h, int code, const std::string &msg)
+{
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail ((h), ICP_EHIP, std::string (#expr) + ": " + hipGetErrorString (e_));   \
+    } while (0)
+
+void drop_graphs (icp_context *h)
+{
+    for (auto &kv : h->graphs) {
+        if (kv.second.exec) (void) hipGraphExecDestroy (kv.second.exec);
+        if (kv.second.graph) (void) hipGraphDestroy (kv.second.graph);
+    }
+    h->graphs.clear ();
+}
+
+void free_all (icp_context *h)
+{
+    drop_graphs (h);
+    for (void *q : h->dev_allocs) (void) hipFree (q);
+    h->dev_allocs.clear ();
+    if (h->hF) (void) hipHostFree (h->hF);
+    if (h->hM) (void) hipHostFree (h->hM);
+    if (h->hT) (void) hipHostFree (h->hT);
+    if (h->dCloud) (void) hipFree (h->dCloud);
+    if (h->dCloudOut) (void) hipFree (h->dCloudOut);
+    h->hF = h->hM = h->hT = nullptr; h->dCloud = h->dCloudOut = nullptr; h->cloud_cap = 0;
+    h->dF = h->dM = nullptr; h->ownF = h->ownM = true;
+    h->inited = h->built = false;
+}
+
+template <typename T>
+int dalloc (icp_context *h, T **ptr, size_t count, bool zero = true)
+{
+    void *q = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof (T);
+    hipError_t e = hipMalloc (&q, bytes);
+    if (e != hipSuccess) return fail (h, ICP_ENOMEM, std::string ("hipMalloc: ") + hipGetErrorString (e));
+    h->dev_allocs.push_back (q);
+    if (zero) {
+        e = hipMemsetAsync (q, 0, bytes, h->stream);
+        if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("hipMemsetAsync: ") + hipGetErrorString (e));
+    }
+    *ptr = static_cast<T *> (q);
+    return ICP_OK;
+}
+
+// landmark-grid / representative-grid validation — src/ICP/algorithms.cpp:842-854 generalised (oracle: orc_reps_grid)
+bool reps_grid (uint32_t m, uint32_t nr, uint32_t *nrx, uint32_t *nry, uint32_t *side)
+{
+    if (m == 0 || nr == 0 || nr > m) return false;
+    if (nr & (nr - 1)) return false;
+    uint32_t g = (uint32_t) std::floor (std::sqrt ((double) m) + 0.5);
+    if ((uint64_t) g * g != m) return false;
+    uint32_t pw = 0; while ((1u << (pw + 1)) <= nr) ++pw;
+    uint32_t x = 1u << (pw - pw / 2), y = 1u << (pw / 2);
+    if (g % x || g % y) return false;
+    *nrx = x; *nry = y; *side = g;
+    return true;
+}
+
+int need (icp_context *h, bool built)
+{
+    if (!h) return ICP_EINVAL;
+    if (!h->inited) return fail (h, ICP_ESTATE, "icp_init has not been called");
+    if (built && !h->built) return fail (h, ICP_ESTATE, "icp_build_rbc has not been called");
+    return ICP_OK;
+}
+
+int set_device (icp_context *h)
+{
+    HIPCHK (h, hipSetDevice (h->device));
+    return ICP_OK;
+}
+
+// Capture `iterations` iterations into a graph (cached until a parameter changes).
+int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *out)
+{
+    uint64_t key = ((uint64_t) iterations << 1) | (uint64_t) (check ? 1 : 0);
+    auto it = h->graphs.find (key);
+    if (it != h->graphs.end ()) { *out = it->second.exec; return ICP_OK; }
+    icp_params p = h->p;
+    p.check = check;
+    graph_entry ge;
+    HIPCHK (h, hipStreamBeginCapture (h->stream, hipStreamCaptureModeThreadLocal));
+    for (uint32_t k = 0; k < iterations; ++k) icp_launch_iteration (p, h->stream);
+    hipError_t e = hipStreamEndCapture (h->stream, &ge.graph);
+    if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("hipStreamEndCapture: ") + hipGetErrorString (e));
+    HIPCHK (h, hipGraphInstantiate (&ge.exec, ge.graph, nullptr, nullptr, 0));
+    h->graphs[key] = ge;
+    *out = ge.exec;
+    return ICP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *icp_version (void) { return "icp_amd 0.1 (gfx950)"; }
+
+const char *icp_last_error (icp_handle h) { return h ? h->err.c_str () : g_create_error.c_str (); }
+
+int icp_device_count (int *n)
+{
+    int c = 0;
+    hipError_t e = hipGetDeviceCount (&c);
+    if (e != hipSuccess) { *n = 0; return fail (nullptr, ICP_ENODEVICE, std::string ("hipGetDeviceCount: ") + hipGetErrorString (e)); }
+    *n = c;
+    return ICP_OK;
+}
+
+int icp_create (icp_handle *out, int device, int rot, int weighted)
+{
+    if (!out) return ICP_EINVAL;
+    *out = nullptr;
+    if ((rot != ICP_ROT_EIGEN && rot != ICP_ROT_POWER_METHOD) || (weighted != 0 && weighted != 1))
+        return fail (nullptr, ICP_EINVAL, "icp_create: rot must be 0|1 and weighted 0|1");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount (&count);
+    if (e != hipSuccess || count <= 0)
+        return fail (nullptr, ICP_ENODEVICE, "icp_create: no HIP device visible (the engine has no CPU fallback)");
+    if (device < 0 || device >= count) return fail (nullptr, ICP_EINVAL, "icp_create: device ordinal out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties (&prop, device);
+    if (e != hipSuccess) return fail (nullptr, ICP_EHIP, std::string ("hipGetDeviceProperties: ") + hipGetErrorString (e));
+    if (std::strncmp (prop.gcnArchName, "gfx950", 6) != 0)
+        return fail (nullptr, ICP_ENODEVICE, std::string ("icp_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    icp_context *h = new icp_context ();
+    h->device = device;
+    h->p.rot = rot; h->p.weighted = weighted; h->p.power_mode = ICP_POWER_LITERAL;
+    e = hipSetDevice (device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags (&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate (&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate (&h->ev1);
+    if (e != hipSuccess) { std::string m = hipGetErrorString (e); delete h; return fail (nullptr, ICP_EHIP, "icp_create: " + m); }
+    *out = h;
+    return ICP_OK;
+}
+
+int icp_destroy (icp_handle h)
+{
+    if (!h) return ICP_EINVAL;
+    (void) hipSetDevice (h->device);
+    if (h->stream) (void) hipStreamSynchronize (h->stream);
+    free_all (h);
+    if (h->dTin) (void) hipFree (h->dTin);
+    if (h->ev0) (void) hipEventDestroy (h->ev0);
+    if (h->ev1) (void) hipEventDestroy (h->ev1);
+    if (h->stream) (void) hipStreamDestroy (h->stream);
+    delete h;
+    return ICP_OK;
+}
+
+int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, float a, float c,
+                      uint32_t max_iterations, double angle_threshold, double translation_threshold)
+{
+    if (!h) return ICP_EINVAL;
+    // argument checks of the reference: src/ICP/algorithms.cpp:4413-4420, :1573, :842-854
+    if (m == 0) return fail (h, ICP_EINVAL, "The sets of landmarks cannot have zero points");
+    if (nr == 0) return fail (h, ICP_EINVAL, "The sets of representatives cannot have zero points");
+    if (a == 0.f) return fail (h, ICP_EINVAL, "The alpha parameter cannot be equal to zero");
+    if (m % 2) return fail (h, ICP_EINVAL, "The number of points in the array must be a multiple of 2");
+    if (batch == 0 || batch > 65535u) return fail (h, ICP_EINVAL, "batch must be in [1, 65535]");
+    if (max_iterations == 0) return fail (h, ICP_EINVAL, "max_iterations must be positive");
+    uint32_t nrx, nry, side;
+    if (!reps_grid (m, nr, &nrx, &nry, &side))
+        return fail (h, ICP_EINVAL, "nr must be a power of two whose grid tiles the sqrt(m) x sqrt(m) landmark grid");
+    if (nr > 32768u) return fail (h, ICP_EINVAL, "nr must be <= 32768");
+    if (m > (1u << 24)) return fail (h, ICP_EINVAL, "m must be <= 2^24");
+    int rc = set_device (h); if (rc) return rc;
+    if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
+    int rot = h->p.rot, weighted = h->p.weighted, pmode = h->p.power_mode;
+    free_all (h);
+    icp_params &p = h->p;
+    p = icp_params {};
+    p.rot = rot; p.weighted = weighted; p.power_mode = pmode; p.check = 0;
+    p.m = m; p.nr = nr; p.batch = batch; p.side = side; p.nrx = nrx; p.nry = nry;
+    p.a = a; p.c = c;
+    h->max_iterations = max_iterations; h->angle_threshold = angle_threshold; h->translation_threshold = translation_threshold;
+    p.tan_half_thr = std::tan (angle_threshold * M_PI / 360.0);
+    p.trans_thr = translation_threshold;
+    p.nwg = (m + 127u) / 128u;                                       // src/ICP/algorithms.cpp:1038
+    p.nwp = p.nwg; if (p.nwp != 1 && (p.nwp % 4)) p.nwp += 4 - p.nwp % 4;          // :1040
+    uint32_t n4 = m; if (n4 % 4) n4 += 4 - n4 % 4;
+    p.G = n4 / 4;                                                    // :2344-2346
+    p.nsp = (p.G + 511u) / 512u; if (p.nsp != 1 && (p.nsp % 4)) p.nsp += 4 - p.nsp % 4;   // :140-142
+    p.nchunk = (m + ICP_CHUNK - 1) / ICP_CHUNK;
+
+    const size_t B = batch;
+    float *F = nullptr, *M = nullptr;
+    if ((rc = dalloc (h, &F, B * m * 8))) return rc;
+    if ((rc = dalloc (h, &M, B * m * 8))) return rc;
+    h->dF = F; h->dM = M; p.F = F; p.M = M;
+    if ((rc = dalloc (h, &p.R, B * nr * 8))) return rc;
+    if ((rc = dalloc (h, &p.XP, B * m * 8))) return rc;
+    if ((rc = dalloc (h, &p.rep_src, B * nr))) return rc;
+    if ((rc = dalloc (h, &p.owner, B * m))) return rc;
+    if ((rc = dalloc (h, &p.N, B * nr))) return rc;
+    if ((rc = dalloc (h, &p.O, B * nr))) return rc;
+    if ((rc = dalloc (h, &p.perm, B * m))) return rc;
+    if ((rc = dalloc (h, &p.chunk_hist, B * p.nchunk * nr))) return rc;
+    if ((rc = dalloc (h, &p.rid, B * m))) return rc;
+    if ((rc = dalloc (h, &p.nn_id, B * m))) return rc;
+    if ((rc = dalloc (h, &p.PF, B * m))) return rc;
+    if ((rc = dalloc (h, &p.PM, B * m))) return rc;
+    if ((rc = dalloc (h, &p.wpart, B * p.nwp))) return rc;          // padding stays 0.f (identity operands)
+    if ((rc = dalloc (h, &p.mpart, B * 2 * p.nwg))) return rc;
+    if ((rc = dalloc (h, &p.mscr, B * 2 * ((p.nwg + 127u) / 128u)))) return rc;
+    if ((rc = dalloc (h, &p.spart, B * 11 * p.nsp))) return rc;
+    if ((rc = dalloc (h, &p.sscr, B * 11 * ((((p.nsp + 511u) / 512u) + 3u) & ~3u)))) return rc;
+    if ((rc = dalloc (h, &p.st, B))) return rc;
+    if (!h->dTin) HIPCHK (h, hipMalloc ((void **) &h->dTin, 8 * sizeof (float)));
+    HIPCHK (h, hipHostMalloc ((void **) &h->hF, B * m * 8 * sizeof (float), hipHostMallocDefault));
+    HIPCHK (h, hipHostMalloc ((void **) &h->hM, B * m * 8 * sizeof (float), hipHostMallocDefault));
+    HIPCHK (h, hipHostMalloc ((void **) &h->hT, 64 * sizeof (float), hipHostMallocDefault));
+    icp_launch_reset_state (p, h->stream, 1);
+    HIPCHK (h, hipGetLastError ());
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    h->inited = true; h->built = false;
+    return ICP_OK;
+}
+
+int icp_init (icp_handle h, uint32_t m, uint32_t nr, float a, float c, uint32_t max_iterations,
+              double angle_threshold, double translation_threshold)
+{
+    return icp_init_batched (h, 1, m, nr, a, c, max_iterations, angle_threshold, translation_threshold);
+}
+
+int icp_write_b (icp_handle h, uint32_t b, int mem, const void *host_ptr, int block)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if (b >= h->p.batch) return fail (h, ICP_EINVAL, "batch index out of range");
+    if ((rc = set_device (h))) return rc;
+    const size_t fm = (size_t) h->p.m * 8 * sizeof (float);
+    switch (mem) {
+        case ICP_MEM_F:
+        case ICP_MEM_M: {
+            float *stage = (mem == ICP_MEM_F ? h->hF : h->hM) + (size_t) b * h->p.m * 8;
+            float *dst = (mem == ICP_MEM_F ? h->dF : h->dM) + (size_t) b * h->p.m * 8;
+            // the staging buffer may still feed an earlier asynchronous copy
+            HIPCHK (h, hipStreamSynchronize (h->stream));
+            if (host_ptr) std::memcpy (stage, host_ptr, fm);           // algorithms.cpp:4604-4606
+            HIPCHK (h, hipMemcpyAsync (dst, stage, fm, hipMemcpyHostToDevice, h->stream));
+            break;
+        }
+        case ICP_MEM_T: {
+            HIPCHK (h, hipStreamSynchronize (h->stream));
+            if (host_ptr) std::memcpy (h->hT, host_ptr, 8 * sizeof (float));   // :4613-4617
+            HIPCHK (h, hipMemcpyAsync (h->dTin, h->hT, 8 * sizeof (float), hipMemcpyHostToDevice, h->stream));
+            icp_launch_set_T (h->p, b, h->dTin, h->stream);
+            HIPCHK (h, hipGetLastError ());
+            break;
+        }
+        default:
+            return fail (h, ICP_EINVAL, "icp_write: mem must be ICP_MEM_F, ICP_MEM_M or ICP_MEM_T");
+    }
+    if (block) HIPCHK (h, hipStreamSynchronize (h->stream));
+    return ICP_OK;
+}
+
+int icp_write (icp_handle h, int mem, const void *host_ptr, int block) { return icp_write_b (h, 0, mem, host_ptr, block); }
+
+size_t icp_mem_size (icp_handle h, int mem)
+{
+    if (!h || !h->inited) return 0;
+    const icp_params &p = h->p;
+    switch (mem) {
+        case ICP_MEM_F: case ICP_MEM_M: case ICP_MEM_RBC_XP: return (size_t) p.m * 32;
+        case ICP_MEM_T: case ICP_MEM_TK: case ICP_MEM_MEANS: return 32;
+        case ICP_MEM_S: return 44;
+        case ICP_MEM_NN_ID: return (size_t) p.m * 8;
+        case ICP_MEM_W: case ICP_MEM_RBC_PERM: case ICP_MEM_RBC_OWNER: case ICP_MEM_RID: return (size_t) p.m * 4;
+        case ICP_MEM_SUM_W: return 8;
+        case ICP_MEM_REPS: return (size_t) p.nr * 32;
+        case ICP_MEM_RBC_N: case ICP_MEM_RBC_O: return (size_t) p.nr * 4;
+        case ICP_MEM_R: case ICP_MEM_RK: return 36;
+        case ICP_MEM_NN: case ICP_MEM_QT: return (size_t) p.m * 16;
+        default: return 0;
+    }
+}
+
+static int mem_ptr (icp_context *h, uint32_t b, int mem, const void **src)
+{
+    const icp_params &p = h->p;
+    const char *st = reinterpret_cast<const char *> (p.st + b);
+    switch (mem) {
+        case ICP_MEM_F: *src = h->dF + (size_t) b * p.m * 8; break;
+        case ICP_MEM_M: *src = h->dM + (size_t) b * p.m * 8; break;
+        case ICP_MEM_RBC_XP: *src = p.XP + (size_t) b * p.m * 8; break;
+        case ICP_MEM_T: *src = st + offsetof (icp_reg_state, T); break;
+        case ICP_MEM_TK: *src = st + offsetof (icp_reg_state, Tk); break;
+        case ICP_MEM_MEANS: *src = st + offsetof (icp_reg_state, means); break;
+        case ICP_MEM_S: *src = st + offsetof (icp_reg_state, S); break;
+        case ICP_MEM_SUM_W: *src = st + offsetof (icp_reg_state, sum_w); break;
+        case ICP_MEM_R: *src = st + offsetof (icp_reg_state, R); break;
+        case ICP_MEM_RK: *src = st + offsetof (icp_reg_state, Rk); break;
+        case ICP_MEM_NN_ID: *src = p.nn_id + (size_t) b * p.m; break;
+        case ICP_MEM_RBC_PERM: *src = p.perm + (size_t) b * p.m; break;
+        case ICP_MEM_RBC_OWNER: *src = p.owner + (size_t) b * p.m; break;
+        case ICP_MEM_RID: *src = p.rid + (size_t) b * p.m; break;
+        case ICP_MEM_REPS: *src = p.R + (size_t) b * p.nr * 8; break;
+        case ICP_MEM_RBC_N: *src = p.N + (size_t) b * p.nr; break;
+        case ICP_MEM_RBC_O: *src = p.O + (size_t) b * p.nr; break;
+        case ICP_MEM_NN: *src = p.PF + (size_t) b * p.m; break;
+        case ICP_MEM_QT: *src = p.PM + (size_t) b * p.m; break;
+        case ICP_MEM_W: *src = reinterpret_cast<const float *> (p.PF + (size_t) b * p.m) + 3; break;
+        default: return fail (h, ICP_EINVAL, "unknown icp_mem value");
+    }
+    return ICP_OK;
+}
+
+int icp_read_b (icp_handle h, uint32_t b, int mem, void *host_dst, size_t bytes)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if (!host_dst) return fail (h, ICP_EINVAL, "icp_read: null destination");
+    if (b >= h->p.batch) return fail (h, ICP_EINVAL, "batch index out of range");
+    size_t full = icp_mem_size (h, mem);
+    if (full == 0) return fail (h, ICP_EINVAL, "unknown icp_mem value");
+    if (bytes > full) return fail (h, ICP_EINVAL, "icp_read: more bytes requested than the object holds");
+    if ((rc = set_device (h))) return rc;
+    const void *src = nullptr;
+    if ((rc = mem_ptr (h, b, mem, &src))) return rc;
+    if (mem == ICP_MEM_W) {                        // weights live in the .w lane of the matched points
+        size_t rows = bytes / 4;
+        HIPCHK (h, hipMemcpy2DAsync (host_dst, 4, src, 16, 4, rows, hipMemcpyDeviceToHost, h->stream));
+    } else
+        HIPCHK (h, hipMemcpyAsync (host_dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    return ICP_OK;
+}
+
+int icp_read (icp_handle h, int mem, void *host_dst, size_t bytes) { return icp_read_b (h, 0, mem, host_dst, bytes); }
+
+int icp_device_ptr (icp_handle h, int mem, void **dptr)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if (!dptr) return fail (h, ICP_EINVAL, "null pointer");
+    const void *src = nullptr;
+    if ((rc = mem_ptr (h, 0, mem, &src))) return rc;
+    *dptr = const_cast<void *> (src);
+    return ICP_OK;
+}
+
+int icp_adopt_device_buffer (icp_handle h, int mem, void *dptr)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if (!dptr) return fail (h, ICP_EINVAL, "null pointer");
+    if (mem == ICP_MEM_F) { h->dF = static_cast<float *> (dptr); h->p.F = h->dF; h->ownF = false; h->built = false; }
+    else if (mem == ICP_MEM_M) { h->dM = static_cast<float *> (dptr); h->p.M = h->dM; h->ownM = false; }
+    else return fail (h, ICP_EINVAL, "only ICP_MEM_F and ICP_MEM_M can be adopted");
+    drop_graphs (h);
+    return ICP_OK;
+}
+
+int icp_build_rbc (icp_handle h)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if ((rc = set_device (h))) return rc;
+    icp_launch_build_rbc (h->p, h->stream);
+    icp_launch_reset_state (h->p, h->stream, 0);                     // ICP::buildRBC: k = 0 (:4796)
+    HIPCHK (h, hipGetLastError ());
+    h->built = true;
+    return ICP_OK;
+}
+
+int icp_step (icp_handle h, int config)
+{
+    (void) config;   // the reference sizes the list-scan launch from a host read when config is set; nothing to configure here
+    int rc = need (h, true); if (rc) return rc;
+    if ((rc = set_device (h))) return rc;
+    icp_params p = h->p; p.check = 0;
+    icp_launch_iteration (p, h->stream);
+    HIPCHK (h, hipGetLastError ());
+    return ICP_OK;
+}
+
+int icp_run_fixed (icp_handle h, uint32_t iterations)
+{
+    int rc = need (h, true); if (rc) return rc;
+    if (iterations == 0) return ICP_OK;
+    if ((rc = set_device (h))) return rc;
+    hipGraphExec_t exec;
+    if ((rc = get_graph (h, iterations, 0, &exec))) return rc;
+    HIPCHK (h, hipGraphLaunch (exec, h->stream));
+    return ICP_OK;
+}
+
+int icp_run (icp_handle h, uint32_t *k)
+{
+    int rc = need (h, true); if (rc) return rc;
+    if ((rc = set_device (h))) return rc;
+    hipGraphExec_t exec;
+    if ((rc = get_graph (h, h->max_iterations, 1, &exec))) return rc;
+    HIPCHK (h, hipGraphLaunch (exec, h->stream));
+    HIPCHK (h, hipStreamSynchronize (h->stream));                    // queue.finish () — :4813
+    if (k) {
+        icp_reg_state st;
+        HIPCHK (h, hipMemcpy (&st, h->p.st, sizeof st, hipMemcpyDeviceToHost));
+        *k = st.k;
+    }
+    return ICP_OK;
+}
+
+int icp_sync (icp_handle h)
+{
+    if (!h) return ICP_EINVAL;
+    int rc = set_device (h); if (rc) return rc;
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    return ICP_OK;
+}
+
+int icp_get_alpha (icp_handle h, float *a) { if (!h || !a) return ICP_EINVAL; *a = h->p.a; return ICP_OK; }
+int icp_set_alpha (icp_handle h, float a)
+{   // setAlpha updates construct and search (src/ICP/algorithms.cpp:4712-4717); lists must be rebuilt by the caller
+    if (!h) return ICP_EINVAL;
+    if (a == 0.f) return fail (h, ICP_EINVAL, "The alpha parameter cannot be equal to zero");
+    h->p.a = a; drop_graphs (h); return ICP_OK;
+}
+int icp_get_scaling (icp_handle h, float *c) { if (!h || !c) return ICP_EINVAL; *c = h->p.c; return ICP_OK; }
+int icp_set_scaling (icp_handle h, float c) { if (!h) return ICP_EINVAL; h->p.c = c; drop_graphs (h); return ICP_OK; }
+int icp_get_max_iterations (icp_handle h, uint32_t *n) { if (!h || !n) return ICP_EINVAL; *n = h->max_iterations; return ICP_OK; }
+int icp_set_max_iterations (icp_handle h, uint32_t n)
+{
+    if (!h) return ICP_EINVAL;
+    if (n == 0) return fail (h, ICP_EINVAL, "max_iterations must be positive");
+    h->max_iterations = n; return ICP_OK;
+}
+int icp_get_angle_threshold (icp_handle h, double *d) { if (!h || !d) return ICP_EINVAL; *d = h->angle_threshold; return ICP_OK; }
+int icp_set_angle_threshold (icp_handle h, double d)
+{
+    if (!h) return ICP_EINVAL;
+    h->angle_threshold = d; h->p.tan_half_thr = std::tan (d * M_PI / 360.0); drop_graphs (h); return ICP_OK;
+}
+int icp_get_translation_threshold (icp_handle h, double *d) { if (!h || !d) return ICP_EINVAL; *d = h->translation_threshold; return ICP_OK; }
+int icp_set_translation_threshold (icp_handle h, double d)
+{
+    if (!h) return ICP_EINVAL;
+    h->translation_threshold = d; h->p.trans_thr = d; drop_graphs (h); return ICP_OK;
+}
+int icp_set_power_mode (icp_handle h, int mode)
+{
+    if (!h) return ICP_EINVAL;
+    if (mode != ICP_POWER_LITERAL && mode != ICP_POWER_SQUARED) return fail (h, ICP_EINVAL, "unknown power mode");
+    h->p.power_mode = mode; drop_graphs (h); return ICP_OK;
+}
+
+int icp_state_b (icp_handle h, uint32_t b, icp_state_t *out)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if (!out) return fail (h, ICP_EINVAL, "null pointer");
+    if (b >= h->p.batch) return fail (h, ICP_EINVAL, "batch index out of range");
+    if ((rc = set_device (h))) return rc;
+    icp_reg_state st;
+    HIPCHK (h, hipMemcpyAsync (&st, h->p.st + b, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    std::memcpy (out->R, st.R, sizeof st.R); std::memcpy (out->Rk, st.Rk, sizeof st.Rk);
+    std::memcpy (out->q, st.T, 16); std::memcpy (out->t, st.T + 4, 12); out->s = st.T[7];
+    std::memcpy (out->qk, st.Tk, 16); std::memcpy (out->tk, st.Tk + 4, 12); out->sk = st.Tk[7];
+    out->k = st.k; out->converged = st.done; out->power_iterations = st.pm_iters; out->reserved = 0;
+    return ICP_OK;
+}
+
+int icp_state (icp_handle h, icp_state_t *out) { return icp_state_b (h, 0, out); }
+
+int icp_write_cloud (icp_handle h, int which, const void *cloud, int block)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if (h->p.m != 16384u) return fail (h, ICP_EINVAL, "getLMs produces 128 x 128 landmarks: m must be 16384");
+    if (which != ICP_MEM_F && which != ICP_MEM_M) return fail (h, ICP_EINVAL, "which must be ICP_MEM_F or ICP_MEM_M");
+    if (!cloud) return fail (h, ICP_EINVAL, "null pointer");
+    if ((rc = set_device (h))) return rc;
+    const uint32_t n = 640u * 480u;
+    if (h->cloud_cap < n) {
+        if (h->dCloud) (void) hipFree (h->dCloud);
+        if (h->dCloudOut) (void) hipFree (h->dCloudOut);
+        h->dCloud = h->dCloudOut = nullptr; h->cloud_cap = 0;
+        HIPCHK (h, hipMalloc ((void **) &h->dCloud, (size_t) n * 32));
+        HIPCHK (h, hipMalloc ((void **) &h->dCloudOut, (size_t) n * 32));
+        h->cloud_cap = n;
+    }
+    HIPCHK (h, hipMemcpyAsync (h->dCloud, cloud, (size_t) n * 32, hipMemcpyHostToDevice, h->stream));
+    icp_launch_get_lms (h->dCloud, which == ICP_MEM_F ? h->dF : h->dM, h->stream);
+    HIPCHK (h, hipGetLastError ());
+    HIPCHK (h, hipStreamSynchronize (h->stream));   // the source is pageable host memory
+    (void) block;
+    return ICP_OK;
+}
+
+int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint32_t n)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if (!host_in || !host_out || n == 0) return fail (h, ICP_EINVAL, "bad arguments");
+    if ((rc = set_device (h))) return rc;
+    if (h->cloud_cap < n) {
+        if (h->dCloud) (void) hipFree (h->dCloud);
+        if (h->dCloudOut) (void) hipFree (h->dCloudOut);
+        h->dCloud = h->dCloudOut = nullptr; h->cloud_cap = 0;
+        HIPCHK (h, hipMalloc ((void **) &h->dCloud, (size_t) n * 32));
+        HIPCHK (h, hipMalloc ((void **) &h->dCloudOut, (size_t) n * 32));
+        h->cloud_cap = n;
+    }
+    HIPCHK (h, hipMemcpyAsync (h->dCloud, host_in, (size_t) n * 32, hipMemcpyHostToDevice, h->stream));
+    icp_launch_transform_cloud (h->dCloud, h->dCloudOut, h->p.st, n, h->stream);
+    HIPCHK (h, hipGetLastError ());
+    HIPCHK (h, hipMemcpyAsync (host_out, h->dCloudOut, (size_t) n * 32, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    return ICP_OK;
+}
+
+int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, float *ms_total)
+{
+    int rc = need (h, true); if (rc) return rc;
+    if (!ms_total || iterations == 0 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
+    if ((rc = set_device (h))) return rc;
+    hipGraphExec_t exec;
+    if ((rc = get_graph (h, iterations, 0, &exec))) return rc;
+    HIPCHK (h, hipEventRecord (h->ev0, h->stream));
+    for (uint32_t r = 0; r < reps; ++r) HIPCHK (h, hipGraphLaunch (exec, h->stream));
+    HIPCHK (h, hipEventRecord (h->ev1, h->stream));
+    HIPCHK (h, hipEventSynchronize (h->ev1));
+    HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));
+    return ICP_OK;
+}
+
+int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4)
+{
+    int rc = need (h, true); if (rc) return rc;
+    if (!out_ms4 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
+    if ((rc = set_device (h))) return rc;
+    icp_params p = h->p; p.check = 0;
+    std::vector<hipEvent_t> ev ((size_t) reps * 5);
+    for (auto &e : ev) HIPCHK (h, hipEventCreate (&e));
+    for (uint32_t r = 0; r < reps; ++r) {
+        hipEvent_t *e = &ev[(size_t) r * 5];
+        HIPCHK (h, hipEventRecord (e[0], h->stream)); icp_launch_search (p, h->stream);
+        HIPCHK (h, hipEventRecord (e[1], h->stream)); icp_launch_means (p, h->stream);
+        HIPCHK (h, hipEventRecord (e[2], h->stream)); icp_launch_sij (p, h->stream);
+        HIPCHK (h, hipEventRecord (e[3], h->stream)); icp_launch_finalize (p, h->stream);
+        HIPCHK (h, hipEventRecord (e[4], h->stream));
+    }
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    double acc[4] = { 0, 0, 0, 0 };
+    for (uint32_t r = 0; r < reps; ++r)
+        for (int k = 0; k < 4; ++k) {
+            float ms = 0.f;
+            HIPCHK (h, hipEventElapsedTime (&ms, ev[(size_t) r * 5 + k], ev[(size_t) r * 5 + k + 1]));
+            acc[k] += ms;
+        }
+    for (int k = 0; k < 4; ++k) out_ms4[k] = (float) (acc[k] / reps);
+    for (auto &e : ev) (void) hipEventDestroy (e);
+    return ICP_OK;
+}
+
+}  // extern "C"

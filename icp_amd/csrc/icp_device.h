@@ -1,0 +1,353 @@
+// icp_device.h — canonical arithmetic of the ICP iteration on gfx950 (device functions).
+//
+// Everything here is the GPU twin of DESIGN.md §3 / oracle/icp_oracle.c: fp32 round-to-nearest,
+// no FMA contraction (the translation unit is built with -ffp-contract=off), IEEE divide/sqrt,
+// reduction trees of the reference's shape for a 64-wide wavefront.  One wavefront == one
+// reference work-group, so the reference's LDS tree
+//     data[0..128) ; for d = 64,32,..,1 : data[i] += data[i+d]            (kernels/icp_kernels.cl:170-175)
+// becomes: lane i holds data[i] + data[i+64], then an xor-butterfly over 32,16,8,4,2,1 (float add is
+// commutative, so every lane ends with the bit pattern the reference leaves in data[0]).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ICP_WF 64
+
+struct icp_dist_id { float dist; uint32_t id; };   // kernels/icp_kernels.cl:34-38
+
+// Device-resident state of one registration (what the reference keeps on the host in
+// ICPStep::{R,q,t,s,Rk,qk,tk,sk} + ICP::k, src/ICP/algorithms.cpp:4683-4695, 4826).
+struct icp_reg_state {
+    float T[8];          // [q | t, s] cumulative — D_IO_T
+    float Tk[8];         // [qk | tk, sk]
+    float R[9];          // cumulative rotation, row-major
+    float Rk[9];
+    float S[11];
+    float pad0;
+    float means[8];      // [mean_f,0 | mean_m,0]
+    double sum_w;
+    uint32_t k;          // iterations executed
+    uint32_t done;       // 1: ICP::check() said stop
+    uint32_t pm_iters;
+    uint32_t pad1;
+};
+
+// ------------------------------------------------------------------------------------------
+// wave trees
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_tree_f (float v)
+{
+    v = v + __shfl_xor (v, 32);
+    v = v + __shfl_xor (v, 16);
+    v = v + __shfl_xor (v, 8);
+    v = v + __shfl_xor (v, 4);
+    v = v + __shfl_xor (v, 2);
+    v = v + __shfl_xor (v, 1);
+    return v;
+}
+
+__device__ __forceinline__ double wave_tree_d (double v)
+{
+    v = v + __shfl_xor (v, 32);
+    v = v + __shfl_xor (v, 16);
+    v = v + __shfl_xor (v, 8);
+    v = v + __shfl_xor (v, 4);
+    v = v + __shfl_xor (v, 2);
+    v = v + __shfl_xor (v, 1);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// element-wise pieces
+// ------------------------------------------------------------------------------------------
+
+// ASSUMPTION-METRIC — the single swap point on the GPU side (CPU twin: orc_metric8).
+// d = ((dx^2+dy^2)+dz^2) + a*((dr^2+dg^2)+db^2), lanes 3 and 7 ignored
+// (metric text: src/ICP/algorithms.cpp:4393-4398; RandomBallCover source is un-vendored).
+__device__ __forceinline__ float icp_metric8 (float qx, float qy, float qz, float qr, float qg, float qb,
+                                              float x, float y, float z, float r, float g, float b, float a)
+{
+    float dx = qx - x, dy = qy - y, dz = qz - z;
+    float dr = qr - r, dg = qg - g, db = qb - b;
+    float geo = (dx * dx + dy * dy) + dz * dz;
+    float pho = (dr * dr + dg * dg) + db * db;
+    return geo + a * pho;
+}
+
+// icpTransform_Quaternion — kernels/icp_kernels.cl:789-801:
+//   p' = t.w * (p + cross (2 q.xyz, cross (q.xyz, p) + q.w p)) + t.xyz
+__device__ __forceinline__ void icp_transform_point (const float *T, float px, float py, float pz,
+                                                     float &ox, float &oy, float &oz)
+{
+    float qx = T[0], qy = T[1], qz = T[2], qw = T[3];
+    float ux = (qy * pz - qz * py) + qw * px;
+    float uy = (qz * px - qx * pz) + qw * py;
+    float uz = (qx * py - qy * px) + qw * pz;
+    float ax = 2 * qx, ay = 2 * qy, az = 2 * qz;
+    float vx = ay * uz - az * uy;
+    float vy = az * ux - ax * uz;
+    float vz = ax * uy - ay * ux;
+    ox = T[7] * (px + vx) + T[4];
+    oy = T[7] * (py + vy) + T[5];
+    oz = T[7] * (pz + vz) + T[6];
+}
+
+// ------------------------------------------------------------------------------------------
+// a9  icpPowerMethod — kernels/icp_kernels.cl:977-1054 (canonical forms: oracle power_impl)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pm_dot4 (const float *a, const float *b)
+{
+    float s = 0.f;
+    s = s + a[0] * b[0]; s = s + a[1] * b[1]; s = s + a[2] * b[2]; s = s + a[3] * b[3];
+    return s;
+}
+
+__device__ __forceinline__ void pm_prod4 (const float *N, const float *x, float *y)
+{
+    y[0] = pm_dot4 (N, x); y[1] = pm_dot4 (N + 4, x); y[2] = pm_dot4 (N + 8, x); y[3] = pm_dot4 (N + 12, x);
+}
+
+__device__ __forceinline__ void pm_normalize4 (float *x)
+{
+    float s = 0.f;
+    s = s + x[0] * x[0]; s = s + x[1] * x[1]; s = s + x[2] * x[2]; s = s + x[3] * x[3];
+    float n = sqrtf (s);
+    x[0] = x[0] / n; x[1] = x[1] / n; x[2] = x[2] / n; x[3] = x[3] / n;
+}
+
+__device__ __forceinline__ float pm_distance4 (const float *a, const float *b)
+{
+    float s = 0.f, d;
+    d = a[0] - b[0]; s = s + d * d; d = a[1] - b[1]; s = s + d * d;
+    d = a[2] - b[2]; s = s + d * d; d = a[3] - b[3]; s = s + d * d;
+    return sqrtf (s);
+}
+
+__device__ __forceinline__ void pm_rescale16 (float *B)
+{   // exact power-of-two rescale so that max|entry| lies in [1,2)
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { float a = fabsf (B[i]); if (a > mx) mx = a; }
+    uint32_t e = (__float_as_uint (mx) >> 23) & 0xFFu;
+    if (e == 0u || e >= 254u) return;
+    float sc = __uint_as_float ((254u - e) << 23);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) B[i] = B[i] * sc;
+}
+
+#define ICP_PM_SQUARINGS 10
+
+// Returns the number of loop trips.  S[11], means[8] -> Tk[8] = [qk | tk, sk].
+__device__ inline int icp_power_method (const float *S, const float *means, float *Tk, int squared_start)
+{
+    float Sxx = S[0], Sxy = S[1], Sxz = S[2], Syx = S[3], Syy = S[4], Syz = S[5],
+          Szx = S[6], Szy = S[7], Szz = S[8];
+    float N[16] = {                                                   // icp_kernels.cl:993-999
+        Sxx - Syy - Szz,       Sxy + Syx,         Szx + Sxz,       Syz - Szy,
+              Sxy + Syx, - Sxx + Syy - Szz,       Syz + Szy,       Szx - Sxz,
+              Szx + Sxz,       Syz + Szy, - Sxx - Syy + Szz,       Sxy - Syx,
+              Syz - Szy,       Szx - Sxz,         Sxy - Syx, Sxx + Syy + Szz };
+    float x[4] = { 1.f, 1.f, 1.f, 1.f }, xn[4];
+    int iters = 0;
+    for (;;) {
+        if (squared_start) {
+            float B[16], C[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) B[i] = N[i];
+            pm_rescale16 (B);
+            for (int s = 0; s < ICP_PM_SQUARINGS; ++s) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc = acc + B[i * 4 + k] * B[k * 4 + j];
+                        C[i * 4 + j] = acc;
+                    }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) B[i] = C[i];
+                pm_rescale16 (B);
+            }
+            pm_prod4 (B, x, xn); pm_normalize4 (xn);
+            x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];
+        }
+        float error, error_new = __builtin_inff ();
+        for (uint32_t it = 0; it < 1000; ++it) {                      // icp_kernels.cl:1012-1022
+            pm_prod4 (N, x, xn);
+            pm_normalize4 (xn);
+            ++iters;
+            error = error_new;
+            error_new = pm_distance4 (x, xn);
+            if (error_new == error) break;
+            x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];
+        }
+        float lambda = pm_dot4 (N, xn) / xn[0];                        // :1024
+        if (lambda < 0) {
+            N[0] -= lambda; N[5] -= lambda; N[10] -= lambda; N[15] -= lambda;
+            x[0] = x[1] = x[2] = x[3] = 1.f;
+        } else break;
+    }
+    x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];           // :1039-1041
+    pm_prod4 (N, x, xn);
+    pm_normalize4 (xn);
+
+    float sk = sqrtf (S[9] / S[10]);                                   // :989
+    const float *mf = means, *mm = means + 4;
+    float qx = xn[0], qy = xn[1], qz = xn[2], qw = xn[3];
+    float c1x = (qy * mm[2] - qz * mm[1]) + qw * mm[0];                // :1050
+    float c1y = (qz * mm[0] - qx * mm[2]) + qw * mm[1];
+    float c1z = (qx * mm[1] - qy * mm[0]) + qw * mm[2];
+    float ax = 2 * qx, ay = 2 * qy, az = 2 * qz;
+    float c2x = ay * c1z - az * c1y;
+    float c2y = az * c1x - ax * c1z;
+    float c2z = ax * c1y - ay * c1x;
+    Tk[0] = qx; Tk[1] = qy; Tk[2] = qz; Tk[3] = qw;
+    Tk[4] = mf[0] - sk * (mm[0] + c2x);
+    Tk[5] = mf[1] - sk * (mm[1] + c2y);
+    Tk[6] = mf[2] - sk * (mm[2] + c2z);
+    Tk[7] = sk;
+    return iters;
+}
+
+// ------------------------------------------------------------------------------------------
+// a10  host composition of the reference moved on-device (src/ICP/algorithms.cpp:4683-4695);
+//      Eigen formulas restated (oracle: orc_quat_to_rot / orc_rot_to_quat / compose).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void icp_quat_to_rot (const float *q, float *R)
+{
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    float tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    float twx = tx * w, twy = ty * w, twz = tz * w;
+    float txx = tx * x, txy = ty * x, txz = tz * x;
+    float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+__device__ inline void icp_rot_to_quat (const float *m, float *q)
+{
+    float t = (m[0] + m[4]) + m[8];
+    if (t > 0.f) {
+        t = sqrtf (t + 1.f);
+        q[3] = 0.5f * t;
+        t = 0.5f / t;
+        q[0] = (m[7] - m[5]) * t;
+        q[1] = (m[2] - m[6]) * t;
+        q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[i * 4]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrtf (((m[i * 4] - m[j * 4]) - m[k * 4]) + 1.f);
+        float qi = 0.5f * t;
+        t = 0.5f / t;
+        float qw = (m[k * 3 + j] - m[j * 3 + k]) * t;
+        float qj = (m[j * 3 + i] + m[i * 3 + j]) * t;
+        float qk = (m[k * 3 + i] + m[i * 3 + k]) * t;
+        q[3] = qw;
+        // scatter without dynamic register indexing
+        q[0] = (i == 0) ? qi : ((j == 0) ? qj : qk);
+        q[1] = (i == 1) ? qi : ((j == 1) ? qj : qk);
+        q[2] = (i == 2) ? qi : ((j == 2) ? qj : qk);
+    }
+}
+
+// a12  EIGEN branch (src/ICP/algorithms.cpp:3867-3909) — one-sided Jacobi SVD, oracle orc_svd_rotation.
+__device__ inline void icp_svd_rotation (const float *S11, const float *means, float *Rk, float *Tk)
+{
+    float A[9], V[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    for (int i = 0; i < 9; ++i) A[i] = S11[i];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        float off = 0.f;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                float alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 3; ++i) {
+                    alpha = alpha + A[i * 3 + p] * A[i * 3 + p];
+                    beta  = beta  + A[i * 3 + q] * A[i * 3 + q];
+                    gamma = gamma + A[i * 3 + p] * A[i * 3 + q];
+                }
+                if (gamma == 0.f) continue;
+                off = fmaxf (off, fabsf (gamma) / sqrtf (alpha * beta));
+                float zeta = (beta - alpha) / (2.f * gamma);
+                float t = (zeta >= 0.f ? 1.f : -1.f) / (fabsf (zeta) + sqrtf (1.f + zeta * zeta));
+                float cs = 1.f / sqrtf (1.f + t * t), sn = cs * t;
+                for (int i = 0; i < 3; ++i) {
+                    float ap = A[i * 3 + p], aq = A[i * 3 + q];
+                    A[i * 3 + p] = cs * ap - sn * aq; A[i * 3 + q] = sn * ap + cs * aq;
+                    float vp = V[i * 3 + p], vq = V[i * 3 + q];
+                    V[i * 3 + p] = cs * vp - sn * vq; V[i * 3 + q] = sn * vp + cs * vq;
+                }
+            }
+        if (off < 1e-7f) break;
+    }
+    float U[9], sig[3];
+    for (int j = 0; j < 3; ++j) {
+        sig[j] = sqrtf ((A[j] * A[j] + A[3 + j] * A[3 + j]) + A[6 + j] * A[6 + j]);
+        for (int i = 0; i < 3; ++i) U[i * 3 + j] = sig[j] > 0.f ? A[i * 3 + j] / sig[j] : 0.f;
+    }
+    int smin = 0;
+    for (int j = 1; j < 3; ++j) if (sig[j] < sig[smin]) smin = j;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Rk[i * 3 + j] = (V[i * 3] * U[j * 3] + V[i * 3 + 1] * U[j * 3 + 1]) + V[i * 3 + 2] * U[j * 3 + 2];
+    float det = Rk[0] * (Rk[4] * Rk[8] - Rk[5] * Rk[7]) - Rk[1] * (Rk[3] * Rk[8] - Rk[5] * Rk[6])
+              + Rk[2] * (Rk[3] * Rk[7] - Rk[4] * Rk[6]);
+    if (det < 0.f) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                float acc = 0.f;
+                for (int k = 0; k < 3; ++k)
+                    acc = acc + V[i * 3 + k] * (k == smin ? det : 1.f) * U[j * 3 + k];
+                Rk[i * 3 + j] = acc;
+            }
+    }
+    float qk[4]; icp_rot_to_quat (Rk, qk);
+    float sk = sqrtf (S11[9] / S11[10]);
+    const float *mf = means, *mm = means + 4;
+    Tk[0] = qk[0]; Tk[1] = qk[1]; Tk[2] = qk[2]; Tk[3] = qk[3];
+    for (int i = 0; i < 3; ++i)
+        Tk[4 + i] = mf[i] - ((sk * Rk[i * 3]) * mm[0] + (sk * Rk[i * 3 + 1]) * mm[1] + (sk * Rk[i * 3 + 2]) * mm[2]);
+    Tk[7] = sk;
+}
+
+// compose: R = Rk R ; q = quat(R) ; t = sk Rk t + tk ; s = sk s   (algorithms.cpp:4688-4691)
+__device__ inline void icp_compose (icp_reg_state *st, const float *Tk, const float *Rk_in, int have_rk)
+{
+    float Rk[9];
+    if (have_rk) { for (int i = 0; i < 9; ++i) Rk[i] = Rk_in[i]; }
+    else icp_quat_to_rot (Tk, Rk);
+    float sk = Tk[7];
+    float Rn[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Rn[i * 3 + j] = (Rk[i * 3] * st->R[j] + Rk[i * 3 + 1] * st->R[3 + j]) + Rk[i * 3 + 2] * st->R[6 + j];
+    float q[4]; icp_rot_to_quat (Rn, q);
+    float t0 = st->T[4], t1 = st->T[5], t2 = st->T[6];
+    float tn[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float r0 = sk * Rk[i * 3], r1 = sk * Rk[i * 3 + 1], r2 = sk * Rk[i * 3 + 2];
+        tn[i] = ((r0 * t0 + r1 * t1) + r2 * t2) + Tk[4 + i];
+    }
+    float s = sk * st->T[7];
+    for (int i = 0; i < 9; ++i) { st->R[i] = Rn[i]; st->Rk[i] = Rk[i]; }
+    for (int i = 0; i < 8; ++i) st->Tk[i] = Tk[i];
+    st->T[0] = q[0]; st->T[1] = q[1]; st->T[2] = q[2]; st->T[3] = q[3];
+    st->T[4] = tn[0]; st->T[5] = tn[1]; st->T[6] = tn[2]; st->T[7] = s;
+}
+
+// ICP::check — src/ICP/algorithms.cpp:4824-4834 (predicate form: oracle check_converged)
+__device__ __forceinline__ int icp_check_converged (const float *Tk, double tan_half_thr, double trans_thr)
+{
+    float vn = sqrtf ((Tk[0] * Tk[0] + Tk[1] * Tk[1]) + Tk[2] * Tk[2]);
+    float tn = sqrtf ((Tk[4] * Tk[4] + Tk[5] * Tk[5]) + Tk[6] * Tk[6]);
+    int ang = (Tk[3] > 0.f) && ((double) vn < (double) Tk[3] * tan_half_thr);
+    int tra = (double) tn < trans_thr;
+    return ang && tra;
+}

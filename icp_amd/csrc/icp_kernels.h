@@ -1,0 +1,49 @@
+// icp_kernels.h — launch parameters shared by the HIP kernels and the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "icp_device.h"
+
+#define ICP_CHUNK 1024u          // fixed points per block in the stable RBC placement
+
+struct icp_params {
+    // problem
+    uint32_t m, nr, batch;
+    uint32_t side, nrx, nry;     // landmark grid side and representative grid (getReps)
+    float a, c;
+    int weighted, rot, power_mode, check;
+    double tan_half_thr, trans_thr;
+    // derived sizes
+    uint32_t nwg;                // 128-element groups = ceil(m/128)         (weights / means partials)
+    uint32_t nwp;                // weight partials padded (multiple of 4 unless 1)
+    uint32_t G;                  // S columns = ceil4(m)/4                    (icpSijProducts work-items)
+    uint32_t nsp;                // S partials per row, padded (multiple of 4 unless 1)
+    uint32_t nchunk;             // ceil(m / ICP_CHUNK)
+    // inputs / RBC
+    const float *F, *M;          // [batch][m][8]
+    float *R;                    // [batch][nr][8]
+    float *XP;                   // [batch][m][8]
+    uint32_t *rep_src, *owner, *N, *O, *perm, *chunk_hist;   // [batch][...]
+    // per-iteration
+    uint32_t *rid;               // [batch][m]
+    icp_dist_id *nn_id;          // [batch][m]
+    float4 *PF, *PM;             // [batch][m]  (nn.xyz, w) / (q'.xyz, dist)
+    float *wpart;                // [batch][nwp]
+    float4 *mpart;               // [batch][2][nwg]
+    float4 *mscr;                // [batch][2][ceil(nwg/128)]  scratch of the multi-level icpGMean
+    float *spart;                // [batch][11][nsp]
+    float *sscr;                 // [batch][11][..] scratch of the multi-level reduce_sum_f
+    icp_reg_state *st;           // [batch]
+};
+
+// launchers (icp_kernels.hip)
+void icp_launch_build_rbc (const icp_params &p, hipStream_t s);
+void icp_launch_search (const icp_params &p, hipStream_t s);
+void icp_launch_means (const icp_params &p, hipStream_t s);
+void icp_launch_sij (const icp_params &p, hipStream_t s);
+void icp_launch_finalize (const icp_params &p, hipStream_t s);
+void icp_launch_iteration (const icp_params &p, hipStream_t s);
+void icp_launch_reset_state (const icp_params &p, hipStream_t s, int reset_T);
+void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStream_t s);
+void icp_launch_get_lms (const float *cloud, float *lms, hipStream_t s);
+void icp_launch_transform_cloud (const float *in, float *out, const icp_reg_state *st, uint32_t n, hipStream_t s);

@@ -1,0 +1,126 @@
+// icp_synth.cpp — deterministic synthetic RGB-D landmark pairs (host only).
+//
+// The reference's sample clouds data/kg_pc8d_{1,2}.bin are absent from the checkout
+// (.MISSING_LARGE_BLOBS); this generator produces the "kg-like" pair of SURVEY.md §8d:
+//   * pinhole model of the Kinect grabber (f = 595, cx = 319.5, cy = 239.5;
+//     src/kinect_frame_grabber.cpp:252-255), point layout [x y z 1 r g b 1], mm / [0,1];
+//   * a smooth depth field with ridges and a procedural texture on a side x side grid;
+//   * the moving frame samples the same scene at a half-cell offset and is moved rigidly
+//     (rotation about `axis`, translation `t`), plus Gaussian geometric / colour noise.
+// RNG: splitmix64 -> xoshiro256**.  Deterministic in (seed, side, parameters) on one libm.
+#include "../../include/icp_amd.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace {
+
+struct rng {
+    uint64_t s[4];
+    static uint64_t splitmix (uint64_t &x)
+    {
+        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    explicit rng (uint64_t seed) { for (auto &v : s) v = splitmix (seed); }
+    static uint64_t rotl (uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next ()
+    {
+        uint64_t r = rotl (s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl (s[3], 45);
+        return r;
+    }
+    double uniform () { return (double) (next () >> 11) * (1.0 / 9007199254740992.0); }
+    double normal ()
+    {
+        double u1 = uniform (), u2 = uniform ();
+        if (u1 < 1e-300) u1 = 1e-300;
+        return std::sqrt (-2.0 * std::log (u1)) * std::cos (2.0 * M_PI * u2);
+    }
+};
+
+void scene (double u, double v, double G, double *xyz, double *rgb)
+{
+    const double tau = 2.0 * M_PI;
+    double ridge = std::fabs (std::sin (tau * 3.0 * (u + 0.5 * v) / G));
+    double z = 1500.0 + 400.0 * std::sin (tau * u / G * 1.5) * std::cos (tau * v / G) + 150.0 * ridge;
+    xyz[0] = (u * 640.0 / G - 319.5) * z / 595.0;
+    xyz[1] = (v * 480.0 / G - 239.5) * z / 595.0;
+    xyz[2] = z;
+    double chk = (double) (((int) std::floor (8.0 * u / G) + (int) std::floor (8.0 * v / G)) & 1);
+    double r = 0.5 + 0.35 * std::sin (tau * 2.0 * u / G + 1.0) * std::cos (tau * v / G) + 0.1 * chk;
+    double g = 0.5 + 0.35 * std::cos (tau * 3.0 * v / G + 0.5) - 0.1 * chk;
+    double b = 0.5 + 0.30 * std::sin (tau * (u + 2.0 * v) / G);
+    rgb[0] = std::fmin (1.0, std::fmax (0.0, r));
+    rgb[1] = std::fmin (1.0, std::fmax (0.0, g));
+    rgb[2] = std::fmin (1.0, std::fmax (0.0, b));
+}
+
+void rotation (double deg, const float *axis, double R[9])
+{
+    double n = std::sqrt ((double) axis[0] * axis[0] + (double) axis[1] * axis[1] + (double) axis[2] * axis[2]);
+    double x = axis[0] / n, y = axis[1] / n, z = axis[2] / n;
+    double th = deg * M_PI / 180.0, c = std::cos (th), s = std::sin (th), C = 1.0 - c;
+    R[0] = c + x * x * C;     R[1] = x * y * C - z * s; R[2] = x * z * C + y * s;
+    R[3] = y * x * C + z * s; R[4] = c + y * y * C;     R[5] = y * z * C - x * s;
+    R[6] = z * x * C - y * s; R[7] = z * y * C + x * s; R[8] = c + z * z * C;
+}
+
+}  // namespace
+
+extern "C" int icp_synth_pair (uint64_t seed, uint32_t side, float rot_deg, const float *axis3, const float *t3,
+                               float noise_mm, float noise_rgb, float zero_fraction, float *F, float *M)
+{
+    if (!F || !M || side == 0 || !axis3 || !t3) return ICP_EINVAL;
+    rng g (seed);
+    double R[9]; rotation (rot_deg, axis3, R);
+    const double G = (double) side;
+    for (uint32_t v = 0; v < side; ++v)
+        for (uint32_t u = 0; u < side; ++u) {
+            size_t i = (size_t) v * side + u;
+            double p[3], c[3];
+            scene ((double) u, (double) v, G, p, c);
+            float *f = F + i * 8;
+            f[0] = (float) p[0]; f[1] = (float) p[1]; f[2] = (float) p[2]; f[3] = 1.f;
+            f[4] = (float) c[0]; f[5] = (float) c[1]; f[6] = (float) c[2]; f[7] = 1.f;
+            scene ((double) u + 0.5, (double) v + 0.5, G, p, c);
+            double q[3];
+            for (int k = 0; k < 3; ++k)
+                q[k] = R[k * 3] * p[0] + R[k * 3 + 1] * p[1] + R[k * 3 + 2] * p[2] + (double) t3[k] + noise_mm * g.normal ();
+            float *mo = M + i * 8;
+            mo[0] = (float) q[0]; mo[1] = (float) q[1]; mo[2] = (float) q[2]; mo[3] = 1.f;
+            for (int k = 0; k < 3; ++k) {
+                double cc = c[k] + noise_rgb * g.normal ();
+                mo[4 + k] = (float) std::fmin (1.0, std::fmax (0.0, cc));
+            }
+            mo[7] = 1.f;
+            // invalid points: zero coordinates, as the Kinect pipeline leaves them (kernels/icp_kernels.cl:50-51)
+            double zf = g.uniform (), zm = g.uniform ();
+            if (zf < zero_fraction) { f[0] = f[1] = f[2] = 0.f; f[4] = f[5] = f[6] = 0.f; }
+            if (zm < zero_fraction) { mo[0] = mo[1] = mo[2] = 0.f; mo[4] = mo[5] = mo[6] = 0.f; }
+        }
+    return ICP_OK;
+}
+
+extern "C" int icp_synth_cloud_vga (uint64_t seed, int moved, float *cloud)
+{
+    if (!cloud) return ICP_EINVAL;
+    rng g (seed);
+    const float axis[3] = { 0.3f, 0.9f, 0.1f };
+    double R[9]; rotation (moved ? 3.0 : 0.0, axis, R);
+    const double t[3] = { moved ? 25.0 : 0.0, moved ? -10.0 : 0.0, moved ? 15.0 : 0.0 };
+    for (uint32_t v = 0; v < 480; ++v)
+        for (uint32_t u = 0; u < 640; ++u) {
+            // scene() is parametrised on a square grid: map the VGA pixel onto a 640-wide one
+            double p[3], c[3];
+            scene ((double) u + (moved ? 0.5 : 0.0), ((double) v + (moved ? 0.5 : 0.0)) * 640.0 / 480.0, 640.0, p, c);
+            float *o = cloud + ((size_t) v * 640 + u) * 8;
+            for (int k = 0; k < 3; ++k)
+                o[k] = (float) (R[k * 3] * p[0] + R[k * 3 + 1] * p[1] + R[k * 3 + 2] * p[2] + t[k] + (moved ? g.normal () : 0.0));
+            o[3] = 1.f; o[4] = (float) c[0]; o[5] = (float) c[1]; o[6] = (float) c[2]; o[7] = 1.f;
+        }
+    return ICP_OK;
+}

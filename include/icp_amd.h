@@ -1,0 +1,203 @@
+/* icp_amd.h — C-ABI of the MI355X-native photogeometric ICP iteration engine.
+ *
+ * Drop-in boundary for the hot path of nlamprian/ICP: every entry point below names the
+ * reference interface it replaces (paths relative to the reference checkout).  Plain C: opaque
+ * handle, plain pointers and sizes, int status codes; no OpenCL, Eigen, CLUtils or torch types.
+ * The C++ facade include/ICP/algorithms.hpp re-creates the reference's class templates
+ * (cl_algo::ICP::ICPStep<CR,CW>, ICP<CR,CW>) on top of this file.
+ *
+ * Data layouts (unchanged from the reference):
+ *   landmark   float[8]  = [x y z 1 r g b 1], xyz in mm, rgb in [0,1]   (src/kinect_frame_grabber.cpp:252-261)
+ *   transform  float[8]  = [qx qy qz qw | tx ty tz s]                   (include/ICP/algorithms.hpp:2245-2254)
+ *   dist/id    {float dist; uint32 id}                                  (kernels/icp_kernels.cl:34-38)
+ *
+ * Threading: a handle owns one device, one HIP stream and all its buffers; it is not
+ * thread-safe, distinct handles are independent (one per GPU / host thread for batched work).
+ * Errors: no exit(), no exceptions: every call returns an icp_status; icp_last_error() gives
+ * the text (reference: exit(EXIT_FAILURE) from library code, src/ICP/algorithms.cpp:4411-4427).
+ */
+#ifndef ICP_AMD_H
+#define ICP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct icp_context *icp_handle;
+
+typedef enum {
+    ICP_OK = 0,
+    ICP_EINVAL = 1,        /* bad argument (reference: throw const char* -> exit)            */
+    ICP_EHIP = 2,          /* HIP runtime failure (reference: cl::Error exception)           */
+    ICP_ENOMEM = 3,
+    ICP_ESTATE = 4,        /* call order violated (e.g. run before init / buildRBC)          */
+    ICP_ENODEVICE = 5      /* no usable gfx950 device: the engine has NO CPU fallback        */
+} icp_status;
+
+/* ICPStepConfigT / ICPStepConfigW — include/ICP/algorithms.hpp:1544-1564 */
+typedef enum { ICP_ROT_EIGEN = 0, ICP_ROT_POWER_METHOD = 1 } icp_rot;
+typedef enum { ICP_W_REGULAR = 0, ICP_W_WEIGHTED = 1 } icp_weighting;
+
+/* How the power method starts.  LITERAL = the reference loop from x=(1,1,1,1)
+ * (kernels/icp_kernels.cl:1003-1022); SQUARED = same loop started from normalize(N^1024 * 1). */
+typedef enum { ICP_POWER_LITERAL = 0, ICP_POWER_SQUARED = 1 } icp_power_mode;
+
+/* Memory objects.  F/M/T are the reference's ICPStep::Memory D_IN_F / D_IN_M / D_IO_T
+ * (include/ICP/algorithms.hpp:2241-2267); the rest are the intermediates the reference exposes
+ * through the get() of its sub-objects (src/ICP/algorithms.cpp:4499-4581). */
+typedef enum {
+    ICP_MEM_F = 0,         /* in   m x float8   fixed landmarks                         */
+    ICP_MEM_M = 1,         /* in   m x float8   moving landmarks                        */
+    ICP_MEM_T = 2,         /* io   float8       cumulative [q | t, s]   (D_IO_T)        */
+    ICP_MEM_TK = 3,        /* out  float8       incremental [qk | tk, sk]               */
+    ICP_MEM_MEANS = 4,     /* out  2 x float4   [mean_fixed | mean_moving]              */
+    ICP_MEM_S = 5,         /* out  float[11]    S (row-major, a=moving,b=fixed), Sf2, Sm2 */
+    ICP_MEM_NN_ID = 6,     /* out  m x {dist,id}  query order, id = index into F        */
+    ICP_MEM_W = 7,         /* out  m x float    weights 100/(100+dist)                  */
+    ICP_MEM_SUM_W = 8,     /* out  double       sum of weights                          */
+    ICP_MEM_REPS = 9,      /* out  nr x float8  representatives                         */
+    ICP_MEM_RBC_N = 10,    /* out  nr x uint32  list sizes        (RBCConstruct D_OUT_N)   */
+    ICP_MEM_RBC_O = 11,    /* out  nr x uint32  list offsets      (RBCConstruct D_OUT_O)   */
+    ICP_MEM_RBC_PERM = 12, /* out  m x uint32   list position -> index into F           */
+    ICP_MEM_RBC_OWNER = 13,/* out  m x uint32   owner representative of each fixed point */
+    ICP_MEM_RBC_XP = 14,   /* out  m x float8   permuted database (RBCConstruct D_OUT_X_P) */
+    ICP_MEM_RID = 15,      /* out  m x uint32   nearest representative of each query    */
+    ICP_MEM_R = 16,        /* out  float[9]     cumulative rotation, row-major          */
+    ICP_MEM_RK = 17,       /* out  float[9]     incremental rotation, row-major         */
+    ICP_MEM_NN = 18,       /* out  m x float4   matched fixed xyz (+ weight in .w)      */
+    ICP_MEM_QT = 19,       /* out  m x float4   transformed moving xyz (+ dist in .w)   */
+    ICP_MEM_COUNT_
+} icp_mem;
+
+/* Host-visible state of one registration: the public members Rk qk tk sk R q t s k of
+ * ICPStep / ICP (include/ICP/algorithms.hpp:2302-2320, 2462). */
+typedef struct {
+    float R[9], q[4], t[3], s;         /* cumulative, up to iteration k   */
+    float Rk[9], qk[4], tk[3], sk;     /* incremental, iteration k        */
+    uint32_t k;                        /* iterations executed             */
+    uint32_t converged;                /* ICP::check() said stop before max_iterations */
+    uint32_t power_iterations;         /* power-method loop trips of the last step */
+    uint32_t reserved;
+} icp_state_t;
+
+/* ---- life cycle ------------------------------------------------------------------------- */
+
+/* ICPStep<CR,CW>::ICPStep (env, infoRBC, infoICP) — include/ICP/algorithms.hpp:2269,
+ * src/ICP/algorithms.cpp:4348-4358.  `device` replaces the CLEnv/CLEnvInfo pair. */
+int icp_create (icp_handle *h, int device, int rot, int weighted);
+int icp_destroy (icp_handle h);
+
+/* ICP<CR,CW>::init (m, nr, a, c, max_iterations, angle_threshold, translation_threshold, staging)
+ * — include/ICP/algorithms.hpp:2437-2440, src/ICP/algorithms.cpp:4777-4786 and ICPStep::init
+ * :4403-4582.  Rejects m == 0, nr == 0, a == 0 (reference :4413-4420), odd m (:1573),
+ * nr not a power of two or not tiling the sqrt(m) landmark grid (:842-854).
+ * `batch` >= 1 independent registrations share the launch set (SURVEY §8e "replicas only"). */
+int icp_init (icp_handle h, uint32_t m, uint32_t nr, float a, float c,
+              uint32_t max_iterations, double angle_threshold, double translation_threshold);
+int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, float a, float c,
+                      uint32_t max_iterations, double angle_threshold,
+                      double translation_threshold);
+
+/* ---- data movement ------------------------------------------------------------------------ */
+
+/* ICPStep::write (mem, ptr, block, events, event) — include/ICP/algorithms.hpp:2273,
+ * src/ICP/algorithms.cpp:4596-4622.  mem in {ICP_MEM_F, ICP_MEM_M, ICP_MEM_T}.  Host -> pinned
+ * staging -> device on the handle's stream; block != 0 waits for completion. */
+int icp_write (icp_handle h, int mem, const void *host_ptr, int block);
+int icp_write_b (icp_handle h, uint32_t batch_index, int mem, const void *host_ptr, int block);
+
+/* ICPStep::read (mem, block, events, event) — include/ICP/algorithms.hpp:2275,
+ * src/ICP/algorithms.cpp:4634-4649; also the read() of the sub-objects (ICPMean :1757, ICPS :2496,
+ * ICPPowerMethod :3123, ICPWeights :1198).  Copies `bytes` (<= object size) to host_dst; always blocking. */
+int icp_read (icp_handle h, int mem, void *host_dst, size_t bytes);
+int icp_read_b (icp_handle h, uint32_t batch_index, int mem, void *host_dst, size_t bytes);
+size_t icp_mem_size (icp_handle h, int mem);
+
+/* cl::Memory& ICPStep::get (Memory) — include/ICP/algorithms.hpp:2270,
+ * src/ICP/algorithms.cpp:4366-4383: the device buffer itself, for zero-copy chaining.
+ * adopt: the caller's device buffer replaces the handle's (must be called after init and stay
+ * valid for the handle's lifetime; F/M only). */
+int icp_device_ptr (icp_handle h, int mem, void **dptr);
+int icp_adopt_device_buffer (icp_handle h, int mem, void *dptr);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+
+/* ICPStep::buildRBC (events, event) — include/ICP/algorithms.hpp:2277,
+ * src/ICP/algorithms.cpp:4655-4660 (getReps + RBCConstruct); ICP::buildRBC also resets k (:4796). */
+int icp_build_rbc (icp_handle h);
+
+/* ICPStep::run (events, event, config) — include/ICP/algorithms.hpp:2278,
+ * src/ICP/algorithms.cpp:4670-4698: one iteration; on return T, Tk, R.. are updated on the
+ * device (the reference blocks on a 32-byte read here; this call only enqueues). */
+int icp_step (icp_handle h, int config);
+
+/* ICP::run () — include/ICP/algorithms.hpp:2446, src/ICP/algorithms.cpp:4806-4834: iterate until
+ * check() stops; blocking.  *k receives the iteration count (ICP::k) of registration 0. */
+int icp_run (icp_handle h, uint32_t *k);
+
+/* ICP::run (timer) — include/ICP/algorithms.hpp:2482-2494: exactly `iterations` steps, no
+ * convergence test (the reference's profiling run; 40 there).  Enqueue only. */
+int icp_run_fixed (icp_handle h, uint32_t iterations);
+
+/* Blocks until everything enqueued on the handle's stream is done (queue.finish ()). */
+int icp_sync (icp_handle h);
+
+/* ---- parameters ---------------------------------------------------------------------------- */
+/* getAlpha/setAlpha/getScaling/setScaling — include/ICP/algorithms.hpp:2279-2295;
+ * get/setMaxIterations, AngleThreshold, TranslationThreshold — :2447-2460. */
+int icp_get_alpha (icp_handle h, float *a);
+int icp_set_alpha (icp_handle h, float a);
+int icp_get_scaling (icp_handle h, float *c);
+int icp_set_scaling (icp_handle h, float c);
+int icp_get_max_iterations (icp_handle h, uint32_t *n);
+int icp_set_max_iterations (icp_handle h, uint32_t n);
+int icp_get_angle_threshold (icp_handle h, double *deg);
+int icp_set_angle_threshold (icp_handle h, double deg);
+int icp_get_translation_threshold (icp_handle h, double *mm);
+int icp_set_translation_threshold (icp_handle h, double mm);
+int icp_set_power_mode (icp_handle h, int mode);      /* icp_power_mode */
+
+/* Public state members of ICPStep/ICP (Rk qk tk sk R q t s k) — blocking. */
+int icp_state (icp_handle h, icp_state_t *out);
+int icp_state_b (icp_handle h, uint32_t batch_index, icp_state_t *out);
+
+/* ---- adjacent steps -------------------------------------------------------------- */
+
+/* ICPLMs: getLMs — kernels/icp_kernels.cl:63-76, src/ICP/algorithms.cpp:621-785.
+ * cloud: 640x480 float8 on the host; which = ICP_MEM_F or ICP_MEM_M (m must be 16384). */
+int icp_write_cloud (icp_handle h, int which, const void *host_cloud_640x480x8, int block);
+
+/* ICPTransform<QUATERNION> on an arbitrary cloud with the handle's current T —
+ * src/ocl_icp_reg.cpp:175 (full-cloud transform after run()).  Host in, host out; n points. */
+int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint32_t n);
+
+/* ---- measurement (bench.py, HIP events on the handle's stream) --------------------------------- */
+
+/* Times `reps` back-to-back icp_run_fixed(iterations) passes with hipEvents recorded on the
+ * handle's own stream; *ms_total = elapsed ms over all reps. */
+int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, float *ms_total);
+/* Times each kernel class of the iteration separately (events around each launch, `reps`
+ * iterations): out_ms[0..3] = mean ms of {search, means, sij, finalize}. */
+int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4);
+
+/* ---- utilities ---------------------------------------------------------------------------------- */
+
+const char *icp_last_error (icp_handle h);      /* h may be NULL: error of the last failed create */
+const char *icp_version (void);
+int icp_device_count (int *n);
+
+/* Synthetic RGB-D landmark pair: side x side grid, fixed and moving frame.
+ * Host only; deterministic in (seed, side). */
+int icp_synth_pair (uint64_t seed, uint32_t side, float rot_deg, const float *axis3,
+                    const float *t3, float noise_mm, float noise_rgb, float zero_fraction,
+                    float *F, float *M);
+/* Synthetic 640x480 float8 cloud for the getLMs path. */
+int icp_synth_cloud_vga (uint64_t seed, int moved, float *cloud);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICP_AMD_H */

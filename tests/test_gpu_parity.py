@@ -1,0 +1,281 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle.
+
+Bar: bit-exact for indices AND for every float the iteration produces (the canonical arithmetic of
+DESIGN.md §3 makes the fp32 reductions reproducible), so comparisons are on the raw bit patterns.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+A, C_ = 2e2, 1e-6
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.float64:
+        return a.view(np.uint64)
+    return a.view(np.uint32)
+
+
+def assert_bits(got, want, what):
+    got = np.ascontiguousarray(got)
+    want = np.ascontiguousarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    bad = np.nonzero(bits(got).reshape(-1) != bits(want).reshape(-1))[0]
+    assert bad.size == 0, "%s: %d of %d words differ, first at %d: got %r want %r" % (
+        what, bad.size, got.size, bad[0], got.reshape(-1)[bad[0]], want.reshape(-1)[bad[0]])
+
+
+def make(engine, oracle, side, nr, rot=1, weighted=1, power_fast=False, zero_fraction=0.0, seed=0x1C9D5EED,
+         max_iterations=40):
+    m = side * side
+    F, M = engine.synth_pair(side, seed=seed, zero_fraction=zero_fraction)
+    g = engine.ICP(0, rot, weighted)
+    g.init(m, nr, A, C_, max_iterations=max_iterations)
+    if power_fast:
+        g.setPowerMode(engine.PowerMode.SQUARED)
+    g.write(engine.Memory.F, F)
+    g.write(engine.Memory.M, M)
+    o = oracle.OracleICP(m, nr, A, C_, rot=rot, weighted=weighted, power_fast=power_fast, threads=8,
+                         max_iterations=max_iterations)
+    o.write_f(F)
+    o.write_m(M)
+    return g, o, F, M
+
+
+def check_rbc(engine, g, o):
+    Mem = engine.Memory
+    assert_bits(g.read(Mem.REPS), o.reps, "representatives")
+    assert np.array_equal(g.read(Mem.RBC_OWNER), o.rbc_owner), "owner"
+    assert np.array_equal(g.read(Mem.RBC_N), o.rbc_N), "N"
+    assert np.array_equal(g.read(Mem.RBC_O), o.rbc_O), "O"
+    assert np.array_equal(g.read(Mem.RBC_PERM), o.rbc_perm), "perm"
+
+
+def check_step(engine, g, o, weighted=True):
+    Mem = engine.Memory
+    assert np.array_equal(g.read(Mem.RID), o.rid), "nearest representative"
+    gn, on = g.read(Mem.NN_ID), o.nn_id
+    assert np.array_equal(gn["id"], on["id"]), "correspondence ids: %d differ" % np.count_nonzero(gn["id"] != on["id"])
+    assert_bits(gn["dist"], on["dist"], "correspondence distances")
+    if weighted:
+        assert_bits(g.read(Mem.W), o.W, "weights")
+        assert_bits(g.read(Mem.SUM_W), np.array([o.sum_w]), "sum of weights")
+    assert_bits(g.read(Mem.MEANS), o.means, "means")
+    assert_bits(g.read(Mem.S), o.S, "S")
+    assert_bits(g.read(Mem.TK), o.Tk, "Tk")
+    assert_bits(g.read(Mem.RK).reshape(3, 3), o.Rk, "Rk")
+    assert_bits(g.read(Mem.R).reshape(3, 3), o.R, "R")
+    assert_bits(g.read(Mem.T), o.T, "T")
+
+
+@pytest.mark.parametrize("side,nr", [(128, 256), (32, 16), (64, 64), (30, 4), (6, 4), (16, 256)])
+def test_build_rbc(engine, oracle, side, nr):
+    g, o, F, M = make(engine, oracle, side, nr)
+    g.buildRBC()
+    o.build_rbc()
+    check_rbc(engine, g, o)
+    XP = g.read(engine.Memory.RBC_XP)
+    assert_bits(XP, F[o.rbc_perm], "permuted database")
+    g.close()
+
+
+@pytest.mark.parametrize("side,nr", [(128, 256), (32, 16), (30, 4), (6, 4)])
+def test_steps_bit_exact(engine, oracle, side, nr):
+    """config 2 (kg-like pair, power method, weighted) and small / ragged sizes: 4 free-running steps."""
+    g, o, F, M = make(engine, oracle, side, nr)
+    g.buildRBC()
+    o.build_rbc()
+    for it in range(4):
+        g.step()
+        o.step()
+        check_step(engine, g, o)
+        assert g.state().power_iterations == o.power_iters
+    assert g.k == 4
+    g.close()
+
+
+@pytest.mark.parametrize("rot,weighted,fast", [(1, 0, False), (0, 1, False), (0, 0, False), (1, 1, True)])
+def test_variants(engine, oracle, rot, weighted, fast):
+    """The other ICPStep specialisations (REGULAR weighting, EIGEN rotation) and the squared power start."""
+    g, o, F, M = make(engine, oracle, 64, 64, rot=rot, weighted=weighted, power_fast=fast)
+    g.buildRBC()
+    o.build_rbc()
+    for it in range(3):
+        g.step()
+        o.step()
+        check_step(engine, g, o, weighted=bool(weighted))
+    g.close()
+
+
+def test_zero_points(engine, oracle):
+    """10 % invalid (all-zero) points collapse onto one representative list (kernels/icp_kernels.cl:50-51)."""
+    g, o, F, M = make(engine, oracle, 64, 64, zero_fraction=0.1)
+    g.buildRBC()
+    o.build_rbc()
+    check_rbc(engine, g, o)
+    assert o.rbc_N.max() > 300
+    for it in range(2):
+        g.step()
+        o.step()
+        check_step(engine, g, o)
+    g.close()
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_run_to_convergence(engine, oracle, fast):
+    """ICP::run: same iteration count, same convergence decision, final R|t identical (required: 1e-5 relative)."""
+    g, o, F, M = make(engine, oracle, 128, 256, power_fast=fast)
+    g.buildRBC()
+    o.build_rbc()
+    kg = g.run()
+    ko = o.run()
+    assert kg == ko and kg == g.k
+    assert bool(g.state().converged) == o.converged
+    T, To = g.read(engine.Memory.T), o.T
+    assert np.allclose(T, To, rtol=1e-5, atol=0)          # the north-star tolerance
+    assert_bits(T, To, "final T")                          # what the canonical arithmetic actually gives
+    assert_bits(g.R, o.R, "final R")
+    check_step(engine, g, o)
+    g.close()
+
+
+def test_run_fixed_matches_steps(engine, oracle):
+    g, o, F, M = make(engine, oracle, 64, 64)
+    g.buildRBC()
+    o.build_rbc()
+    g.run_fixed(7)
+    for _ in range(7):
+        o.step()
+    check_step(engine, g, o)
+    assert g.k == 7
+    g.close()
+
+
+def test_teacher_forced(engine, oracle):
+    """Feed the oracle's T_k before every step: correspondences must match exactly at every k."""
+    g, o, F, M = make(engine, oracle, 64, 64)
+    g.buildRBC()
+    o.build_rbc()
+    for it in range(6):
+        g.write(engine.Memory.T, o.T, block=True)
+        g.step()
+        o.step()
+        gn, on = g.read(engine.Memory.NN_ID), o.nn_id
+        assert np.array_equal(gn["id"], on["id"])
+        assert_bits(gn["dist"], on["dist"], "dist")
+    g.close()
+
+
+def test_max_iterations_and_thresholds(engine, oracle):
+    g, o, F, M = make(engine, oracle, 64, 64, max_iterations=5)
+    g.buildRBC()
+    o.build_rbc()
+    assert g.run() == o.run() == 5
+    assert not g.state().converged
+    assert_bits(g.read(engine.Memory.T), o.T, "T after max_iterations")
+    # loose thresholds: stops after the first iteration that meets them
+    g2, o2, _, _ = make(engine, oracle, 64, 64)
+    g2.setAngleThreshold(1.0)
+    g2.setTranslationThreshold(5.0)
+    o2 = oracle.OracleICP(64 * 64, 64, A, C_, angle_threshold=1.0, translation_threshold=5.0, threads=8)
+    o2.write_f(F)
+    o2.write_m(M)
+    g2.buildRBC()
+    o2.build_rbc()
+    assert g2.run() == o2.run()
+    assert g2.state().converged and o2.converged
+    assert_bits(g2.read(engine.Memory.T), o2.T, "T at loose thresholds")
+    g.close()
+    g2.close()
+
+
+def test_batched(engine, oracle):
+    """config 4 in miniature: independent registrations in one launch set, each equal to its own oracle."""
+    B, side, nr = 3, 64, 64
+    g = engine.ICP(0)
+    g.init(side * side, nr, A, C_, batch=B)
+    oracles = []
+    for b in range(B):
+        F, M = engine.synth_pair(side, seed=0x1C9D5EED + b, rot_deg=2.0 + b)
+        g.write(engine.Memory.F, F, batch_index=b)
+        g.write(engine.Memory.M, M, batch_index=b)
+        o = oracle.OracleICP(side * side, nr, A, C_, threads=8)
+        o.write_f(F)
+        o.write_m(M)
+        o.build_rbc()
+        oracles.append(o)
+    g.buildRBC()
+    k0 = g.run()
+    for b, o in enumerate(oracles):
+        ko = o.run()
+        st = g.state(b)
+        assert st.k == ko, (b, st.k, ko)
+        assert_bits(g.read(engine.Memory.T, b), o.T, "T of registration %d" % b)
+        assert np.array_equal(g.read(engine.Memory.NN_ID, b)["id"], o.nn_id["id"])
+    assert k0 == oracles[0].k
+    g.close()
+
+
+def test_config3_one_step(engine, oracle):
+    """config 3: |F|=|M|=65536, |R|=1024 (the reference itself cannot run it: SURVEY §0.7)."""
+    g, o, F, M = make(engine, oracle, 256, 1024)
+    g.buildRBC()
+    o.build_rbc()
+    check_rbc(engine, g, o)
+    for _ in range(2):
+        g.step()
+        o.step()
+        check_step(engine, g, o)
+    g.close()
+
+
+def test_config5_properties(engine, oracle):
+    """config 5: |F|=|M|=2^20, |R|=4096 — full oracle pass is minutes of CPU, so: exact parity of the RBC
+    search on a random subset of queries, exact sum of weights / means / S from the GPU's own
+    correspondences (the oracle's reduction code on the GPU's nn_id), and list-structure invariants."""
+    side, nr = 1024, 4096
+    m = side * side
+    F, M = engine.synth_pair(side)
+    g = engine.ICP(0)
+    g.init(m, nr, A, C_)
+    g.write(engine.Memory.F, F)
+    g.write(engine.Memory.M, M)
+    g.buildRBC()
+    Mem = engine.Memory
+    N, O, perm = g.read(Mem.RBC_N), g.read(Mem.RBC_O), g.read(Mem.RBC_PERM)
+    assert int(N.sum()) == m
+    assert np.array_equal(O, np.concatenate([[0], np.cumsum(N[:-1], dtype=np.uint64)]).astype(np.uint32))
+    assert np.array_equal(np.sort(perm), np.arange(m, dtype=np.uint32))           # a permutation
+    owner = g.read(Mem.RBC_OWNER)
+    assert np.array_equal(owner[perm], np.repeat(np.arange(nr, dtype=np.uint32), N))  # grouped by owner
+    starts = np.zeros(m, bool)
+    starts[O[N > 0]] = True
+    assert np.all((np.diff(perm.astype(np.int64)) > 0) | starts[1:])              # stable inside every list
+    R, src = oracle.get_reps(F, nr)
+    assert_bits(g.read(Mem.REPS), R, "representatives")
+    rng = np.random.default_rng(7)
+    sub = np.sort(rng.choice(m, 4096, replace=False))
+    rbc = dict(owner=owner, N=N, O=O, perm=perm, XP=np.ascontiguousarray(F[perm]))
+    own_o = oracle.rbc_search(F[sub], R, rbc, src, A)[2]                           # nearest rep of fixed points = owner
+    assert np.array_equal(own_o, owner[sub])
+    g.step()
+    nn = g.read(Mem.NN_ID)
+    nn_o, NN_o, rid_o = oracle.rbc_search(M[sub], R, rbc, src, A)                  # T = identity at k = 0
+    assert np.array_equal(g.read(Mem.RID)[sub], rid_o)
+    assert np.array_equal(nn["id"][sub], nn_o["id"])
+    assert_bits(nn["dist"][sub], nn_o["dist"], "dist")
+    # reductions: oracle code on the GPU's correspondences
+    Wt, sw = oracle.weights(nn)
+    assert_bits(g.read(Mem.W), Wt, "weights")
+    assert_bits(g.read(Mem.SUM_W), np.array([sw]), "sum_w")
+    NNp = np.ascontiguousarray(F[nn["id"]])
+    means = oracle.mean_weighted(NNp, M, Wt, sw)
+    assert_bits(g.read(Mem.MEANS), means, "means")
+    DF, DM = oracle.devs(NNp, M, means)
+    S = oracle.sij(DM, DF, Wt, C_)
+    assert_bits(g.read(Mem.S), S, "S")
+    Tk, _ = oracle.power_method(S, means)
+    assert_bits(g.read(Mem.TK), Tk, "Tk")
+    g.close()

@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py — ICP iterations/sec at |F|=|M|=16384, |R|=256 (BASELINE.json metric) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one fixed-length registration pass of the hot path: ITERS_PER_STEP (=40, the length of
+the reference's profiling run, include/ICP/algorithms.hpp:2482-2494) ICP iterations of the
+power-method / weighted pipeline on the synthetic kg-like pair (config 2 of BASELINE.json), inputs
+resident in HBM, RBC already built (steady state).  One hipGraph launch per step.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): a frame pair does not shard
+ — "replicas only": every rank registers its own independent pair (seed + rank), no
+data-path collective; value = iterations of all ranks / max-over-ranks time  ("scaling": "weak").
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel (k_search): algorithmic bytes per launch (72 m + 32 |R| + 64,
+                SURVEY.md §8d) / its average duration measured with HIP events on the engine's stream
+  cpu_baseline  the CPU oracle ("port") timed on this host on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+M_POINTS, N_REPS, SIDE = 16384, 256, 128
+ALPHA, SCALING = 2e2, 1e-6                       # src/ocl_icp_reg.cpp:88
+ITERS_PER_STEP = 40
+HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8 TB/s spec
+ALGO_BYTES_PER_ITER = 72 * M_POINTS + 32 * N_REPS + 64
+
+
+def aggregate(dist, elapsed_s, units):
+    """Whole-job numbers from per-rank ones: time = MAX over ranks, units = SUM over ranks.
+
+    `dist` is torch.distributed (initialised) or None for a single process."""
+    if dist is None:
+        return elapsed_s, units
+    import torch
+    t = torch.tensor([elapsed_s], dtype=torch.float64)
+    u = torch.tensor([float(units)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(u.item())
+
+
+def cpu_baseline(F, M, budget_s=12.0):
+    """The oracle (CPU port of the same iteration) on this host's cores, bounded to ~budget_s."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    o = O.OracleICP(M_POINTS, N_REPS, ALPHA, SCALING, threads=cores)
+    o.write_f(F)
+    o.write_m(M)
+    o.build_rbc()
+    o.step()                                     # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        o.step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 2000:
+            break
+    return {"value": n / el, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": "%d iterations of the same pair (|F|=|M|=%d, |R|=%d) in %.1f s; search loops OpenMP over "
+                      "%d threads, reductions serial" % (n, M_POINTS, N_REPS, el, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--power-mode", choices=["literal", "squared"], default="squared")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # torch first (when present) so that the process holds ONE HIP runtime: libicp_amd.so then binds
+    # to the libamdhip64.so.7 torch has already loaded.  torch is plumbing here (barrier / reductions).
+    dist = None
+    torch = None
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        torch = None
+    if world > 1:
+        if torch is None:
+            raise SystemExit("bench.py: torch.distributed is required for --gpus > 1")
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+
+    import icp_amd
+    F, M = icp_amd.synth_pair(SIDE, seed=0x1C9D5EED + rank)
+    g = icp_amd.ICP(local_rank)
+    g.init(M_POINTS, N_REPS, ALPHA, SCALING)
+    g.setPowerMode(icp_amd.PowerMode.SQUARED if args.power_mode == "squared" else icp_amd.PowerMode.LITERAL)
+    g.write(icp_amd.Memory.F, F)
+    g.write(icp_amd.Memory.M, M)
+    g.buildRBC()
+    g.sync()
+
+    def barrier():
+        if dist is not None:
+            if torch.cuda.is_available():
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
+        g.sync()
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        g.run_fixed(ITERS_PER_STEP)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.run_fixed(ITERS_PER_STEP)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    total_t, total_iters = aggregate(dist, elapsed, args.steps * ITERS_PER_STEP)
+
+    # dominant kernel, HIP events on the engine's own stream
+    kt = g.time_kernels(200)
+    search_us = kt["search"] * 1e3
+    achieved = ALGO_BYTES_PER_ITER / (kt["search"] * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_search_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        line = {
+            "metric": "ICP iterations/sec at |F|=|M|=16384, |R|=256",
+            "value": total_iters / total_t,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": total_t / args.steps * 1e3,
+            "us_per_iteration": total_t / (args.steps * ITERS_PER_STEP) * 1e6,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic kg-like pair, |F|=|M|=16384, |R|=256, power method, weighted, "
+                                   "a=2e2 c=1e-6; step = %d fixed iterations (one hipGraph), RBC prebuilt" % ITERS_PER_STEP,
+                       "parallelism": "replicas" if world > 1 else "single", "power_start": args.power_mode},
+            "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ITER, "avg_launch_us": search_us,
+                         "kernel_us": {k: v * 1e3 for k, v in kt.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(F, M)
+        print(json.dumps(line))
+    g.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

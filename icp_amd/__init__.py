@@ -16,7 +16,7 @@ __all__ = ["ICP", "ICPStep", "ICPError", "Memory", "ICPStepConfigT", "ICPStepCon
            "PowerMode", "lib", "lib_path", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libicp_amd.so")
+_SO = os.environ.get("ICP_AMD_LIB", os.path.join(_HERE, "libicp_amd.so"))   # override: A/B builds of the same ABI
 
 DIST_ID = np.dtype([("dist", np.float32), ("id", np.uint32)])
 
@@ -111,6 +111,7 @@ def lib():
     sig("icp_transform_cloud", i32, vp, vp, vp, u32)
     sig("icp_time_run_fixed", i32, vp, u32, u32, C.POINTER(f32))
     sig("icp_time_kernels", i32, vp, u32, C.POINTER(f32))
+    sig("icp_time_masked", i32, vp, u32, u32, u32, C.POINTER(f32))
     sig("icp_last_error", C.c_char_p, vp)
     sig("icp_version", C.c_char_p)
     sig("icp_device_count", i32, C.POINTER(i32))
@@ -275,6 +276,12 @@ class ICPStep:
         ms = C.c_float()
         self._chk(self._L.icp_time_run_fixed(self._h, iterations, reps, C.byref(ms)))
         return ms.value
+
+    def time_masked(self, mask, iterations=40, reps=20):
+        """us per iteration of a graph holding only the kernels in `mask` (diagnostic)."""
+        ms = C.c_float()
+        self._chk(self._L.icp_time_masked(self._h, mask, iterations, reps, C.byref(ms)))
+        return ms.value * 1e3 / (iterations * reps)
 
     def time_kernels(self, reps):
         out = (C.c_float * 4)()

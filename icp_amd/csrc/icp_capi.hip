@@ -221,7 +221,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if (!reps_grid (m, nr, &nrx, &nry, &side))
         return fail (h, ICP_EINVAL, "nr must be a power of two whose grid tiles the sqrt(m) x sqrt(m) landmark grid");
     if (nr > 32768u) return fail (h, ICP_EINVAL, "nr must be <= 32768");
-    if (m > (1u << 24)) return fail (h, ICP_EINVAL, "m must be <= 2^24");
+    if (m > (1u << 20)) return fail (h, ICP_EINVAL, "m must be <= 2^20");
     int rc = set_device (h); if (rc) return rc;
     if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
     int rot = h->p.rot, weighted = h->p.weighted, pmode = h->p.power_mode;
@@ -248,6 +248,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     h->dF = F; h->dM = M; p.F = F; p.M = M;
     if ((rc = dalloc (h, &p.R, B * nr * 8))) return rc;
     if ((rc = dalloc (h, &p.XP, B * m * 8))) return rc;
+    if ((rc = dalloc (h, &p.XQ, B * m * 8))) return rc;
     if ((rc = dalloc (h, &p.rep_src, B * nr))) return rc;
     if ((rc = dalloc (h, &p.owner, B * m))) return rc;
     if ((rc = dalloc (h, &p.N, B * nr))) return rc;
@@ -258,10 +259,10 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &p.nn_id, B * m))) return rc;
     if ((rc = dalloc (h, &p.PF, B * m))) return rc;
     if ((rc = dalloc (h, &p.PM, B * m))) return rc;
-    if ((rc = dalloc (h, &p.wpart, B * p.nwp))) return rc;          // padding stays 0.f (identity operands)
+    if ((rc = dalloc (h, &p.wpart, B * 2 * p.nwp))) return rc;      // two half-trees per group; padding stays 0.f
     if ((rc = dalloc (h, &p.mpart, B * 2 * p.nwg))) return rc;
     if ((rc = dalloc (h, &p.mscr, B * 2 * ((p.nwg + 127u) / 128u)))) return rc;
-    if ((rc = dalloc (h, &p.spart, B * 11 * p.nsp))) return rc;
+    if ((rc = dalloc (h, &p.spart, B * 11 * p.nsp * 8))) return rc;    // 8 sub-trees per work-group; padding stays 0.f
     if ((rc = dalloc (h, &p.sscr, B * 11 * ((((p.nsp + 511u) / 512u) + 3u) & ~3u)))) return rc;
     if ((rc = dalloc (h, &p.st, B))) return rc;
     if (!h->dTin) HIPCHK (h, hipMalloc ((void **) &h->dTin, 8 * sizeof (float)));
@@ -574,6 +575,42 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, float 
     HIPCHK (h, hipEventRecord (h->ev1, h->stream));
     HIPCHK (h, hipEventSynchronize (h->ev1));
     HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));
+    return ICP_OK;
+}
+
+int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t reps, float *ms_total)
+{
+    int rc = need (h, true); if (rc) return rc;
+    if (!ms_total || iterations == 0 || reps == 0 || mask == 0) return fail (h, ICP_EINVAL, "bad arguments");
+    if ((rc = set_device (h))) return rc;
+    icp_params p = h->p; p.check = 0;
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    HIPCHK (h, hipStreamBeginCapture (h->stream, hipStreamCaptureModeThreadLocal));
+    for (uint32_t k = 0; k < iterations; ++k) icp_launch_masked (p, h->stream, mask);
+    HIPCHK (h, hipStreamEndCapture (h->stream, &graph));
+    HIPCHK (h, hipGraphInstantiate (&exec, graph, nullptr, nullptr, 0));
+    HIPCHK (h, hipGraphLaunch (exec, h->stream));                       // warm-up
+    HIPCHK (h, hipEventRecord (h->ev0, h->stream));
+    for (uint32_t r = 0; r < reps; ++r) HIPCHK (h, hipGraphLaunch (exec, h->stream));
+    HIPCHK (h, hipEventRecord (h->ev1, h->stream));
+    HIPCHK (h, hipEventSynchronize (h->ev1));
+    HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));
+    (void) hipGraphExecDestroy (exec); (void) hipGraphDestroy (graph);
+    return ICP_OK;
+}
+
+int icp_debug_stamps (icp_handle h, unsigned long long *out, uint32_t nblocks)
+{   // diagnostic builds (ICP_DBG_STAMPS): one k_search launch, per-block s_memtime stamps
+    int rc = need (h, true); if (rc) return rc;
+    if ((rc = set_device (h))) return rc;
+    unsigned long long *d = nullptr;
+    HIPCHK (h, hipMalloc ((void **) &d, (size_t) nblocks * 16 * 8));
+    HIPCHK (h, hipMemset (d, 0, (size_t) nblocks * 16 * 8));
+    icp_params p = h->p; p.check = 0; p.dbg = d;
+    icp_launch_search (p, h->stream);
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    HIPCHK (h, hipMemcpy (out, d, (size_t) nblocks * 16 * 8, hipMemcpyDeviceToHost));
+    (void) hipFree (d);
     return ICP_OK;
 }
 

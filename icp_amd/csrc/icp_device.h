@@ -5,8 +5,8 @@
 // reduction trees of the reference's shape for a 64-wide wavefront.  One wavefront == one
 // reference work-group, so the reference's LDS tree
 //     data[0..128) ; for d = 64,32,..,1 : data[i] += data[i+d]            (kernels/icp_kernels.cl:170-175)
-// becomes: lane i holds data[i] + data[i+64], then an xor-butterfly over 32,16,8,4,2,1 (float add is
-// commutative, so every lane ends with the bit pattern the reference leaves in data[0]).
+// is evaluated by 16-lane DPP rows that hold 8 positions per lane (see "row trees" below): same
+// additions, same order, so lane 0 of the row ends with the bit pattern the reference leaves in data[0].
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,28 +33,66 @@ struct icp_reg_state {
 };
 
 // ------------------------------------------------------------------------------------------
-// wave trees
+// row trees
+//
+// The canonical tree over 128 positions P[0..128) (result in P[0]):
+//     for d = 64, 32, 16, 8, 4, 2, 1 :  P[i] += P[i+d]   (i < d)
+// is evaluated by one 16-lane DPP row: lane l holds P[l + 16k], k = 0..7.  The levels d = 64, 32, 16
+// pair positions held by the same lane (register adds); d = 8, 4, 2, 1 pair lane l with lane l+d of
+// the row: v_add_f32_dpp row_shl:d.  Only lane 0 of the row ends with P[0]; the other lanes hold
+// values the reference tree also computes and discards.  No LDS, no ds_bpermute, no cross-row traffic.
+// All 64 lanes must be active when these are called (DPP reads of disabled lanes return 0).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_tree_f (float v)
+template <int CTRL> __device__ __forceinline__ float icp_dpp (float v)
 {
-    v = v + __shfl_xor (v, 32);
-    v = v + __shfl_xor (v, 16);
-    v = v + __shfl_xor (v, 8);
-    v = v + __shfl_xor (v, 4);
-    v = v + __shfl_xor (v, 2);
-    v = v + __shfl_xor (v, 1);
+    return __builtin_bit_cast (float, __builtin_amdgcn_update_dpp (0, __builtin_bit_cast (int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ double icp_dpp_d (double v)
+{
+    unsigned long long u = __builtin_bit_cast (unsigned long long, v);
+    int lo = (int) (u & 0xFFFFFFFFull), hi = (int) (u >> 32);
+    lo = __builtin_amdgcn_update_dpp (0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp (0, hi, CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast (double, ((unsigned long long) (unsigned int) hi << 32) | (unsigned int) lo);
+}
+#define ICP_ROW_SHL(n) (0x100 + (n))
+#define ICP_QUAD_BCAST(k) ((k) * 0x55)
+
+// levels d = 8, 4, 2, 1 across the 16 lanes of a row
+__device__ __forceinline__ float row_tree_tail (float v)
+{
+    v = v + icp_dpp<ICP_ROW_SHL (8)> (v);
+    v = v + icp_dpp<ICP_ROW_SHL (4)> (v);
+    v = v + icp_dpp<ICP_ROW_SHL (2)> (v);
+    v = v + icp_dpp<ICP_ROW_SHL (1)> (v);
     return v;
 }
-
-__device__ __forceinline__ double wave_tree_d (double v)
+__device__ __forceinline__ double row_tree_tail_d (double v)
 {
-    v = v + __shfl_xor (v, 32);
-    v = v + __shfl_xor (v, 16);
-    v = v + __shfl_xor (v, 8);
-    v = v + __shfl_xor (v, 4);
-    v = v + __shfl_xor (v, 2);
-    v = v + __shfl_xor (v, 1);
+    v = v + icp_dpp_d<ICP_ROW_SHL (8)> (v);
+    v = v + icp_dpp_d<ICP_ROW_SHL (4)> (v);
+    v = v + icp_dpp_d<ICP_ROW_SHL (2)> (v);
+    v = v + icp_dpp_d<ICP_ROW_SHL (1)> (v);
     return v;
+}
+// full 128-position tree: a[k] = P[l + 16k]
+__device__ __forceinline__ float row_tree8 (const float *a)
+{
+    float b0 = a[0] + a[4], b1 = a[1] + a[5], b2 = a[2] + a[6], b3 = a[3] + a[7];     // d = 64
+    float c0 = b0 + b2, c1 = b1 + b3;                                                 // d = 32
+    return row_tree_tail (c0 + c1);                                                   // d = 16, then 8..1
+}
+__device__ __forceinline__ double row_tree8_d (const double *a)
+{
+    double b0 = a[0] + a[4], b1 = a[1] + a[5], b2 = a[2] + a[6], b3 = a[3] + a[7];
+    double c0 = b0 + b2, c1 = b1 + b3;
+    return row_tree_tail_d (c0 + c1);
+}
+// 64-position tree (levels d = 32 .. 1 of a tree whose d = 64 level was applied, or is absent): a[k] = P[l + 16k], k < 4
+__device__ __forceinline__ float row_tree4 (const float *a)
+{
+    float c0 = a[0] + a[2], c1 = a[1] + a[3];
+    return row_tree_tail (c0 + c1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -195,6 +233,141 @@ __device__ inline int icp_power_method (const float *S, const float *means, floa
     float sk = sqrtf (S[9] / S[10]);                                   // :989
     const float *mf = means, *mm = means + 4;
     float qx = xn[0], qy = xn[1], qz = xn[2], qw = xn[3];
+    float c1x = (qy * mm[2] - qz * mm[1]) + qw * mm[0];                // :1050
+    float c1y = (qz * mm[0] - qx * mm[2]) + qw * mm[1];
+    float c1z = (qx * mm[1] - qy * mm[0]) + qw * mm[2];
+    float ax = 2 * qx, ay = 2 * qy, az = 2 * qz;
+    float c2x = ay * c1z - az * c1y;
+    float c2y = az * c1x - ax * c1z;
+    float c2z = ax * c1y - ay * c1x;
+    Tk[0] = qx; Tk[1] = qy; Tk[2] = qz; Tk[3] = qw;
+    Tk[4] = mf[0] - sk * (mm[0] + c2x);
+    Tk[5] = mf[1] - sk * (mm[1] + c2y);
+    Tk[6] = mf[2] - sk * (mm[2] + c2z);
+    Tk[7] = sk;
+    return iters;
+}
+
+// Lane-parallel form of the same power method: every quad of the wave runs it redundantly, lane
+// (l & 3) = i owns row i of N (and of B) and component i of x.  The operations and their order are
+// exactly those of icp_power_method / oracle power_impl; only the placement changes:
+//   N x        : y_i = (((0 + N[i][0] x_0) + N[i][1] x_1) + N[i][2] x_2) + N[i][3] x_3, x_k by quad broadcast
+//   B B        : C[i][j] = sum_k B[i][k] B[k][j] with B[k][j] read as B[j][k] from lane j (B is exactly
+//                symmetric: N is, and the fixed k order keeps every square symmetric bit for bit)
+//   sums of 4  : sequential ((0 + v_0) + v_1) + v_2) + v_3 through quad broadcasts
+// All 64 lanes must be active.  Returns the loop-trip count; Tk is valid in every lane.
+__device__ __forceinline__ float pmq_seq4 (float v)
+{
+    float s = 0.f;
+    s = s + icp_dpp<ICP_QUAD_BCAST (0)> (v);
+    s = s + icp_dpp<ICP_QUAD_BCAST (1)> (v);
+    s = s + icp_dpp<ICP_QUAD_BCAST (2)> (v);
+    s = s + icp_dpp<ICP_QUAD_BCAST (3)> (v);
+    return s;
+}
+__device__ __forceinline__ float pmq_matvec (const float *Nrow, float x)
+{
+    float s = 0.f;
+    s = s + Nrow[0] * icp_dpp<ICP_QUAD_BCAST (0)> (x);
+    s = s + Nrow[1] * icp_dpp<ICP_QUAD_BCAST (1)> (x);
+    s = s + Nrow[2] * icp_dpp<ICP_QUAD_BCAST (2)> (x);
+    s = s + Nrow[3] * icp_dpp<ICP_QUAD_BCAST (3)> (x);
+    return s;
+}
+__device__ __forceinline__ float pmq_normalize (float y)
+{
+    float n = sqrtf (pmq_seq4 (y * y));
+    return y / n;
+}
+__device__ __forceinline__ void pmq_rescale (float *Brow)
+{
+    float mx = fmaxf (fmaxf (fabsf (Brow[0]), fabsf (Brow[1])), fmaxf (fabsf (Brow[2]), fabsf (Brow[3])));
+    mx = fmaxf (mx, icp_dpp<0xB1> (mx));          // quad_perm [1,0,3,2]
+    mx = fmaxf (mx, icp_dpp<0x4E> (mx));          // quad_perm [2,3,0,1]
+    uint32_t e = (__float_as_uint (mx) >> 23) & 0xFFu;
+    if (e == 0u || e >= 254u) return;
+    float sc = __uint_as_float ((254u - e) << 23);
+    Brow[0] = Brow[0] * sc; Brow[1] = Brow[1] * sc; Brow[2] = Brow[2] * sc; Brow[3] = Brow[3] * sc;
+}
+
+__device__ inline int icp_power_method_quad (const float *S, const float *means, float *Tk, int squared_start, uint32_t lane)
+{
+    const uint32_t i = lane & 3u;
+    float Sxx = S[0], Sxy = S[1], Sxz = S[2], Syx = S[3], Syy = S[4], Syz = S[5],
+          Szx = S[6], Szy = S[7], Szz = S[8];
+    // rows of N — icp_kernels.cl:993-999
+    float r0[4] = { Sxx - Syy - Szz,       Sxy + Syx,         Szx + Sxz,       Syz - Szy };
+    float r1[4] = {       Sxy + Syx, - Sxx + Syy - Szz,       Syz + Szy,       Szx - Sxz };
+    float r2[4] = {       Szx + Sxz,       Syz + Szy, - Sxx - Syy + Szz,       Sxy - Syx };
+    float r3[4] = {       Syz - Szy,       Szx - Sxz,         Sxy - Syx, Sxx + Syy + Szz };
+    float Nrow[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Nrow[k] = (i == 0) ? r0[k] : (i == 1) ? r1[k] : (i == 2) ? r2[k] : r3[k];
+
+    float x = 1.f, xn = 0.f;
+    int iters = 0;
+    for (;;) {
+        if (squared_start) {
+            float Brow[4] = { Nrow[0], Nrow[1], Nrow[2], Nrow[3] };
+            pmq_rescale (Brow);
+            for (int s = 0; s < ICP_PM_SQUARINGS; ++s) {
+                float C[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float acc = 0.f;
+                    if (j == 0) {
+                        acc = acc + Brow[0] * icp_dpp<ICP_QUAD_BCAST (0)> (Brow[0]);
+                        acc = acc + Brow[1] * icp_dpp<ICP_QUAD_BCAST (0)> (Brow[1]);
+                        acc = acc + Brow[2] * icp_dpp<ICP_QUAD_BCAST (0)> (Brow[2]);
+                        acc = acc + Brow[3] * icp_dpp<ICP_QUAD_BCAST (0)> (Brow[3]);
+                    } else if (j == 1) {
+                        acc = acc + Brow[0] * icp_dpp<ICP_QUAD_BCAST (1)> (Brow[0]);
+                        acc = acc + Brow[1] * icp_dpp<ICP_QUAD_BCAST (1)> (Brow[1]);
+                        acc = acc + Brow[2] * icp_dpp<ICP_QUAD_BCAST (1)> (Brow[2]);
+                        acc = acc + Brow[3] * icp_dpp<ICP_QUAD_BCAST (1)> (Brow[3]);
+                    } else if (j == 2) {
+                        acc = acc + Brow[0] * icp_dpp<ICP_QUAD_BCAST (2)> (Brow[0]);
+                        acc = acc + Brow[1] * icp_dpp<ICP_QUAD_BCAST (2)> (Brow[1]);
+                        acc = acc + Brow[2] * icp_dpp<ICP_QUAD_BCAST (2)> (Brow[2]);
+                        acc = acc + Brow[3] * icp_dpp<ICP_QUAD_BCAST (2)> (Brow[3]);
+                    } else {
+                        acc = acc + Brow[0] * icp_dpp<ICP_QUAD_BCAST (3)> (Brow[0]);
+                        acc = acc + Brow[1] * icp_dpp<ICP_QUAD_BCAST (3)> (Brow[1]);
+                        acc = acc + Brow[2] * icp_dpp<ICP_QUAD_BCAST (3)> (Brow[2]);
+                        acc = acc + Brow[3] * icp_dpp<ICP_QUAD_BCAST (3)> (Brow[3]);
+                    }
+                    C[j] = acc;
+                }
+                Brow[0] = C[0]; Brow[1] = C[1]; Brow[2] = C[2]; Brow[3] = C[3];
+                pmq_rescale (Brow);
+            }
+            x = pmq_normalize (pmq_matvec (Brow, x));
+        }
+        float error, error_new = __builtin_inff ();
+        for (uint32_t it = 0; it < 1000; ++it) {                      // icp_kernels.cl:1012-1022
+            xn = pmq_normalize (pmq_matvec (Nrow, x));
+            ++iters;
+            error = error_new;
+            float d = x - xn;
+            error_new = sqrtf (pmq_seq4 (d * d));
+            if (error_new == error) break;
+            x = xn;
+        }
+        float lam_num = icp_dpp<ICP_QUAD_BCAST (0)> (pmq_matvec (Nrow, xn));
+        float lambda = lam_num / icp_dpp<ICP_QUAD_BCAST (0)> (xn);   // :1024
+        if (lambda < 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Nrow[k] = (i == (uint32_t) k) ? Nrow[k] - lambda : Nrow[k];
+            x = 1.f;
+        } else break;
+    }
+    x = xn;                                                           // :1039-1041
+    xn = pmq_normalize (pmq_matvec (Nrow, x));
+
+    float qx = icp_dpp<ICP_QUAD_BCAST (0)> (xn), qy = icp_dpp<ICP_QUAD_BCAST (1)> (xn);
+    float qz = icp_dpp<ICP_QUAD_BCAST (2)> (xn), qw = icp_dpp<ICP_QUAD_BCAST (3)> (xn);
+    float sk = sqrtf (S[9] / S[10]);                                   // :989
+    const float *mf = means, *mm = means + 4;
     float c1x = (qy * mm[2] - qz * mm[1]) + qw * mm[0];                // :1050
     float c1y = (qz * mm[0] - qx * mm[2]) + qw * mm[1];
     float c1z = (qx * mm[1] - qy * mm[0]) + qw * mm[2];

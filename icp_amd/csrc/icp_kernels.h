@@ -17,23 +17,25 @@ struct icp_params {
     uint32_t nwg;                // 128-element groups = ceil(m/128)         (weights / means partials)
     uint32_t nwp;                // weight partials padded (multiple of 4 unless 1)
     uint32_t G;                  // S columns = ceil4(m)/4                    (icpSijProducts work-items)
-    uint32_t nsp;                // S partials per row, padded (multiple of 4 unless 1)
+    uint32_t nsp;                // reduce_sum_f work-groups per S row, padded (multiple of 4 unless 1)
     uint32_t nchunk;             // ceil(m / ICP_CHUNK)
     // inputs / RBC
     const float *F, *M;          // [batch][m][8]
     float *R;                    // [batch][nr][8]
-    float *XP;                   // [batch][m][8]
+    float *XP;                   // [batch][m][8]  permuted database (RBCConstruct D_OUT_X_P)
+    float *XQ;                   // [batch][m][8]  same, lane 3 = original index bits (search copy)
     uint32_t *rep_src, *owner, *N, *O, *perm, *chunk_hist;   // [batch][...]
     // per-iteration
     uint32_t *rid;               // [batch][m]
     icp_dist_id *nn_id;          // [batch][m]
     float4 *PF, *PM;             // [batch][m]  (nn.xyz, w) / (q'.xyz, dist)
-    float *wpart;                // [batch][nwp]
+    float *wpart;                // [batch][2*nwp]   even / odd half-trees of every 128-query group
     float4 *mpart;               // [batch][2][nwg]
     float4 *mscr;                // [batch][2][ceil(nwg/128)]  scratch of the multi-level icpGMean
-    float *spart;                // [batch][11][nsp]
+    float *spart;                // [batch][11][nsp*8] 8 residue sub-trees per work-group
     float *sscr;                 // [batch][11][..] scratch of the multi-level reduce_sum_f
     icp_reg_state *st;           // [batch]
+    unsigned long long *dbg;     // diagnostic builds only (ICP_DBG_STAMPS): [blocks][16] s_memtime stamps
 };
 
 // launchers (icp_kernels.hip)
@@ -43,6 +45,7 @@ void icp_launch_means (const icp_params &p, hipStream_t s);
 void icp_launch_sij (const icp_params &p, hipStream_t s);
 void icp_launch_finalize (const icp_params &p, hipStream_t s);
 void icp_launch_iteration (const icp_params &p, hipStream_t s);
+void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask);
 void icp_launch_reset_state (const icp_params &p, hipStream_t s, int reset_T);
 void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStream_t s);
 void icp_launch_get_lms (const float *cloud, float *lms, hipStream_t s);

@@ -20,41 +20,79 @@
 // ------------------------------------------------------------------------------------------
 static __device__ __forceinline__ float sum4 (float4 v) { return ((v.x + v.y) + v.z) + v.w; }
 
-// Sum of weights from the 128-element partials: reduce_sum_fd (kernels/icp_kernels.cl:295-329),
-// chunks of 512 partials summed in index order (oracle orc_weights).  One wave; every lane returns it.
-static __device__ double finalize_sum_w (const float *wpart, uint32_t nwp, uint32_t lane)
+// Sum of weights.  k_search leaves, per 128-query group g, the two half-trees hp[2g] (even positions)
+// and hp[2g+1] (odd positions); their float sum is the work-group partial of
+// icpComputeReduceWeights_WG (kernels/icp_kernels.cl:244-253, last tree level).  The partials then go
+// through reduce_sum_fd (:295-329): position p = ((w[4p] + w[4p+1]) + w[4p+2]) + w[4p+3] in double, tree
+// over 128 positions; chunks of 512 partials are summed in index order (oracle orc_weights).
+// Executed by every 16-lane row (all lanes active); the result is valid in lane 0 of each row.
+static __device__ double sum_w_row (const float *hp, uint32_t nwp, uint32_t l)
 {
-    if (nwp == 1) return (double) wpart[0];
+    if (nwp == 1) return (double) (hp[0] + hp[1]);
     double total = 0.0;
     for (uint32_t c0 = 0; c0 < nwp; c0 += 512) {
-        uint32_t i0 = c0 + 4 * lane, i1 = c0 + 4 * (lane + 64);
-        double d0 = 0.0, d1 = 0.0;
-        if (i0 < nwp) {
-            float4 v = *reinterpret_cast<const float4 *> (wpart + i0);
-            d0 = (((double) v.x + (double) v.y) + (double) v.z) + (double) v.w;
+        double a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t w0 = c0 + 4u * (l + 16u * k);
+            a[k] = 0.0;
+            if (w0 < nwp) {
+                float4 h0 = *reinterpret_cast<const float4 *> (hp + 2 * (size_t) w0);
+                float4 h1 = *reinterpret_cast<const float4 *> (hp + 2 * (size_t) w0 + 4);
+                float p0 = h0.x + h0.y, p1 = h0.z + h0.w, p2 = h1.x + h1.y, p3 = h1.z + h1.w;
+                a[k] = (((double) p0 + (double) p1) + (double) p2) + (double) p3;
+            }
         }
-        if (i1 < nwp) {
-            float4 v = *reinterpret_cast<const float4 *> (wpart + i1);
-            d1 = (((double) v.x + (double) v.y) + (double) v.z) + (double) v.w;
-        }
-        double cs = wave_tree_d (d0 + d1);
+        double cs = row_tree8_d (a);
         total = (c0 == 0) ? cs : total + cs;
     }
     return total;
 }
 
-// icpGMean over <= 128 block means of one set (kernels/icp_kernels.cl:530-566). One wave.
-static __device__ float4 gmean_128 (const float4 *blk, uint32_t nblk, uint32_t lane)
+// icpGMean over <= 128 block means of one set (kernels/icp_kernels.cl:530-566) by one 16-lane row.
+static __device__ float4 gmean_row (const float4 *blk, uint32_t nblk, uint32_t l)
 {
-    float4 a = make_float4 (0.f, 0.f, 0.f, 0.f), b = a;
-    if (lane < nblk) a = blk[lane];
-    if (lane + 64 < nblk) b = blk[lane + 64];
+    float x[8], y[8], z[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t i = l + 16u * k;
+        float4 v = make_float4 (0.f, 0.f, 0.f, 0.f);
+        if (i < nblk) v = blk[i];
+        x[k] = v.x; y[k] = v.y; z[k] = v.z;
+    }
     float4 r;
-    r.x = wave_tree_f (a.x + b.x);
-    r.y = wave_tree_f (a.y + b.y);
-    r.z = wave_tree_f (a.z + b.z);
-    r.w = 0.f;
+    r.x = row_tree8 (x); r.y = row_tree8 (y); r.z = row_tree8 (z); r.w = 0.f;
     return r;
+}
+
+// Final S value of one row of the 11 x G product matrix from the first-level partials of k_sij.
+// k_sij leaves, per 512-column work-group w, the 8 sub-trees over positions = r (mod 8); the remaining
+// levels d = 4, 2, 1 of reduce_sum_f's tree (kernels/reduce_kernels.cl:254-259) combine them, then the
+// second reduce_sum_f pass (src/ICP/algorithms.cpp:140-173) runs over the work-group partials.
+// One 16-lane row, all lanes active; valid in lane 0 of the row.  nwgp = padded work-group count.
+static __device__ float s_reduce_row (const float *sp, uint32_t nwgp, uint32_t l)
+{
+    if (nwgp == 1) {
+        float4 a = *reinterpret_cast<const float4 *> (sp), b = *reinterpret_cast<const float4 *> (sp + 4);
+        return ((a.x + b.x) + (a.z + b.z)) + ((a.y + b.y) + (a.w + b.w));
+    }
+    float pos[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t w0 = 4u * (l + 16u * k);
+        pos[k] = 0.f;
+        if (w0 < nwgp) {
+            float R[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float *s8 = sp + (size_t) (w0 + q) * 8;
+                float4 a = *reinterpret_cast<const float4 *> (s8), b = *reinterpret_cast<const float4 *> (s8 + 4);
+                R[q] = ((a.x + b.x) + (a.z + b.z)) + ((a.y + b.y) + (a.w + b.w));
+            }
+            pos[k] = ((R[0] + R[1]) + R[2]) + R[3];
+        }
+    }
+    return row_tree8 (pos);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -248,88 +286,220 @@ __global__ __launch_bounds__ (1024) void k_place (icp_params p)
         const float4 *F4 = reinterpret_cast<const float4 *> (p.F + (size_t) b * p.m * 8);
         float4 *X4 = reinterpret_cast<float4 *> (p.XP + (size_t) b * p.m * 8);
         p.perm[(size_t) b * p.m + pos] = i;
-        X4[2 * (size_t) pos] = F4[2 * (size_t) i];
-        X4[2 * (size_t) pos + 1] = F4[2 * (size_t) i + 1];
+        float4 g = F4[2 * (size_t) i], c = F4[2 * (size_t) i + 1];
+        X4[2 * (size_t) pos] = g;
+        X4[2 * (size_t) pos + 1] = c;
+        // search copy: the unused homogeneous lane carries the original index (saves the perm[] round trip)
+        float4 *Q4 = reinterpret_cast<float4 *> (p.XQ + (size_t) b * p.m * 8);
+        Q4[2 * (size_t) pos] = make_float4 (g.x, g.y, g.z, __uint_as_float (i));
+        Q4[2 * (size_t) pos + 1] = c;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K1  search: transform + RBC one-shot search + weights (first-level tree)
-//     block = 128 queries x SPLIT slices; wave (2*slice + grp) serves queries grp*64 + lane.
+// K1  search: transform (a3) + RBC one-shot search (a4) + weights and their first tree levels (a5)
+//
+//   block  = 64 queries x 8 slices (512 threads); the 64 queries are the even (or odd) positions of one
+//            128-query group, so that the block owns a closed sub-tree of the weight reduction;
+//   wave s = slice s: 1/8 of the representatives (stage 1) and every 8th list position (stage 2);
+//   representatives are staged through LDS in tiles (coalesced float4 loads, broadcast ds_read_b128).
 // ------------------------------------------------------------------------------------------
-template <int SPLIT>
-__global__ __launch_bounds__ (128 * SPLIT) void k_search (icp_params p)
+#define KS_SPLIT 8
+#define KS_TILE 1024u            // representatives per LDS tile
+
+typedef float float2v __attribute__ ((ext_vector_type (2)));
+
+#ifdef ICP_DBG_STAMPS
+#define KS_STAMP(k)                                                                                       \
+    {                                                                                                     \
+        unsigned long long t_;                                                                            \
+        asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        if (tid == 0 && p.dbg) p.dbg[(size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = t_;    \
+    }
+#else
+#define KS_STAMP(k)
+#endif
+
+// candidate j of a list: XQ = [x y z id | r g b -]; keeps the best (distance, position, point)
+#define KS_CAND(G, C, J)                                                                              \
+    {                                                                                                 \
+        float d_ = icp_metric8 (qx, qy, qz, qr, qg, qb, (G).x, (G).y, (G).z, (C).x, (C).y, (C).z, alpha); \
+        if (d_ < best2) { best2 = d_; bj = (J); bnn = (G); }                                          \
+    }
+
+__global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
 {
     const uint32_t b = blockIdx.y;
     icp_reg_state *st = p.st + b;
-    if (st->done) return;
+#ifdef ICP_DBG_STAMPS
+    { const uint32_t tid = threadIdx.x; unsigned long long t_; asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+      if (tid == 0 && p.dbg) p.dbg[(size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 16 + 8] = t_; }
+#endif
+    if (p.check && st->done) return;
 
-    __shared__ float s_best[SPLIT][128];
-    __shared__ uint32_t s_idx[SPLIT][128];
-    __shared__ float s_w[128];
+    // representatives of the current tile, pair-interleaved for packed fp32 math:
+    //   pair P = reps (2P, 2P+1) -> 3 float4: [x0 x1 y0 y1] [z0 z1 r0 r1] [g0 g1 b0 b1]
+    __shared__ float4 s_pair[3 * KS_TILE / 2];
+    __shared__ uint2 s_on[KS_TILE];                  // (offset, size) of every representative's list
+    __shared__ float s_best[KS_SPLIT][64];
+    __shared__ uint32_t s_idx[KS_SPLIT][64];
+    __shared__ float4 s_nn[KS_SPLIT][64];
+    __shared__ float s_w[64];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane (tid >> 6);
-    const uint32_t grp = wave & 1u, slice = wave >> 1;
-    const uint32_t ql = grp * 64u + lane;
-    const uint32_t i = blockIdx.x * 128u + ql;
+    const uint32_t slice = __builtin_amdgcn_readfirstlane (tid >> 6);
+    const uint32_t grp = blockIdx.x >> 1, parity = blockIdx.x & 1u;
+    const uint32_t i = grp * 128u + 2u * lane + parity;
     const bool valid = i < p.m;
-
-    float T[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) T[k] = st->T[k];
 
     const float4 *M4 = reinterpret_cast<const float4 *> (p.M + (size_t) b * p.m * 8);
     const float4 *R4 = reinterpret_cast<const float4 *> (p.R + (size_t) b * p.nr * 8);
-    const float4 *X4 = reinterpret_cast<const float4 *> (p.XP + (size_t) b * p.m * 8);
+    const float4 *XQ4 = reinterpret_cast<const float4 *> (p.XQ + (size_t) b * p.m * 8);
+    const uint32_t *gO = p.O + (size_t) b * p.nr, *gN = p.N + (size_t) b * p.nr;
 
+    // every independent global load of the prologue is issued before anything waits: first tile of
+    // representatives (+ list offsets / sizes), the query point, the transform
+    float *s_pairf = reinterpret_cast<float *> (s_pair);
+    const uint32_t tn0 = min (KS_TILE, p.nr);
+    float4 rg[2], rc[2]; uint2 ron[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        uint32_t k = tid + (uint32_t) u * 64u * KS_SPLIT;
+        rg[u] = make_float4 (0.f, 0.f, 0.f, 0.f); rc[u] = rg[u]; ron[u] = make_uint2 (0u, 0u);
+        if (k < tn0) { rg[u] = R4[2 * (size_t) k]; rc[u] = R4[2 * (size_t) k + 1]; ron[u] = make_uint2 (gO[k], gN[k]); }
+    }
     float4 mg = make_float4 (0.f, 0.f, 0.f, 1.f), mc = mg;
     if (valid) { mg = M4[2 * (size_t) i]; mc = M4[2 * (size_t) i + 1]; }
+    float T[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) T[k] = st->T[k];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        uint32_t k = tid + (uint32_t) u * 64u * KS_SPLIT;
+        if (k < tn0) {
+            float *dst = s_pairf + (k >> 1) * 12u + (k & 1u);
+            dst[0] = rg[u].x; dst[2] = rg[u].y; dst[4] = rg[u].z; dst[6] = rc[u].x; dst[8] = rc[u].y; dst[10] = rc[u].z;
+            s_on[k] = ron[u];
+        }
+    }
     float qx, qy, qz;
     icp_transform_point (T, mg.x, mg.y, mg.z, qx, qy, qz);
     const float qr = mc.x, qg = mc.y, qb = mc.z;
+    const float alpha = p.a;
+    KS_STAMP (0)
 
-    // ---- stage 1: nearest representative (this wave's slice of the representatives) ----
-    const uint32_t per = (p.nr + SPLIT - 1) / SPLIT;
-    const uint32_t r0 = min (slice * per, p.nr), r1 = min (r0 + per, p.nr);
-    float best = __builtin_inff (); uint32_t bid = r0;
-    nearest_rep_range (R4, r0, r1, qx, qy, qz, qr, qg, qb, p.a, best, bid);
-    s_best[slice][ql] = best; s_idx[slice][ql] = bid;
-    __syncthreads ();
-    float dr = s_best[0][ql]; uint32_t rstar = s_idx[0][ql];
-#pragma unroll
-    for (int s = 1; s < SPLIT; ++s) {
-        float d = s_best[s][ql]; uint32_t id = s_idx[s][ql];
-        if (d < dr) { dr = d; rstar = id; }
-    }
-    __syncthreads ();
-
-    // ---- stage 2: exhaustive scan of that representative's list, positions interleaved over slices ----
-    const uint32_t o = p.O[(size_t) b * p.nr + rstar], n = p.N[(size_t) b * p.nr + rstar];
-    float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
-    if (valid)
-        for (uint32_t j = o + slice; j < o + n; j += SPLIT) {
-            float4 g = X4[2 * (size_t) j], c = X4[2 * (size_t) j + 1];
-            float d = icp_metric8 (qx, qy, qz, qr, qg, qb, g.x, g.y, g.z, c.x, c.y, c.z, p.a);
-            if (d < best2) { best2 = d; bj = j; }
+    // ---- stage 1: nearest representative, two representatives per packed instruction ----
+    float best = __builtin_inff (); uint32_t bid = 0;
+#ifdef ICP_DBG_SKIP_S1
+    best = 0.f; bid = (i * 7u) % p.nr;
+    for (uint32_t t0 = p.nr; t0 < p.nr; t0 += KS_TILE) {
+#else
+    for (uint32_t t0 = 0; t0 < p.nr; t0 += KS_TILE) {
+#endif
+        const uint32_t tn = min (KS_TILE, p.nr - t0);
+        if (t0) {                                    // further tiles (nr > KS_TILE)
+            __syncthreads ();
+            for (uint32_t k = tid; k < tn; k += 64 * KS_SPLIT) {
+                float4 g = R4[2 * (size_t) (t0 + k)], c = R4[2 * (size_t) (t0 + k) + 1];
+                float *dst = s_pairf + (k >> 1) * 12u + (k & 1u);
+                dst[0] = g.x; dst[2] = g.y; dst[4] = g.z; dst[6] = c.x; dst[8] = c.y; dst[10] = c.z;
+                s_on[k] = make_uint2 (gO[t0 + k], gN[t0 + k]);
+            }
         }
-    s_best[slice][ql] = best2; s_idx[slice][ql] = bj;
+        if ((tn & 1u) && tid == 0) {                 // odd tile (nr == 1): the pad slot never wins (NaN distance)
+            float *dst = s_pairf + (tn >> 1) * 12u + 1u;
+            const float qnan = __builtin_nanf ("");
+            dst[0] = qnan; dst[2] = qnan; dst[4] = qnan; dst[6] = qnan; dst[8] = qnan; dst[10] = qnan;
+        }
+        __syncthreads ();
+        KS_STAMP (1)
+        const uint32_t npair = (tn + 1u) >> 1;
+        const uint32_t per = (npair + KS_SPLIT - 1) / KS_SPLIT;
+        const uint32_t p0 = min (slice * per, npair), p1 = min (p0 + per, npair);
+        const float2v vqx = { qx, qx }, vqy = { qy, qy }, vqz = { qz, qz }, vqr = { qr, qr }, vqg = { qg, qg }, vqb = { qb, qb };
+        const float2v va = { alpha, alpha };
+#pragma unroll 8
+        for (uint32_t P = p0; P < p1; ++P) {
+            float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];
+            float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
+            float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
+            float2v geo = (dx * dx + dy * dy) + dz * dz;
+            float2v pho = (dr * dr + dg * dg) + db * db;
+            float2v d = geo + va * pho;
+            const uint32_t r0 = t0 + 2u * P;
+            if (d.x < best) { best = d.x; bid = r0; }        // ascending index, strict '<': lowest index on ties
+            if (d.y < best) { best = d.y; bid = r0 + 1u; }
+        }
+    }
+    KS_STAMP (2)
+    s_best[slice][lane] = best; s_idx[slice][lane] = bid;
     __syncthreads ();
+    KS_STAMP (3)
+    float dr = s_best[0][lane]; uint32_t rstar = s_idx[0][lane];
+#pragma unroll
+    for (int s = 1; s < KS_SPLIT; ++s) {
+        float d = s_best[s][lane]; uint32_t id = s_idx[s][lane];
+        if (d < dr || (d == dr && id < rstar)) { dr = d; rstar = id; }
+    }
+    uint32_t o, n;
+    if (p.nr <= KS_TILE) { uint2 on = s_on[rstar]; o = on.x; n = on.y; }
+    else { o = gO[rstar]; n = gN[rstar]; }
+    __syncthreads ();
+
+    // ---- stage 2: exhaustive scan of that representative's list, positions interleaved over the slices ----
+    float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
+    float4 bnn = make_float4 (0.f, 0.f, 0.f, 0.f);
+#ifdef ICP_DBG_SKIP_S2
+    if (valid && n == 0xFFFFFFFFu) {
+#else
+    if (valid) {
+#endif
+        uint32_t j = o + slice;
+        const uint32_t je = o + n;
+        for (; j + 3 * KS_SPLIT < je; j += 4 * KS_SPLIT) {      // four candidates in flight
+            float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
+            float4 g1 = XQ4[2 * (size_t) (j + KS_SPLIT)], c1 = XQ4[2 * (size_t) (j + KS_SPLIT) + 1];
+            float4 g2 = XQ4[2 * (size_t) (j + 2 * KS_SPLIT)], c2 = XQ4[2 * (size_t) (j + 2 * KS_SPLIT) + 1];
+            float4 g3 = XQ4[2 * (size_t) (j + 3 * KS_SPLIT)], c3 = XQ4[2 * (size_t) (j + 3 * KS_SPLIT) + 1];
+            KS_CAND (g0, c0, j); KS_CAND (g1, c1, j + KS_SPLIT); KS_CAND (g2, c2, j + 2 * KS_SPLIT); KS_CAND (g3, c3, j + 3 * KS_SPLIT);
+        }
+        if (j + KS_SPLIT < je) {
+            float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
+            float4 g1 = XQ4[2 * (size_t) (j + KS_SPLIT)], c1 = XQ4[2 * (size_t) (j + KS_SPLIT) + 1];
+            KS_CAND (g0, c0, j); KS_CAND (g1, c1, j + KS_SPLIT);
+            j += 2 * KS_SPLIT;
+        }
+        if (j < je) {
+            float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
+            KS_CAND (g0, c0, j);
+            j += KS_SPLIT;
+        }
+        if (j < je) {
+            float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
+            KS_CAND (g0, c0, j);
+        }
+    }
+    KS_STAMP (4)
+    s_best[slice][lane] = best2; s_idx[slice][lane] = bj; s_nn[slice][lane] = bnn;
+    __syncthreads ();
+    KS_STAMP (5)
 
     if (slice == 0) {
-        float d = s_best[0][ql]; uint32_t j = s_idx[0][ql];
+        float d = s_best[0][lane]; uint32_t j = s_idx[0][lane]; int sw = 0;
 #pragma unroll
-        for (int s = 1; s < SPLIT; ++s) {
-            float ds = s_best[s][ql]; uint32_t js = s_idx[s][ql];
-            if (ds < d || (ds == d && js < j)) { d = ds; j = js; }     // ties -> lowest list position
+        for (int s = 1; s < KS_SPLIT; ++s) {
+            float ds = s_best[s][lane]; uint32_t js = s_idx[s][lane];
+            if (ds < d || (ds == d && js < j)) { d = ds; j = js; sw = s; }     // ties -> lowest list position
         }
         float w = 0.f;
         if (valid) {
             uint32_t id; float4 nn;
             if (n == 0) {            // empty list: fall back to the representative itself
-                d = dr; id = p.rep_src[(size_t) b * p.nr + rstar]; nn = R4[2 * rstar];
+                d = dr; id = p.rep_src[(size_t) b * p.nr + rstar]; nn = R4[2 * (size_t) rstar];
+            } else if (j == 0xFFFFFFFFu) {   // every distance inf / NaN: first list element, as the serial scan would
+                nn = XQ4[2 * (size_t) o]; id = __float_as_uint (nn.w);
             } else {
-                id = p.perm[(size_t) b * p.m + j]; nn = X4[2 * (size_t) j];
+                nn = s_nn[sw][lane]; id = __float_as_uint (nn.w);
             }
             w = p.weighted ? 100.f / (100.f + d) : 1.f;                // icp_kernels.cl:232
             icp_dist_id di; di.dist = d; di.id = id;
@@ -338,13 +508,19 @@ __global__ __launch_bounds__ (128 * SPLIT) void k_search (icp_params p)
             p.PM[(size_t) b * p.m + i] = make_float4 (qx, qy, qz, d);
             p.rid[(size_t) b * p.m + i] = rstar;
         }
-        s_w[ql] = w;
+        s_w[lane] = w;
     }
+    KS_STAMP (6)
     __syncthreads ();
-    if (wave == 0 && p.weighted) {   // icpComputeReduceWeights_WG tree — icp_kernels.cl:244-253
-        float v = wave_tree_f (s_w[lane] + s_w[lane + 64]);
-        if (lane == 0) p.wpart[(size_t) b * p.nwp + blockIdx.x] = v;
+    if (slice == 0 && p.weighted) {
+        // tree levels d = 64 .. 2 restricted to this block's parity class (icp_kernels.cl:244-249):
+        // element e of the class is position 2e + parity; levels pair e with e+32, e+16, .., e+1.
+        const uint32_t l = lane & 15u;
+        float a[4] = { s_w[l], s_w[l + 16], s_w[l + 32], s_w[l + 48] };
+        float v = row_tree4 (a);
+        if (lane == 0) p.wpart[(size_t) b * 2 * p.nwp + blockIdx.x] = v;
     }
+    KS_STAMP (7)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -354,130 +530,145 @@ __global__ __launch_bounds__ (64) void k_sum_w (icp_params p)
 {
     uint32_t b = blockIdx.y, lane = threadIdx.x;
     icp_reg_state *st = p.st + b;
-    if (st->done) return;
-    double sw = finalize_sum_w (p.wpart + (size_t) b * p.nwp, p.nwp, lane);
+    if (p.check && st->done) return;
+    double sw = sum_w_row (p.wpart + (size_t) b * 2 * p.nwp, p.nwp, lane & 15u);
     if (lane == 0) st->sum_w = sw;
 }
 
 // multi-level icpGMean: groups of 128 block means per pass until one vector per set remains
+// (nwg <= 8192 here, i.e. at most two passes; one 16-lane row per group)
 __global__ __launch_bounds__ (1024) void k_gmean (icp_params p)
 {
-    uint32_t b = blockIdx.y, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t b = blockIdx.y, l = threadIdx.x & 15u, row = threadIdx.x >> 4;      // 64 rows
     icp_reg_state *st = p.st + b;
-    if (st->done) return;
-    uint32_t nscr = (p.nwg + 127u) / 128u;
+    if (p.check && st->done) return;
+    const uint32_t ng = (p.nwg + 127u) / 128u;                                    // <= 64
     for (uint32_t set = 0; set < 2; ++set) {
         const float4 *cur = p.mpart + ((size_t) b * 2 + set) * p.nwg;
-        float4 *scr = p.mscr + ((size_t) b * 2 + set) * nscr;
-        uint32_t n = p.nwg;
-        while (n > 1) {
-            uint32_t ng = (n + 127u) / 128u;
-            __syncthreads ();
-            float4 keep[8]; uint32_t cnt = 0;                 // results first (scr may alias cur)
-            for (uint32_t g = wave; g < ng && cnt < 8; g += 16) keep[cnt++] = gmean_128 (cur + (size_t) g * 128, min (128u, n - g * 128u), lane);
-            __syncthreads ();
-            cnt = 0;
-            for (uint32_t g = wave; g < ng && cnt < 8; g += 16) { if (lane == 0) scr[g] = keep[cnt]; ++cnt; }
-            __threadfence_block ();
-            __syncthreads ();
-            cur = scr; n = ng;
-        }
+        float4 *scr = p.mscr + ((size_t) b * 2 + set) * ng;
+        float4 r = gmean_row (cur + (size_t) min (row, ng - 1) * 128, row < ng ? min (128u, p.nwg - row * 128u) : 0u, l);
+        if (row < ng && l == 0) scr[row] = r;
+        __syncthreads ();
+        float4 f = gmean_row (scr, ng, l);
         if (threadIdx.x == 0) {
-            float4 r = cur[0];
-            st->means[set * 4 + 0] = r.x; st->means[set * 4 + 1] = r.y; st->means[set * 4 + 2] = r.z; st->means[set * 4 + 3] = 0.f;
+            st->means[set * 4 + 0] = f.x; st->means[set * 4 + 1] = f.y; st->means[set * 4 + 2] = f.z; st->means[set * 4 + 3] = 0.f;
         }
         __syncthreads ();
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K3  means: icpMean(_Weighted) — kernels/icp_kernels.cl:371-411, 455-495.  One wave per 128 pairs.
+// K2  means: icpMean(_Weighted) — kernels/icp_kernels.cl:371-411, 455-495.
+//     One 16-lane row per 128-pair work-group (8 pairs per lane), 4 work-groups per wave.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__ (64) void k_means (icp_params p)
 {
-    const uint32_t b = blockIdx.y, lane = threadIdx.x, g = blockIdx.x;
+    const uint32_t b = blockIdx.y, lane = threadIdx.x, l = lane & 15u;
+    const uint32_t g = blockIdx.x * 4u + (lane >> 4);
     icp_reg_state *st = p.st + b;
-    if (st->done) return;
+    if (p.check && st->done) return;
 
+    const float4 *PF = p.PF + (size_t) b * p.m, *PM = p.PM + (size_t) b * p.m;
+    float4 pf[8], pm[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t e = g * 128u + l + 16u * k;
+        bool ok = (e & ~1u) < p.m;                   // the pair's flag guards both points (icp_kernels.cl:390-392)
+        pf[k] = make_float4 (0.f, 0.f, 0.f, 0.f); pm[k] = pf[k];
+        if (ok) { pf[k] = PF[e]; pm[k] = PM[e]; }
+    }
     double sum_w = 1.0;
     if (p.weighted) {
         if (p.nwp <= 512) {
-            sum_w = finalize_sum_w (p.wpart + (size_t) b * p.nwp, p.nwp, lane);
-            if (g == 0 && lane == 0) st->sum_w = sum_w;
+            double sw = sum_w_row (p.wpart + (size_t) b * 2 * p.nwp, p.nwp, l);
+            unsigned long long u = __builtin_bit_cast (unsigned long long, sw);
+            uint32_t lo = __builtin_amdgcn_readfirstlane ((uint32_t) u), hi = __builtin_amdgcn_readfirstlane ((uint32_t) (u >> 32));
+            sum_w = __builtin_bit_cast (double, ((unsigned long long) hi << 32) | lo);
+            if (blockIdx.x == 0 && lane == 0) st->sum_w = sum_w;
         } else sum_w = st->sum_w;                    // written by k_sum_w
     }
-    const float4 *PF = p.PF + (size_t) b * p.m, *PM = p.PM + (size_t) b * p.m;
-    const uint32_t e0 = g * 128u + lane, e1 = e0 + 64u;
-    float f[2][3], q[2][3];
+    float fx[8], fy[8], fz[8], qx[8], qy[8], qz[8];
+    const float nf = (float) p.m;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        uint32_t e = h ? e1 : e0;
-        bool ok = (e & ~1u) < p.m;                   // the pair's flag guards both points (icp_kernels.cl:390-392)
-        float4 pf = make_float4 (0.f, 0.f, 0.f, 0.f), pm = pf;
-        if (ok) { pf = PF[e]; pm = PM[e]; }
+    for (int k = 0; k < 8; ++k) {
+        uint32_t e = g * 128u + l + 16u * k;
+        bool ok = (e & ~1u) < p.m;
         if (p.weighted) {
-            float k = (float) ((double) pf.w / sum_w);                   // icp_kernels.cl:475
-            f[h][0] = ok ? k * pf.x : 0.f; f[h][1] = ok ? k * pf.y : 0.f; f[h][2] = ok ? k * pf.z : 0.f;
-            q[h][0] = ok ? k * pm.x : 0.f; q[h][1] = ok ? k * pm.y : 0.f; q[h][2] = ok ? k * pm.z : 0.f;
-        } else {
-            float nf = (float) p.m;                                      // icp_kernels.cl:391
-            f[h][0] = ok ? pf.x / nf : 0.f; f[h][1] = ok ? pf.y / nf : 0.f; f[h][2] = ok ? pf.z / nf : 0.f;
-            q[h][0] = ok ? pm.x / nf : 0.f; q[h][1] = ok ? pm.y / nf : 0.f; q[h][2] = ok ? pm.z / nf : 0.f;
+            float kk = (float) ((double) pf[k].w / sum_w);               // icp_kernels.cl:475
+            fx[k] = ok ? kk * pf[k].x : 0.f; fy[k] = ok ? kk * pf[k].y : 0.f; fz[k] = ok ? kk * pf[k].z : 0.f;
+            qx[k] = ok ? kk * pm[k].x : 0.f; qy[k] = ok ? kk * pm[k].y : 0.f; qz[k] = ok ? kk * pm[k].z : 0.f;
+        } else {                                                         // icp_kernels.cl:391
+            fx[k] = ok ? pf[k].x / nf : 0.f; fy[k] = ok ? pf[k].y / nf : 0.f; fz[k] = ok ? pf[k].z / nf : 0.f;
+            qx[k] = ok ? pm[k].x / nf : 0.f; qy[k] = ok ? pm[k].y / nf : 0.f; qz[k] = ok ? pm[k].z / nf : 0.f;
         }
     }
     float4 mf, mm;
-    mf.x = wave_tree_f (f[0][0] + f[1][0]); mf.y = wave_tree_f (f[0][1] + f[1][1]); mf.z = wave_tree_f (f[0][2] + f[1][2]); mf.w = 0.f;
-    mm.x = wave_tree_f (q[0][0] + q[1][0]); mm.y = wave_tree_f (q[0][1] + q[1][1]); mm.z = wave_tree_f (q[0][2] + q[1][2]); mm.w = 0.f;
-    if (lane == 0) {
+    mf.x = row_tree8 (fx); mf.y = row_tree8 (fy); mf.z = row_tree8 (fz); mf.w = 0.f;
+    mm.x = row_tree8 (qx); mm.y = row_tree8 (qy); mm.z = row_tree8 (qz); mm.w = 0.f;
+    if (l == 0 && g < p.nwg) {
         p.mpart[((size_t) b * 2 + 0) * p.nwg + g] = mf;
         p.mpart[((size_t) b * 2 + 1) * p.nwg + g] = mm;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K4  S matrix: icpSubtractMean + icpSijProducts(_Weighted) + reduce_sum_f first level
+// K3  S matrix: icpSubtractMean + icpSijProducts(_Weighted) + reduce_sum_f first level
 //     kernels/icp_kernels.cl:588-602, 633-671, 703-743; kernels/reduce_kernels.cl:230-264.
-//     Block = 512 columns = one reduce_sum_f work-group; thread = one column (4 strided points).
+//     reduce_sum_f work-group w covers 512 columns = 128 positions of 4 columns.  One wave takes the
+//     16 positions = r (mod 8) of a work-group (64 columns, one per lane, 4 strided points each) and
+//     runs the tree levels d = 64, 32, 16, 8, which stay inside that class.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__ (512) void k_sij (icp_params p)
+__global__ __launch_bounds__ (64) void k_sij (icp_params p)
 {
-    const uint32_t b = blockIdx.y, tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane (tid >> 6);
+    const uint32_t b = blockIdx.y, lane = threadIdx.x, l = lane & 15u, row = lane >> 4;
     icp_reg_state *st = p.st + b;
-    if (st->done) return;
+    if (p.check && st->done) return;
 
-    __shared__ float4 s_mean[2];
-    __shared__ float s_pos[11][128];
+    __shared__ __attribute__ ((aligned (16))) float s_col[11][64];
 
-    if (p.nwg <= 128) {                              // icpGMean in the prologue (one wave per set)
-        if (wave < 2) {
-            float4 r = gmean_128 (p.mpart + ((size_t) b * 2 + wave) * p.nwg, p.nwg, lane);
-            if (lane == 0) {
-                s_mean[wave] = r;
-                if (blockIdx.x == 0) { st->means[wave * 4] = r.x; st->means[wave * 4 + 1] = r.y; st->means[wave * 4 + 2] = r.z; st->means[wave * 4 + 3] = 0.f; }
-            }
-        }
-    } else if (tid < 2) {                            // written by k_gmean
-        s_mean[tid] = make_float4 (st->means[tid * 4], st->means[tid * 4 + 1], st->means[tid * 4 + 2], 0.f);
-    }
-    __syncthreads ();
-    const float4 mf = s_mean[0], mm = s_mean[1];
-
+    const uint32_t wg = blockIdx.x >> 3, res = blockIdx.x & 7u;
+    const uint32_t col = wg * 512u + 4u * (res + 8u * (lane >> 2)) + (lane & 3u);
     const float4 *PF = p.PF + (size_t) b * p.m, *PM = p.PM + (size_t) b * p.m;
-    const uint32_t col = blockIdx.x * 512u + tid;
+    float4 pf[4], pm[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                                        // icp_kernels.cl:718: pi = gX + k gXdim
+        uint32_t pi = col + (uint32_t) k * p.G;
+        pf[k] = make_float4 (0.f, 0.f, 0.f, 0.f); pm[k] = pf[k];
+        if (col < p.G && pi < p.m) { pf[k] = PF[pi]; pm[k] = PM[pi]; }
+    }
+    float4 mf, mm;
+    if (p.nwg <= 128) {                              // icpGMean in the prologue
+        float4 r0 = gmean_row (p.mpart + ((size_t) b * 2 + 0) * p.nwg, p.nwg, l);
+        float4 r1 = gmean_row (p.mpart + ((size_t) b * 2 + 1) * p.nwg, p.nwg, l);
+        mf.x = __builtin_bit_cast (float, __builtin_amdgcn_readfirstlane (__builtin_bit_cast (uint32_t, r0.x)));
+        mf.y = __builtin_bit_cast (float, __builtin_amdgcn_readfirstlane (__builtin_bit_cast (uint32_t, r0.y)));
+        mf.z = __builtin_bit_cast (float, __builtin_amdgcn_readfirstlane (__builtin_bit_cast (uint32_t, r0.z)));
+        mm.x = __builtin_bit_cast (float, __builtin_amdgcn_readfirstlane (__builtin_bit_cast (uint32_t, r1.x)));
+        mm.y = __builtin_bit_cast (float, __builtin_amdgcn_readfirstlane (__builtin_bit_cast (uint32_t, r1.y)));
+        mm.z = __builtin_bit_cast (float, __builtin_amdgcn_readfirstlane (__builtin_bit_cast (uint32_t, r1.z)));
+        if (blockIdx.x == 0 && lane == 0) {
+            st->means[0] = mf.x; st->means[1] = mf.y; st->means[2] = mf.z; st->means[3] = 0.f;
+            st->means[4] = mm.x; st->means[5] = mm.y; st->means[6] = mm.z; st->means[7] = 0.f;
+        }
+    } else {                                         // written by k_gmean
+        mf = make_float4 (st->means[0], st->means[1], st->means[2], 0.f);
+        mm = make_float4 (st->means[4], st->means[5], st->means[6], 0.f);
+    }
+
     const float c = p.c;
     float A[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) A[k] = 0.f;
-    if (col < p.G)
-        for (uint32_t pi = col; pi < p.m; pi += p.G) {                   // icp_kernels.cl:718
-            float4 pf = PF[pi], pm = PM[pi];
-            float Mp[3] = { c * (pm.x - mm.x), c * (pm.y - mm.y), c * (pm.z - mm.z) };
-            float Fp[3] = { c * (pf.x - mf.x), c * (pf.y - mf.y), c * (pf.z - mf.z) };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t pi = col + (uint32_t) k * p.G;
+        if (col < p.G && pi < p.m) {
+            float Mp[3] = { c * (pm[k].x - mm.x), c * (pm[k].y - mm.y), c * (pm[k].z - mm.z) };
+            float Fp[3] = { c * (pf[k].x - mf.x), c * (pf[k].y - mf.y), c * (pf[k].z - mf.z) };
             float ff = (Fp[0] * Fp[0] + Fp[1] * Fp[1]) + Fp[2] * Fp[2];
             float m2 = (Mp[0] * Mp[0] + Mp[1] * Mp[1]) + Mp[2] * Mp[2];
             if (p.weighted) {
-                float w = pf.w;
+                float w = pf[k].w;
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -491,64 +682,55 @@ __global__ __launch_bounds__ (512) void k_sij (icp_params p)
                 A[9] = A[9] + ff; A[10] = A[10] + m2;
             }
         }
-    // position p = ((c[4p] + c[4p+1]) + c[4p+2]) + c[4p+3]  — reduce_kernels.cl:245-251
-    const uint32_t qb = lane & ~3u;
-#pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        float v = A[k];
-        float s = __shfl (v, qb) + __shfl (v, qb + 1);
-        s = s + __shfl (v, qb + 2);
-        s = s + __shfl (v, qb + 3);
-        if ((tid & 3u) == 0) s_pos[k][tid >> 2] = s;
     }
+#pragma unroll
+    for (int k = 0; k < 11; ++k) s_col[k][lane] = A[k];
     __syncthreads ();
-    for (uint32_t row = wave; row < 11; row += 8) {
-        float v = wave_tree_f (s_pos[row][lane] + s_pos[row][lane + 64]);
-        if (lane == 0) p.spart[((size_t) b * 11 + row) * p.nsp + blockIdx.x] = v;
+    // position j (= quad j) = ((c0 + c1) + c2) + c3 — reduce_kernels.cl:245-251; row `row` takes S rows row, row+4, row+8
+    const uint32_t nsp8 = p.nsp * 8u;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        uint32_t a = row + 4u * it;
+        float4 v = *reinterpret_cast<const float4 *> (&s_col[min (a, 10u)][4 * l]);
+        float t = row_tree_tail (sum4 (v));
+        if (l == 0 && a < 11) p.spart[((size_t) b * 11 + a) * nsp8 + blockIdx.x] = t;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K5  finalize: reduce_sum_f second level, rotation, composition, convergence. One wave per registration.
+// K4  finalize: S final tree (a8), rotation (a9 / a12), composition (a10), convergence (a11).
+//     One block of 3 waves per registration: 11 rows reduce the 11 rows of S, then wave 0 runs the
+//     lane-parallel power method and lane 0 composes.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__ (64) void k_finalize (icp_params p)
+__global__ __launch_bounds__ (192) void k_finalize (icp_params p)
 {
-    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, l = tid & 15u, row = tid >> 4;
     icp_reg_state *st = p.st + b;
-    if (st->done) return;
+    if (p.check && st->done) return;
 
-    float S[11];
-    for (int row = 0; row < 11; ++row) {
-        const float *cur = p.spart + ((size_t) b * 11 + row) * p.nsp;
-        uint32_t n = p.nsp;
-        float *scr = p.sscr + ((size_t) b * 11 + row) * (((p.nsp + 511u) / 512u + 3u) & ~3u);
-        while (n > 1) {                              // same shape as the first level: 512 columns per group
-            uint32_t wg = (n + 511u) / 512u, wgp = wg;
-            if (wgp != 1 && (wgp & 3u)) wgp += 4u - (wgp & 3u);
-            float res = 0.f;
-            for (uint32_t g = 0; g < wgp; ++g) {
-                uint32_t c0 = g * 512u + 4u * lane, c1 = c0 + 256u;
-                float a0 = (c0 < n) ? sum4 (*reinterpret_cast<const float4 *> (cur + c0)) : 0.f;
-                float a1 = (c1 < n) ? sum4 (*reinterpret_cast<const float4 *> (cur + c1)) : 0.f;
-                float v = wave_tree_f (a0 + a1);
-                if (wgp == 1) res = v; else if (lane == 0) scr[g] = v;
-            }
-            if (wgp == 1) { S[row] = res; n = 1; break; }
-            __threadfence_block ();
-            cur = scr; n = wgp;
-        }
-        if (p.nsp == 1) S[row] = cur[0];
+    __shared__ float s_S[12];
+    {
+        const uint32_t a = min (row, 10u);
+        float v = s_reduce_row (p.spart + ((size_t) b * 11 + a) * p.nsp * 8u, p.nsp, l);
+        if (l == 0 && row < 11) s_S[row] = v;
     }
-    float means[8];
+    __syncthreads ();
+    if (tid >= 64) return;
+
+    float S[11], means[8];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) S[k] = s_S[k];
+#pragma unroll
     for (int k = 0; k < 8; ++k) means[k] = st->means[k];
 
     float Tk[8], Rk[9];
     int iters = 0;
-    if (p.rot == 1) iters = icp_power_method (S, means, Tk, p.power_mode);
+    if (p.rot == 1) iters = icp_power_method_quad (S, means, Tk, p.power_mode, lane);
     else icp_svd_rotation (S, means, Rk, Tk);
 
     if (lane == 0) {
         icp_compose (st, Tk, Rk, p.rot != 1);
+#pragma unroll
         for (int k = 0; k < 11; ++k) st->S[k] = S[k];
         st->pm_iters = (uint32_t) iters;
         st->k = st->k + 1;
@@ -593,25 +775,37 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 
 void icp_launch_search (const icp_params &p, hipStream_t s)
 {
-    dim3 grid ((p.m + 127) / 128, p.batch);
-    hipLaunchKernelGGL (k_search<4>, grid, dim3 (512), 0, s, p);
+    dim3 grid (2 * p.nwg, p.batch);
+    hipLaunchKernelGGL (k_search, grid, dim3 (64 * KS_SPLIT), 0, s, p);
 }
 
 void icp_launch_means (const icp_params &p, hipStream_t s)
 {
     if (p.weighted && p.nwp > 512) hipLaunchKernelGGL (k_sum_w, dim3 (1, p.batch), dim3 (64), 0, s, p);
-    hipLaunchKernelGGL (k_means, dim3 (p.nwg, p.batch), dim3 (64), 0, s, p);
+    hipLaunchKernelGGL (k_means, dim3 ((p.nwg + 3) / 4, p.batch), dim3 (64), 0, s, p);
 }
 
 void icp_launch_sij (const icp_params &p, hipStream_t s)
 {
     if (p.nwg > 128) hipLaunchKernelGGL (k_gmean, dim3 (1, p.batch), dim3 (1024), 0, s, p);
-    hipLaunchKernelGGL (k_sij, dim3 ((p.G + 511) / 512, p.batch), dim3 (512), 0, s, p);
+    hipLaunchKernelGGL (k_sij, dim3 (((p.G + 511) / 512) * 8, p.batch), dim3 (64), 0, s, p);
 }
 
 void icp_launch_finalize (const icp_params &p, hipStream_t s)
 {
-    hipLaunchKernelGGL (k_finalize, dim3 (p.batch), dim3 (64), 0, s, p);
+    hipLaunchKernelGGL (k_finalize, dim3 (p.batch), dim3 (192), 0, s, p);
+}
+
+__global__ void k_nop (icp_params p) { if (p.m == 0xFFFFFFFFu) p.st->k = 0; }
+
+// diagnostic: any subset of the iteration's kernels (bit 0 search, 1 means, 2 sij, 3 finalize, 4 empty kernel)
+void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask)
+{
+    if (mask & 1u) icp_launch_search (p, s);
+    if (mask & 2u) icp_launch_means (p, s);
+    if (mask & 4u) icp_launch_sij (p, s);
+    if (mask & 8u) icp_launch_finalize (p, s);
+    if (mask & 16u) hipLaunchKernelGGL (k_nop, dim3 (256, p.batch), dim3 (64), 0, s, p);
 }
 
 void icp_launch_iteration (const icp_params &p, hipStream_t s)

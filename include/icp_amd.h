@@ -183,6 +183,10 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, float 
  * iterations): out_ms[0..3] = mean ms of {search, means, sij, finalize}. */
 int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4);
 
+/* Diagnostic: a graph of `iterations` x (the kernels selected by mask: bit 0 search, 1 means, 2 sij,
+ * 3 finalize, 4 an empty 256-block kernel), launched `reps` times; *ms_total = elapsed ms. */
+int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t reps, float *ms_total);
+
 /* ---- utilities ---------------------------------------------------------------------------------- */
 
 const char *icp_last_error (icp_handle h);      /* h may be NULL: error of the last failed create */

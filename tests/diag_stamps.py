@@ -1,0 +1,23 @@
+"""Diagnostic (not a test): per-phase s_memtime stamps of k_search (needs the ICP_DBG_STAMPS build)."""
+import sys, os, ctypes as C
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import icp_amd
+side, nr = 128, 256
+F, M = icp_amd.synth_pair(side)
+g = icp_amd.ICP(0); g.init(side * side, nr, 2e2, 1e-6); g.setPowerMode(1)
+g.write(icp_amd.Memory.F, F); g.write(icp_amd.Memory.M, M); g.buildRBC(); g.run_fixed(3); g.sync()
+L = icp_amd.lib(); nb = 256
+out = np.zeros((nb, 16), np.uint64)
+for rep in range(3):
+    rc = L.icp_debug_stamps(g._h, out.ctypes.data_as(C.c_void_p), nb); assert rc == 0
+t = out.astype(np.int64)
+t0 = t[:, 8].min()
+names = ["loads+transform", "stage reps->LDS", "S1 loop", "S1 sync", "S2 loop", "S2 sync", "epilogue", "tree"]
+prev = t[:, 8]
+print("block start spread (ticks): %d" % (t[:, 8].max() - t0))
+for k in range(8):
+    d = t[:, k] - prev
+    print("%-18s mean %8.0f  min %8d  max %8d" % (names[k], d.mean(), d.min(), d.max()))
+    prev = t[:, k]
+print("kernel span (first start -> last end): %d ticks; per-block mean %0.f" % (t[:, 7].max() - t0, (t[:, 7] - t[:, 8]).mean()))

@@ -1,0 +1,246 @@
+/*! \file ICP/algorithms.hpp
+ *  \brief C++ facade with the names of the reference's `cl_algo::ICP` pipeline classes, forwarding
+ *         to the MI355X engine's C-ABI (include/icp_amd.h).
+ *
+ *  A user of nlamprian/ICP's `ICPStep<CR,CW>` / `ICP<CR,CW>` (reference: include/ICP/algorithms.hpp:
+ *  1582-2496, src/ICP/algorithms.cpp:3158-4903) switches by replacing the OpenCL plumbing types:
+ *
+ *      reference                                     here
+ *      clutils::CLEnv &env, CLEnvInfo<1> infoRBC,    icp::Env env (device ordinal)
+ *        CLEnvInfo<1> infoICP
+ *      cl::Memory& get (Memory)                      void*& get (Memory)   (device pointer)
+ *      const std::vector<cl::Event>*, cl::Event*     dropped (one in-order HIP stream per object)
+ *      Eigen::Matrix3f / Quaternionf / Vector3f      icp::Matrix3f / Quaternionf / Vector3f (PODs)
+ *
+ *  Everything else keeps its name, argument order, defaults and meaning: init, write, read, buildRBC,
+ *  run, getAlpha/setAlpha, getScaling/setScaling, the ICP thresholds, and the public state members
+ *  Rk qk tk sk R q t s k hPtrInF hPtrInM hPtrIOT.  Argument errors throw std::runtime_error
+ *  (the reference prints and calls exit(), src/ICP/algorithms.cpp:4411-4427).
+ */
+#ifndef ICP_ALGORITHMS_HPP
+#define ICP_ALGORITHMS_HPP
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../icp_amd.h"
+
+namespace icp
+{
+    /*! \brief Replaces the clutils::CLEnv / CLEnvInfo pair: which GPU the object lives on. */
+    struct Env { int device; explicit Env (int d = 0) : device (d) {} };
+
+    struct Vector3f
+    {
+        float v[3] = { 0.f, 0.f, 0.f };
+        float& operator() (int i) { return v[i]; }
+        float operator() (int i) const { return v[i]; }
+        float x () const { return v[0]; } float y () const { return v[1]; } float z () const { return v[2]; }
+        float norm () const { return std::sqrt ((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
+    };
+
+    /*! \brief Unit quaternion stored like Eigen::Quaternionf::coeffs (): x, y, z, w. */
+    struct Quaternionf
+    {
+        float c[4] = { 0.f, 0.f, 0.f, 1.f };
+        float x () const { return c[0]; } float y () const { return c[1]; }
+        float z () const { return c[2]; } float w () const { return c[3]; }
+        Vector3f vec () const { Vector3f r; r.v[0] = c[0]; r.v[1] = c[1]; r.v[2] = c[2]; return r; }
+        const float* coeffs () const { return c; }
+    };
+
+    /*! \brief Row-major 3x3. */
+    struct Matrix3f
+    {
+        float m[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f };
+        float& operator() (int r, int c) { return m[r * 3 + c]; }
+        float operator() (int r, int c) const { return m[r * 3 + c]; }
+    };
+}
+
+namespace cl_algo
+{
+namespace ICP
+{
+    /*! \brief Rotation computation of an ICP step — reference include/ICP/algorithms.hpp:1544. */
+    enum class ICPStepConfigT : uint8_t { EIGEN, POWER_METHOD, JACOBI };
+    /*! \brief Residual weighting of an ICP step — reference include/ICP/algorithms.hpp:1560. */
+    enum class ICPStepConfigW : uint8_t { REGULAR, WEIGHTED };
+    /*! \brief Staging buffers to instantiate — reference include/ICP/common.hpp. */
+    enum class Staging : uint8_t { NONE, I, O, IO };
+
+    /*! \brief One ICP iteration — mirrors the four specialisations of the reference's
+     *         `ICPStep<CR, CW>` (include/ICP/algorithms.hpp:1613, 1825, 2038, 2234).
+     */
+    template <ICPStepConfigT CR, ICPStepConfigW CW>
+    class ICPStep
+    {
+    public:
+        /*! \brief reference include/ICP/algorithms.hpp:2241-2267 */
+        enum class Memory : uint8_t { H_IN_F, H_IN_M, H_IO_T, D_IN_F, D_IN_M, D_IO_T };
+
+        ICPStep (icp::Env _env) : env (_env), h (nullptr), m (0), nr (0), a (1e2f), c (1e-6f)
+        {
+            static_assert (CR != ICPStepConfigT::JACOBI, "JACOBI is a \\todo in the reference as well");
+            int rc = icp_create (&h, env.device, CR == ICPStepConfigT::POWER_METHOD ? ICP_ROT_POWER_METHOD : ICP_ROT_EIGEN,
+                                 CW == ICPStepConfigW::WEIGHTED ? ICP_W_WEIGHTED : ICP_W_REGULAR);
+            if (rc != ICP_OK) throw std::runtime_error (std::string ("ICPStep: ") + icp_last_error (nullptr));
+            hPtrInF = hPtrInM = hPtrIOT = nullptr; sk = 1.f; s = 1.f;
+        }
+        ICPStep (const ICPStep&) = delete;
+        ICPStep& operator= (const ICPStep&) = delete;
+        virtual ~ICPStep () { if (h) icp_destroy (h); }
+
+        /*! \brief Device pointer of a buffer (reference: cl::Memory& get (Memory), algorithms.cpp:4366-4383).
+         *  \note Assigning a pointer before `init` makes the object adopt that buffer, as the reference does. */
+        void*& get (Memory mem)
+        {
+            switch (mem)
+            {
+                case Memory::D_IN_F: return dPtr[0];
+                case Memory::D_IN_M: return dPtr[1];
+                case Memory::D_IO_T: return dPtr[2];
+                default: throw std::runtime_error ("ICPStep::get: host staging buffers are reached through hPtrInF/hPtrInM/hPtrIOT");
+            }
+        }
+
+        /*! \brief reference include/ICP/algorithms.hpp:2271, src/ICP/algorithms.cpp:4403-4582 */
+        void init (unsigned int _m, unsigned int _nr, float _a = 1e2f, float _c = 1e-6f, Staging _staging = Staging::IO)
+        { init_ (_m, _nr, _a, _c, 40, 0.001, 0.01, _staging); }
+
+        /*! \brief reference include/ICP/algorithms.hpp:2273, src/ICP/algorithms.cpp:4596-4622 */
+        void write (Memory mem = Memory::D_IN_F, void *ptr = nullptr, bool block = false)
+        {
+            if (!(staging == Staging::I || staging == Staging::IO)) return;
+            int which; float *stage; size_t n = (size_t) m * 8;
+            switch (mem)
+            {
+                case Memory::D_IN_F: which = ICP_MEM_F; stage = hPtrInF; break;
+                case Memory::D_IN_M: which = ICP_MEM_M; stage = hPtrInM; break;
+                case Memory::D_IO_T: which = ICP_MEM_T; stage = hPtrIOT; n = 8; break;
+                default: return;
+            }
+            if (ptr != nullptr) std::memcpy (stage, ptr, n * sizeof (float));
+            check (icp_write (h, which, stage, block ? 1 : 0));
+        }
+
+        /*! \brief reference include/ICP/algorithms.hpp:2275, src/ICP/algorithms.cpp:4634-4649 */
+        void* read (Memory mem = Memory::H_IO_T, bool block = true)
+        {
+            (void) block;
+            if (!(staging == Staging::O || staging == Staging::IO)) return nullptr;
+            if (mem != Memory::H_IO_T) return nullptr;
+            check (icp_read (h, ICP_MEM_T, hPtrIOT, 8 * sizeof (float)));
+            return hPtrIOT;
+        }
+
+        /*! \brief reference include/ICP/algorithms.hpp:2277, src/ICP/algorithms.cpp:4655-4660 */
+        void buildRBC () { check (icp_build_rbc (h)); }
+
+        /*! \brief One iteration; updates Rk qk tk sk R q t s like the reference (src/ICP/algorithms.cpp:4670-4698). */
+        void run (bool config = false) { check (icp_step (h, config ? 1 : 0)); pull (); }
+
+        float getAlpha () { return a; }
+        void setAlpha (float _a) { check (icp_set_alpha (h, _a)); a = _a; }
+        float getScaling () { return c; }
+        void setScaling (float _c) { check (icp_set_scaling (h, _c)); c = _c; }
+
+        float *hPtrInF;  /*!< Staging buffer of the fixed set (reference: mapped H_IN_F). */
+        float *hPtrInM;  /*!< Staging buffer of the moving set. */
+        float *hPtrIOT;  /*!< Staging buffer of [q | t, s]. */
+
+        icp::Matrix3f Rk; icp::Quaternionf qk; icp::Vector3f tk; float sk;   /*!< iteration k */
+        icp::Matrix3f R;  icp::Quaternionf q;  icp::Vector3f t;  float s;    /*!< up to iteration k */
+
+        icp_handle handle () { return h; }
+
+    protected:
+        void check (int rc) { if (rc != ICP_OK) throw std::runtime_error (std::string ("ICP: ") + icp_last_error (h)); }
+
+        void init_ (unsigned int _m, unsigned int _nr, float _a, float _c, unsigned int max_it, double ang, double tra, Staging _staging)
+        {
+            m = _m; nr = _nr; a = _a; c = _c; staging = _staging;
+            check (icp_init (h, m, nr, a, c, max_it, ang, tra));
+            if (dPtr[0]) check (icp_adopt_device_buffer (h, ICP_MEM_F, dPtr[0]));
+            if (dPtr[1]) check (icp_adopt_device_buffer (h, ICP_MEM_M, dPtr[1]));
+            check (icp_device_ptr (h, ICP_MEM_F, &dPtr[0]));
+            check (icp_device_ptr (h, ICP_MEM_M, &dPtr[1]));
+            check (icp_device_ptr (h, ICP_MEM_T, &dPtr[2]));
+            stageF.assign (staging == Staging::I || staging == Staging::IO ? (size_t) m * 8 : 0, 0.f);
+            stageM.assign (stageF.size (), 0.f);
+            hPtrInF = stageF.empty () ? nullptr : stageF.data ();
+            hPtrInM = stageM.empty () ? nullptr : stageM.data ();
+            const float T0[8] = { 0, 0, 0, 1, 0, 0, 0, 1 };
+            std::memcpy (stageT, T0, sizeof T0); hPtrIOT = stageT;
+            R = icp::Matrix3f (); q = icp::Quaternionf (); t = icp::Vector3f (); s = 1.f;
+        }
+
+        void pull ()
+        {
+            icp_state_t st; check (icp_state (h, &st));
+            std::memcpy (R.m, st.R, sizeof st.R); std::memcpy (q.c, st.q, sizeof st.q); std::memcpy (t.v, st.t, sizeof st.t); s = st.s;
+            std::memcpy (Rk.m, st.Rk, sizeof st.Rk); std::memcpy (qk.c, st.qk, sizeof st.qk); std::memcpy (tk.v, st.tk, sizeof st.tk); sk = st.sk;
+            std::memcpy (hPtrIOT, st.q, 16); std::memcpy (hPtrIOT + 4, st.t, 12); hPtrIOT[7] = st.s;
+            k_ = st.k;
+        }
+
+        icp::Env env;
+        icp_handle h;
+        Staging staging = Staging::IO;
+        float a, c;
+        unsigned int m, nr;
+        unsigned int k_ = 0;
+        void *dPtr[3] = { nullptr, nullptr, nullptr };
+        std::vector<float> stageF, stageM;
+        float stageT[8];
+    };
+
+    /*! \brief The iterative registration — mirrors `ICP<CR, CW>` (include/ICP/algorithms.hpp:2433-2496,
+     *         src/ICP/algorithms.cpp:4750-4903).
+     */
+    template <ICPStepConfigT CR, ICPStepConfigW CW>
+    class ICP : public ICPStep<CR, CW>
+    {
+    public:
+        ICP (icp::Env _env) : ICPStep<CR, CW> (_env), k (0), max_iterations (40), angle_threshold (0.001), translation_threshold (0.01) {}
+
+        void init (unsigned int _m, unsigned int _nr, float _a = 1e2f, float _c = 1e-6f, unsigned int _max_iterations = 40,
+                   double _angle_threshold = 0.001, double _translation_threshold = 0.01, Staging _staging = Staging::IO)
+        {
+            max_iterations = _max_iterations; angle_threshold = _angle_threshold; translation_threshold = _translation_threshold;
+            this->init_ (_m, _nr, _a, _c, _max_iterations, _angle_threshold, _translation_threshold, _staging);
+        }
+
+        void buildRBC () { ICPStep<CR, CW>::buildRBC (); k = 0; }
+
+        /*! \brief Blocking; iterates until check () stops (src/ICP/algorithms.cpp:4806-4834). */
+        void run ()
+        {
+            uint32_t kk = 0;
+            this->check (icp_run (this->h, &kk));
+            this->pull ();
+            k = kk;
+        }
+
+        unsigned int getMaxIterations () { return max_iterations; }
+        void setMaxIterations (unsigned int n) { this->check (icp_set_max_iterations (this->h, n)); max_iterations = n; }
+        double getAngleThreshold () { return angle_threshold; }
+        void setAngleThreshold (double d) { this->check (icp_set_angle_threshold (this->h, d)); angle_threshold = d; }
+        double getTranslationThreshold () { return translation_threshold; }
+        void setTranslationThreshold (double d) { this->check (icp_set_translation_threshold (this->h, d)); translation_threshold = d; }
+
+        unsigned int k;  /*!< iterations executed (reference: ICP::k, include/ICP/algorithms.hpp:2462) */
+
+    protected:
+        unsigned int max_iterations;
+        double angle_threshold;
+        double translation_threshold;
+    };
+}
+}
+
+#endif  // ICP_ALGORITHMS_HPP

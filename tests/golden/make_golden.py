@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/oracle_vectors.npz from the CPU oracle and the synthetic generator.
+
+The reference itself cannot be built or run in this image (CLUtils / RandomBallCover / Eigen /
+OpenCL device absent; its CPU twins need <RBC/data_types.hpp>), so these vectors are the
+oracle's own outputs on seeded inputs: they pin the oracle (and the engine) against regressions.
+The reference-held literals live in reference_kat.json.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+import icp_amd  # noqa: E402  (host-only generator; no GPU needed)
+
+
+def main():
+    out = {}
+    side, nr = 32, 16
+    F, M = icp_amd.synth_pair(side)
+    out["F_head"] = F[:64]
+    out["M_head"] = M[:64]
+    out["F_sum"] = F.astype(np.float64).sum(0)
+    out["M_sum"] = M.astype(np.float64).sum(0)
+    o = O.OracleICP(side * side, nr, 2e2, 1e-6)
+    o.write_f(F)
+    o.write_m(M)
+    o.build_rbc()
+    out["rbc_N"], out["rbc_O"] = o.rbc_N, o.rbc_O
+    out["rbc_perm"], out["rbc_owner"] = o.rbc_perm, o.rbc_owner
+    Ts, Tks, Ss, ms, sws, ids, dists = [], [], [], [], [], [], []
+    for _ in range(5):
+        o.step()
+        Ts.append(o.T); Tks.append(o.Tk); Ss.append(o.S); ms.append(o.means); sws.append(o.sum_w)
+        nn = o.nn_id
+        ids.append(nn["id"][:64].copy()); dists.append(nn["dist"][:64].copy())
+    out.update(T=np.array(Ts), Tk=np.array(Tks), S=np.array(Ss), means=np.array(ms), sum_w=np.array(sws),
+               nn_id_head=np.array(ids), nn_dist_head=np.array(dists))
+    k = o.run()
+    out["run_k"] = np.array([o.k])
+    out["run_T"] = o.T
+    # config 1 plumbing: SVD rotation path on the CPU oracle, kg-like pair at 16384 / 256 is covered by
+    # tests; here a small one
+    s = O.OracleICP(side * side, nr, 2e2, 1e-6, rot=O.ROT_SVD)
+    s.write_f(F); s.write_m(M); s.build_rbc()
+    out["svd_k"] = np.array([s.run()])
+    out["svd_T"] = s.T
+    np.savez_compressed(os.path.join(HERE, "oracle_vectors.npz"), **out)
+    print("wrote", os.path.join(HERE, "oracle_vectors.npz"), {k: np.asarray(v).shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

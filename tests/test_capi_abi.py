@@ -1,0 +1,87 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU, exports every symbol the
+header declares, and fails loudly (no CPU fallback) when no device is visible."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "icp_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(icp_[a-z_0-9]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_header_is_plain_c():
+    """The header must compile as C (extern "C", plain pointers and sizes, no torch / HIP types)."""
+    code = '#include "icp_amd.h"\nint main(void){ icp_state_t s; (void) s; return (int) sizeof (icp_handle) - (int) sizeof (void *); }\n'
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        "-x", "c", "-", "-o", "/dev/null"], input=code.encode(), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    hdr = open(os.path.join(ROOT, "include", "icp_amd.h")).read()
+    incs = re.findall(r"#include\s*[<\"]([^>\"]+)", hdr)
+    assert sorted(incs) == ["stddef.h", "stdint.h"], incs          # nothing but plain C in the signatures
+
+
+def test_library_exports_every_declared_symbol(engine):
+    L = engine.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 35
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+    assert L.icp_version().startswith(b"icp_amd")
+
+
+def test_no_cpu_fallback(engine):
+    """Without a device icp_create must fail with ICP_ENODEVICE and a message; with one it must succeed."""
+    L = engine.lib()
+    n = C.c_int(-1)
+    L.icp_device_count(C.byref(n))
+    h = C.c_void_p()
+    rc = L.icp_create(C.byref(h), 0, 1, 1)
+    if n.value <= 0:
+        assert rc == 5 and not h.value
+        assert b"no HIP device" in L.icp_last_error(None)
+        with pytest.raises(engine.ICPError):
+            engine.ICP(0)
+    else:
+        assert rc == 0 and h.value
+        L.icp_destroy(h)
+
+
+def test_create_argument_checks(engine):
+    L = engine.lib()
+    h = C.c_void_p()
+    assert L.icp_create(C.byref(h), 0, 7, 1) == 1          # ICP_EINVAL before touching the device
+    assert L.icp_create(None, 0, 1, 1) == 1
+    assert L.icp_destroy(None) == 1 and L.icp_sync(None) == 1
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under icp_amd/ or include/ may mention it."""
+    for base in ("icp_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp")):
+                    txt = open(os.path.join(dp, f)).read()
+                    assert "libicp_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(dp, f)
+
+
+def test_synth_generator_is_host_only_and_deterministic(engine):
+    F1, M1 = engine.synth_pair(16)
+    F2, M2 = engine.synth_pair(16)
+    assert np.array_equal(F1, F2) and np.array_equal(M1, M2)
+    assert np.all(F1[:, 3] == 1) and np.all(F1[:, 7] == 1) and F1[:, 4:7].min() >= 0 and F1[:, 4:7].max() <= 1
+    assert 1000 < F1[:, 2].mean() < 2200                       # depth in mm
+    F3, M3 = engine.synth_pair(16, seed=5)
+    assert np.array_equal(F1, F3) and not np.array_equal(M1, M3)   # the seed drives the noise only
+    Fz, Mz = engine.synth_pair(32, zero_fraction=0.25)
+    assert 0.1 < np.mean(np.all(Fz[:, :3] == 0, axis=1)) < 0.4
+    cloud = engine.synth_cloud_vga()
+    assert cloud.shape == (640 * 480, 8) and np.isfinite(cloud).all()

@@ -1,0 +1,88 @@
+"""GPU tests of the C++ facade (include/ICP/algorithms.hpp), getLMs / full-cloud transform and
+the host-visible error behaviour, all through the C-ABI."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_facade_matches_oracle(engine, oracle):
+    exe = os.path.join(ROOT, "tests", "cpp", "facade_test")
+    subprocess.check_call(["make", "-C", ROOT, "-s", "facade_test"])
+    out = subprocess.run([exe, "64", "64"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = {l.split()[0]: l.split()[1:] for l in out.stdout.strip().splitlines()}
+    F, M = engine.synth_pair(64)
+    o = oracle.OracleICP(4096, 64, 2e2, 1e-6, threads=8)
+    o.write_f(F); o.write_m(M); o.build_rbc()
+    k = o.run()
+    assert int(lines["k"][0]) == k
+    T = np.array([float(x) for x in lines["T"]], np.float32)
+    assert np.array_equal(T.view(np.uint32), o.T.view(np.uint32))
+    s = oracle.OracleICP(4096, 64, 2e2, 1e-6, threads=8)
+    s.write_f(F); s.write_m(M); s.build_rbc(); s.step(); s.step()
+    S = np.array([float(x) for x in lines["S"]], np.float32)
+    assert np.array_equal(S.view(np.uint32), s.T.view(np.uint32))
+    assert "alpha parameter cannot be equal to zero" in " ".join(lines["ERR"])
+
+
+def test_get_lms_and_cloud_transform(engine, oracle):
+    cloud_f = engine.synth_cloud_vga(moved=False)
+    cloud_m = engine.synth_cloud_vga(moved=True)
+    g = engine.ICP(0)
+    g.init(16384, 256, 2e2, 1e-6)
+    g.write_cloud(engine.Memory.F, cloud_f)
+    g.write_cloud(engine.Memory.M, cloud_m)
+    assert np.array_equal(g.read(engine.Memory.F), oracle.get_lms(cloud_f))        # exact, tests/testsICP.cpp:66
+    assert np.array_equal(g.read(engine.Memory.M), oracle.get_lms(cloud_m))
+    g.buildRBC()
+    k = g.run()
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8)
+    o.write_f(oracle.get_lms(cloud_f)); o.write_m(oracle.get_lms(cloud_m)); o.build_rbc()
+    assert k == o.run()
+    T = g.read(engine.Memory.T)
+    assert np.array_equal(T.view(np.uint32), o.T.view(np.uint32))
+    moved = g.transform_cloud(cloud_m)                                              # src/ocl_icp_reg.cpp:175
+    want = oracle.transform_q(cloud_m, o.T)
+    assert np.array_equal(moved.view(np.uint32), want.view(np.uint32))
+    g.close()
+
+
+def test_error_paths(engine):
+    g = engine.ICP(0)
+    for args in [(0, 4), (16, 0), (15, 4), (16, 3), (1000, 4), (16, 64)]:
+        with pytest.raises(engine.ICPError):
+            g.init(*args)
+    with pytest.raises(engine.ICPError):
+        g.init(16, 4, 0.0)                                  # alpha == 0 (src/ICP/algorithms.cpp:4419)
+    with pytest.raises(engine.ICPError):
+        g.buildRBC()                                        # before init
+    g.init(16, 4)
+    with pytest.raises(engine.ICPError):
+        g.run()                                             # before buildRBC
+    with pytest.raises(ValueError):
+        g.write(engine.Memory.F, np.zeros(7, np.float32))
+    assert g.getAlpha() == pytest.approx(100.0) and g.getScaling() == pytest.approx(1e-6)
+    g.setAlpha(50.0); g.setScaling(1e-5); g.setMaxIterations(7); g.setAngleThreshold(0.5); g.setTranslationThreshold(2.0)
+    assert (g.getAlpha(), g.getMaxIterations(), g.getAngleThreshold(), g.getTranslationThreshold()) == (50.0, 7, 0.5, 2.0)
+    with pytest.raises(engine.ICPError):
+        g.setAlpha(0.0)
+    g.close()
+
+
+def test_set_alpha_changes_the_metric(engine, oracle):
+    F, M = engine.synth_pair(32)
+    g = engine.ICP(0)
+    g.init(1024, 16, 2e2, 1e-6)
+    g.write(engine.Memory.F, F); g.write(engine.Memory.M, M)
+    g.setAlpha(1e-9)                                         # "really small a": colour ignored (data/README.md:12)
+    g.buildRBC(); g.step()
+    o = oracle.OracleICP(1024, 16, 1e-9, 1e-6)
+    o.write_f(F); o.write_m(M); o.build_rbc(); o.step()
+    assert np.array_equal(g.read(engine.Memory.NN_ID)["id"], o.nn_id["id"])
+    assert np.array_equal(g.read(engine.Memory.T).view(np.uint32), o.T.view(np.uint32))
+    g.close()

@@ -1,0 +1,53 @@
+"""The N > 1 path of bench.py on CPU: two gloo ranks, 'replicas only' aggregation
+(time = max over ranks, units = sum over ranks, no data-path collective)."""
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t, u = bench.aggregate(dist, 1.0 + rank, 100 * (rank + 1))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, t, u))
+
+
+def test_aggregate_world_size_2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, t, u in res:
+        assert t == pytest.approx(2.0)       # MAX over ranks
+        assert u == pytest.approx(300.0)     # SUM over ranks
+
+
+def test_aggregate_single_process():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.aggregate(None, 0.5, 40) == (0.5, 40)
+    assert bench.ALGO_BYTES_PER_ITER == 72 * 16384 + 32 * 256 + 64 == 1187904

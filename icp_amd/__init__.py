@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["ICP", "ICPStep", "ICPError", "Memory", "ICPStepConfigT", "ICPStepConfigW",
-           "PowerMode", "lib", "lib_path", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
+           "PowerMode", "ReduceMode", "lib", "lib_path", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("ICP_AMD_LIB", os.path.join(_HERE, "libicp_amd.so"))   # override: A/B builds of the same ABI
@@ -40,6 +40,11 @@ class ICPStepConfigW:            # include/ICP/algorithms.hpp:1560
 class PowerMode:
     LITERAL = 0
     SQUARED = 1
+
+
+class ReduceMode:
+    REFERENCE_ORDER = 0
+    FUSED = 1
 
 
 class Memory:                    # icp_mem in include/icp_amd.h
@@ -105,6 +110,7 @@ def lib():
     sig("icp_get_translation_threshold", i32, vp, C.POINTER(f64))
     sig("icp_set_translation_threshold", i32, vp, f64)
     sig("icp_set_power_mode", i32, vp, i32)
+    sig("icp_set_reduce_mode", i32, vp, i32)
     sig("icp_state", i32, vp, C.POINTER(_State))
     sig("icp_state_b", i32, vp, u32, C.POINTER(_State))
     sig("icp_write_cloud", i32, vp, i32, vp, i32)
@@ -252,6 +258,9 @@ class ICPStep:
     # -- extensions ------------------------------------------------------------------------
     def setPowerMode(self, mode):
         self._chk(self._L.icp_set_power_mode(self._h, mode))
+
+    def setReduceMode(self, mode):
+        self._chk(self._L.icp_set_reduce_mode(self._h, mode))
 
     def sync(self):
         self._chk(self._L.icp_sync(self._h))

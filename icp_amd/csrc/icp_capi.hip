@@ -224,11 +224,11 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if (m > (1u << 20)) return fail (h, ICP_EINVAL, "m must be <= 2^20");
     int rc = set_device (h); if (rc) return rc;
     if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
-    int rot = h->p.rot, weighted = h->p.weighted, pmode = h->p.power_mode;
+    int rot = h->p.rot, weighted = h->p.weighted, pmode = h->p.power_mode, fused = h->p.fused;
     free_all (h);
     icp_params &p = h->p;
     p = icp_params {};
-    p.rot = rot; p.weighted = weighted; p.power_mode = pmode; p.check = 0;
+    p.rot = rot; p.weighted = weighted; p.power_mode = pmode; p.check = 0; p.fused = fused;
     p.m = m; p.nr = nr; p.batch = batch; p.side = side; p.nrx = nrx; p.nry = nry;
     p.a = a; p.c = c;
     h->max_iterations = max_iterations; h->angle_threshold = angle_threshold; h->translation_threshold = translation_threshold;
@@ -240,6 +240,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     p.G = n4 / 4;                                                    // :2344-2346
     p.nsp = (p.G + 511u) / 512u; if (p.nsp != 1 && (p.nsp % 4)) p.nsp += 4 - p.nsp % 4;   // :140-142
     p.nchunk = (m + ICP_CHUNK - 1) / ICP_CHUNK;
+    p.nb = (m + 63u) / 64u;
 
     const size_t B = batch;
     float *F = nullptr, *M = nullptr;
@@ -264,6 +265,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &p.mscr, B * 2 * ((p.nwg + 127u) / 128u)))) return rc;
     if ((rc = dalloc (h, &p.spart, B * 11 * p.nsp * 8))) return rc;    // 8 sub-trees per work-group; padding stays 0.f
     if ((rc = dalloc (h, &p.sscr, B * 11 * ((((p.nsp + 511u) / 512u) + 3u) & ~3u)))) return rc;
+    if ((rc = dalloc (h, &p.mom, B * 18 * p.nb))) return rc;
     if ((rc = dalloc (h, &p.st, B))) return rc;
     if (!h->dTin) HIPCHK (h, hipMalloc ((void **) &h->dTin, 8 * sizeof (float)));
     HIPCHK (h, hipHostMalloc ((void **) &h->hF, B * m * 8 * sizeof (float), hipHostMallocDefault));
@@ -498,6 +500,13 @@ int icp_set_power_mode (icp_handle h, int mode)
     if (!h) return ICP_EINVAL;
     if (mode != ICP_POWER_LITERAL && mode != ICP_POWER_SQUARED) return fail (h, ICP_EINVAL, "unknown power mode");
     h->p.power_mode = mode; drop_graphs (h); return ICP_OK;
+}
+
+int icp_set_reduce_mode (icp_handle h, int mode)
+{
+    if (!h) return ICP_EINVAL;
+    if (mode != ICP_REDUCE_REFERENCE_ORDER && mode != ICP_REDUCE_FUSED) return fail (h, ICP_EINVAL, "unknown reduce mode");
+    h->p.fused = mode; drop_graphs (h); return ICP_OK;
 }
 
 int icp_state_b (icp_handle h, uint32_t b, icp_state_t *out)

@@ -12,6 +12,7 @@ struct icp_params {
     uint32_t side, nrx, nry;     // landmark grid side and representative grid (getReps)
     float a, c;
     int weighted, rot, power_mode, check;
+    int fused;                   // 0: reference-order reductions (3 global trees), 1: single-pass double moments
     double tan_half_thr, trans_thr;
     // derived sizes
     uint32_t nwg;                // 128-element groups = ceil(m/128)         (weights / means partials)
@@ -19,6 +20,7 @@ struct icp_params {
     uint32_t G;                  // S columns = ceil4(m)/4                    (icpSijProducts work-items)
     uint32_t nsp;                // reduce_sum_f work-groups per S row, padded (multiple of 4 unless 1)
     uint32_t nchunk;             // ceil(m / ICP_CHUNK)
+    uint32_t nb;                 // fused mode: blocks of 64 pairs = ceil(m/64)
     // inputs / RBC
     const float *F, *M;          // [batch][m][8]
     float *R;                    // [batch][nr][8]
@@ -34,6 +36,7 @@ struct icp_params {
     float4 *mscr;                // [batch][2][ceil(nwg/128)]  scratch of the multi-level icpGMean
     float *spart;                // [batch][11][nsp*8] 8 residue sub-trees per work-group
     float *sscr;                 // [batch][11][..] scratch of the multi-level reduce_sum_f
+    double *mom;                 // [batch][18][nb]  fused mode: per-block moment partials
     icp_reg_state *st;           // [batch]
     unsigned long long *dbg;     // diagnostic builds only (ICP_DBG_STAMPS): [blocks][16] s_memtime stamps
 };

@@ -327,6 +327,20 @@ typedef float float2v __attribute__ ((ext_vector_type (2)));
         if (d_ < best2) { best2 = d_; bj = (J); bnn = (G); }                                          \
     }
 
+#define ICP_NMOM 18
+
+// fused mode: query index of local element e of block b (CPU twin: orc_fused_query).  8 x 8 tiles of the
+// landmark grid when its side is a multiple of 8, else 64 consecutive queries.
+static __device__ __forceinline__ uint32_t fused_query_index (uint32_t m, uint32_t side, uint32_t b, uint32_t e)
+{
+    if (side && (side & 7u) == 0u && side * side == m) {
+        uint32_t tpr = side >> 3, ty = b / tpr, tx = b - ty * tpr;
+        return (8u * ty + (e >> 3)) * side + 8u * tx + (e & 7u);
+    }
+    return b * 64u + e;
+}
+
+template <bool FUSED>
 __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
 {
     const uint32_t b = blockIdx.y;
@@ -345,11 +359,14 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
     __shared__ uint32_t s_idx[KS_SPLIT][64];
     __shared__ float4 s_nn[KS_SPLIT][64];
     __shared__ float s_w[64];
+    __shared__ double s_mom[FUSED ? ICP_NMOM : 1][64];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t slice = __builtin_amdgcn_readfirstlane (tid >> 6);
-    const uint32_t grp = blockIdx.x >> 1, parity = blockIdx.x & 1u;
-    const uint32_t i = grp * 128u + 2u * lane + parity;
+    // reference-order mode: the 64 even (or odd) positions of one 128-query group (a closed sub-tree of
+    // the weight reduction); fused mode: an 8 x 8 tile of the landmark grid (spatially coherent lists)
+    const uint32_t i = FUSED ? fused_query_index (p.m, p.side, blockIdx.x, lane)
+                             : (blockIdx.x >> 1) * 128u + 2u * lane + (blockIdx.x & 1u);
     const bool valid = i < p.m;
 
     const float4 *M4 = reinterpret_cast<const float4 *> (p.M + (size_t) b * p.m * 8);
@@ -492,6 +509,7 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
             if (ds < d || (ds == d && js < j)) { d = ds; j = js; sw = s; }     // ties -> lowest list position
         }
         float w = 0.f;
+        float s_nn_x = 0.f, s_nn_y = 0.f, s_nn_z = 0.f;
         if (valid) {
             uint32_t id; float4 nn;
             if (n == 0) {            // empty list: fall back to the representative itself
@@ -507,12 +525,36 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
             p.PF[(size_t) b * p.m + i] = make_float4 (nn.x, nn.y, nn.z, w);
             p.PM[(size_t) b * p.m + i] = make_float4 (qx, qy, qz, d);
             p.rid[(size_t) b * p.m + i] = rstar;
+            s_nn_x = nn.x; s_nn_y = nn.y; s_nn_z = nn.z;
         }
-        s_w[lane] = w;
+        if (FUSED) {
+            // the 18 moments of this pair in double (oracle orc_moments_fused); invalid lanes contribute 0
+            double W = (double) w;
+            double f0 = valid ? (double) s_nn_x : 0.0, f1 = valid ? (double) s_nn_y : 0.0, f2 = valid ? (double) s_nn_z : 0.0;
+            double q0 = (double) qx, q1 = (double) qy, q2 = (double) qz;
+            if (!valid) { W = 0.0; q0 = q1 = q2 = 0.0; }
+            double wq0 = W * q0, wq1 = W * q1, wq2 = W * q2;
+            s_mom[0][lane] = W;
+            s_mom[1][lane] = W * f0; s_mom[2][lane] = W * f1; s_mom[3][lane] = W * f2;
+            s_mom[4][lane] = wq0; s_mom[5][lane] = wq1; s_mom[6][lane] = wq2;
+            s_mom[7][lane] = wq0 * f0; s_mom[8][lane] = wq0 * f1; s_mom[9][lane] = wq0 * f2;
+            s_mom[10][lane] = wq1 * f0; s_mom[11][lane] = wq1 * f1; s_mom[12][lane] = wq1 * f2;
+            s_mom[13][lane] = wq2 * f0; s_mom[14][lane] = wq2 * f1; s_mom[15][lane] = wq2 * f2;
+            s_mom[16][lane] = W * ((f0 * f0 + f1 * f1) + f2 * f2);
+            s_mom[17][lane] = W * ((q0 * q0 + q1 * q1) + q2 * q2);
+        } else
+            s_w[lane] = w;
     }
     KS_STAMP (6)
     __syncthreads ();
-    if (slice == 0 && p.weighted) {
+    if (FUSED) {
+        // halving tree over the block's 64 pairs, one 16-lane row per moment (rows 0..17 of the 32 rows)
+        const uint32_t l = lane & 15u, mrow = slice * 4u + (lane >> 4);
+        const uint32_t k = min (mrow, (uint32_t) ICP_NMOM - 1u);
+        double c0 = s_mom[k][l] + s_mom[k][l + 32], c1 = s_mom[k][l + 16] + s_mom[k][l + 48];
+        double v = row_tree_tail_d (c0 + c1);
+        if (l == 0 && mrow < ICP_NMOM) p.mom[((size_t) b * ICP_NMOM + mrow) * p.nb + blockIdx.x] = v;
+    } else if (slice == 0 && p.weighted) {
         // tree levels d = 64 .. 2 restricted to this block's parity class (icp_kernels.cl:244-249):
         // element e of the class is position 2e + parity; levels pair e with e+32, e+16, .., e+1.
         const uint32_t l = lane & 15u;
@@ -739,6 +781,88 @@ __global__ __launch_bounds__ (192) void k_finalize (icp_params p)
 }
 
 // ------------------------------------------------------------------------------------------
+// fused mode finalize: 128-position double trees over the block moments, means / S from the moments
+// (oracle orc_moments_fused / orc_moments_finish), then rotation, composition, convergence.
+// One block of 5 waves per registration: row k (of 20) reduces moment k.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__ (320) void k_finalize_fused (icp_params p)
+{
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, l = tid & 15u, row = tid >> 4;
+    icp_reg_state *st = p.st + b;
+    if (p.check && st->done) return;
+
+    __shared__ double s_l1[ICP_NMOM][128];
+    __shared__ double s_t[ICP_NMOM];
+    {
+        const uint32_t k = min (row, (uint32_t) ICP_NMOM - 1u);
+        const double *src = p.mom + ((size_t) b * ICP_NMOM + k) * p.nb;
+        const uint32_t ng = (p.nb + 127u) / 128u;                   // <= 128 (m <= 2^20)
+        double res = 0.0;
+        for (uint32_t g = 0; g < ng; ++g) {
+            double a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                uint32_t i = g * 128u + l + 16u * q;
+                a[q] = (i < p.nb) ? src[i] : 0.0;
+            }
+            double v = row_tree8_d (a);
+            if (ng == 1) res = v; else if (l == 0) s_l1[k][g] = v;
+        }
+        if (p.nb == 1) res = src[0];
+        if (ng > 1) {
+            __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier ();
+            double a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                uint32_t i = l + 16u * q;
+                a[q] = (i < ng) ? s_l1[k][i] : 0.0;
+            }
+            res = row_tree8_d (a);
+        }
+        if (l == 0 && row < ICP_NMOM) s_t[row] = res;
+    }
+    __syncthreads ();
+    if (tid >= 64) return;
+
+    double t[ICP_NMOM];
+#pragma unroll
+    for (int k = 0; k < ICP_NMOM; ++k) t[k] = s_t[k];
+    // oracle orc_moments_finish
+    const double sw = t[0];
+    double mf[3], mq[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mf[a] = t[1 + a] / sw; mq[a] = t[4 + a] / sw; }
+    const double c2 = (double) p.c * (double) p.c;
+    float S[11], means[8];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) S[3 * a + bb] = (float) (c2 * (t[7 + 3 * a + bb] - t[4 + a] * mf[bb]));
+    S[9]  = (float) (c2 * (t[16] - ((t[1] * mf[0] + t[2] * mf[1]) + t[3] * mf[2])));
+    S[10] = (float) (c2 * (t[17] - ((t[4] * mq[0] + t[5] * mq[1]) + t[6] * mq[2])));
+    means[0] = (float) mf[0]; means[1] = (float) mf[1]; means[2] = (float) mf[2]; means[3] = 0.f;
+    means[4] = (float) mq[0]; means[5] = (float) mq[1]; means[6] = (float) mq[2]; means[7] = 0.f;
+
+    float Tk[8], Rk[9];
+    int iters = 0;
+    if (p.rot == 1) iters = icp_power_method_quad (S, means, Tk, p.power_mode, lane);
+    else icp_svd_rotation (S, means, Rk, Tk);
+
+    if (lane == 0) {
+        icp_compose (st, Tk, Rk, p.rot != 1);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) st->S[k] = S[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st->means[k] = means[k];
+        st->sum_w = sw;
+        st->pm_iters = (uint32_t) iters;
+        st->k = st->k + 1;
+        if (p.check && icp_check_converged (Tk, p.tan_half_thr, p.trans_thr)) st->done = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 void icp_launch_reset_state (const icp_params &p, hipStream_t s, int reset_T)
@@ -775,8 +899,8 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 
 void icp_launch_search (const icp_params &p, hipStream_t s)
 {
-    dim3 grid (2 * p.nwg, p.batch);
-    hipLaunchKernelGGL (k_search, grid, dim3 (64 * KS_SPLIT), 0, s, p);
+    if (p.fused) hipLaunchKernelGGL (k_search<true>, dim3 (p.nb, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
+    else hipLaunchKernelGGL (k_search<false>, dim3 (2 * p.nwg, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
 }
 
 void icp_launch_means (const icp_params &p, hipStream_t s)
@@ -793,7 +917,8 @@ void icp_launch_sij (const icp_params &p, hipStream_t s)
 
 void icp_launch_finalize (const icp_params &p, hipStream_t s)
 {
-    hipLaunchKernelGGL (k_finalize, dim3 (p.batch), dim3 (192), 0, s, p);
+    if (p.fused) hipLaunchKernelGGL (k_finalize_fused, dim3 (p.batch), dim3 (320), 0, s, p);
+    else hipLaunchKernelGGL (k_finalize, dim3 (p.batch), dim3 (192), 0, s, p);
 }
 
 __global__ void k_nop (icp_params p) { if (p.m == 0xFFFFFFFFu) p.st->k = 0; }
@@ -802,8 +927,8 @@ __global__ void k_nop (icp_params p) { if (p.m == 0xFFFFFFFFu) p.st->k = 0; }
 void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask)
 {
     if (mask & 1u) icp_launch_search (p, s);
-    if (mask & 2u) icp_launch_means (p, s);
-    if (mask & 4u) icp_launch_sij (p, s);
+    if ((mask & 2u) && !p.fused) icp_launch_means (p, s);
+    if ((mask & 4u) && !p.fused) icp_launch_sij (p, s);
     if (mask & 8u) icp_launch_finalize (p, s);
     if (mask & 16u) hipLaunchKernelGGL (k_nop, dim3 (256, p.batch), dim3 (64), 0, s, p);
 }
@@ -811,7 +936,9 @@ void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask)
 void icp_launch_iteration (const icp_params &p, hipStream_t s)
 {
     icp_launch_search (p, s);
-    icp_launch_means (p, s);
-    icp_launch_sij (p, s);
+    if (!p.fused) {
+        icp_launch_means (p, s);
+        icp_launch_sij (p, s);
+    }
     icp_launch_finalize (p, s);
 }

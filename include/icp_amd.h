@@ -45,6 +45,13 @@ typedef enum { ICP_W_REGULAR = 0, ICP_W_WEIGHTED = 1 } icp_weighting;
  * (kernels/icp_kernels.cl:1003-1022); SQUARED = same loop started from normalize(N^1024 * 1). */
 typedef enum { ICP_POWER_LITERAL = 0, ICP_POWER_SQUARED = 1 } icp_power_mode;
 
+/* How the three reductions of an iteration are evaluated.
+ * REFERENCE_ORDER: sum of weights -> means -> S as three global trees in the reference's order
+ * (kernels/icp_kernels.cl:213-329, 455-566, 588-743); every intermediate matches the literal oracle.
+ * FUSED: one pass accumulating 18 moments in double, means and S derived from them; one global tree;
+ * correspondences identical for identical T, means / S / T within 1 ulp of the coordinates. */
+typedef enum { ICP_REDUCE_REFERENCE_ORDER = 0, ICP_REDUCE_FUSED = 1 } icp_reduce_mode;
+
 /* Memory objects.  F/M/T are the reference's ICPStep::Memory D_IN_F / D_IN_M / D_IO_T
  * (include/ICP/algorithms.hpp:2241-2267); the rest are the intermediates the reference exposes
  * through the get() of its sub-objects (src/ICP/algorithms.cpp:4499-4581). */
@@ -159,6 +166,7 @@ int icp_set_angle_threshold (icp_handle h, double deg);
 int icp_get_translation_threshold (icp_handle h, double *mm);
 int icp_set_translation_threshold (icp_handle h, double mm);
 int icp_set_power_mode (icp_handle h, int mode);      /* icp_power_mode */
+int icp_set_reduce_mode (icp_handle h, int mode);     /* icp_reduce_mode */
 
 /* Public state members of ICPStep/ICP (Rk qk tk sk R q t s k) — blocking. */
 int icp_state (icp_handle h, icp_state_t *out);

@@ -685,12 +685,107 @@ void orc_svd_rotation (const float *S11, const float *means, float *Rk, float *T
 }
 
 /* ======================================================================================= */
+/* FUSED reduction mode (build's single-pass formulation).                  */
+/*   The reference chains three global reductions (sum of weights -> means -> S,            */
+/*   kernels/icp_kernels.cl:213-329, 455-566, 588-743).  Algebraically                       */
+/*       mean_f = sum(w f)/sum(w),   S_ab = c^2 (sum(w q_a f_b) - sum(w q_a) mean_f_b), ...   */
+/*   so one pass over the pairs that accumulates 18 moments in DOUBLE gives the same means,  */
+/*   S and scale terms (to ~1e-15 relative before the final rounding to float), with one     */
+/*   global reduction instead of three.  Canonical order: blocks of 64 pairs (8x8 tiles of   */
+/*   the landmark grid when its side is a multiple of 8, else 64 consecutive pairs), halving */
+/*   tree inside a block, then the 128-position tree over block partials until one remains.  */
+/* ======================================================================================= */
+#define NMOM 18
+
+static double tree64_d (double *data)
+{
+    for (uint32_t d = 32; d > 0; d >>= 1)
+        for (uint32_t i = 0; i < d; ++i) data[i] = data[i] + data[i + d];
+    return data[0];
+}
+
+/* query index of local element e of block b (the GPU twin: fused_query_index in icp_kernels.hip) */
+uint32_t orc_fused_query (uint32_t m, uint32_t side, uint32_t b, uint32_t e)
+{
+    if (side && (side % 8u) == 0 && (uint64_t) side * side == m) {
+        uint32_t tpr = side / 8u, ty = b / tpr, tx = b % tpr;
+        return (8u * ty + (e >> 3)) * side + 8u * tx + (e & 7u);
+    }
+    return b * 64u + e;
+}
+
+/* NN/tM are m x float8 (xyz used), W may be NULL (REGULAR: w = 1).  Outputs: sum_w, means[8], S[11]. */
+void orc_moments_fused (const float *NN, const float *tM, const float *Wt, uint32_t m, uint32_t side,
+                        float c, double *sum_w, float *mean8, float *S11)
+{
+    uint32_t nb = (m + 63u) / 64u;
+    double *part = (double *) calloc ((size_t) nb * NMOM, sizeof (double));
+    double data[NMOM][64];
+    for (uint32_t b = 0; b < nb; ++b) {
+        for (uint32_t e = 0; e < 64; ++e) {
+            uint32_t i = orc_fused_query (m, side, b, e);
+            double t[NMOM];
+            for (int k = 0; k < NMOM; ++k) t[k] = 0.0;
+            if (i < m) {
+                double w = Wt ? (double) Wt[i] : 1.0;
+                double f[3] = { NN[(size_t) i * 8], NN[(size_t) i * 8 + 1], NN[(size_t) i * 8 + 2] };
+                double q[3] = { tM[(size_t) i * 8], tM[(size_t) i * 8 + 1], tM[(size_t) i * 8 + 2] };
+                t[0] = w;
+                for (int a = 0; a < 3; ++a) { t[1 + a] = w * f[a]; t[4 + a] = w * q[a]; }
+                for (int a = 0; a < 3; ++a)
+                    for (int bb = 0; bb < 3; ++bb) t[7 + 3 * a + bb] = (w * q[a]) * f[bb];
+                t[16] = w * ((f[0] * f[0] + f[1] * f[1]) + f[2] * f[2]);
+                t[17] = w * ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
+            }
+            for (int k = 0; k < NMOM; ++k) data[k][e] = t[k];
+        }
+        for (int k = 0; k < NMOM; ++k) part[(size_t) b * NMOM + k] = tree64_d (data[k]);
+    }
+    /* 128-position tree over the block partials, repeated until one value per moment remains */
+    uint32_t n = nb;
+    double d128[WF2];
+    while (n > 1) {
+        uint32_t ng = (n + WF2 - 1) / WF2;
+        for (uint32_t g = 0; g < ng; ++g)
+            for (int k = 0; k < NMOM; ++k) {
+                for (uint32_t p = 0; p < WF2; ++p) {
+                    uint32_t i = g * WF2 + p;
+                    d128[p] = (i < n) ? part[(size_t) i * NMOM + k] : 0.0;
+                }
+                double r = tree_d (d128);
+                part[(size_t) g * NMOM + k] = r;      /* g <= i for every i of the group: in-place is safe per moment */
+            }
+        n = ng;
+    }
+    double t[NMOM];
+    for (int k = 0; k < NMOM; ++k) t[k] = part[k];
+    free (part);
+    orc_moments_finish (t, c, sum_w, mean8, S11);
+}
+
+/* moments -> sum of weights, means (float), S (float) */
+void orc_moments_finish (const double *t, float c, double *sum_w, float *mean8, float *S11)
+{
+    double sw = t[0], mf[3], mq[3];
+    for (int a = 0; a < 3; ++a) { mf[a] = t[1 + a] / sw; mq[a] = t[4 + a] / sw; }
+    double c2 = (double) c * (double) c;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) S11[3 * a + b] = (float) (c2 * (t[7 + 3 * a + b] - t[4 + a] * mf[b]));
+    S11[9]  = (float) (c2 * (t[16] - ((t[1] * mf[0] + t[2] * mf[1]) + t[3] * mf[2])));
+    S11[10] = (float) (c2 * (t[17] - ((t[4] * mq[0] + t[5] * mq[1]) + t[6] * mq[2])));
+    for (int a = 0; a < 3; ++a) { mean8[a] = (float) mf[a]; mean8[4 + a] = (float) mq[a]; }
+    mean8[3] = 0.f; mean8[7] = 0.f;
+    *sum_w = sw;
+}
+
+/* ======================================================================================= */
 /* pipeline object — ICPStep<CR,CW> / ICP<CR,CW>                                            */
 /*   init   src/ICP/algorithms.cpp:4403-4582     buildRBC :4655-4660                        */
 /*   run    :4670-4698 (POWER_METHOD), :3867-3909 (EIGEN)     ICP::run/check :4806-4834     */
 /* ======================================================================================= */
 struct orc_icp {
-    int rot, weighted, fast, threads;
+    int rot, weighted, fast, threads, fused;
+    uint32_t side;
     uint32_t m, nr, max_it, k;
     float a, c;
     double angle_thr, trans_thr, tan_half_thr;
@@ -735,7 +830,7 @@ int orc_icp_init (orc_icp *h, uint32_t m, uint32_t nr, float a, float c, uint32_
     if (m % 2) return -1;                                      /* :1573 (means need even n) */
     if (orc_reps_grid (m, nr, &nrx, &nry, &g)) return -1;
     free_bufs (h);
-    h->m = m; h->nr = nr; h->a = a; h->c = c; h->max_it = max_it;
+    h->m = m; h->nr = nr; h->a = a; h->c = c; h->max_it = max_it; h->side = g;
     h->angle_thr = angle_thr; h->trans_thr = trans_thr;
     h->tan_half_thr = tan (angle_thr * M_PI / 360.0);
     size_t fm = (size_t) m * 8;
@@ -751,6 +846,7 @@ int orc_icp_init (orc_icp *h, uint32_t m, uint32_t nr, float a, float c, uint32_
 }
 
 void orc_icp_set_power_fast (orc_icp *h, int fast) { h->fast = fast; }
+void orc_icp_set_fused (orc_icp *h, int fused) { h->fused = fused; }
 void orc_icp_set_threads (orc_icp *h, int threads) { h->threads = threads > 0 ? threads : 1; }
 void orc_icp_write_f (orc_icp *h, const float *F) { memcpy (h->F, F, (size_t) h->m * 32); }
 void orc_icp_write_m (orc_icp *h, const float *M) { memcpy (h->M, M, (size_t) h->m * 32); }
@@ -809,6 +905,10 @@ void orc_icp_step (orc_icp *h)
     orc_transform_q (h->M, h->tM, h->T, h->m);                                     /* transform.run */
     orc_rbc_search (h->tM, h->m, h->R, h->nr, h->XP, h->perm, h->O, h->N, h->rep_src, h->a,
                     h->nn_id, h->NN, h->rid);                                      /* rbcS.run      */
+    if (h->fused) {
+        if (h->weighted) for (uint32_t i = 0; i < h->m; ++i) h->W[i] = 100.f / (100.f + h->nn_id[i].dist);
+        orc_moments_fused (h->NN, h->tM, h->weighted ? h->W : NULL, h->m, h->side, h->c, &h->sum_w, h->means, h->S);
+    } else {
     if (h->weighted) {
         orc_weights (h->nn_id, h->m, h->W, &h->sum_w);                             /* weights.run   */
         orc_mean_weighted (h->NN, h->tM, h->W, h->sum_w, h->m, h->means);          /* means.run     */
@@ -816,6 +916,7 @@ void orc_icp_step (orc_icp *h)
         orc_mean (h->NN, h->tM, h->m, h->means);
     orc_devs (h->NN, h->tM, h->means, h->m, h->DF, h->DM);                         /* devs.run      */
     orc_sij (h->DM, h->DF, h->weighted ? h->W : NULL, h->m, h->c, h->S);           /* matrixS.run   */
+    }
     if (h->rot == ORC_ROT_POWER)
         h->pm_iters = h->fast ? orc_power_method_fast (h->S, h->means, h->Tk)      /* powMethod.run */
                               : orc_power_method (h->S, h->means, h->Tk);

@@ -11,12 +11,13 @@
  * NO fused multiply-add (build with -ffp-contract=off), IEEE divide and sqrt, reduction
  * trees of the reference's shape for a 64-wide wavefront (W = 64).
  *
- * PINNING STATUS
- *   - kernels a1,a3,a5..a9 (getReps, transform, weights, means, deviations, S matrix,
- *     power method): pinned against the reference's own CPU twins
- *     (include/ICP/tests/helper_funcs.hpp) compiled from /root/reference into
- *     oracle/_ref/ (see oracle/Makefile), against the power-method known-answer test
- *     (tests/testsICP.cpp:1008-1046) and the committed golden fixtures in tests/golden/.
+ * PINNING STATUS (details: DESIGN.md §2)
+ *   - The reference cannot be built or run in this image (CLUtils, RandomBallCover, Eigen and an
+ *     OpenCL device are absent; its CPU twins include <RBC/data_types.hpp>), so there is no
+ *     oracle/_ref.  The oracle is pinned against the reference's own known-answer literals and
+ *     test tolerances (tests/golden/reference_kat.json: power-method KAT tests/testsICP.cpp:
+ *     1008-1052, transform literals :821-822, :917-922, per-kernel tolerances), exact index
+ *     formulas (getLMs, getReps) and the committed golden vectors (tests/golden/).
  *   - RBC construct/search (a2,a4): ** PARITY UNPINNED **.  The algorithm lives in
  *     github.com/nlamprian/RandomBallCover (un-vendored, no pinned version:
  *     external/RandomBallCover/CMakeLists.txt:5-12) and the reference holds no test or
@@ -63,6 +64,10 @@ void     orc_devs (const float *F, const float *M, const float *mean8, uint32_t 
                    float *DF, float *DM);
 void     orc_sij (const float *DM, const float *DF, const float *W, uint32_t m, float c,
                   float *S11);
+uint32_t orc_fused_query (uint32_t m, uint32_t side, uint32_t b, uint32_t e);
+void     orc_moments_finish (const double *t18, float c, double *sum_w, float *mean8, float *S11);
+void     orc_moments_fused (const float *NN, const float *tM, const float *W, uint32_t m, uint32_t side,
+                            float c, double *sum_w, float *mean8, float *S11);
 int      orc_power_method (const float *S11, const float *mean8, float *Tk8);
 int      orc_power_method_fast (const float *S11, const float *mean8, float *Tk8);
 void     orc_svd_rotation (const float *S11, const float *mean8, float *Rk9, float *Tk8);
@@ -80,6 +85,7 @@ int      orc_icp_init (orc_icp *h, uint32_t m, uint32_t nr, float a, float c,
                        uint32_t max_iterations, double angle_threshold,
                        double translation_threshold);
 void     orc_icp_set_power_fast (orc_icp *h, int fast);
+void     orc_icp_set_fused (orc_icp *h, int fused);
 void     orc_icp_set_threads (orc_icp *h, int threads);
 void     orc_icp_write_f (orc_icp *h, const float *F);
 void     orc_icp_write_m (orc_icp *h, const float *M);

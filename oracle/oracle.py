@@ -71,6 +71,8 @@ def lib():
     sig("orc_icp_destroy", None, vp)
     sig("orc_icp_init", C.c_int, vp, u32, u32, C.c_float, C.c_float, u32, C.c_double, C.c_double)
     sig("orc_icp_set_power_fast", None, vp, C.c_int)
+    sig("orc_icp_set_fused", None, vp, C.c_int)
+    sig("orc_moments_fused", None, vp, vp, vp, u32, u32, C.c_float, C.POINTER(C.c_double), vp, vp)
     sig("orc_icp_set_threads", None, vp, C.c_int)
     sig("orc_icp_write_f", None, vp, vp)
     sig("orc_icp_write_m", None, vp, vp)
@@ -232,6 +234,21 @@ def sij(DM, DF, Wt, c):
     return out
 
 
+def moments_fused(NN, tM, Wt, side, c):
+    NN = _f32(NN)
+    tM = _f32(tM)
+    m = NN.shape[0]
+    means = np.empty(8, np.float32)
+    S = np.empty(11, np.float32)
+    sw = C.c_double()
+    wp = None
+    if Wt is not None:
+        Wt = _f32(Wt)
+        wp = _p(Wt)
+    lib().orc_moments_fused(_p(NN), _p(tM), wp, m, side, c, C.byref(sw), _p(means), _p(S))
+    return sw.value, means, S
+
+
 def power_method(S, means, fast=False):
     S = _f32(S)
     means = _f32(means)
@@ -277,7 +294,7 @@ class OracleICP:
 
     def __init__(self, m, nr, a=2e2, c=1e-6, rot=ROT_POWER, weighted=W_WEIGHTED,
                  max_iterations=40, angle_threshold=0.001, translation_threshold=0.01,
-                 power_fast=False, threads=1):
+                 power_fast=False, threads=1, fused=False):
         self.L = lib()
         self.h = self.L.orc_icp_create(rot, weighted)
         self.m, self.nr = m, nr
@@ -288,6 +305,7 @@ class OracleICP:
             raise ValueError("orc_icp_init rejected the arguments")
         self.L.orc_icp_set_power_fast(self.h, int(power_fast))
         self.L.orc_icp_set_threads(self.h, threads)
+        self.L.orc_icp_set_fused(self.h, int(fused))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -28,17 +28,19 @@ def assert_bits(got, want, what):
 
 
 def make(engine, oracle, side, nr, rot=1, weighted=1, power_fast=False, zero_fraction=0.0, seed=0x1C9D5EED,
-         max_iterations=40):
+         max_iterations=40, fused=False):
     m = side * side
     F, M = engine.synth_pair(side, seed=seed, zero_fraction=zero_fraction)
     g = engine.ICP(0, rot, weighted)
     g.init(m, nr, A, C_, max_iterations=max_iterations)
     if power_fast:
         g.setPowerMode(engine.PowerMode.SQUARED)
+    if fused:
+        g.setReduceMode(engine.ReduceMode.FUSED)
     g.write(engine.Memory.F, F)
     g.write(engine.Memory.M, M)
     o = oracle.OracleICP(m, nr, A, C_, rot=rot, weighted=weighted, power_fast=power_fast, threads=8,
-                         max_iterations=max_iterations)
+                         max_iterations=max_iterations, fused=fused)
     o.write_f(F)
     o.write_m(M)
     return g, o, F, M
@@ -278,4 +280,71 @@ def test_config5_properties(engine, oracle):
     assert_bits(g.read(Mem.S), S, "S")
     Tk, _ = oracle.power_method(S, means)
     assert_bits(g.read(Mem.TK), Tk, "Tk")
+    g.close()
+
+
+# ---- fused reduction mode: bit-exact against the oracle's fused restatement, and within the
+# ---- north-star tolerance of the reference-order mode
+
+@pytest.mark.parametrize("side,nr,rot,weighted", [(128, 256, 1, 1), (32, 16, 1, 1), (30, 4, 1, 1), (6, 4, 1, 1),
+                                                   (64, 64, 1, 0), (64, 64, 0, 1)])
+def test_fused_steps_bit_exact(engine, oracle, side, nr, rot, weighted):
+    g, o, F, M = make(engine, oracle, side, nr, rot=rot, weighted=weighted, power_fast=True, fused=True)
+    g.buildRBC()
+    o.build_rbc()
+    for it in range(4):
+        g.step()
+        o.step()
+        check_step(engine, g, o, weighted=False)
+        if weighted:
+            assert_bits(g.read(engine.Memory.W), o.W, "weights")
+            assert_bits(g.read(engine.Memory.SUM_W), np.array([o.sum_w]), "sum of weights")
+    g.close()
+
+
+def test_fused_run_and_cross_mode_tolerance(engine, oracle):
+    """config 2 in fused mode: identical to the fused oracle; against the reference-order run: same k, the
+    same correspondences at the end, final [q | t, s] within 1e-5 relative (north star)."""
+    g, o, F, M = make(engine, oracle, 128, 256, power_fast=True, fused=True)
+    g.buildRBC()
+    o.build_rbc()
+    kg, ko = g.run(), o.run()
+    assert kg == ko
+    T = g.read(engine.Memory.T)
+    assert_bits(T, o.T, "final T (fused)")
+    check_step(engine, g, o, weighted=False)
+    r, orf, _, _ = make(engine, oracle, 128, 256, power_fast=True, fused=False)
+    r.buildRBC()
+    kr = r.run()
+    Tr = r.read(engine.Memory.T)
+    assert kr == kg
+    assert np.allclose(T, Tr, rtol=1e-5, atol=0), (T, Tr)
+    ids_f, ids_r = g.read(engine.Memory.NN_ID)["id"], r.read(engine.Memory.NN_ID)["id"]
+    assert np.mean(ids_f == ids_r) > 0.9995
+    g.close()
+    r.close()
+
+
+def test_fused_first_iteration_correspondences_equal_reference_order(engine, oracle):
+    """Same T => the search is the same code: ids and distances are bit-identical across the two modes."""
+    a, _, F, M = make(engine, oracle, 64, 64, fused=True)
+    b, _, _, _ = make(engine, oracle, 64, 64, fused=False)
+    for x in (a, b):
+        x.buildRBC()
+        x.step()
+    na, nb = a.read(engine.Memory.NN_ID), b.read(engine.Memory.NN_ID)
+    assert np.array_equal(na["id"], nb["id"])
+    assert_bits(na["dist"], nb["dist"], "dist")
+    a.close()
+    b.close()
+
+
+def test_fused_batched_and_large(engine, oracle):
+    g, o, F, M = make(engine, oracle, 256, 1024, power_fast=True, fused=True)          # config 3
+    g.buildRBC()
+    o.build_rbc()
+    for _ in range(2):
+        g.step()
+        o.step()
+        check_step(engine, g, o, weighted=False)
     g.close()

@@ -300,3 +300,42 @@ def test_init_rejects(oracle):
             oracle.OracleICP(bad[0], bad[1])
     with pytest.raises(ValueError):
         oracle.OracleICP(16, 4, a=0.0)
+
+
+def test_fused_mode_agrees_with_reference_order(oracle, engine):
+    """the single-pass double-moment formulation gives the reference-order means / S / T to
+    within fp32 rounding of the coordinates, the same iteration count and the same final correspondences."""
+    F, M = engine.synth_pair(64)
+    res = []
+    for fused in (False, True):
+        o = oracle.OracleICP(4096, 64, 2e2, 1e-6, threads=8, fused=fused)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        o.step()
+        first = (o.S, o.means, o.sum_w, o.nn_id["id"])
+        k = o.run()
+        res.append((first, k, o.T, o.nn_id["id"]))
+    (S0, m0, sw0, id0), k0, T0, idf0 = res[0]
+    (S1, m1, sw1, id1), k1, T1, idf1 = res[1]
+    assert np.array_equal(id0, id1)                                       # same T0 => same correspondences
+    assert abs(sw0 - sw1) < 4200 * EPS                                    # tests/testsICP.cpp:263
+    assert np.all(np.abs(S0 - S1) <= 4200 * EPS * np.abs(S0).max())      # :736
+    assert np.all(np.abs(m0 - m1) < 420000 * EPS)                         # :446
+    assert k0 == k1
+    assert np.allclose(T0, T1, rtol=1e-5, atol=0)
+    assert np.mean(idf0 == idf1) > 0.999
+
+
+def test_fused_moments_against_float64(oracle):
+    r = rng(9)
+    n, c = 4096, 1e-6
+    NN = cloud8(r, n, 0, 2000); Q = cloud8(r, n, 0, 2000); W = r.uniform(0.2, 1, n).astype(np.float32)
+    sw, means, S = oracle.moments_fused(NN, Q, W, 64, c)
+    w = W.astype(np.float64)
+    f, q = NN[:, :3].astype(np.float64), Q[:, :3].astype(np.float64)
+    mf, mq = (w[:, None] * f).sum(0) / w.sum(), (w[:, None] * q).sum(0) / w.sum()
+    Sref = c * c * np.einsum("i,ia,ib->ab", w, q - mq, f - mf).reshape(-1)
+    assert abs(sw - w.sum()) < 1e-9 * w.sum()
+    assert np.all(np.abs(means[:3] - mf) <= EPS * np.abs(mf)) and np.all(np.abs(means[4:7] - mq) <= EPS * np.abs(mq))
+    assert np.all(np.abs(S[:9] - Sref) <= 4 * EPS * np.abs(Sref).max())
+    assert abs(S[9] - c * c * (w * ((f - mf) ** 2).sum(1)).sum()) <= 4 * EPS * S[9]
+    assert abs(S[10] - c * c * (w * ((q - mq) ** 2).sum(1)).sum()) <= 4 * EPS * S[10]

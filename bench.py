@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--power-mode", choices=["literal", "squared"], default="squared")
+    ap.add_argument("--reduce-mode", choices=["reference", "fused"], default="fused")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,6 +106,7 @@ def main():
     g = icp_amd.ICP(local_rank)
     g.init(M_POINTS, N_REPS, ALPHA, SCALING)
     g.setPowerMode(icp_amd.PowerMode.SQUARED if args.power_mode == "squared" else icp_amd.PowerMode.LITERAL)
+    g.setReduceMode(icp_amd.ReduceMode.FUSED if args.reduce_mode == "fused" else icp_amd.ReduceMode.REFERENCE_ORDER)
     g.write(icp_amd.Memory.F, F)
     g.write(icp_amd.Memory.M, M)
     g.buildRBC()
@@ -160,7 +162,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic kg-like pair, |F|=|M|=16384, |R|=256, power method, weighted, "
                                    "a=2e2 c=1e-6; step = %d fixed iterations (one hipGraph), RBC prebuilt" % ITERS_PER_STEP,
-                       "parallelism": "replicas" if world > 1 else "single", "power_start": args.power_mode},
+                       "parallelism": "replicas" if world > 1 else "single", "power_start": args.power_mode,
+                       "reduce_mode": args.reduce_mode},
             "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ITER, "avg_launch_us": search_us,

@@ -138,7 +138,8 @@ int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *o
     p.check = check;
     graph_entry ge;
     HIPCHK (h, hipStreamBeginCapture (h->stream, hipStreamCaptureModeThreadLocal));
-    for (uint32_t k = 0; k < iterations; ++k) icp_launch_iteration (p, h->stream);
+    if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations);        // one launch per iteration
+    else for (uint32_t k = 0; k < iterations; ++k) icp_launch_iteration (p, h->stream);
     hipError_t e = hipStreamEndCapture (h->stream, &ge.graph);
     if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("hipStreamEndCapture: ") + hipGetErrorString (e));
     HIPCHK (h, hipGraphInstantiate (&ge.exec, ge.graph, nullptr, nullptr, 0));
@@ -265,7 +266,8 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &p.mscr, B * 2 * ((p.nwg + 127u) / 128u)))) return rc;
     if ((rc = dalloc (h, &p.spart, B * 11 * p.nsp * 8))) return rc;    // 8 sub-trees per work-group; padding stays 0.f
     if ((rc = dalloc (h, &p.sscr, B * 11 * ((((p.nsp + 511u) / 512u) + 3u) & ~3u)))) return rc;
-    if ((rc = dalloc (h, &p.mom, B * 18 * p.nb))) return rc;
+    if ((rc = dalloc (h, &p.mom, B * 2 * 18 * p.nb))) return rc;
+    if ((rc = dalloc (h, &p.cst, B * 2))) return rc;
     if ((rc = dalloc (h, &p.st, B))) return rc;
     if (!h->dTin) HIPCHK (h, hipMalloc ((void **) &h->dTin, 8 * sizeof (float)));
     HIPCHK (h, hipHostMalloc ((void **) &h->hF, B * m * 8 * sizeof (float), hipHostMallocDefault));

@@ -29,7 +29,7 @@ struct icp_reg_state {
     uint32_t k;          // iterations executed
     uint32_t done;       // 1: ICP::check() said stop
     uint32_t pm_iters;
-    uint32_t pad1;
+    uint32_t pending;    // chained fused mode: moments of an iteration are waiting to be turned into T
 };
 
 // ------------------------------------------------------------------------------------------
@@ -513,6 +513,28 @@ __device__ inline void icp_compose (icp_reg_state *st, const float *Tk, const fl
     for (int i = 0; i < 8; ++i) st->Tk[i] = Tk[i];
     st->T[0] = q[0]; st->T[1] = q[1]; st->T[2] = q[2]; st->T[3] = q[3];
     st->T[4] = tn[0]; st->T[5] = tn[1]; st->T[6] = tn[2]; st->T[7] = s;
+}
+
+// same composition as icp_compose, from explicit inputs to explicit outputs (chained fused mode)
+__device__ inline void icp_compose_pure (const float *Tprev, const float *Rprev, const float *Tk, const float *Rk_in, int have_rk,
+                                         float *Tn, float *Rn, float *Rk)
+{
+    if (have_rk) { for (int i = 0; i < 9; ++i) Rk[i] = Rk_in[i]; }
+    else icp_quat_to_rot (Tk, Rk);
+    float sk = Tk[7];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Rn[i * 3 + j] = (Rk[i * 3] * Rprev[j] + Rk[i * 3 + 1] * Rprev[3 + j]) + Rk[i * 3 + 2] * Rprev[6 + j];
+    float q[4]; icp_rot_to_quat (Rn, q);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float r0 = sk * Rk[i * 3], r1 = sk * Rk[i * 3 + 1], r2 = sk * Rk[i * 3 + 2];
+        Tn[4 + i] = ((r0 * Tprev[4] + r1 * Tprev[5]) + r2 * Tprev[6]) + Tk[4 + i];
+    }
+    Tn[0] = q[0]; Tn[1] = q[1]; Tn[2] = q[2]; Tn[3] = q[3];
+    Tn[7] = sk * Tprev[7];
 }
 
 // ICP::check — src/ICP/algorithms.cpp:4824-4834 (predicate form: oracle check_converged)

@@ -36,7 +36,9 @@ struct icp_params {
     float4 *mscr;                // [batch][2][ceil(nwg/128)]  scratch of the multi-level icpGMean
     float *spart;                // [batch][11][nsp*8] 8 residue sub-trees per work-group
     float *sscr;                 // [batch][11][..] scratch of the multi-level reduce_sum_f
-    double *mom;                 // [batch][18][nb]  fused mode: per-block moment partials
+    double *mom;                 // [batch][2][18][nb]  fused mode: per-block moment partials (double-buffered for the chain)
+    icp_reg_state *cst;          // [batch][2]  chained fused mode: state slots, launch j reads slot j&1 and writes the other
+    uint32_t slot;               // chained fused mode: slot this launch reads
     icp_reg_state *st;           // [batch]
     unsigned long long *dbg;     // diagnostic builds only (ICP_DBG_STAMPS): [blocks][16] s_memtime stamps
 };
@@ -49,6 +51,8 @@ void icp_launch_sij (const icp_params &p, hipStream_t s);
 void icp_launch_finalize (const icp_params &p, hipStream_t s);
 void icp_launch_iteration (const icp_params &p, hipStream_t s);
 void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask);
+void icp_launch_chain (const icp_params &p, hipStream_t s, uint32_t iterations);
+bool icp_chain_supported (const icp_params &p);
 void icp_launch_reset_state (const icp_params &p, hipStream_t s, int reset_T);
 void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStream_t s);
 void icp_launch_get_lms (const float *cloud, float *lms, hipStream_t s);

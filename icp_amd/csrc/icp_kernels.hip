@@ -340,16 +340,119 @@ static __device__ __forceinline__ uint32_t fused_query_index (uint32_t m, uint32
     return b * 64u + e;
 }
 
-template <bool FUSED>
+
+// Result of turning one iteration's moments into the next transform (all in LDS, one per block)
+struct icp_fin_result {
+    float T[8], Tk[8], R[9], Rk[9], S[11], means[8];
+    double sum_w;
+    uint32_t iters, done, k, pad;
+};
+
+// Block-cooperative: 128-position double trees over the block moments (rows 0..17 of the calling block,
+// needs >= 288 threads), then wave 0: means / S from the moments (oracle orc_moments_finish), rotation,
+// composition with (Tprev, Rprev), convergence.  Every thread of the block must call it; `res` is valid
+// for all threads after the call.  NG = capacity of the second tree level (groups of 128 blocks).
+template <int NG>
+static __device__ void fused_finalize_block (const icp_params &p, const double *mom, const float *Tprev, const float *Rprev,
+                                             uint32_t kprev, icp_fin_result *res, double (*s_l1)[NG], double *s_t)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, l = tid & 15u, row = tid >> 4;
+    if (row < 20) {                                  // whole waves 0..4
+        const uint32_t k = min (row, (uint32_t) ICP_NMOM - 1u);
+        const double *src = mom + (size_t) k * p.nb;
+        const uint32_t ng = (p.nb + 127u) / 128u;
+        double r = 0.0;
+        for (uint32_t g = 0; g < ng; ++g) {
+            double a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                uint32_t i = g * 128u + l + 16u * q;
+                a[q] = (i < p.nb) ? src[i] : 0.0;
+            }
+            double v = row_tree8_d (a);
+            if (ng == 1) r = v; else if (l == 0) s_l1[k][g] = v;
+        }
+        if (p.nb == 1) r = src[0];
+        if (ng > 1) {
+            __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier ();
+            double a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                uint32_t i = l + 16u * q;
+                a[q] = (i < ng) ? s_l1[k][i] : 0.0;
+            }
+            r = row_tree8_d (a);
+        }
+        if (l == 0 && row < ICP_NMOM) s_t[row] = r;
+    }
+    __syncthreads ();
+    if (tid < 64) {
+        double t[ICP_NMOM];
+#pragma unroll
+        for (int k = 0; k < ICP_NMOM; ++k) t[k] = s_t[k];
+        const double sw = t[0];
+        double mf[3], mq[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mf[a] = t[1 + a] / sw; mq[a] = t[4 + a] / sw; }
+        const double c2 = (double) p.c * (double) p.c;
+        float S[11], means[8];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) S[3 * a + bb] = (float) (c2 * (t[7 + 3 * a + bb] - t[4 + a] * mf[bb]));
+        S[9]  = (float) (c2 * (t[16] - ((t[1] * mf[0] + t[2] * mf[1]) + t[3] * mf[2])));
+        S[10] = (float) (c2 * (t[17] - ((t[4] * mq[0] + t[5] * mq[1]) + t[6] * mq[2])));
+        means[0] = (float) mf[0]; means[1] = (float) mf[1]; means[2] = (float) mf[2]; means[3] = 0.f;
+        means[4] = (float) mq[0]; means[5] = (float) mq[1]; means[6] = (float) mq[2]; means[7] = 0.f;
+        float Tk[8], Rk[9], Rkin[9];
+        int iters = 0;
+        if (p.rot == 1) iters = icp_power_method_quad (S, means, Tk, p.power_mode, lane);
+        else icp_svd_rotation (S, means, Rkin, Tk);
+        if (lane == 0) {
+            float Tn[8], Rn[9];
+            icp_compose_pure (Tprev, Rprev, Tk, Rkin, p.rot != 1, Tn, Rn, Rk);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { res->T[k] = Tn[k]; res->Tk[k] = Tk[k]; res->means[k] = means[k]; }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { res->R[k] = Rn[k]; res->Rk[k] = Rk[k]; }
+#pragma unroll
+            for (int k = 0; k < 11; ++k) res->S[k] = S[k];
+            res->sum_w = sw; res->iters = (uint32_t) iters; res->k = kprev + 1u;
+            res->done = (p.check && icp_check_converged (Tk, p.tan_half_thr, p.trans_thr)) ? 1u : 0u;
+        }
+    }
+    __syncthreads ();
+}
+
+static __device__ void fin_result_to_state (const icp_fin_result *res, icp_reg_state *st, uint32_t pending)
+{
+    for (int k = 0; k < 8; ++k) { st->T[k] = res->T[k]; st->Tk[k] = res->Tk[k]; st->means[k] = res->means[k]; }
+    for (int k = 0; k < 9; ++k) { st->R[k] = res->R[k]; st->Rk[k] = res->Rk[k]; }
+    for (int k = 0; k < 11; ++k) st->S[k] = res->S[k];
+    st->sum_w = res->sum_w; st->pm_iters = res->iters; st->k = res->k; st->done = res->done; st->pending = pending;
+}
+
+// CHAIN (fused mode only): launch j reads state slot j&1 and the moments buffer j&1, turns the previous
+// iteration's moments into T in its prologue (every block redundantly; block 0 publishes the result in the
+// other slot), searches, and leaves its own moments in the other buffer: ONE launch per ICP iteration.
+template <bool FUSED, bool CHAIN>
 __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
 {
     const uint32_t b = blockIdx.y;
-    icp_reg_state *st = p.st + b;
+    icp_reg_state *st = CHAIN ? p.cst + (size_t) b * 2 + p.slot : p.st + b;
 #ifdef ICP_DBG_STAMPS
     { const uint32_t tid = threadIdx.x; unsigned long long t_; asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
       if (tid == 0 && p.dbg) p.dbg[(size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 16 + 8] = t_; }
 #endif
-    if (p.check && st->done) return;
+    icp_reg_state *sout = CHAIN ? p.cst + (size_t) b * 2 + (p.slot ^ 1u) : st;
+    if constexpr (CHAIN) {
+        if (p.check && st->done) {                   // converged earlier: carry the state forward, nothing to do
+            if (blockIdx.x == 0 && threadIdx.x < sizeof (icp_reg_state) / 4)
+                reinterpret_cast<uint32_t *> (sout)[threadIdx.x] = reinterpret_cast<const uint32_t *> (st)[threadIdx.x];
+            return;
+        }
+    } else if (p.check && st->done) return;
 
     // representatives of the current tile, pair-interleaved for packed fp32 math:
     //   pair P = reps (2P, 2P+1) -> 3 float4: [x0 x1 y0 y1] [z0 z1 r0 r1] [g0 g1 b0 b1]
@@ -360,6 +463,9 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
     __shared__ float4 s_nn[KS_SPLIT][64];
     __shared__ float s_w[64];
     __shared__ double s_mom[FUSED ? ICP_NMOM : 1][64];
+    __shared__ icp_fin_result s_fin;
+    __shared__ double s_l1[CHAIN ? ICP_NMOM : 1][CHAIN ? 32 : 1];
+    __shared__ double s_t[ICP_NMOM];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t slice = __builtin_amdgcn_readfirstlane (tid >> 6);
@@ -390,6 +496,23 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
     float T[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) T[k] = st->T[k];
+    if constexpr (CHAIN) {
+        const bool pending = st->pending != 0;
+        if (pending) {
+            float Rp[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Rp[k] = st->R[k];
+            fused_finalize_block<32> (p, p.mom + ((size_t) b * 2 + p.slot) * ICP_NMOM * p.nb, T, Rp, st->k, &s_fin, s_l1, s_t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) T[k] = s_fin.T[k];
+            if (blockIdx.x == 0 && tid == 0) fin_result_to_state (&s_fin, sout, s_fin.done ? 0u : 1u);
+            if (s_fin.done) return;
+        } else if (blockIdx.x == 0 && tid < sizeof (icp_reg_state) / 4) {
+            uint32_t v = reinterpret_cast<const uint32_t *> (st)[tid];
+            if (tid == offsetof (icp_reg_state, pending) / 4) v = 1u;
+            reinterpret_cast<uint32_t *> (sout)[tid] = v;
+        }
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         uint32_t k = tid + (uint32_t) u * 64u * KS_SPLIT;
@@ -527,7 +650,7 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
             p.rid[(size_t) b * p.m + i] = rstar;
             s_nn_x = nn.x; s_nn_y = nn.y; s_nn_z = nn.z;
         }
-        if (FUSED) {
+        if constexpr (FUSED) {
             // the 18 moments of this pair in double (oracle orc_moments_fused); invalid lanes contribute 0
             double W = (double) w;
             double f0 = valid ? (double) s_nn_x : 0.0, f1 = valid ? (double) s_nn_y : 0.0, f2 = valid ? (double) s_nn_z : 0.0;
@@ -547,13 +670,14 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
     }
     KS_STAMP (6)
     __syncthreads ();
-    if (FUSED) {
+    if constexpr (FUSED) {
         // halving tree over the block's 64 pairs, one 16-lane row per moment (rows 0..17 of the 32 rows)
         const uint32_t l = lane & 15u, mrow = slice * 4u + (lane >> 4);
         const uint32_t k = min (mrow, (uint32_t) ICP_NMOM - 1u);
         double c0 = s_mom[k][l] + s_mom[k][l + 32], c1 = s_mom[k][l + 16] + s_mom[k][l + 48];
         double v = row_tree_tail_d (c0 + c1);
-        if (l == 0 && mrow < ICP_NMOM) p.mom[((size_t) b * ICP_NMOM + mrow) * p.nb + blockIdx.x] = v;
+        const uint32_t obuf = CHAIN ? (p.slot ^ 1u) : 0u;
+        if (l == 0 && mrow < ICP_NMOM) p.mom[(((size_t) b * 2 + obuf) * ICP_NMOM + mrow) * p.nb + blockIdx.x] = v;
     } else if (slice == 0 && p.weighted) {
         // tree levels d = 64 .. 2 restricted to this block's parity class (icp_kernels.cl:244-249):
         // element e of the class is position 2e + parity; levels pair e with e+32, e+16, .., e+1.
@@ -787,79 +911,56 @@ __global__ __launch_bounds__ (192) void k_finalize (icp_params p)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__ (320) void k_finalize_fused (icp_params p)
 {
-    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, l = tid & 15u, row = tid >> 4;
+    const uint32_t b = blockIdx.x;
     icp_reg_state *st = p.st + b;
     if (p.check && st->done) return;
-
+    __shared__ icp_fin_result s_fin;
     __shared__ double s_l1[ICP_NMOM][128];
     __shared__ double s_t[ICP_NMOM];
-    {
-        const uint32_t k = min (row, (uint32_t) ICP_NMOM - 1u);
-        const double *src = p.mom + ((size_t) b * ICP_NMOM + k) * p.nb;
-        const uint32_t ng = (p.nb + 127u) / 128u;                   // <= 128 (m <= 2^20)
-        double res = 0.0;
-        for (uint32_t g = 0; g < ng; ++g) {
-            double a[8];
+    float T[8], Rp[9];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                uint32_t i = g * 128u + l + 16u * q;
-                a[q] = (i < p.nb) ? src[i] : 0.0;
-            }
-            double v = row_tree8_d (a);
-            if (ng == 1) res = v; else if (l == 0) s_l1[k][g] = v;
-        }
-        if (p.nb == 1) res = src[0];
-        if (ng > 1) {
-            __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier ();
-            double a[8];
+    for (int k = 0; k < 8; ++k) T[k] = st->T[k];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                uint32_t i = l + 16u * q;
-                a[q] = (i < ng) ? s_l1[k][i] : 0.0;
-            }
-            res = row_tree8_d (a);
-        }
-        if (l == 0 && row < ICP_NMOM) s_t[row] = res;
+    for (int k = 0; k < 9; ++k) Rp[k] = st->R[k];
+    fused_finalize_block<128> (p, p.mom + (size_t) b * 2 * ICP_NMOM * p.nb, T, Rp, st->k, &s_fin, s_l1, s_t);
+    if (threadIdx.x == 0) fin_result_to_state (&s_fin, st, 0u);
+}
+
+// chain begin: user-visible state -> slot 0; chain end: finalize the last iteration's moments (slot given by
+// p.slot) into the user-visible state.
+__global__ void k_chain_begin (icp_params p)
+{
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    if (t < sizeof (icp_reg_state) / 4) {
+        uint32_t v = reinterpret_cast<const uint32_t *> (p.st + b)[t];
+        if (t == offsetof (icp_reg_state, pending) / 4) v = 0u;
+        reinterpret_cast<uint32_t *> (p.cst + (size_t) b * 2)[t] = v;
     }
-    __syncthreads ();
-    if (tid >= 64) return;
+}
 
-    double t[ICP_NMOM];
-#pragma unroll
-    for (int k = 0; k < ICP_NMOM; ++k) t[k] = s_t[k];
-    // oracle orc_moments_finish
-    const double sw = t[0];
-    double mf[3], mq[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { mf[a] = t[1 + a] / sw; mq[a] = t[4 + a] / sw; }
-    const double c2 = (double) p.c * (double) p.c;
-    float S[11], means[8];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int bb = 0; bb < 3; ++bb) S[3 * a + bb] = (float) (c2 * (t[7 + 3 * a + bb] - t[4 + a] * mf[bb]));
-    S[9]  = (float) (c2 * (t[16] - ((t[1] * mf[0] + t[2] * mf[1]) + t[3] * mf[2])));
-    S[10] = (float) (c2 * (t[17] - ((t[4] * mq[0] + t[5] * mq[1]) + t[6] * mq[2])));
-    means[0] = (float) mf[0]; means[1] = (float) mf[1]; means[2] = (float) mf[2]; means[3] = 0.f;
-    means[4] = (float) mq[0]; means[5] = (float) mq[1]; means[6] = (float) mq[2]; means[7] = 0.f;
-
-    float Tk[8], Rk[9];
-    int iters = 0;
-    if (p.rot == 1) iters = icp_power_method_quad (S, means, Tk, p.power_mode, lane);
-    else icp_svd_rotation (S, means, Rk, Tk);
-
-    if (lane == 0) {
-        icp_compose (st, Tk, Rk, p.rot != 1);
-#pragma unroll
-        for (int k = 0; k < 11; ++k) st->S[k] = S[k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) st->means[k] = means[k];
-        st->sum_w = sw;
-        st->pm_iters = (uint32_t) iters;
-        st->k = st->k + 1;
-        if (p.check && icp_check_converged (Tk, p.tan_half_thr, p.trans_thr)) st->done = 1;
+__global__ __launch_bounds__ (320) void k_chain_end (icp_params p)
+{
+    const uint32_t b = blockIdx.x;
+    const icp_reg_state *sin = p.cst + (size_t) b * 2 + p.slot;
+    icp_reg_state *st = p.st + b;
+    __shared__ icp_fin_result s_fin;
+    __shared__ double s_l1[ICP_NMOM][32];
+    __shared__ double s_t[ICP_NMOM];
+    if ((p.check && sin->done) || !sin->pending) {
+        if (threadIdx.x < sizeof (icp_reg_state) / 4) {
+            uint32_t v = reinterpret_cast<const uint32_t *> (sin)[threadIdx.x];
+            if (threadIdx.x == offsetof (icp_reg_state, pending) / 4) v = 0u;
+            reinterpret_cast<uint32_t *> (st)[threadIdx.x] = v;
+        }
+        return;
     }
+    float T[8], Rp[9];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) T[k] = sin->T[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rp[k] = sin->R[k];
+    fused_finalize_block<32> (p, p.mom + ((size_t) b * 2 + p.slot) * ICP_NMOM * p.nb, T, Rp, sin->k, &s_fin, s_l1, s_t);
+    if (threadIdx.x == 0) fin_result_to_state (&s_fin, st, 0u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -899,8 +1000,8 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 
 void icp_launch_search (const icp_params &p, hipStream_t s)
 {
-    if (p.fused) hipLaunchKernelGGL (k_search<true>, dim3 (p.nb, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
-    else hipLaunchKernelGGL (k_search<false>, dim3 (2 * p.nwg, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
+    if (p.fused) hipLaunchKernelGGL ((k_search<true, false>), dim3 (p.nb, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
+    else hipLaunchKernelGGL ((k_search<false, false>), dim3 (2 * p.nwg, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
 }
 
 void icp_launch_means (const icp_params &p, hipStream_t s)
@@ -931,6 +1032,21 @@ void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask)
     if ((mask & 4u) && !p.fused) icp_launch_sij (p, s);
     if (mask & 8u) icp_launch_finalize (p, s);
     if (mask & 16u) hipLaunchKernelGGL (k_nop, dim3 (256, p.batch), dim3 (64), 0, s, p);
+}
+
+// chained fused run: begin, one launch per iteration, end (icp_chain_supported: second tree level fits 32 groups)
+bool icp_chain_supported (const icp_params &p) { return p.fused && p.nb <= 4096u; }
+
+void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations)
+{
+    icp_params p = p0;
+    hipLaunchKernelGGL (k_chain_begin, dim3 (p.batch), dim3 (64), 0, s, p);
+    for (uint32_t j = 0; j < iterations; ++j) {
+        p.slot = j & 1u;
+        hipLaunchKernelGGL ((k_search<true, true>), dim3 (p.nb, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
+    }
+    p.slot = iterations & 1u;
+    hipLaunchKernelGGL (k_chain_end, dim3 (p.batch), dim3 (320), 0, s, p);
 }
 
 void icp_launch_iteration (const icp_params &p, hipStream_t s)

@@ -348,3 +348,59 @@ def test_fused_batched_and_large(engine, oracle):
         o.step()
         check_step(engine, g, o, weighted=False)
     g.close()
+
+
+def test_fused_chain_fixed_run_and_limits(engine, oracle):
+    """The chained graph (one launch per iteration): fixed runs, max_iterations, repeated runs, batches."""
+    g, o, F, M = make(engine, oracle, 64, 64, power_fast=True, fused=True)
+    g.buildRBC()
+    o.build_rbc()
+    g.run_fixed(7)
+    for _ in range(7):
+        o.step()
+    check_step(engine, g, o, weighted=False)
+    assert g.k == 7
+    g.run_fixed(1)                                  # odd / even launch counts both end in the visible state
+    o.step()
+    check_step(engine, g, o, weighted=False)
+    g.step()                                        # the two-kernel path continues from the chain's state
+    o.step()
+    check_step(engine, g, o, weighted=False)
+    g.close()
+    g, o, F, M = make(engine, oracle, 64, 64, power_fast=True, fused=True, max_iterations=5)
+    g.buildRBC()
+    o.build_rbc()
+    assert g.run() == o.run() == 5
+    assert_bits(g.read(engine.Memory.T), o.T, "T after max_iterations (chain)")
+    g.buildRBC()                                    # second registration on the same handle: k resets, T persists
+    o.build_rbc()
+    assert g.run() == o.run()
+    assert_bits(g.read(engine.Memory.T), o.T, "T after the second run")
+    g.close()
+
+
+def test_fused_chain_batched(engine, oracle):
+    B, side, nr = 3, 64, 64
+    g = engine.ICP(0)
+    g.init(side * side, nr, A, C_, batch=B)
+    g.setPowerMode(engine.PowerMode.SQUARED)
+    g.setReduceMode(engine.ReduceMode.FUSED)
+    oracles = []
+    for b in range(B):
+        F, M = engine.synth_pair(side, seed=77 + b, rot_deg=1.0 + 2 * b)
+        g.write(engine.Memory.F, F, batch_index=b)
+        g.write(engine.Memory.M, M, batch_index=b)
+        o = oracle.OracleICP(side * side, nr, A, C_, threads=8, power_fast=True, fused=True)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        oracles.append(o)
+    g.buildRBC()
+    g.run()
+    ks = []
+    for b, o in enumerate(oracles):
+        ko = o.run()
+        ks.append(ko)
+        st = g.state(b)
+        assert st.k == ko and bool(st.converged) == o.converged, (b, st.k, ko)
+        assert_bits(g.read(engine.Memory.T, b), o.T, "T of registration %d" % b)
+    assert len(set(ks)) > 1                          # registrations really stop at different iterations
+    g.close()

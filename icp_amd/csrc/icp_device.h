@@ -132,146 +132,35 @@ __device__ __forceinline__ void icp_transform_point (const float *T, float px, f
 
 // ------------------------------------------------------------------------------------------
 // a9  icpPowerMethod — kernels/icp_kernels.cl:977-1054 (canonical forms: oracle power_impl)
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float pm_dot4 (const float *a, const float *b)
-{
-    float s = 0.f;
-    s = s + a[0] * b[0]; s = s + a[1] * b[1]; s = s + a[2] * b[2]; s = s + a[3] * b[3];
-    return s;
-}
-
-__device__ __forceinline__ void pm_prod4 (const float *N, const float *x, float *y)
-{
-    y[0] = pm_dot4 (N, x); y[1] = pm_dot4 (N + 4, x); y[2] = pm_dot4 (N + 8, x); y[3] = pm_dot4 (N + 12, x);
-}
-
-__device__ __forceinline__ void pm_normalize4 (float *x)
-{
-    float s = 0.f;
-    s = s + x[0] * x[0]; s = s + x[1] * x[1]; s = s + x[2] * x[2]; s = s + x[3] * x[3];
-    float n = sqrtf (s);
-    x[0] = x[0] / n; x[1] = x[1] / n; x[2] = x[2] / n; x[3] = x[3] / n;
-}
-
-__device__ __forceinline__ float pm_distance4 (const float *a, const float *b)
-{
-    float s = 0.f, d;
-    d = a[0] - b[0]; s = s + d * d; d = a[1] - b[1]; s = s + d * d;
-    d = a[2] - b[2]; s = s + d * d; d = a[3] - b[3]; s = s + d * d;
-    return sqrtf (s);
-}
-
-__device__ __forceinline__ void pm_rescale16 (float *B)
-{   // exact power-of-two rescale so that max|entry| lies in [1,2)
-    float mx = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { float a = fabsf (B[i]); if (a > mx) mx = a; }
-    uint32_t e = (__float_as_uint (mx) >> 23) & 0xFFu;
-    if (e == 0u || e >= 254u) return;
-    float sc = __uint_as_float ((254u - e) << 23);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) B[i] = B[i] * sc;
-}
-
-#define ICP_PM_SQUARINGS 10
-
-// Returns the number of loop trips.  S[11], means[8] -> Tk[8] = [qk | tk, sk].
-__device__ inline int icp_power_method (const float *S, const float *means, float *Tk, int squared_start)
-{
-    float Sxx = S[0], Sxy = S[1], Sxz = S[2], Syx = S[3], Syy = S[4], Syz = S[5],
-          Szx = S[6], Szy = S[7], Szz = S[8];
-    float N[16] = {                                                   // icp_kernels.cl:993-999
-        Sxx - Syy - Szz,       Sxy + Syx,         Szx + Sxz,       Syz - Szy,
-              Sxy + Syx, - Sxx + Syy - Szz,       Syz + Szy,       Szx - Sxz,
-              Szx + Sxz,       Syz + Szy, - Sxx - Syy + Szz,       Sxy - Syx,
-              Syz - Szy,       Szx - Sxz,         Sxy - Syx, Sxx + Syy + Szz };
-    float x[4] = { 1.f, 1.f, 1.f, 1.f }, xn[4];
-    int iters = 0;
-    for (;;) {
-        if (squared_start) {
-            float B[16], C[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) B[i] = N[i];
-            pm_rescale16 (B);
-            for (int s = 0; s < ICP_PM_SQUARINGS; ++s) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float acc = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) acc = acc + B[i * 4 + k] * B[k * 4 + j];
-                        C[i * 4 + j] = acc;
-                    }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) B[i] = C[i];
-                pm_rescale16 (B);
-            }
-            pm_prod4 (B, x, xn); pm_normalize4 (xn);
-            x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];
-        }
-        float error, error_new = __builtin_inff ();
-        for (uint32_t it = 0; it < 1000; ++it) {                      // icp_kernels.cl:1012-1022
-            pm_prod4 (N, x, xn);
-            pm_normalize4 (xn);
-            ++iters;
-            error = error_new;
-            error_new = pm_distance4 (x, xn);
-            if (error_new == error) break;
-            x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];
-        }
-        float lambda = pm_dot4 (N, xn) / xn[0];                        // :1024
-        if (lambda < 0) {
-            N[0] -= lambda; N[5] -= lambda; N[10] -= lambda; N[15] -= lambda;
-            x[0] = x[1] = x[2] = x[3] = 1.f;
-        } else break;
-    }
-    x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];           // :1039-1041
-    pm_prod4 (N, x, xn);
-    pm_normalize4 (xn);
-
-    float sk = sqrtf (S[9] / S[10]);                                   // :989
-    const float *mf = means, *mm = means + 4;
-    float qx = xn[0], qy = xn[1], qz = xn[2], qw = xn[3];
-    float c1x = (qy * mm[2] - qz * mm[1]) + qw * mm[0];                // :1050
-    float c1y = (qz * mm[0] - qx * mm[2]) + qw * mm[1];
-    float c1z = (qx * mm[1] - qy * mm[0]) + qw * mm[2];
-    float ax = 2 * qx, ay = 2 * qy, az = 2 * qz;
-    float c2x = ay * c1z - az * c1y;
-    float c2y = az * c1x - ax * c1z;
-    float c2z = ax * c1y - ay * c1x;
-    Tk[0] = qx; Tk[1] = qy; Tk[2] = qz; Tk[3] = qw;
-    Tk[4] = mf[0] - sk * (mm[0] + c2x);
-    Tk[5] = mf[1] - sk * (mm[1] + c2y);
-    Tk[6] = mf[2] - sk * (mm[2] + c2z);
-    Tk[7] = sk;
-    return iters;
-}
-
-// Lane-parallel form of the same power method: every quad of the wave runs it redundantly, lane
-// (l & 3) = i owns row i of N (and of B) and component i of x.  The operations and their order are
-// exactly those of icp_power_method / oracle power_impl; only the placement changes:
-//   N x        : y_i = (((0 + N[i][0] x_0) + N[i][1] x_1) + N[i][2] x_2) + N[i][3] x_3, x_k by quad broadcast
-//   B B        : C[i][j] = sum_k B[i][k] B[k][j] with B[k][j] read as B[j][k] from lane j (B is exactly
-//                symmetric: N is, and the fixed k order keeps every square symmetric bit for bit)
-//   sums of 4  : sequential ((0 + v_0) + v_1) + v_2) + v_3 through quad broadcasts
+//
+// Lane-parallel: every quad of the wave holds the same data, lane (l & 3) = i owns row i of N (and of B)
+// and component i of x.  The operations and their order are exactly those of the oracle; only the
+// placement changes:
+//   N x        : y_i = (((0 + N[i][0] x_0) + N[i][1] x_1) + N[i][2] x_2) + N[i][3] x_3, x_k read from lane k
+//   sums of 4  : sequential (((0 + v_0) + v_1) + v_2) + v_3 with v_k read from lane k
+//   B B        : (squared start) four v_mfma_f32_4x4x1 steps: with one (symmetric) row per lane the A and B
+//                operands of step k are the same register, and the result comes back one row per lane; the
+//                instruction evaluates the k-ordered fmaf chain the oracle writes (tests/cpp/mfma4_test.hip)
 // All 64 lanes must be active.  Returns the loop-trip count; Tk is valid in every lane.
+// ------------------------------------------------------------------------------------------
+#define ICP_PM_SQUARINGS 10
+typedef float icp_f4 __attribute__ ((ext_vector_type (4)));
+
+__device__ __forceinline__ float pmq_lane (float v, int k)
+{
+    return __builtin_bit_cast (float, __builtin_amdgcn_readlane (__builtin_bit_cast (int, v), k));
+}
 __device__ __forceinline__ float pmq_seq4 (float v)
 {
     float s = 0.f;
-    s = s + icp_dpp<ICP_QUAD_BCAST (0)> (v);
-    s = s + icp_dpp<ICP_QUAD_BCAST (1)> (v);
-    s = s + icp_dpp<ICP_QUAD_BCAST (2)> (v);
-    s = s + icp_dpp<ICP_QUAD_BCAST (3)> (v);
+    s = s + pmq_lane (v, 0); s = s + pmq_lane (v, 1); s = s + pmq_lane (v, 2); s = s + pmq_lane (v, 3);
     return s;
 }
 __device__ __forceinline__ float pmq_matvec (const float *Nrow, float x)
 {
     float s = 0.f;
-    s = s + Nrow[0] * icp_dpp<ICP_QUAD_BCAST (0)> (x);
-    s = s + Nrow[1] * icp_dpp<ICP_QUAD_BCAST (1)> (x);
-    s = s + Nrow[2] * icp_dpp<ICP_QUAD_BCAST (2)> (x);
-    s = s + Nrow[3] * icp_dpp<ICP_QUAD_BCAST (3)> (x);
+    s = s + Nrow[0] * pmq_lane (x, 0); s = s + Nrow[1] * pmq_lane (x, 1);
+    s = s + Nrow[2] * pmq_lane (x, 2); s = s + Nrow[3] * pmq_lane (x, 3);
     return s;
 }
 __device__ __forceinline__ float pmq_normalize (float y)
@@ -280,10 +169,9 @@ __device__ __forceinline__ float pmq_normalize (float y)
     return y / n;
 }
 __device__ __forceinline__ void pmq_rescale (float *Brow)
-{
+{   // exact power-of-two rescale so that max|entry| lies in [1,2)
     float mx = fmaxf (fmaxf (fabsf (Brow[0]), fabsf (Brow[1])), fmaxf (fabsf (Brow[2]), fabsf (Brow[3])));
-    mx = fmaxf (mx, icp_dpp<0xB1> (mx));          // quad_perm [1,0,3,2]
-    mx = fmaxf (mx, icp_dpp<0x4E> (mx));          // quad_perm [2,3,0,1]
+    mx = fmaxf (fmaxf (pmq_lane (mx, 0), pmq_lane (mx, 1)), fmaxf (pmq_lane (mx, 2), pmq_lane (mx, 3)));
     uint32_t e = (__float_as_uint (mx) >> 23) & 0xFFu;
     if (e == 0u || e >= 254u) return;
     float sc = __uint_as_float ((254u - e) << 23);
@@ -311,35 +199,13 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
             float Brow[4] = { Nrow[0], Nrow[1], Nrow[2], Nrow[3] };
             pmq_rescale (Brow);
             for (int s = 0; s < ICP_PM_SQUARINGS; ++s) {
-                float C[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float acc = 0.f;
-                    if (j == 0) {
-                        acc = acc + Brow[0] * icp_dpp<ICP_QUAD_BCAST (0)> (Brow[0]);
-                        acc = acc + Brow[1] * icp_dpp<ICP_QUAD_BCAST (0)> (Brow[1]);
-                        acc = acc + Brow[2] * icp_dpp<ICP_QUAD_BCAST (0)> (Brow[2]);
-                        acc = acc + Brow[3] * icp_dpp<ICP_QUAD_BCAST (0)> (Brow[3]);
-                    } else if (j == 1) {
-                        acc = acc + Brow[0] * icp_dpp<ICP_QUAD_BCAST (1)> (Brow[0]);
-                        acc = acc + Brow[1] * icp_dpp<ICP_QUAD_BCAST (1)> (Brow[1]);
-                        acc = acc + Brow[2] * icp_dpp<ICP_QUAD_BCAST (1)> (Brow[2]);
-                        acc = acc + Brow[3] * icp_dpp<ICP_QUAD_BCAST (1)> (Brow[3]);
-                    } else if (j == 2) {
-                        acc = acc + Brow[0] * icp_dpp<ICP_QUAD_BCAST (2)> (Brow[0]);
-                        acc = acc + Brow[1] * icp_dpp<ICP_QUAD_BCAST (2)> (Brow[1]);
-                        acc = acc + Brow[2] * icp_dpp<ICP_QUAD_BCAST (2)> (Brow[2]);
-                        acc = acc + Brow[3] * icp_dpp<ICP_QUAD_BCAST (2)> (Brow[3]);
-                    } else {
-                        acc = acc + Brow[0] * icp_dpp<ICP_QUAD_BCAST (3)> (Brow[0]);
-                        acc = acc + Brow[1] * icp_dpp<ICP_QUAD_BCAST (3)> (Brow[1]);
-                        acc = acc + Brow[2] * icp_dpp<ICP_QUAD_BCAST (3)> (Brow[2]);
-                        acc = acc + Brow[3] * icp_dpp<ICP_QUAD_BCAST (3)> (Brow[3]);
-                    }
-                    C[j] = acc;
-                }
-                Brow[0] = C[0]; Brow[1] = C[1]; Brow[2] = C[2]; Brow[3] = C[3];
-                pmq_rescale (Brow);
+                icp_f4 acc = { 0.f, 0.f, 0.f, 0.f };
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32 (Brow[0], Brow[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32 (Brow[1], Brow[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32 (Brow[2], Brow[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32 (Brow[3], Brow[3], acc, 0, 0, 0);
+                Brow[0] = acc[0]; Brow[1] = acc[1]; Brow[2] = acc[2]; Brow[3] = acc[3];
+                if (s % 3 == 2) pmq_rescale (Brow);
             }
             x = pmq_normalize (pmq_matvec (Brow, x));
         }
@@ -353,8 +219,8 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
             if (error_new == error) break;
             x = xn;
         }
-        float lam_num = icp_dpp<ICP_QUAD_BCAST (0)> (pmq_matvec (Nrow, xn));
-        float lambda = lam_num / icp_dpp<ICP_QUAD_BCAST (0)> (xn);   // :1024
+        float lam_num = pmq_lane (pmq_matvec (Nrow, xn), 0);
+        float lambda = lam_num / pmq_lane (xn, 0);                    // :1024
         if (lambda < 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) Nrow[k] = (i == (uint32_t) k) ? Nrow[k] - lambda : Nrow[k];
@@ -364,8 +230,7 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
     x = xn;                                                           // :1039-1041
     xn = pmq_normalize (pmq_matvec (Nrow, x));
 
-    float qx = icp_dpp<ICP_QUAD_BCAST (0)> (xn), qy = icp_dpp<ICP_QUAD_BCAST (1)> (xn);
-    float qz = icp_dpp<ICP_QUAD_BCAST (2)> (xn), qw = icp_dpp<ICP_QUAD_BCAST (3)> (xn);
+    float qx = pmq_lane (xn, 0), qy = pmq_lane (xn, 1), qz = pmq_lane (xn, 2), qw = pmq_lane (xn, 3);
     float sk = sqrtf (S[9] / S[10]);                                   // :989
     const float *mf = means, *mm = means + 4;
     float c1x = (qy * mm[2] - qz * mm[1]) + qw * mm[0];                // :1050

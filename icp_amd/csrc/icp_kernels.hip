@@ -329,6 +329,17 @@ typedef float float2v __attribute__ ((ext_vector_type (2)));
 
 #define ICP_NMOM 18
 
+#ifdef ICP_DBG_STAMPS
+#define FF_STAMP(k)                                                                                       \
+    {                                                                                                     \
+        unsigned long long t_;                                                                            \
+        asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        if (threadIdx.x == 0 && p.dbg) p.dbg[(size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = t_;    \
+    }
+#else
+#define FF_STAMP(k)
+#endif
+
 // fused mode: query index of local element e of block b (CPU twin: orc_fused_query).  8 x 8 tiles of the
 // landmark grid when its side is a multiple of 8, else 64 consecutive queries.
 static __device__ __forceinline__ uint32_t fused_query_index (uint32_t m, uint32_t side, uint32_t b, uint32_t e)
@@ -387,6 +398,7 @@ static __device__ void fused_finalize_block (const icp_params &p, const double *
         if (l == 0 && row < ICP_NMOM) s_t[row] = r;
     }
     __syncthreads ();
+    FF_STAMP (10)
     if (tid < 64) {
         double t[ICP_NMOM];
 #pragma unroll
@@ -407,8 +419,10 @@ static __device__ void fused_finalize_block (const icp_params &p, const double *
         means[4] = (float) mq[0]; means[5] = (float) mq[1]; means[6] = (float) mq[2]; means[7] = 0.f;
         float Tk[8], Rk[9], Rkin[9];
         int iters = 0;
+        FF_STAMP (11)
         if (p.rot == 1) iters = icp_power_method_quad (S, means, Tk, p.power_mode, lane);
         else icp_svd_rotation (S, means, Rkin, Tk);
+        FF_STAMP (12)
         if (lane == 0) {
             float Tn[8], Rn[9];
             icp_compose_pure (Tprev, Rprev, Tk, Rkin, p.rot != 1, Tn, Rn, Rk);
@@ -506,6 +520,7 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
 #pragma unroll
             for (int k = 0; k < 8; ++k) T[k] = s_fin.T[k];
             if (blockIdx.x == 0 && tid == 0) fin_result_to_state (&s_fin, sout, s_fin.done ? 0u : 1u);
+            KS_STAMP (9)
             if (s_fin.done) return;
         } else if (blockIdx.x == 0 && tid < sizeof (icp_reg_state) / 4) {
             uint32_t v = reinterpret_cast<const uint32_t *> (st)[tid];
@@ -587,6 +602,8 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
     __syncthreads ();
 
     // ---- stage 2: exhaustive scan of that representative's list, positions interleaved over the slices ----
+    // (Staging the block's lists through LDS first was measured and is slower: enumerating the distinct lists and
+    //  the extra barrier cost more than the L1/TA-bound direct gathers they replace.)
     float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
     float4 bnn = make_float4 (0.f, 0.f, 0.f, 0.f);
 #ifdef ICP_DBG_SKIP_S2

@@ -531,17 +531,19 @@ static int power_impl (const float *S, const float *means, float *Tk, int fast)
     for (;;) {
         if (fast) {
             /* build's accelerated start: B = N^(2^PM_SQUARINGS) by repeated
-             * squaring with exact power-of-two rescaling, x = normalize (B * 1).  The loop
+             * squaring (fmaf chains, exact power-of-two rescaling every third squaring), x = normalize (B * 1).  The loop
              * below is the reference's loop and polishes x with the un-squared N. */
             float B[16], C[16]; memcpy (B, N, sizeof B); rescale16 (B);
             for (int s = 0; s < PM_SQUARINGS; ++s) {
+                /* C = B B as a k-ordered fmaf chain (what v_mfma_f32_4x4x1 evaluates: one rounding per step) */
                 for (int i = 0; i < 4; ++i)
                     for (int j = 0; j < 4; ++j) {
                         float acc = 0.f;
-                        for (int k = 0; k < 4; ++k) acc = acc + B[i * 4 + k] * B[k * 4 + j];
+                        for (int k = 0; k < 4; ++k) acc = fmaf (B[i * 4 + k], B[k * 4 + j], acc);
                         C[i * 4 + j] = acc;
                     }
-                memcpy (B, C, sizeof B); rescale16 (B);
+                memcpy (B, C, sizeof B);
+                if (s % 3 == 2) rescale16 (B);      /* max|entry| < 2 after a rescale, < 2^22 three squarings later */
             }
             prod4 (B, x, xn); normalize4 (xn);
             memcpy (x, xn, sizeof x);

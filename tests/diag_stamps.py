@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import icp_amd
 side, nr = 128, 256
 F, M = icp_amd.synth_pair(side)
-g = icp_amd.ICP(0); g.init(side * side, nr, 2e2, 1e-6); g.setPowerMode(1)
+g = icp_amd.ICP(0); g.init(side * side, nr, 2e2, 1e-6); g.setPowerMode(1); g.setReduceMode(int(os.environ.get('FUSED','0')))
 g.write(icp_amd.Memory.F, F); g.write(icp_amd.Memory.M, M); g.buildRBC(); g.run_fixed(3); g.sync()
 L = icp_amd.lib(); nb = 256
 out = np.zeros((nb, 16), np.uint64)
@@ -20,4 +20,14 @@ for k in range(8):
     d = t[:, k] - prev
     print("%-18s mean %8.0f  min %8d  max %8d" % (names[k], d.mean(), d.min(), d.max()))
     prev = t[:, k]
+if t[:, 13].max() > 0:
+    d = t[:, 13] - t[:, 3]; print("  %-18s mean %8.0f  min %8d  max %8d" % ("S1 combine+stage lists", d.mean(), d.min(), d.max()))
+    d = t[:, 4] - t[:, 13]; print("  %-18s mean %8.0f  min %8d  max %8d" % ("list scan", d.mean(), d.min(), d.max()))
+if t[:, 9].max() > 0:
+    d = t[:, 9] - t[:, 8]
+    print("%-18s mean %8.0f  min %8d  max %8d   (start -> end of the chained prologue)" % ("prologue", d.mean(), d.min(), d.max()))
+if t[:, 12].max() > 0:
+    for a, b_, n in ((8, 10, "moments->trees"), (10, 11, "finish (f64 divs)"), (11, 12, "power method"), (12, 9, "compose+publish")):
+        d = t[:, b_] - t[:, a]
+        print("  %-18s mean %8.0f  min %8d  max %8d" % (n, d.mean(), d.min(), d.max()))
 print("kernel span (first start -> last end): %d ticks; per-block mean %0.f" % (t[:, 7].max() - t0, (t[:, 7] - t[:, 8]).mean()))

@@ -13,8 +13,9 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): a frame pair does n
 data-path collective; value = iterations of all ranks / max-over-ranks time  ("scaling": "weak").
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel (k_search): algorithmic bytes per launch (72 m + 32 |R| + 64,
-                SURVEY.md §8d) / its average duration measured with HIP events on the engine's stream
+  roofline      dominant kernel (k_search; in the default fused/chained mode it is the ONLY kernel of an
+                iteration): algorithmic bytes per launch (72 m + 32 |R| + 64) / its average
+                launch-to-launch time, measured with HIP events on the engine's own stream over the timed region
   cpu_baseline  the CPU oracle ("port") timed on this host on a bounded sample (rank 0, N = 1 only)
 """
 import argparse
@@ -48,11 +49,11 @@ def aggregate(dist, elapsed_s, units):
     return float(t.item()), float(u.item())
 
 
-def cpu_baseline(F, M, budget_s=12.0):
+def cpu_baseline(F, M, fused, budget_s=12.0):
     """The oracle (CPU port of the same iteration) on this host's cores, bounded to ~budget_s."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
-    o = O.OracleICP(M_POINTS, N_REPS, ALPHA, SCALING, threads=cores)
+    cores = int(os.environ.get("ICP_BASELINE_THREADS", min(os.cpu_count() or 1, 16)))   # the search loops stop scaling at ~16 threads
+    o = O.OracleICP(M_POINTS, N_REPS, ALPHA, SCALING, threads=cores, power_fast=True, fused=fused)
     o.write_f(F)
     o.write_m(M)
     o.build_rbc()
@@ -62,7 +63,7 @@ def cpu_baseline(F, M, budget_s=12.0):
         o.step()
         n += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= 2000:
+        if el >= budget_s or n >= 20000:
             break
     return {"value": n / el, "unit": "iterations/s", "cores": cores, "kind": "port",
             "sample": "%d iterations of the same pair (|F|=|M|=%d, |R|=%d) in %.1f s; search loops OpenMP over "
@@ -126,17 +127,24 @@ def main():
         g.run_fixed(ITERS_PER_STEP)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        g.run_fixed(ITERS_PER_STEP)
+    # the K steps; the engine brackets them with hipEvents on its own stream (roofline duration)
+    ev_ms = g.time_run_fixed(ITERS_PER_STEP, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
 
     total_t, total_iters = aggregate(dist, elapsed, args.steps * ITERS_PER_STEP)
 
-    # dominant kernel, HIP events on the engine's own stream
-    kt = g.time_kernels(200)
-    search_us = kt["search"] * 1e3
-    achieved = ALGO_BYTES_PER_ITER / (kt["search"] * 1e-3) / 1e9
+    # dominant kernel: in fused mode one k_search launch IS one iteration, so its average launch-to-launch
+    # time is the event time of the region / launches; in reference-order mode k_search is timed in a graph of its own
+    fused = args.reduce_mode == "fused"
+    if fused:
+        search_us = ev_ms * 1e3 / (args.steps * ITERS_PER_STEP)
+        kernel_us = {"search(chained: finalize prologue + search + moments)": search_us}
+    else:
+        kernel_us = {n: g.time_masked(mk, ITERS_PER_STEP, 20) for n, mk in (("search", 1), ("means", 2), ("sij", 4), ("finalize", 8))}
+        search_us = kernel_us["search"]
+        g.buildRBC(); g.sync()
+    achieved = ALGO_BYTES_PER_ITER / (search_us * 1e-6) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -167,10 +175,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ITER, "avg_launch_us": search_us,
-                         "kernel_us": {k: v * 1e3 for k, v in kt.items()}},
+                         "kernel_us": kernel_us,
+                         "note": "cache-resident at this size (1.19 MB/iteration): latency/VALU-bound, see DESIGN.md §5"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(F, M)
+            line["cpu_baseline"] = cpu_baseline(F, M, fused)
         print(json.dumps(line))
     g.close()
     if dist is not None:

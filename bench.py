@@ -42,8 +42,9 @@ def aggregate(dist, elapsed_s, units):
     if dist is None:
         return elapsed_s, units
     import torch
-    t = torch.tensor([elapsed_s], dtype=torch.float64)
-    u = torch.tensor([float(units)], dtype=torch.float64)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
+    u = torch.tensor([float(units)], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t.item()), float(u.item())
@@ -97,14 +98,14 @@ def main():
             raise SystemExit("bench.py: torch.distributed is required for --gpus > 1")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("ICP_BENCH_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")   # nccl == RCCL
         if torch.cuda.is_available():
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(int(os.environ.get("ICP_BENCH_DEVICE", local_rank)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     import icp_amd
     F, M = icp_amd.synth_pair(SIDE, seed=0x1C9D5EED + rank)
-    g = icp_amd.ICP(local_rank)
+    g = icp_amd.ICP(int(os.environ.get("ICP_BENCH_DEVICE", local_rank)))   # override: self-test of the N>1 path on a 1-GPU box
     g.init(M_POINTS, N_REPS, ALPHA, SCALING)
     g.setPowerMode(icp_amd.PowerMode.SQUARED if args.power_mode == "squared" else icp_amd.PowerMode.LITERAL)
     g.setReduceMode(icp_amd.ReduceMode.FUSED if args.reduce_mode == "fused" else icp_amd.ReduceMode.REFERENCE_ORDER)
@@ -115,8 +116,8 @@ def main():
 
     def barrier():
         if dist is not None:
-            if torch.cuda.is_available():
-                dist.barrier(device_ids=[local_rank])
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[torch.cuda.current_device()])
             else:
                 dist.barrier()
         g.sync()

@@ -115,7 +115,8 @@ def lib():
     sig("icp_state_b", i32, vp, u32, C.POINTER(_State))
     sig("icp_write_cloud", i32, vp, i32, vp, i32)
     sig("icp_transform_cloud", i32, vp, vp, vp, u32)
-    sig("icp_time_run_fixed", i32, vp, u32, u32, C.POINTER(f32))
+    sig("icp_time_run_fixed", i32, vp, u32, u32, i32, C.POINTER(f32))
+    sig("icp_reset_transform", i32, vp)
     sig("icp_time_kernels", i32, vp, u32, C.POINTER(f32))
     sig("icp_time_masked", i32, vp, u32, u32, u32, C.POINTER(f32))
     sig("icp_last_error", C.c_char_p, vp)
@@ -281,10 +282,14 @@ class ICPStep:
         self._chk(self._L.icp_transform_cloud(self._h, _p(cloud), _p(out), cloud.shape[0]))
         return out
 
-    def time_run_fixed(self, iterations, reps):
+    def time_run_fixed(self, iterations, reps, from_identity=False):
         ms = C.c_float()
-        self._chk(self._L.icp_time_run_fixed(self._h, iterations, reps, C.byref(ms)))
+        self._chk(self._L.icp_time_run_fixed(self._h, iterations, reps, int(from_identity), C.byref(ms)))
         return ms.value
+
+    def reset_transform(self):
+        """T <- identity, k <- 0 (enqueue only)."""
+        self._chk(self._L.icp_reset_transform(self._h))
 
     def time_masked(self, mask, iterations=40, reps=20):
         """us per iteration of a graph holding only the kernels in `mask` (diagnostic)."""

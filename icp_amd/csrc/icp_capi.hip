@@ -184,6 +184,7 @@ int icp_create (icp_handle *out, int device, int rot, int weighted)
     icp_context *h = new icp_context ();
     h->device = device;
     h->p.rot = rot; h->p.weighted = weighted; h->p.power_mode = ICP_POWER_LITERAL;
+    { const char *e = std::getenv ("ICP_AMD_CHAIN"); h->p.chain = (e && e[0] == '1') ? 1 : 0; }   // experimental, see icp_chain_supported
     e = hipSetDevice (device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags (&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate (&h->ev0);
@@ -225,11 +226,11 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if (m > (1u << 20)) return fail (h, ICP_EINVAL, "m must be <= 2^20");
     int rc = set_device (h); if (rc) return rc;
     if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
-    int rot = h->p.rot, weighted = h->p.weighted, pmode = h->p.power_mode, fused = h->p.fused;
+    int rot = h->p.rot, weighted = h->p.weighted, pmode = h->p.power_mode, fused = h->p.fused, chain = h->p.chain;
     free_all (h);
     icp_params &p = h->p;
     p = icp_params {};
-    p.rot = rot; p.weighted = weighted; p.power_mode = pmode; p.check = 0; p.fused = fused;
+    p.rot = rot; p.weighted = weighted; p.power_mode = pmode; p.check = 0; p.fused = fused; p.chain = chain;
     p.m = m; p.nr = nr; p.batch = batch; p.side = side; p.nrx = nrx; p.nry = nry;
     p.a = a; p.c = c;
     h->max_iterations = max_iterations; h->angle_threshold = angle_threshold; h->translation_threshold = translation_threshold;
@@ -574,7 +575,16 @@ int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint
     return ICP_OK;
 }
 
-int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, float *ms_total)
+int icp_reset_transform (icp_handle h)
+{   // T <- identity, k <- 0 (what ICPStep::init uploads, src/ICP/algorithms.cpp:4486-4493); enqueue only
+    int rc = need (h, false); if (rc) return rc;
+    if ((rc = set_device (h))) return rc;
+    icp_launch_reset_state (h->p, h->stream, 1);
+    HIPCHK (h, hipGetLastError ());
+    return ICP_OK;
+}
+
+int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int from_identity, float *ms_total)
 {
     int rc = need (h, true); if (rc) return rc;
     if (!ms_total || iterations == 0 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
@@ -582,7 +592,10 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, float 
     hipGraphExec_t exec;
     if ((rc = get_graph (h, iterations, 0, &exec))) return rc;
     HIPCHK (h, hipEventRecord (h->ev0, h->stream));
-    for (uint32_t r = 0; r < reps; ++r) HIPCHK (h, hipGraphLaunch (exec, h->stream));
+    for (uint32_t r = 0; r < reps; ++r) {
+        if (from_identity) icp_launch_reset_state (h->p, h->stream, 1);   // every pass is a fresh registration
+        HIPCHK (h, hipGraphLaunch (exec, h->stream));
+    }
     HIPCHK (h, hipEventRecord (h->ev1, h->stream));
     HIPCHK (h, hipEventSynchronize (h->ev1));
     HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));

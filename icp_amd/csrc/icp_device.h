@@ -216,7 +216,7 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
             error = error_new;
             float d = x - xn;
             error_new = sqrtf (pmq_seq4 (d * d));
-            if (error_new == error) break;
+            if (squared_start ? (error_new >= error) : (error_new == error)) break;     // oracle power_impl
             x = xn;
         }
         float lam_num = pmq_lane (pmq_matvec (Nrow, xn), 0);

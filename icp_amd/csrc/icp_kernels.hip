@@ -367,35 +367,36 @@ template <int NG>
 static __device__ void fused_finalize_block (const icp_params &p, const double *mom, const float *Tprev, const float *Rprev,
                                              uint32_t kprev, icp_fin_result *res, double (*s_l1)[NG], double *s_t)
 {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, l = tid & 15u, row = tid >> 4;
-    if (row < 20) {                                  // whole waves 0..4
-        const uint32_t k = min (row, (uint32_t) ICP_NMOM - 1u);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, l = tid & 15u, row = tid >> 4, nrow = blockDim.x >> 4;
+    const uint32_t ng = (p.nb + 127u) / 128u;
+    // first tree level: one 16-lane row per (moment k, group g) task; rows loop over the tasks (whole waves stay converged)
+    const uint32_t ntask = ICP_NMOM * ng, npass = (ntask + nrow - 1u) / nrow;
+    for (uint32_t ps = 0; ps < npass; ++ps) {
+        const uint32_t task = min (ps * nrow + row, ntask - 1u), k = task / ng, g = task - k * ng;
         const double *src = mom + (size_t) k * p.nb;
-        const uint32_t ng = (p.nb + 127u) / 128u;
-        double r = 0.0;
-        for (uint32_t g = 0; g < ng; ++g) {
-            double a[8];
+        double a[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                uint32_t i = g * 128u + l + 16u * q;
-                a[q] = (i < p.nb) ? src[i] : 0.0;
-            }
-            double v = row_tree8_d (a);
-            if (ng == 1) r = v; else if (l == 0) s_l1[k][g] = v;
+        for (int q = 0; q < 8; ++q) {
+            uint32_t i = g * 128u + l + 16u * q;
+            a[q] = (i < p.nb) ? src[i] : 0.0;
         }
-        if (p.nb == 1) r = src[0];
-        if (ng > 1) {
-            __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier ();
+        double v = row_tree8_d (a);
+        if (p.nb == 1) v = src[0];
+        if (l == 0 && ps * nrow + row < ntask) { if (ng == 1) s_t[k] = v; else s_l1[k][g] = v; }
+    }
+    if (ng > 1) {                                    // second level: rows 0..17, one moment each
+        __syncthreads ();
+        if (row < 20) {
+            const uint32_t k = min (row, (uint32_t) ICP_NMOM - 1u);
             double a[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 uint32_t i = l + 16u * q;
                 a[q] = (i < ng) ? s_l1[k][i] : 0.0;
             }
-            r = row_tree8_d (a);
+            double r = row_tree8_d (a);
+            if (l == 0 && row < ICP_NMOM) s_t[row] = r;
         }
-        if (l == 0 && row < ICP_NMOM) s_t[row] = r;
     }
     __syncthreads ();
     FF_STAMP (10)
@@ -926,7 +927,7 @@ __global__ __launch_bounds__ (192) void k_finalize (icp_params p)
 // (oracle orc_moments_fused / orc_moments_finish), then rotation, composition, convergence.
 // One block of 5 waves per registration: row k (of 20) reduces moment k.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__ (320) void k_finalize_fused (icp_params p)
+__global__ __launch_bounds__ (1024) void k_finalize_fused (icp_params p)
 {
     const uint32_t b = blockIdx.x;
     icp_reg_state *st = p.st + b;
@@ -1035,7 +1036,7 @@ void icp_launch_sij (const icp_params &p, hipStream_t s)
 
 void icp_launch_finalize (const icp_params &p, hipStream_t s)
 {
-    if (p.fused) hipLaunchKernelGGL (k_finalize_fused, dim3 (p.batch), dim3 (320), 0, s, p);
+    if (p.fused) hipLaunchKernelGGL (k_finalize_fused, dim3 (p.batch), dim3 (1024), 0, s, p);
     else hipLaunchKernelGGL (k_finalize, dim3 (p.batch), dim3 (192), 0, s, p);
 }
 
@@ -1052,7 +1053,9 @@ void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask)
 }
 
 // chained fused run: begin, one launch per iteration, end (icp_chain_supported: second tree level fits 32 groups)
-bool icp_chain_supported (const icp_params &p) { return p.fused && p.nb <= 4096u; }
+// Measured at |F|=|M|=16384: the replicated prologue (every block fetching the 36 KB of fresh moment partials)
+// costs more than the launch boundary it removes (15.7 vs 14.9 us per iteration), so the chain is opt-in.
+bool icp_chain_supported (const icp_params &p) { return p.fused && p.chain && p.nb <= 4096u; }
 
 void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations)
 {

@@ -149,6 +149,9 @@ int icp_run (icp_handle h, uint32_t *k);
  * convergence test (the reference's profiling run; 40 there).  Enqueue only. */
 int icp_run_fixed (icp_handle h, uint32_t iterations);
 
+/* T <- identity, k <- 0: the state ICPStep::init uploads (src/ICP/algorithms.cpp:4486-4493). Enqueue only. */
+int icp_reset_transform (icp_handle h);
+
 /* Blocks until everything enqueued on the handle's stream is done (queue.finish ()). */
 int icp_sync (icp_handle h);
 
@@ -185,8 +188,9 @@ int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint
 /* ---- measurement (bench.py, HIP events on the handle's stream) --------------------------------- */
 
 /* Times `reps` back-to-back icp_run_fixed(iterations) passes with hipEvents recorded on the
- * handle's own stream; *ms_total = elapsed ms over all reps. */
-int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, float *ms_total);
+ * handle's own stream; *ms_total = elapsed ms over all reps.  from_identity != 0: every pass starts from
+ * the identity transform (a fresh registration, like the reference's 40-step profiling run). */
+int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int from_identity, float *ms_total);
 /* Times each kernel class of the iteration separately (events around each launch, `reps`
  * iterations): out_ms[0..3] = mean ms of {search, means, sij, finalize}. */
 int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4);

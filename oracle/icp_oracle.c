@@ -554,7 +554,11 @@ static int power_impl (const float *S, const float *means, float *Tk, int fast)
             normalize4 (xn);
             ++iters;
             error = error_new;
-            if ((error_new = distance4 (x, xn)) == error) break;
+            error_new = distance4 (x, xn);
+            /* reference rule: stop when the step length repeats (:1019).  Squared start: x is already at the
+             * fixed point to ~1e-6, the step lengths fall to the rounding floor within two or three trips, so the
+             * loop stops as soon as they stop decreasing (a superset of "repeats"). */
+            if (fast ? (error_new >= error) : (error_new == error)) break;
             memcpy (x, xn, sizeof x);
         }
         float lambda = dot4 (N, xn) / xn[0];                 /* :1024 */

@@ -320,6 +320,22 @@ typedef float float2v __attribute__ ((ext_vector_type (2)));
 #define KS_STAMP(k)
 #endif
 
+// minimum over each group of 8 consecutive lanes, returned in all 8 (min is exact: any pairing gives the same bits)
+static __device__ __forceinline__ float ks_grp8_min_f (float v)
+{
+    v = fminf (v, icp_dpp<0xB1> (v));                // quad_perm [1,0,3,2]
+    v = fminf (v, icp_dpp<0x4E> (v));                // quad_perm [2,3,0,1]
+    v = fminf (v, icp_dpp<0x141> (v));               // row_half_mirror: lane i <-> 7 - i
+    return v;
+}
+static __device__ __forceinline__ uint32_t ks_grp8_min_u (uint32_t v)
+{
+    v = min (v, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0xB1, 0xF, 0xF, true));
+    v = min (v, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x4E, 0xF, 0xF, true));
+    v = min (v, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x141, 0xF, 0xF, true));
+    return v;
+}
+
 // candidate j of a list: XQ = [x y z id | r g b -]; keeps the best (distance, position, point)
 #define KS_CAND(G, C, J)                                                                              \
     {                                                                                                 \
@@ -602,53 +618,48 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
     else { o = gO[rstar]; n = gN[rstar]; }
     __syncthreads ();
 
-    // ---- stage 2: exhaustive scan of that representative's list, positions interleaved over the slices ----
-    // (Staging the block's lists through LDS first was measured and is slower: enumerating the distinct lists and
-    //  the extra barrier cost more than the L1/TA-bound direct gathers they replace.)
-    float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
-    float4 bnn = make_float4 (0.f, 0.f, 0.f, 0.f);
-#ifdef ICP_DBG_SKIP_S2
-    if (valid && n == 0xFFFFFFFFu) {
-#else
-    if (valid) {
+    // ---- stage 2: exhaustive scan of that representative's list ----
+    // Re-mapped inside the wave: wave `slice` serves queries 8*slice .. 8*slice+7, eight lanes per query, lane
+    // (L & 7) takes list positions = (L & 7) mod 8.  The eight lanes of a query read eight consecutive candidates
+    // (256 contiguous bytes) per load, so an instruction touches 16 cache lines instead of 64 scattered ones —
+    // the scan with lane = query was bound by the L1/TA rate of one 16-byte lane access per clock.
+    {
+        const uint32_t e = slice * 8u + (lane >> 3), ss = lane & 7u;
+        const float ex = __shfl (qx, (int) e), ey = __shfl (qy, (int) e), ez = __shfl (qz, (int) e);
+        const float er = __shfl (qr, (int) e), eg = __shfl (qg, (int) e), eb = __shfl (qb, (int) e);
+        const uint32_t oe = (uint32_t) __shfl ((int) o, (int) e), ne = (uint32_t) __shfl ((int) (valid ? n : 0u), (int) e);
+        float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
+        float4 bnn = make_float4 (0.f, 0.f, 0.f, 0.f);
+#ifndef ICP_DBG_SKIP_S2
+        {
+            const float qx = ex, qy = ey, qz = ez, qr = er, qg = eg, qb = eb;      // KS_CAND reads these names
+            uint32_t j = oe + ss;
+            const uint32_t je = oe + ne;
+            for (; j + 3 * KS_SPLIT < je; j += 4 * KS_SPLIT) {      // four candidates in flight
+                float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
+                float4 g1 = XQ4[2 * (size_t) (j + KS_SPLIT)], c1 = XQ4[2 * (size_t) (j + KS_SPLIT) + 1];
+                float4 g2 = XQ4[2 * (size_t) (j + 2 * KS_SPLIT)], c2 = XQ4[2 * (size_t) (j + 2 * KS_SPLIT) + 1];
+                float4 g3 = XQ4[2 * (size_t) (j + 3 * KS_SPLIT)], c3 = XQ4[2 * (size_t) (j + 3 * KS_SPLIT) + 1];
+                KS_CAND (g0, c0, j); KS_CAND (g1, c1, j + KS_SPLIT); KS_CAND (g2, c2, j + 2 * KS_SPLIT); KS_CAND (g3, c3, j + 3 * KS_SPLIT);
+            }
+            for (; j < je; j += KS_SPLIT) {
+                float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
+                KS_CAND (g0, c0, j);
+            }
+        }
 #endif
-        uint32_t j = o + slice;
-        const uint32_t je = o + n;
-        for (; j + 3 * KS_SPLIT < je; j += 4 * KS_SPLIT) {      // four candidates in flight
-            float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
-            float4 g1 = XQ4[2 * (size_t) (j + KS_SPLIT)], c1 = XQ4[2 * (size_t) (j + KS_SPLIT) + 1];
-            float4 g2 = XQ4[2 * (size_t) (j + 2 * KS_SPLIT)], c2 = XQ4[2 * (size_t) (j + 2 * KS_SPLIT) + 1];
-            float4 g3 = XQ4[2 * (size_t) (j + 3 * KS_SPLIT)], c3 = XQ4[2 * (size_t) (j + 3 * KS_SPLIT) + 1];
-            KS_CAND (g0, c0, j); KS_CAND (g1, c1, j + KS_SPLIT); KS_CAND (g2, c2, j + 2 * KS_SPLIT); KS_CAND (g3, c3, j + 3 * KS_SPLIT);
-        }
-        if (j + KS_SPLIT < je) {
-            float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
-            float4 g1 = XQ4[2 * (size_t) (j + KS_SPLIT)], c1 = XQ4[2 * (size_t) (j + KS_SPLIT) + 1];
-            KS_CAND (g0, c0, j); KS_CAND (g1, c1, j + KS_SPLIT);
-            j += 2 * KS_SPLIT;
-        }
-        if (j < je) {
-            float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
-            KS_CAND (g0, c0, j);
-            j += KS_SPLIT;
-        }
-        if (j < je) {
-            float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
-            KS_CAND (g0, c0, j);
-        }
+        // the query's winner among its eight lanes: smallest distance, ties -> lowest list position
+        const float dmin = ks_grp8_min_f (best2);
+        const uint32_t jmin = ks_grp8_min_u (best2 == dmin ? bj : 0xFFFFFFFFu);
+        if (jmin == 0xFFFFFFFFu) { if (ss == 0) { s_best[0][e] = dmin; s_idx[0][e] = jmin; s_nn[0][e] = bnn; } }
+        else if (bj == jmin && best2 == dmin) { s_best[0][e] = dmin; s_idx[0][e] = bj; s_nn[0][e] = bnn; }
     }
     KS_STAMP (4)
-    s_best[slice][lane] = best2; s_idx[slice][lane] = bj; s_nn[slice][lane] = bnn;
     __syncthreads ();
     KS_STAMP (5)
 
     if (slice == 0) {
-        float d = s_best[0][lane]; uint32_t j = s_idx[0][lane]; int sw = 0;
-#pragma unroll
-        for (int s = 1; s < KS_SPLIT; ++s) {
-            float ds = s_best[s][lane]; uint32_t js = s_idx[s][lane];
-            if (ds < d || (ds == d && js < j)) { d = ds; j = js; sw = s; }     // ties -> lowest list position
-        }
+        float d = s_best[0][lane]; uint32_t j = s_idx[0][lane]; const int sw = 0;
         float w = 0.f;
         float s_nn_x = 0.f, s_nn_y = 0.f, s_nn_z = 0.f;
         if (valid) {

@@ -590,6 +590,27 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
         const uint32_t p0 = min (slice * per, npair), p1 = min (p0 + per, npair);
         const float2v vqx = { qx, qx }, vqy = { qy, qy }, vqz = { qz, qz }, vqr = { qr, qr }, vqg = { qg, qg }, vqb = { qb, qb };
         const float2v va = { alpha, alpha };
+        if (p.nr >= 1024u && alpha > 0.f) {
+            // throughput-bound sizes: exact early rejection.  d = geo + a*pho >= geo (a > 0), and an update needs the
+            // strict d < best, so when no lane of the wave has geo < best the photometric half of the pair is skipped
+            // (wave-uniform branch; the block's queries are spatially coherent, so most far pairs are skipped).
+#pragma unroll 4
+            for (uint32_t P = p0; P < p1; ++P) {
+                float4 A = s_pair[3 * P], B = s_pair[3 * P + 1];
+                float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y };
+                float2v dx = vqx - x, dy = vqy - y, dz = vqz - z;
+                float2v geo = (dx * dx + dy * dy) + dz * dz;
+                if (!__any (geo.x < best || geo.y < best)) continue;
+                float4 C = s_pair[3 * P + 2];
+                float2v r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
+                float2v dr = vqr - r, dg = vqg - g, db = vqb - bb;
+                float2v pho = (dr * dr + dg * dg) + db * db;
+                float2v d = geo + va * pho;
+                const uint32_t r0 = t0 + 2u * P;
+                if (d.x < best) { best = d.x; bid = r0; }
+                if (d.y < best) { best = d.y; bid = r0 + 1u; }
+            }
+        } else {
 #pragma unroll 8
         for (uint32_t P = p0; P < p1; ++P) {
             float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];
@@ -601,6 +622,7 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
             const uint32_t r0 = t0 + 2u * P;
             if (d.x < best) { best = d.x; bid = r0; }        // ascending index, strict '<': lowest index on ties
             if (d.y < best) { best = d.y; bid = r0 + 1u; }
+        }
         }
     }
     KS_STAMP (2)

@@ -86,3 +86,23 @@ def test_set_alpha_changes_the_metric(engine, oracle):
     assert np.array_equal(g.read(engine.Memory.NN_ID)["id"], o.nn_id["id"])
     assert np.array_equal(g.read(engine.Memory.T).view(np.uint32), o.T.view(np.uint32))
     g.close()
+
+
+def test_bin_files_register_and_track(engine, oracle, tmp_path):
+    """The reference demo's file format and flow (examples/registration.cpp:285-337, src/ocl_icp_reg.cpp:165-210)."""
+    from icp_amd import io, register
+    f, m = engine.synth_cloud_vga(moved=False), engine.synth_cloud_vga(moved=True)
+    pf, pm, po = tmp_path / "kg_pc8d_1.bin", tmp_path / "kg_pc8d_2.bin", tmp_path / "out.bin"
+    io.save_pc8d(pf, f)
+    io.save_pc8d(pm, m)
+    assert os.path.getsize(pf) == 9830400                      # data/README.md / .MISSING_LARGE_BLOBS size
+    assert np.array_equal(io.load_pc8d(pf), f)
+    register.main([str(pf), str(pm), "-o", str(po)])
+    out = io.load_pc8d(po)
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+    o.write_f(oracle.get_lms(f)); o.write_m(oracle.get_lms(m)); o.build_rbc(); o.run()
+    assert np.array_equal(out.view(np.uint32), oracle.transform_q(m, o.T).view(np.uint32))
+    res = list(register.track([f, m, f]))
+    assert len(res) == 2 and np.array_equal(res[0][0].view(np.uint32), o.T.view(np.uint32))
+    # the second hop maps the first frame back onto the second: roughly the inverse rotation
+    assert np.abs(res[1][0][:3] + res[0][0][:3]).max() < 2e-3

@@ -304,7 +304,10 @@ __global__ __launch_bounds__ (1024) void k_place (icp_params p)
 //   wave s = slice s: 1/8 of the representatives (stage 1) and every 8th list position (stage 2);
 //   representatives are staged through LDS in tiles (coalesced float4 loads, broadcast ds_read_b128).
 // ------------------------------------------------------------------------------------------
-#define KS_SPLIT 8
+#ifndef KS_SPLIT
+#define KS_SPLIT 8              // waves per block = slices of the representatives = lanes per query in stage 2 (8 or 16)
+#endif
+#define KS_QPW (64 / KS_SPLIT)  // queries per wave in stage 2
 #define KS_TILE 1024u            // representatives per LDS tile
 
 typedef float float2v __attribute__ ((ext_vector_type (2)));
@@ -326,6 +329,9 @@ static __device__ __forceinline__ float ks_grp8_min_f (float v)
     v = fminf (v, icp_dpp<0xB1> (v));                // quad_perm [1,0,3,2]
     v = fminf (v, icp_dpp<0x4E> (v));                // quad_perm [2,3,0,1]
     v = fminf (v, icp_dpp<0x141> (v));               // row_half_mirror: lane i <-> 7 - i
+#if KS_SPLIT == 16
+    v = fminf (v, icp_dpp<0x140> (v));               // row_mirror: lane i <-> 15 - i
+#endif
     return v;
 }
 static __device__ __forceinline__ uint32_t ks_grp8_min_u (uint32_t v)
@@ -333,6 +339,9 @@ static __device__ __forceinline__ uint32_t ks_grp8_min_u (uint32_t v)
     v = min (v, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0xB1, 0xF, 0xF, true));
     v = min (v, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x4E, 0xF, 0xF, true));
     v = min (v, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x141, 0xF, 0xF, true));
+#if KS_SPLIT == 16
+    v = min (v, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x140, 0xF, 0xF, true));
+#endif
     return v;
 }
 
@@ -467,8 +476,10 @@ static __device__ void fin_result_to_state (const icp_fin_result *res, icp_reg_s
 // CHAIN (fused mode only): launch j reads state slot j&1 and the moments buffer j&1, turns the previous
 // iteration's moments into T in its prologue (every block redundantly; block 0 publishes the result in the
 // other slot), searches, and leaves its own moments in the other buffer: ONE launch per ICP iteration.
-template <bool FUSED, bool CHAIN>
-__global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
+// MINW = waves per SIMD the register allocation must leave room for: 2 (one block per CU: a single registration,
+// nothing to hide latency behind, no spills) or 4 (two blocks per CU: batched registrations, +70 % throughput)
+template <bool FUSED, bool CHAIN, int MINW>
+__global__ __launch_bounds__ (64 * KS_SPLIT, MINW) void k_search (icp_params p)
 {
     const uint32_t b = blockIdx.y;
     icp_reg_state *st = CHAIN ? p.cst + (size_t) b * 2 + p.slot : p.st + b;
@@ -646,7 +657,7 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
     // (256 contiguous bytes) per load, so an instruction touches 16 cache lines instead of 64 scattered ones —
     // the scan with lane = query was bound by the L1/TA rate of one 16-byte lane access per clock.
     {
-        const uint32_t e = slice * 8u + (lane >> 3), ss = lane & 7u;
+        const uint32_t e = slice * KS_QPW + lane / KS_SPLIT, ss = lane & (KS_SPLIT - 1u);
         const float ex = __shfl (qx, (int) e), ey = __shfl (qy, (int) e), ez = __shfl (qz, (int) e);
         const float er = __shfl (qr, (int) e), eg = __shfl (qg, (int) e), eb = __shfl (qb, (int) e);
         const uint32_t oe = (uint32_t) __shfl ((int) o, (int) e), ne = (uint32_t) __shfl ((int) (valid ? n : 0u), (int) e);
@@ -723,7 +734,7 @@ __global__ __launch_bounds__ (64 * KS_SPLIT) void k_search (icp_params p)
     __syncthreads ();
     if constexpr (FUSED) {
         // halving tree over the block's 64 pairs, one 16-lane row per moment (rows 0..17 of the 32 rows)
-        const uint32_t l = lane & 15u, mrow = slice * 4u + (lane >> 4);
+        const uint32_t l = lane & 15u, mrow = slice * 4u + (lane >> 4);     // first 18 of the block's 4*KS_SPLIT rows
         const uint32_t k = min (mrow, (uint32_t) ICP_NMOM - 1u);
         double c0 = s_mom[k][l] + s_mom[k][l + 32], c1 = s_mom[k][l + 16] + s_mom[k][l + 48];
         double v = row_tree_tail_d (c0 + c1);
@@ -1051,8 +1062,14 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 
 void icp_launch_search (const icp_params &p, hipStream_t s)
 {
-    if (p.fused) hipLaunchKernelGGL ((k_search<true, false>), dim3 (p.nb, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
-    else hipLaunchKernelGGL ((k_search<false, false>), dim3 (2 * p.nwg, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
+    const bool dense = (size_t) p.batch * p.nb > 512u;          // more blocks than one per CU: trade registers for occupancy
+    if (p.fused) {
+        if (dense) hipLaunchKernelGGL ((k_search<true, false, 4>), dim3 (p.nb, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
+        else hipLaunchKernelGGL ((k_search<true, false, 2>), dim3 (p.nb, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
+    } else {
+        if (dense) hipLaunchKernelGGL ((k_search<false, false, 4>), dim3 (2 * p.nwg, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
+        else hipLaunchKernelGGL ((k_search<false, false, 2>), dim3 (2 * p.nwg, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
+    }
 }
 
 void icp_launch_means (const icp_params &p, hipStream_t s)
@@ -1096,7 +1113,7 @@ void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations)
     hipLaunchKernelGGL (k_chain_begin, dim3 (p.batch), dim3 (64), 0, s, p);
     for (uint32_t j = 0; j < iterations; ++j) {
         p.slot = j & 1u;
-        hipLaunchKernelGGL ((k_search<true, true>), dim3 (p.nb, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
+        hipLaunchKernelGGL ((k_search<true, true, 2>), dim3 (p.nb, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
     }
     p.slot = iterations & 1u;
     hipLaunchKernelGGL (k_chain_end, dim3 (p.batch), dim3 (320), 0, s, p);

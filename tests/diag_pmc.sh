@@ -1,21 +1,17 @@
 #!/bin/bash
-# Diagnostic (not a test): PMC passes around a short bench run; prints per-dispatch means for k_search.
+# Diagnostic (not a test): one PMC pass around a short bench run; prints per-dispatch means for k_search.
+# usage: tests/diag_pmc.sh NAME COUNTER...      (TA_* counters abort rocprofv3 on this pool: do not use them)
 export TMPDIR=/tmp
-run() { # name, counters...
-  name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_$name -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$name.log 2>&1
-}
-run l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
-run tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
-run ta TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
-run sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS
-python3 - <<'PY'
-import csv, glob, collections
-for f in sorted(glob.glob('gpurun_out/pmc_*/*/*counter_collection.csv')):
-    acc = collections.defaultdict(list)
+name=$1; shift
+timeout 120 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_$name -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$name.log 2>&1
+python3 - "$name" <<'PY'
+import csv, glob, collections, sys
+for f in sorted(glob.glob('gpurun_out/pmc_%s/*/*counter_collection.csv' % sys.argv[1])):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        if 'k_search' in r['Kernel_Name']:
-            acc[r['Counter_Name']].append(float(r['Counter_Value']))
-    for k, v in acc.items():
-        print("%-40s mean %14.1f  (n=%d)" % (k, sum(v) / len(v), len(v)))
+        acc[r['Kernel_Name'][:40]][r['Counter_Name']].append(float(r['Counter_Value']))
+    for kn, d in acc.items():
+        if 'k_search' in kn or 'finalize' in kn:
+            for k, v in d.items():
+                print("%-42s %-28s mean %14.1f  (n=%d)" % (kn, k, sum(v) / len(v), len(v)))
 PY

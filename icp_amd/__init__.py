@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["ICP", "ICPStep", "ICPError", "Memory", "ICPStepConfigT", "ICPStepConfigW",
-           "PowerMode", "ReduceMode", "lib", "lib_path", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
+           "PowerMode", "ReduceMode", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("ICP_AMD_LIB", os.path.join(_HERE, "libicp_amd.so"))   # override: A/B builds of the same ABI
@@ -119,6 +119,9 @@ def lib():
     sig("icp_reset_transform", i32, vp)
     sig("icp_time_kernels", i32, vp, u32, C.POINTER(f32))
     sig("icp_time_masked", i32, vp, u32, u32, u32, C.POINTER(f32))
+    sig("icp_reduce", i32, i32, i32, vp, u32, u32, vp)
+    sig("icp_scan", i32, i32, i32, vp, u32, u32, vp)
+    sig("icp_reduce_scan_last_error", C.c_char_p)
     sig("icp_last_error", C.c_char_p, vp)
     sig("icp_version", C.c_char_p)
     sig("icp_device_count", i32, C.POINTER(i32))
@@ -126,6 +129,35 @@ def lib():
     sig("icp_synth_cloud_vga", i32, C.c_uint64, i32, vp)
     _lib = L
     return L
+
+
+class ReduceConfig:              # include/ICP/algorithms.hpp:52-57
+    MIN, MAX, SUM = 0, 1, 2
+
+
+def reduce(a, config=ReduceConfig.SUM, device=0):
+    """Row-wise reduce of a rows x cols array — cl_algo::ICP::Reduce<C,T> (MIN: float, MAX: uint32, SUM: float)."""
+    dt = np.uint32 if config == ReduceConfig.MAX else np.float32
+    a = np.ascontiguousarray(a, dt)
+    if a.ndim != 2:
+        raise ValueError("expected a rows x cols array")
+    out = np.empty(a.shape[0], dt)
+    rc = lib().icp_reduce(device, config, _p(a), a.shape[1], a.shape[0], _p(out))
+    if rc:
+        raise ICPError(rc, lib().icp_reduce_scan_last_error().decode())
+    return out
+
+
+def scan(a, inclusive=True, device=0):
+    """Row-wise integer scan of a rows x cols array — cl_algo::ICP::Scan<INCLUSIVE|EXCLUSIVE,int>."""
+    a = np.ascontiguousarray(a, np.int32)
+    if a.ndim != 2:
+        raise ValueError("expected a rows x cols array")
+    out = np.empty_like(a)
+    rc = lib().icp_scan(device, int(inclusive), _p(a), a.shape[1], a.shape[0], _p(out))
+    if rc:
+        raise ICPError(rc, lib().icp_reduce_scan_last_error().decode())
+    return out
 
 
 def device_count():

@@ -185,6 +185,19 @@ int icp_write_cloud (icp_handle h, int which, const void *host_cloud_640x480x8, 
  * src/ocl_icp_reg.cpp:175 (full-cloud transform after run()).  Host in, host out; n points. */
 int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint32_t n);
 
+/* ---- standalone Reduce / Scan classes of the reference ------------------------------ */
+
+/* Reduce<MIN,float> / Reduce<MAX,uint> / Reduce<SUM,float> — include/ICP/algorithms.hpp:52-166,
+ * kernels/reduce_kernels.cl:68, 149, 230, src/ICP/algorithms.cpp:131-322.  Row-wise over rows x cols (cols % 4 == 0);
+ * host buffers in and out (rows results).  SUM reproduces reduce_sum_f's tree bit for bit. */
+typedef enum { ICP_REDUCE_MIN_F = 0, ICP_REDUCE_MAX_UI = 1, ICP_REDUCE_SUM_F = 2 } icp_reduce_op;
+int icp_reduce (int device, int op, const void *host_in, uint32_t cols, uint32_t rows, void *host_out);
+
+/* Scan<INCLUSIVE|EXCLUSIVE,int> — include/ICP/algorithms.hpp:169-290, kernels/scan_kernels.cl:67, 188, 296,
+ * src/ICP/algorithms.cpp:403-600.  Row-wise over rows x cols ints (cols % 4 == 0). */
+int icp_scan (int device, int inclusive, const int32_t *host_in, uint32_t cols, uint32_t rows, int32_t *host_out);
+const char *icp_reduce_scan_last_error (void);
+
 /* ---- measurement (bench.py, HIP events on the handle's stream) --------------------------------- */
 
 /* Times `reps` back-to-back icp_run_fixed(iterations) passes with hipEvents recorded on the

@@ -106,3 +106,22 @@ def test_bin_files_register_and_track(engine, oracle, tmp_path):
     assert len(res) == 2 and np.array_equal(res[0][0].view(np.uint32), o.T.view(np.uint32))
     # the second hop maps the first frame back onto the second: roughly the inverse rotation
     assert np.abs(res[1][0][:3] + res[0][0][:3]).max() < 2e-3
+
+
+def test_standalone_reduce_and_scan(engine, oracle):
+    """Reduce / Scan classes at the reference's own test size, 1024 x 1024 (tests/testsReduce.cpp:64,145,226,
+    tests/testsScan.cpp:65,150), plus ragged shapes.  SUM is bit-identical to the oracle's reduce_sum_f tree."""
+    r = np.random.default_rng(11)
+    for rows, cols in [(1024, 1024), (11, 4096), (3, 4), (5, 516), (2, 262144 * 2)]:
+        a = r.uniform(0, 1, (rows, cols)).astype(np.float32)
+        assert np.array_equal(engine.reduce(a, engine.ReduceConfig.MIN), a.min(1))                    # testsReduce: eps
+        assert np.array_equal(engine.reduce(a, engine.ReduceConfig.SUM).view(np.uint32), oracle.reduce_sum_f(a).view(np.uint32))
+        assert np.all(np.abs(engine.reduce(a, engine.ReduceConfig.SUM) - a.astype(np.float64).sum(1)) < 42000 * np.finfo(np.float32).eps * max(1, cols / 1024))
+        u = r.integers(0, 2 ** 32, (rows, cols), dtype=np.uint32)
+        assert np.array_equal(engine.reduce(u, engine.ReduceConfig.MAX), u.max(1))
+        i = r.integers(0, 256, (rows, cols)).astype(np.int32)
+        inc = np.cumsum(i, axis=1, dtype=np.int32)
+        assert np.array_equal(engine.scan(i, True), inc)                                              # testsScan: exact
+        assert np.array_equal(engine.scan(i, False), inc - i)
+    with pytest.raises(engine.ICPError):
+        engine.reduce(np.zeros((2, 6), np.float32))           # cols % 4 != 0 (src/ICP/algorithms.cpp:151)

@@ -13,9 +13,8 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): a frame pair does n
 data-path collective; value = iterations of all ranks / max-over-ranks time  ("scaling": "weak").
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel (k_search; in the default fused/chained mode it is the ONLY kernel of an
-                iteration): algorithmic bytes per launch (72 m + 32 |R| + 64) / its average
-                launch-to-launch time, measured with HIP events on the engine's own stream over the timed region
+  roofline      dominant kernel (k_search): algorithmic bytes per launch (72 m + 32 |R| + 64) /
+                its average launch-to-launch time, measured with HIP events on the engine's own stream
   cpu_baseline  the CPU oracle ("port") timed on this host on a bounded sample (rank 0, N = 1 only)
 """
 import argparse
@@ -138,16 +137,13 @@ def main():
 
     total_t, total_iters = aggregate(dist, elapsed, args.steps * ITERS_PER_STEP)
 
-    # dominant kernel: in fused mode one k_search launch IS one iteration, so its average launch-to-launch
-    # time is the event time of the region / launches; in reference-order mode k_search is timed in a graph of its own
+    # dominant kernel (k_search): average launch-to-launch time of a graph holding only that kernel, HIP events on
+    # the engine's stream (rocprofv3's per-dispatch average for the same kernel: profiles/r01_final_*_kernel_stats.csv)
     fused = args.reduce_mode == "fused"
-    if fused:
-        search_us = ev_ms * 1e3 / (args.steps * ITERS_PER_STEP)
-        kernel_us = {"search(chained: finalize prologue + search + moments)": search_us}
-    else:
-        kernel_us = {n: g.time_masked(mk, ITERS_PER_STEP, 20) for n, mk in (("search", 1), ("means", 2), ("sij", 4), ("finalize", 8))}
-        search_us = kernel_us["search"]
-        g.buildRBC(); g.sync()
+    names = (("search", 1), ("finalize", 8)) if fused else (("search", 1), ("means", 2), ("sij", 4), ("finalize", 8))
+    kernel_us = {n: g.time_masked(mk, ITERS_PER_STEP, 20) for n, mk in names}
+    kernel_us["iteration (all kernels, from the timed region)"] = ev_ms * 1e3 / (args.steps * ITERS_PER_STEP)
+    search_us = kernel_us["search"]
     achieved = ALGO_BYTES_PER_ITER / (search_us * 1e-6) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -100,16 +100,17 @@ __device__ __forceinline__ float row_tree4 (const float *a)
 // ------------------------------------------------------------------------------------------
 
 // ASSUMPTION-METRIC — the single swap point on the GPU side (CPU twin: orc_metric8).
-// d = ((dx^2+dy^2)+dz^2) + a*((dr^2+dg^2)+db^2), lanes 3 and 7 ignored
-// (metric text: src/ICP/algorithms.cpp:4393-4398; RandomBallCover source is un-vendored).
+// d = fma (a, pho, geo), geo = fma (dz, dz, fma (dy, dy, dx*dx)), pho likewise on r g b; lanes 3 and 7 ignored
+// (metric text: src/ICP/algorithms.cpp:4393-4398; RandomBallCover source is un-vendored).  The fmas are explicit:
+// the translation unit is built with -ffp-contract=off, nothing else is contracted.
 __device__ __forceinline__ float icp_metric8 (float qx, float qy, float qz, float qr, float qg, float qb,
                                               float x, float y, float z, float r, float g, float b, float a)
 {
     float dx = qx - x, dy = qy - y, dz = qz - z;
     float dr = qr - r, dg = qg - g, db = qb - b;
-    float geo = (dx * dx + dy * dy) + dz * dz;
-    float pho = (dr * dr + dg * dg) + db * db;
-    return geo + a * pho;
+    float geo = __builtin_fmaf (dz, dz, __builtin_fmaf (dy, dy, dx * dx));
+    float pho = __builtin_fmaf (db, db, __builtin_fmaf (dg, dg, dr * dr));
+    return __builtin_fmaf (a, pho, geo);
 }
 
 // icpTransform_Quaternion — kernels/icp_kernels.cl:789-801:

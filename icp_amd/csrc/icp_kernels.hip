@@ -610,13 +610,13 @@ __global__ __launch_bounds__ (64 * KS_SPLIT, MINW) void k_search (icp_params p)
                 float4 A = s_pair[3 * P], B = s_pair[3 * P + 1];
                 float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y };
                 float2v dx = vqx - x, dy = vqy - y, dz = vqz - z;
-                float2v geo = (dx * dx + dy * dy) + dz * dz;
+                float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
                 if (!__any (geo.x < best || geo.y < best)) continue;
                 float4 C = s_pair[3 * P + 2];
                 float2v r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
                 float2v dr = vqr - r, dg = vqg - g, db = vqb - bb;
-                float2v pho = (dr * dr + dg * dg) + db * db;
-                float2v d = geo + va * pho;
+                float2v pho = __builtin_elementwise_fma (db, db, __builtin_elementwise_fma (dg, dg, dr * dr));
+                float2v d = __builtin_elementwise_fma (va, pho, geo);
                 const uint32_t r0 = t0 + 2u * P;
                 if (d.x < best) { best = d.x; bid = r0; }
                 if (d.y < best) { best = d.y; bid = r0 + 1u; }
@@ -627,9 +627,9 @@ __global__ __launch_bounds__ (64 * KS_SPLIT, MINW) void k_search (icp_params p)
             float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];
             float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
             float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
-            float2v geo = (dx * dx + dy * dy) + dz * dz;
-            float2v pho = (dr * dr + dg * dg) + db * db;
-            float2v d = geo + va * pho;
+            float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
+            float2v pho = __builtin_elementwise_fma (db, db, __builtin_elementwise_fma (dg, dg, dr * dr));
+            float2v d = __builtin_elementwise_fma (va, pho, geo);
             const uint32_t r0 = t0 + 2u * P;
             if (d.x < best) { best = d.x; bid = r0; }        // ascending index, strict '<': lowest index on ties
             if (d.y < best) { best = d.y; bid = r0 + 1u; }

@@ -176,12 +176,13 @@ void orc_transform_m (const float *M, float *tM, const float *T16, uint32_t m)
  * Reference text: "|x-x'|^2 = f_g(a)|x_g-x'_g|^2 + f_p(a)|x_p-x'_p|^2, see euclideanSquaredMetric8"
  * (src/ICP/algorithms.cpp:4393-4398).  Lanes 3 and 7 (the homogeneous 1s) are ignored. */
 float orc_metric8 (const float *x, const float *y, float a)
-{
+{   /* explicit fused multiply-adds (one rounding each), the form a GPU compiler gives OpenCL's dot();
+     * everything else in this file is built with -ffp-contract=off */
     float dx = x[0] - y[0], dy = x[1] - y[1], dz = x[2] - y[2];
     float dr = x[4] - y[4], dg = x[5] - y[5], db = x[6] - y[6];
-    float g = (dx * dx + dy * dy) + dz * dz;
-    float p = (dr * dr + dg * dg) + db * db;
-    return g + a * p;
+    float g = fmaf (dz, dz, fmaf (dy, dy, dx * dx));
+    float p = fmaf (db, db, fmaf (dg, dg, dr * dr));
+    return fmaf (a, p, g);
 }
 
 static int g_threads = 1;

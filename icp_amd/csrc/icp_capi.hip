@@ -632,7 +632,7 @@ int icp_debug_stamps (icp_handle h, unsigned long long *out, uint32_t nblocks)
     HIPCHK (h, hipMemset (d, 0, (size_t) nblocks * 16 * 8));
     icp_params p = h->p; p.check = 0; p.dbg = d;
     if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, 2);
-    else icp_launch_search (p, h->stream);
+    else { icp_launch_search (p, h->stream); if (p.fused) icp_launch_finalize (p, h->stream); }
     HIPCHK (h, hipStreamSynchronize (h->stream));
     HIPCHK (h, hipMemcpy (out, d, (size_t) nblocks * 16 * 8, hipMemcpyDeviceToHost));
     (void) hipFree (d);

@@ -975,6 +975,7 @@ __global__ __launch_bounds__ (1024) void k_finalize_fused (icp_params p)
 {
     const uint32_t b = blockIdx.x;
     icp_reg_state *st = p.st + b;
+    FF_STAMP (14)
     if (p.check && st->done) return;
     __shared__ icp_fin_result s_fin;
     __shared__ double s_l1[ICP_NMOM][128];

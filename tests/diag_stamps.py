@@ -30,4 +30,8 @@ if t[:, 12].max() > 0:
     for a, b_, n in ((8, 10, "moments->trees"), (10, 11, "finish (f64 divs)"), (11, 12, "power method"), (12, 9, "compose+publish")):
         d = t[:, b_] - t[:, a]
         print("  %-18s mean %8.0f  min %8d  max %8d" % (n, d.mean(), d.min(), d.max()))
+if t[0, 15] > 0 and t[0, 14] > 0:
+    print("finalize kernel (block 0): fetch+trees %d  finish %d  power method %d  compose+publish %d   total %d ticks"
+          % (t[0, 10] - t[0, 14], t[0, 11] - t[0, 10], t[0, 12] - t[0, 11], t[0, 15] - t[0, 12], t[0, 15] - t[0, 14]))
 print("kernel span (first start -> last end): %d ticks; per-block mean %0.f" % (t[:, 7].max() - t0, (t[:, 7] - t[:, 8]).mean()))
+print("row0 raw:", [int(x) for x in t[0]])

@@ -410,3 +410,20 @@ def test_fused_chain_batched(engine, oracle):
         assert_bits(g.read(engine.Memory.T, b), o.T, "T of registration %d" % b)
     assert len(set(ks)) > 1                          # registrations really stop at different iterations
     g.close()
+
+
+def test_opt_in_chain_mode(engine, oracle, monkeypatch):
+    """ICP_AMD_CHAIN=1 (read at icp_create): one launch per iteration, finalize in the next search's prologue,
+    double-buffered state and moments — same bits as the two-launch fused path and as the oracle."""
+    monkeypatch.setenv("ICP_AMD_CHAIN", "1")
+    g, o, F, M = make(engine, oracle, 128, 256, power_fast=True, fused=True)
+    g.buildRBC()
+    o.build_rbc()
+    assert g.run() == o.run()
+    assert_bits(g.read(engine.Memory.T), o.T, "final T (chain)")
+    check_step(engine, g, o, weighted=False)
+    g.run_fixed(3)
+    for _ in range(3):
+        o.step()
+    check_step(engine, g, o, weighted=False)
+    g.close()

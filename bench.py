@@ -145,6 +145,8 @@ def main():
     kernel_us["iteration (all kernels, from the timed region)"] = ev_ms * 1e3 / (args.steps * ITERS_PER_STEP)
     search_us = kernel_us["search"]
     achieved = ALGO_BYTES_PER_ITER / (search_us * 1e-6) / 1e9
+    algo_flop = 18.0 * M_POINTS * (N_REPS + M_POINTS / N_REPS) + 100.0 * M_POINTS      # SURVEY.md §8d / BASELINE.md §3
+    tflops = algo_flop / (search_us * 1e-6) / 1e12
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -176,6 +178,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ITER, "avg_launch_us": search_us,
                          "kernel_us": kernel_us,
+                         "valu_beside_it": {"algorithmic_flop_per_launch": algo_flop, "achieved_tflops": tflops,
+                                            "peak_tflops_fp32_vector": 157.3, "frac": tflops / 157.3},
                          "note": "cache-resident at this size (1.19 MB/iteration): latency/VALU-bound, see DESIGN.md §5"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -266,7 +266,6 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &p.mpart, B * 2 * p.nwg))) return rc;
     if ((rc = dalloc (h, &p.mscr, B * 2 * ((p.nwg + 127u) / 128u)))) return rc;
     if ((rc = dalloc (h, &p.spart, B * 11 * p.nsp * 8))) return rc;    // 8 sub-trees per work-group; padding stays 0.f
-    if ((rc = dalloc (h, &p.sscr, B * 11 * ((((p.nsp + 511u) / 512u) + 3u) & ~3u)))) return rc;
     if ((rc = dalloc (h, &p.mom, B * 2 * 18 * p.nb))) return rc;
     if ((rc = dalloc (h, &p.cst, B * 2))) return rc;
     if ((rc = dalloc (h, &p.st, B))) return rc;

@@ -36,7 +36,6 @@ struct icp_params {
     float4 *mpart;               // [batch][2][nwg]
     float4 *mscr;                // [batch][2][ceil(nwg/128)]  scratch of the multi-level icpGMean
     float *spart;                // [batch][11][nsp*8] 8 residue sub-trees per work-group
-    float *sscr;                 // [batch][11][..] scratch of the multi-level reduce_sum_f
     double *mom;                 // [batch][2][18][nb]  fused mode: per-block moment partials (double-buffered for the chain)
     icp_reg_state *cst;          // [batch][2]  chained fused mode: state slots, launch j reads slot j&1 and writes the other
     uint32_t slot;               // chained fused mode: slot this launch reads

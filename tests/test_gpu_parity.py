@@ -427,3 +427,19 @@ def test_opt_in_chain_mode(engine, oracle, monkeypatch):
         o.step()
     check_step(engine, g, o, weighted=False)
     g.close()
+
+
+@pytest.mark.parametrize("side,nr", [(2, 1), (2, 4), (4, 2), (8, 64), (10, 4), (14, 4)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_tiny_and_odd_shapes(engine, oracle, side, nr, fused):
+    """Smallest sets, one representative (odd LDS pair tile), every point a representative, sides that are not
+    multiples of 8 (fused mode falls back to linear 64-query blocks), partially filled blocks."""
+    g, o, F, M = make(engine, oracle, side, nr, power_fast=True, fused=fused)
+    g.buildRBC()
+    o.build_rbc()
+    check_rbc(engine, g, o)
+    for _ in range(3):
+        g.step()
+        o.step()
+        check_step(engine, g, o, weighted=not fused)
+    g.close()

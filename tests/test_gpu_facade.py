@@ -125,3 +125,63 @@ def test_standalone_reduce_and_scan(engine, oracle):
         assert np.array_equal(engine.scan(i, False), inc - i)
     with pytest.raises(engine.ICPError):
         engine.reduce(np.zeros((2, 6), np.float32))           # cols % 4 != 0 (src/ICP/algorithms.cpp:151)
+
+
+def test_plain_c_program_all_specialisations(engine, oracle):
+    """tests/cpp/capi_example.c (gcc -std=c99): the four ICPStep specialisations through the bare C-ABI."""
+    exe = os.path.join(ROOT, "tests", "cpp", "capi_example")
+    subprocess.check_call(["make", "-C", ROOT, "-s", "capi_example"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    F, M = engine.synth_pair(64)
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 4
+    for line in lines:
+        tok = line.split()
+        rot, w, k = int(tok[1]), int(tok[3]), int(tok[5])
+        T = np.array([float(x) for x in tok[7:15]], np.float32)
+        o = oracle.OracleICP(4096, 64, 2e2, 1e-6, rot=rot, weighted=w, threads=8)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        assert k == o.run(), line
+        assert np.array_equal(T.view(np.uint32), o.T.view(np.uint32)), line
+
+
+def test_handles_are_independent_and_reusable(engine, oracle):
+    """Two handles on one device interleaved; re-init of a handle with another size; adopted device buffers."""
+    F1, M1 = engine.synth_pair(64, seed=1)
+    F2, M2 = engine.synth_pair(32, seed=2)
+    a, b = engine.ICP(0), engine.ICP(0)
+    a.init(4096, 64, 2e2, 1e-6); b.init(1024, 16, 2e2, 1e-6)
+    a.write(engine.Memory.F, F1); b.write(engine.Memory.F, F2)
+    a.write(engine.Memory.M, M1); b.write(engine.Memory.M, M2)
+    a.buildRBC(); b.buildRBC()
+    for _ in range(3):
+        a.step(); b.step()
+    oa = oracle.OracleICP(4096, 64, 2e2, 1e-6, threads=8); ob = oracle.OracleICP(1024, 16, 2e2, 1e-6)
+    for o_, F_, M_ in ((oa, F1, M1), (ob, F2, M2)):
+        o_.write_f(F_); o_.write_m(M_); o_.build_rbc()
+        for _ in range(3):
+            o_.step()
+    assert np.array_equal(a.read(engine.Memory.T).view(np.uint32), oa.T.view(np.uint32))
+    assert np.array_equal(b.read(engine.Memory.T).view(np.uint32), ob.T.view(np.uint32))
+    # re-init `a` at the other size: it must behave like a fresh handle
+    a.init(1024, 16, 2e2, 1e-6)
+    a.write(engine.Memory.F, F2); a.write(engine.Memory.M, M2); a.buildRBC()
+    for _ in range(3):
+        a.step()
+    assert np.array_equal(a.read(engine.Memory.T).view(np.uint32), ob.T.view(np.uint32))
+    # zero-copy chaining (reference: get() before init, src/ocl_icp_reg.cpp:111-113): b's buffers adopted by c
+    import ctypes as C
+    L = engine.lib()
+    c = engine.ICP(0)
+    c.init(1024, 16, 2e2, 1e-6)
+    for mem in (engine.Memory.F, engine.Memory.M):
+        ptr = C.c_void_p()
+        assert L.icp_device_ptr(b._h, mem, C.byref(ptr)) == 0
+        assert L.icp_adopt_device_buffer(c._h, mem, ptr) == 0
+    b.sync()
+    c.buildRBC()
+    for _ in range(3):
+        c.step()
+    assert np.array_equal(c.read(engine.Memory.T).view(np.uint32), ob.T.view(np.uint32))
+    c.close(); a.close(); b.close()

@@ -500,21 +500,22 @@ __global__ __launch_bounds__ (64 * KS_SPLIT, MINW) void k_search (icp_params p)
     //   pair P = reps (2P, 2P+1) -> 3 float4: [x0 x1 y0 y1] [z0 z1 r0 r1] [g0 g1 b0 b1]
     __shared__ float4 s_pair[3 * KS_TILE / 2];
     __shared__ uint2 s_on[KS_TILE];                  // (offset, size) of every representative's list
-    __shared__ float s_best[KS_SPLIT][64];
-    __shared__ uint32_t s_idx[KS_SPLIT][64];
-    __shared__ float4 s_nn[KS_SPLIT][64];
     __shared__ float s_w[64];
     __shared__ double s_mom[FUSED ? ICP_NMOM : 1][64];
     __shared__ icp_fin_result s_fin;
     __shared__ double s_l1[CHAIN ? ICP_NMOM : 1][CHAIN ? 32 : 1];
     __shared__ double s_t[ICP_NMOM];
 
+    // A wave serves KS_QPW (= 8) queries end to end, KS_SPLIT (= 8) lanes per query: lane (L & 7) takes the
+    // representative pairs = (L & 7) mod 8 in stage 1 and the list positions = (L & 7) mod 8 in stage 2, and the
+    // query's winner is an 8-lane DPP reduction — no cross-wave exchange, two block barriers in the whole kernel.
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t slice = __builtin_amdgcn_readfirstlane (tid >> 6);
+    const uint32_t qe = slice * KS_QPW + lane / KS_SPLIT, ss = lane & (KS_SPLIT - 1u);
     // reference-order mode: the 64 even (or odd) positions of one 128-query group (a closed sub-tree of
     // the weight reduction); fused mode: an 8 x 8 tile of the landmark grid (spatially coherent lists)
-    const uint32_t i = FUSED ? fused_query_index (p.m, p.side, blockIdx.x, lane)
-                             : (blockIdx.x >> 1) * 128u + 2u * lane + (blockIdx.x & 1u);
+    const uint32_t i = FUSED ? fused_query_index (p.m, p.side, blockIdx.x, qe)
+                             : (blockIdx.x >> 1) * 128u + 2u * qe + (blockIdx.x & 1u);
     const bool valid = i < p.m;
 
     const float4 *M4 = reinterpret_cast<const float4 *> (p.M + (size_t) b * p.m * 8);
@@ -572,7 +573,7 @@ __global__ __launch_bounds__ (64 * KS_SPLIT, MINW) void k_search (icp_params p)
     KS_STAMP (0)
 
     // ---- stage 1: nearest representative, two representatives per packed instruction ----
-    float best = __builtin_inff (); uint32_t bid = 0;
+    float best = __builtin_inff (); uint32_t bid = 0xFFFFFFFFu;
 #ifdef ICP_DBG_SKIP_S1
     best = 0.f; bid = (i * 7u) % p.nr;
     for (uint32_t t0 = p.nr; t0 < p.nr; t0 += KS_TILE) {
@@ -597,16 +598,16 @@ __global__ __launch_bounds__ (64 * KS_SPLIT, MINW) void k_search (icp_params p)
         __syncthreads ();
         KS_STAMP (1)
         const uint32_t npair = (tn + 1u) >> 1;
-        const uint32_t per = (npair + KS_SPLIT - 1) / KS_SPLIT;
-        const uint32_t p0 = min (slice * per, npair), p1 = min (p0 + per, npair);
         const float2v vqx = { qx, qx }, vqy = { qy, qy }, vqz = { qz, qz }, vqr = { qr, qr }, vqg = { qg, qg }, vqb = { qb, qb };
         const float2v va = { alpha, alpha };
+        // a lane's pairs ascend (P = ss, ss+8, ..) and an update needs a strict '<', so each lane keeps its lowest
+        // index among equal distances; the 8-lane reduction below then takes the lowest index overall
         if (p.nr >= 1024u && alpha > 0.f) {
-            // throughput-bound sizes: exact early rejection.  d = geo + a*pho >= geo (a > 0), and an update needs the
-            // strict d < best, so when no lane of the wave has geo < best the photometric half of the pair is skipped
-            // (wave-uniform branch; the block's queries are spatially coherent, so most far pairs are skipped).
+            // throughput-bound sizes: exact early rejection.  d = fma (a, pho, geo) >= geo (a > 0), and an update needs
+            // the strict d < best, so when no lane of the wave has geo < best the photometric half of the pair is
+            // skipped (wave-uniform branch; the wave's queries are neighbours, so most far pairs are skipped).
 #pragma unroll 4
-            for (uint32_t P = p0; P < p1; ++P) {
+            for (uint32_t P = ss; P < npair; P += KS_SPLIT) {
                 float4 A = s_pair[3 * P], B = s_pair[3 * P + 1];
                 float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y };
                 float2v dx = vqx - x, dy = vqy - y, dz = vqz - z;
@@ -623,86 +624,68 @@ __global__ __launch_bounds__ (64 * KS_SPLIT, MINW) void k_search (icp_params p)
             }
         } else {
 #pragma unroll 8
-        for (uint32_t P = p0; P < p1; ++P) {
-            float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];
-            float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
-            float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
-            float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
-            float2v pho = __builtin_elementwise_fma (db, db, __builtin_elementwise_fma (dg, dg, dr * dr));
-            float2v d = __builtin_elementwise_fma (va, pho, geo);
-            const uint32_t r0 = t0 + 2u * P;
-            if (d.x < best) { best = d.x; bid = r0; }        // ascending index, strict '<': lowest index on ties
-            if (d.y < best) { best = d.y; bid = r0 + 1u; }
-        }
+            for (uint32_t P = ss; P < npair; P += KS_SPLIT) {
+                float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];
+                float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
+                float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
+                float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
+                float2v pho = __builtin_elementwise_fma (db, db, __builtin_elementwise_fma (dg, dg, dr * dr));
+                float2v d = __builtin_elementwise_fma (va, pho, geo);
+                const uint32_t r0 = t0 + 2u * P;
+                if (d.x < best) { best = d.x; bid = r0; }
+                if (d.y < best) { best = d.y; bid = r0 + 1u; }
+            }
         }
     }
     KS_STAMP (2)
-    s_best[slice][lane] = best; s_idx[slice][lane] = bid;
-    __syncthreads ();
+    const float dr = ks_grp8_min_f (best);           // the query's nearest representative: smallest distance,
+    uint32_t rstar = ks_grp8_min_u (best == dr ? bid : 0xFFFFFFFFu);     // ties -> lowest index
+    if (rstar == 0xFFFFFFFFu) rstar = 0u;            // every distance inf / NaN: representative 0, as the serial scan would
     KS_STAMP (3)
-    float dr = s_best[0][lane]; uint32_t rstar = s_idx[0][lane];
-#pragma unroll
-    for (int s = 1; s < KS_SPLIT; ++s) {
-        float d = s_best[s][lane]; uint32_t id = s_idx[s][lane];
-        if (d < dr || (d == dr && id < rstar)) { dr = d; rstar = id; }
-    }
     uint32_t o, n;
     if (p.nr <= KS_TILE) { uint2 on = s_on[rstar]; o = on.x; n = on.y; }
     else { o = gO[rstar]; n = gN[rstar]; }
-    __syncthreads ();
 
-    // ---- stage 2: exhaustive scan of that representative's list ----
-    // Re-mapped inside the wave: wave `slice` serves queries 8*slice .. 8*slice+7, eight lanes per query, lane
-    // (L & 7) takes list positions = (L & 7) mod 8.  The eight lanes of a query read eight consecutive candidates
-    // (256 contiguous bytes) per load, so an instruction touches 16 cache lines instead of 64 scattered ones —
-    // the scan with lane = query was bound by the L1/TA rate of one 16-byte lane access per clock.
-    {
-        const uint32_t e = slice * KS_QPW + lane / KS_SPLIT, ss = lane & (KS_SPLIT - 1u);
-        const float ex = __shfl (qx, (int) e), ey = __shfl (qy, (int) e), ez = __shfl (qz, (int) e);
-        const float er = __shfl (qr, (int) e), eg = __shfl (qg, (int) e), eb = __shfl (qb, (int) e);
-        const uint32_t oe = (uint32_t) __shfl ((int) o, (int) e), ne = (uint32_t) __shfl ((int) (valid ? n : 0u), (int) e);
-        float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
-        float4 bnn = make_float4 (0.f, 0.f, 0.f, 0.f);
+    // ---- stage 2: exhaustive scan of that representative's list: the eight lanes of a query read eight consecutive
+    // candidates (256 contiguous bytes) per load.  (Staging the block's lists through LDS first was measured and is
+    // slower: enumerating the distinct lists and the extra barrier cost more than the direct gathers.)
+    float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
+    float4 bnn = make_float4 (0.f, 0.f, 0.f, 0.f);
 #ifndef ICP_DBG_SKIP_S2
-        {
-            const float qx = ex, qy = ey, qz = ez, qr = er, qg = eg, qb = eb;      // KS_CAND reads these names
-            uint32_t j = oe + ss;
-            const uint32_t je = oe + ne;
-            for (; j + 3 * KS_SPLIT < je; j += 4 * KS_SPLIT) {      // four candidates in flight
-                float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
-                float4 g1 = XQ4[2 * (size_t) (j + KS_SPLIT)], c1 = XQ4[2 * (size_t) (j + KS_SPLIT) + 1];
-                float4 g2 = XQ4[2 * (size_t) (j + 2 * KS_SPLIT)], c2 = XQ4[2 * (size_t) (j + 2 * KS_SPLIT) + 1];
-                float4 g3 = XQ4[2 * (size_t) (j + 3 * KS_SPLIT)], c3 = XQ4[2 * (size_t) (j + 3 * KS_SPLIT) + 1];
-                KS_CAND (g0, c0, j); KS_CAND (g1, c1, j + KS_SPLIT); KS_CAND (g2, c2, j + 2 * KS_SPLIT); KS_CAND (g3, c3, j + 3 * KS_SPLIT);
-            }
-            for (; j < je; j += KS_SPLIT) {
-                float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
-                KS_CAND (g0, c0, j);
-            }
+    if (valid) {
+        uint32_t j = o + ss;
+        const uint32_t je = o + n;
+        for (; j + 3 * KS_SPLIT < je; j += 4 * KS_SPLIT) {      // four candidates in flight
+            float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
+            float4 g1 = XQ4[2 * (size_t) (j + KS_SPLIT)], c1 = XQ4[2 * (size_t) (j + KS_SPLIT) + 1];
+            float4 g2 = XQ4[2 * (size_t) (j + 2 * KS_SPLIT)], c2 = XQ4[2 * (size_t) (j + 2 * KS_SPLIT) + 1];
+            float4 g3 = XQ4[2 * (size_t) (j + 3 * KS_SPLIT)], c3 = XQ4[2 * (size_t) (j + 3 * KS_SPLIT) + 1];
+            KS_CAND (g0, c0, j); KS_CAND (g1, c1, j + KS_SPLIT); KS_CAND (g2, c2, j + 2 * KS_SPLIT); KS_CAND (g3, c3, j + 3 * KS_SPLIT);
         }
-#endif
-        // the query's winner among its eight lanes: smallest distance, ties -> lowest list position
-        const float dmin = ks_grp8_min_f (best2);
-        const uint32_t jmin = ks_grp8_min_u (best2 == dmin ? bj : 0xFFFFFFFFu);
-        if (jmin == 0xFFFFFFFFu) { if (ss == 0) { s_best[0][e] = dmin; s_idx[0][e] = jmin; s_nn[0][e] = bnn; } }
-        else if (bj == jmin && best2 == dmin) { s_best[0][e] = dmin; s_idx[0][e] = bj; s_nn[0][e] = bnn; }
+        for (; j < je; j += KS_SPLIT) {
+            float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
+            KS_CAND (g0, c0, j);
+        }
     }
+#endif
     KS_STAMP (4)
-    __syncthreads ();
+    // the query's winner among its eight lanes: smallest distance, ties -> lowest list position; that lane finishes
+    // the query (lane ss == 0 when the list is empty or no candidate has a finite distance)
+    const float dmin = ks_grp8_min_f (best2);
+    const uint32_t jmin = ks_grp8_min_u (best2 == dmin ? bj : 0xFFFFFFFFu);
+    const bool winner = (jmin == 0xFFFFFFFFu) ? (ss == 0u) : (bj == jmin && best2 == dmin);
     KS_STAMP (5)
-
-    if (slice == 0) {
-        float d = s_best[0][lane]; uint32_t j = s_idx[0][lane]; const int sw = 0;
-        float w = 0.f;
+    if (winner) {
+        float d = dmin; float w = 0.f;
         float s_nn_x = 0.f, s_nn_y = 0.f, s_nn_z = 0.f;
         if (valid) {
             uint32_t id; float4 nn;
             if (n == 0) {            // empty list: fall back to the representative itself
                 d = dr; id = p.rep_src[(size_t) b * p.nr + rstar]; nn = R4[2 * (size_t) rstar];
-            } else if (j == 0xFFFFFFFFu) {   // every distance inf / NaN: first list element, as the serial scan would
+            } else if (jmin == 0xFFFFFFFFu) {   // every distance inf / NaN: first list element, as the serial scan would
                 nn = XQ4[2 * (size_t) o]; id = __float_as_uint (nn.w);
             } else {
-                nn = s_nn[sw][lane]; id = __float_as_uint (nn.w);
+                nn = bnn; id = __float_as_uint (nn.w);
             }
             w = p.weighted ? 100.f / (100.f + d) : 1.f;                // icp_kernels.cl:232
             icp_dist_id di; di.dist = d; di.id = id;
@@ -713,22 +696,22 @@ __global__ __launch_bounds__ (64 * KS_SPLIT, MINW) void k_search (icp_params p)
             s_nn_x = nn.x; s_nn_y = nn.y; s_nn_z = nn.z;
         }
         if constexpr (FUSED) {
-            // the 18 moments of this pair in double (oracle orc_moments_fused); invalid lanes contribute 0
+            // the 18 moments of this pair in double (oracle orc_moments_fused); invalid queries contribute 0
             double W = (double) w;
             double f0 = valid ? (double) s_nn_x : 0.0, f1 = valid ? (double) s_nn_y : 0.0, f2 = valid ? (double) s_nn_z : 0.0;
             double q0 = (double) qx, q1 = (double) qy, q2 = (double) qz;
             if (!valid) { W = 0.0; q0 = q1 = q2 = 0.0; }
             double wq0 = W * q0, wq1 = W * q1, wq2 = W * q2;
-            s_mom[0][lane] = W;
-            s_mom[1][lane] = W * f0; s_mom[2][lane] = W * f1; s_mom[3][lane] = W * f2;
-            s_mom[4][lane] = wq0; s_mom[5][lane] = wq1; s_mom[6][lane] = wq2;
-            s_mom[7][lane] = wq0 * f0; s_mom[8][lane] = wq0 * f1; s_mom[9][lane] = wq0 * f2;
-            s_mom[10][lane] = wq1 * f0; s_mom[11][lane] = wq1 * f1; s_mom[12][lane] = wq1 * f2;
-            s_mom[13][lane] = wq2 * f0; s_mom[14][lane] = wq2 * f1; s_mom[15][lane] = wq2 * f2;
-            s_mom[16][lane] = W * ((f0 * f0 + f1 * f1) + f2 * f2);
-            s_mom[17][lane] = W * ((q0 * q0 + q1 * q1) + q2 * q2);
+            s_mom[0][qe] = W;
+            s_mom[1][qe] = W * f0; s_mom[2][qe] = W * f1; s_mom[3][qe] = W * f2;
+            s_mom[4][qe] = wq0; s_mom[5][qe] = wq1; s_mom[6][qe] = wq2;
+            s_mom[7][qe] = wq0 * f0; s_mom[8][qe] = wq0 * f1; s_mom[9][qe] = wq0 * f2;
+            s_mom[10][qe] = wq1 * f0; s_mom[11][qe] = wq1 * f1; s_mom[12][qe] = wq1 * f2;
+            s_mom[13][qe] = wq2 * f0; s_mom[14][qe] = wq2 * f1; s_mom[15][qe] = wq2 * f2;
+            s_mom[16][qe] = W * ((f0 * f0 + f1 * f1) + f2 * f2);
+            s_mom[17][qe] = W * ((q0 * q0 + q1 * q1) + q2 * q2);
         } else
-            s_w[lane] = w;
+            s_w[qe] = w;
     }
     KS_STAMP (6)
     __syncthreads ();

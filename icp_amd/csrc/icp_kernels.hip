@@ -304,10 +304,9 @@ __global__ __launch_bounds__ (1024) void k_place (icp_params p)
 //   wave s = slice s: 1/8 of the representatives (stage 1) and every 8th list position (stage 2);
 //   representatives are staged through LDS in tiles (coalesced float4 loads, broadcast ds_read_b128).
 // ------------------------------------------------------------------------------------------
-#ifndef KS_SPLIT
-#define KS_SPLIT 8              // waves per block = slices of the representatives = lanes per query in stage 2 (8 or 16)
-#endif
-#define KS_QPW (64 / KS_SPLIT)  // queries per wave in stage 2
+// KS_SPLIT = lanes per query = waves per block (8 or 16); inside k_search it names the template parameter LPQ
+#define KS_SPLIT LPQ
+#define KS_QPW (64 / KS_SPLIT)  // queries per wave
 #define KS_TILE 1024u            // representatives per LDS tile
 
 typedef float float2v __attribute__ ((ext_vector_type (2)));
@@ -323,25 +322,22 @@ typedef float float2v __attribute__ ((ext_vector_type (2)));
 #define KS_STAMP(k)
 #endif
 
-// minimum over each group of 8 consecutive lanes, returned in all 8 (min is exact: any pairing gives the same bits)
-static __device__ __forceinline__ float ks_grp8_min_f (float v)
+// minimum over each group of LPQ (8 or 16) consecutive lanes, returned in all of them (min is exact: any pairing
+// gives the same bits)
+template <int LPQ> static __device__ __forceinline__ float ks_grp_min_f (float v)
 {
     v = fminf (v, icp_dpp<0xB1> (v));                // quad_perm [1,0,3,2]
     v = fminf (v, icp_dpp<0x4E> (v));                // quad_perm [2,3,0,1]
     v = fminf (v, icp_dpp<0x141> (v));               // row_half_mirror: lane i <-> 7 - i
-#if KS_SPLIT == 16
-    v = fminf (v, icp_dpp<0x140> (v));               // row_mirror: lane i <-> 15 - i
-#endif
+    if (LPQ == 16) v = fminf (v, icp_dpp<0x140> (v));   // row_mirror: lane i <-> 15 - i
     return v;
 }
-static __device__ __forceinline__ uint32_t ks_grp8_min_u (uint32_t v)
+template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint32_t v)
 {
     v = min (v, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0xB1, 0xF, 0xF, true));
     v = min (v, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x4E, 0xF, 0xF, true));
     v = min (v, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x141, 0xF, 0xF, true));
-#if KS_SPLIT == 16
-    v = min (v, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x140, 0xF, 0xF, true));
-#endif
+    if (LPQ == 16) v = min (v, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x140, 0xF, 0xF, true));
     return v;
 }
 
@@ -477,9 +473,11 @@ static __device__ void fin_result_to_state (const icp_fin_result *res, icp_reg_s
 // iteration's moments into T in its prologue (every block redundantly; block 0 publishes the result in the
 // other slot), searches, and leaves its own moments in the other buffer: ONE launch per ICP iteration.
 // MINW = waves per SIMD the register allocation must leave room for: 2 (one block per CU: a single registration,
-// nothing to hide latency behind, no spills) or 4 (two blocks per CU: batched registrations, +70 % throughput)
-template <bool FUSED, bool CHAIN, int MINW>
-__global__ __launch_bounds__ (64 * KS_SPLIT, MINW) void k_search (icp_params p)
+// nothing to hide latency behind, no spills) or 4 (two blocks per CU: batched registrations, +70 % throughput).
+// LPQ = lanes per query = waves per block: 16 when the grid is at most one block per CU (more waves per SIMD to
+// overlap the L2-cold loads), 8 when occupancy comes from the number of blocks.
+template <bool FUSED, bool CHAIN, int MINW, int LPQ>
+__global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (icp_params p)
 {
     const uint32_t b = blockIdx.y;
     icp_reg_state *st = CHAIN ? p.cst + (size_t) b * 2 + p.slot : p.st + b;
@@ -638,8 +636,8 @@ __global__ __launch_bounds__ (64 * KS_SPLIT, MINW) void k_search (icp_params p)
         }
     }
     KS_STAMP (2)
-    const float dr = ks_grp8_min_f (best);           // the query's nearest representative: smallest distance,
-    uint32_t rstar = ks_grp8_min_u (best == dr ? bid : 0xFFFFFFFFu);     // ties -> lowest index
+    const float dr = ks_grp_min_f<KS_SPLIT> (best);           // the query's nearest representative: smallest distance,
+    uint32_t rstar = ks_grp_min_u<KS_SPLIT> (best == dr ? bid : 0xFFFFFFFFu);     // ties -> lowest index
     if (rstar == 0xFFFFFFFFu) rstar = 0u;            // every distance inf / NaN: representative 0, as the serial scan would
     KS_STAMP (3)
     uint32_t o, n;
@@ -671,8 +669,8 @@ __global__ __launch_bounds__ (64 * KS_SPLIT, MINW) void k_search (icp_params p)
     KS_STAMP (4)
     // the query's winner among its eight lanes: smallest distance, ties -> lowest list position; that lane finishes
     // the query (lane ss == 0 when the list is empty or no candidate has a finite distance)
-    const float dmin = ks_grp8_min_f (best2);
-    const uint32_t jmin = ks_grp8_min_u (best2 == dmin ? bj : 0xFFFFFFFFu);
+    const float dmin = ks_grp_min_f<KS_SPLIT> (best2);
+    const uint32_t jmin = ks_grp_min_u<KS_SPLIT> (best2 == dmin ? bj : 0xFFFFFFFFu);
     const bool winner = (jmin == 0xFFFFFFFFu) ? (ss == 0u) : (bj == jmin && best2 == dmin);
     KS_STAMP (5)
     if (winner) {
@@ -1048,11 +1046,11 @@ void icp_launch_search (const icp_params &p, hipStream_t s)
 {
     const bool dense = (size_t) p.batch * p.nb > 512u;          // more blocks than one per CU: trade registers for occupancy
     if (p.fused) {
-        if (dense) hipLaunchKernelGGL ((k_search<true, false, 4>), dim3 (p.nb, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
-        else hipLaunchKernelGGL ((k_search<true, false, 2>), dim3 (p.nb, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
+        if (dense) hipLaunchKernelGGL ((k_search<true, false, 4, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p);
+        else hipLaunchKernelGGL ((k_search<true, false, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p);
     } else {
-        if (dense) hipLaunchKernelGGL ((k_search<false, false, 4>), dim3 (2 * p.nwg, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
-        else hipLaunchKernelGGL ((k_search<false, false, 2>), dim3 (2 * p.nwg, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
+        if (dense) hipLaunchKernelGGL ((k_search<false, false, 4, 8>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, p);
+        else hipLaunchKernelGGL ((k_search<false, false, 2, 16>), dim3 (2 * p.nwg, p.batch), dim3 (1024), 0, s, p);
     }
 }
 
@@ -1097,7 +1095,7 @@ void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations)
     hipLaunchKernelGGL (k_chain_begin, dim3 (p.batch), dim3 (64), 0, s, p);
     for (uint32_t j = 0; j < iterations; ++j) {
         p.slot = j & 1u;
-        hipLaunchKernelGGL ((k_search<true, true, 2>), dim3 (p.nb, p.batch), dim3 (64 * KS_SPLIT), 0, s, p);
+        hipLaunchKernelGGL ((k_search<true, true, 2, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p);
     }
     p.slot = iterations & 1u;
     hipLaunchKernelGGL (k_chain_end, dim3 (p.batch), dim3 (320), 0, s, p);

@@ -179,9 +179,16 @@ __device__ __forceinline__ void pmq_rescale (float *Brow)
     Brow[0] = Brow[0] * sc; Brow[1] = Brow[1] * sc; Brow[2] = Brow[2] * sc; Brow[3] = Brow[3] * sc;
 }
 
+#ifdef ICP_DBG_STAMPS
+__device__ unsigned long long icp_pm_stamps[8];
+#define PM_STAMP(k) { unsigned long long t_; asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) icp_pm_stamps[k] = t_; }
+#else
+#define PM_STAMP(k)
+#endif
 __device__ inline int icp_power_method_quad (const float *S, const float *means, float *Tk, int squared_start, uint32_t lane)
 {
     const uint32_t i = lane & 3u;
+    const float sk = sqrtf (S[9] / S[10]);                             // :989 (independent of the eigenvector: issued first)
     float Sxx = S[0], Sxy = S[1], Sxz = S[2], Syx = S[3], Syy = S[4], Syz = S[5],
           Szx = S[6], Szy = S[7], Szz = S[8];
     // rows of N — icp_kernels.cl:993-999
@@ -195,6 +202,7 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
 
     float x = 1.f, xn = 0.f;
     int iters = 0;
+    PM_STAMP (0)
     for (;;) {
         if (squared_start) {
             float Brow[4] = { Nrow[0], Nrow[1], Nrow[2], Nrow[3] };
@@ -208,7 +216,9 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
                 Brow[0] = acc[0]; Brow[1] = acc[1]; Brow[2] = acc[2]; Brow[3] = acc[3];
                 if (s % 3 == 2) pmq_rescale (Brow);
             }
+            PM_STAMP (1)
             x = pmq_normalize (pmq_matvec (Brow, x));
+            PM_STAMP (2)
         }
         float error, error_new = __builtin_inff ();
         for (uint32_t it = 0; it < 1000; ++it) {                      // icp_kernels.cl:1012-1022
@@ -216,10 +226,16 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
             ++iters;
             error = error_new;
             float d = x - xn;
-            error_new = sqrtf (pmq_seq4 (d * d));
-            if (squared_start ? (error_new >= error) : (error_new == error)) break;     // oracle power_impl
+            if (squared_start) {                                      // oracle power_impl: squared step, floor 2^-22
+                error_new = pmq_seq4 (d * d);
+                if (error_new >= error || error_new <= 0x1p-44f) break;
+            } else {
+                error_new = sqrtf (pmq_seq4 (d * d));
+                if (error_new == error) break;
+            }
             x = xn;
         }
+        PM_STAMP (3)
         float lam_num = pmq_lane (pmq_matvec (Nrow, xn), 0);
         float lambda = lam_num / pmq_lane (xn, 0);                    // :1024
         if (lambda < 0) {
@@ -228,11 +244,12 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
             x = 1.f;
         } else break;
     }
+    PM_STAMP (4)
     x = xn;                                                           // :1039-1041
     xn = pmq_normalize (pmq_matvec (Nrow, x));
+    PM_STAMP (5)
 
     float qx = pmq_lane (xn, 0), qy = pmq_lane (xn, 1), qz = pmq_lane (xn, 2), qw = pmq_lane (xn, 3);
-    float sk = sqrtf (S[9] / S[10]);                                   // :989
     const float *mf = means, *mm = means + 4;
     float c1x = (qy * mm[2] - qz * mm[1]) + qw * mm[0];                // :1050
     float c1y = (qz * mm[0] - qx * mm[2]) + qw * mm[1];
@@ -246,6 +263,7 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
     Tk[5] = mf[1] - sk * (mm[1] + c2y);
     Tk[6] = mf[2] - sk * (mm[2] + c2z);
     Tk[7] = sk;
+    PM_STAMP (6)
     return iters;
 }
 

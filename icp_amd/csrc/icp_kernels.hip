@@ -363,49 +363,75 @@ template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint
 
 // fused mode: query index of local element e of block b (CPU twin: orc_fused_query).  8 x 8 tiles of the
 // landmark grid when its side is a multiple of 8, else 64 consecutive queries.
-static __device__ __forceinline__ uint32_t fused_query_index (uint32_t m, uint32_t side, uint32_t b, uint32_t e)
+// tpr_magic = floor (2^32 / tpr) + 1 (host: icp_tpr_magic): b / tpr == umulhi (b, tpr_magic) for b * tpr < 2^32.
+static __device__ __forceinline__ uint32_t fused_query_index (uint32_t m, uint32_t side, uint32_t tpr_magic, uint32_t b, uint32_t e)
 {
-    if (side && (side & 7u) == 0u && side * side == m) {
-        uint32_t tpr = side >> 3, ty = b / tpr, tx = b - ty * tpr;
-        return (8u * ty + (e >> 3)) * side + 8u * tx + (e & 7u);
-    }
-    return b * 64u + e;
+    const uint32_t tpr = side >> 3, ty = __umulhi (b, tpr_magic), tx = b - ty * tpr;
+    const uint32_t tiled = (8u * ty + (e >> 3)) * side + 8u * tx + (e & 7u);
+    return (side && (side & 7u) == 0u && side * side == m) ? tiled : b * 64u + e;
 }
 
 
-// Result of turning one iteration's moments into the next transform (all in LDS, one per block)
-struct icp_fin_result {
-    float T[8], Tk[8], R[9], Rk[9], S[11], means[8];
-    double sum_w;
-    uint32_t iters, done, k, pad;
-};
+// Result of turning one iteration's moments into the next transform: the registration state itself, staged
+// in LDS (one per block) so that one wave publishes it with a single store
+typedef icp_reg_state icp_fin_result;
 
 // Block-cooperative: 128-position double trees over the block moments (rows 0..17 of the calling block,
 // needs >= 288 threads), then wave 0: means / S from the moments (oracle orc_moments_finish), rotation,
-// composition with (Tprev, Rprev), convergence.  Every thread of the block must call it; `res` is valid
+// composition with the previous (T, R), convergence.  Every thread of the block must call it; `res` is valid
 // for all threads after the call.  NG = capacity of the second tree level (groups of 128 blocks).
-template <int NG>
-static __device__ void fused_finalize_block (const icp_params &p, const double *mom, const float *Tprev, const float *Rprev,
-                                             uint32_t kprev, icp_fin_result *res, double (*s_l1)[NG], double *s_t)
+// `sv` = the previous state, lane-distributed: lane j of every wave holds dword j of the icp_reg_state (one
+// coalesced vector load that is in flight together with the moment loads; scalar loads of the state would be
+// waited for before the moment addresses exist).
+static __device__ __forceinline__ uint32_t state_load_lanes (const icp_reg_state *st)
 {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, l = tid & 15u, row = tid >> 4, nrow = blockDim.x >> 4;
-    const uint32_t ng = (p.nb + 127u) / 128u;
+    const uint32_t lane = threadIdx.x & 63u;
+    return reinterpret_cast<const uint32_t *> (st)[min (lane, (uint32_t) sizeof (icp_reg_state) / 4u - 1u)];
+}
+static __device__ __forceinline__ float state_lane_f (uint32_t sv, uint32_t dword)
+{
+    return __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) dword));
+}
+#define ICP_ST_DW(field) (offsetof (icp_reg_state, field) / 4)
+
+// Returns false (for every thread, before any barrier) when the registration had already converged (checked mode).
+template <int NG, int NT>
+static __device__ bool fused_finalize_block (const icp_params &p, const double *mom, uint32_t nb, uint32_t check, uint32_t sv,
+                                             icp_fin_result *res, double (*s_l1)[NG], double *s_t)
+{
+    // NT = threads of the calling block (compile-time: reading blockDim costs a dependent cold load at kernel start)
+    constexpr uint32_t nrow = NT / 16;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, l = tid & 15u, row = tid >> 4;
+    const uint32_t ng = (nb + 127u) / 128u;
     // first tree level: one 16-lane row per (moment k, group g) task; rows loop over the tasks (whole waves stay converged)
     const uint32_t ntask = ICP_NMOM * ng, npass = (ntask + nrow - 1u) / nrow;
-    for (uint32_t ps = 0; ps < npass; ++ps) {
-        const uint32_t task = min (ps * nrow + row, ntask - 1u), k = task / ng, g = task - k * ng;
-        const double *src = mom + (size_t) k * p.nb;
+    auto pass = [&] (uint32_t ps) {
+        const uint32_t task = min (ps * nrow + row, ntask - 1u);
+        uint32_t k, g;
+        if (ng == 1) { k = task; g = 0u; } else if (ng == 2) { k = task >> 1; g = task & 1u; } else { k = task / ng; g = task - k * ng; }
+        const double *src = mom + (size_t) k * nb;
         double a[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            uint32_t i = g * 128u + l + 16u * q;
-            a[q] = (i < p.nb) ? src[i] : 0.0;
+        for (int q = 0; q < 8; ++q) {                // clamped address + select: eight loads back to back, no branches
+            const uint32_t i = g * 128u + l + 16u * q;
+            const double t = src[min (i, nb - 1u)];
+            a[q] = (i < nb) ? t : 0.0;
         }
+        FF_STAMP (13)
         double v = row_tree8_d (a);
-        if (p.nb == 1) v = src[0];
-        if (l == 0 && ps * nrow + row < ntask) { if (ng == 1) s_t[k] = v; else s_l1[k][g] = v; }
-    }
-    if (ng > 1) {                                    // second level: rows 0..17, one moment each
+        if (nb == 1) v = a[0];
+        if (ng == 2) {
+            // the two groups of a moment sit in adjacent rows of one wave, and the second level (a 128-position
+            // tree over [g0, g1, 0, ..]) is (g0 + 0) + (g1 + 0): no LDS round trip, no second barrier
+            const double o = __shfl_down (v, 16);
+            if (l == 0 && !(row & 1u) && ps * nrow + row < ntask) s_t[k] = (v + 0.0) + (o + 0.0);
+        } else if (l == 0 && ps * nrow + row < ntask) { if (ng == 1) s_t[k] = v; else s_l1[k][g] = v; }
+    };
+    if (npass == 1) pass (0u);                       // straight-line for the common sizes (no loop-carried waits)
+    else for (uint32_t ps = 0; ps < npass; ++ps) pass (ps);
+    if (check && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))) return false;    // block-uniform
+    FF_STAMP (9)
+    if (ng > 2) {                                    // second level: rows 0..17, one moment each
         __syncthreads ();
         if (row < 20) {
             const uint32_t k = min (row, (uint32_t) ICP_NMOM - 1u);
@@ -445,6 +471,19 @@ static __device__ void fused_finalize_block (const icp_params &p, const double *
         if (p.rot == 1) iters = icp_power_method_quad (S, means, Tk, p.power_mode, lane);
         else icp_svd_rotation (S, means, Rkin, Tk);
         FF_STAMP (12)
+#ifdef ICP_DBG_STAMPS
+        if (lane < 8 && p.dbg && p.rot == 1) p.dbg[16 + lane] = icp_pm_stamps[lane];
+#endif
+#ifdef ICP_DBG_PM_TWICE
+        if (p.rot == 1) iters = icp_power_method_quad (S, means, Tk, p.power_mode, lane);
+        FF_STAMP (15)
+#endif
+        float Tprev[8], Rprev[9];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Tprev[k] = state_lane_f (sv, ICP_ST_DW (T) + k);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rprev[k] = state_lane_f (sv, ICP_ST_DW (R) + k);
+        const uint32_t kprev = (uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (k));
         if (lane == 0) {
             float Tn[8], Rn[9];
             icp_compose_pure (Tprev, Rprev, Tk, Rkin, p.rot != 1, Tn, Rn, Rk);
@@ -454,19 +493,24 @@ static __device__ void fused_finalize_block (const icp_params &p, const double *
             for (int k = 0; k < 9; ++k) { res->R[k] = Rn[k]; res->Rk[k] = Rk[k]; }
 #pragma unroll
             for (int k = 0; k < 11; ++k) res->S[k] = S[k];
-            res->sum_w = sw; res->iters = (uint32_t) iters; res->k = kprev + 1u;
+            res->sum_w = sw; res->pm_iters = (uint32_t) iters; res->k = kprev + 1u; res->pad0 = 0.f; res->pending = 0u;
             res->done = (p.check && icp_check_converged (Tk, p.tan_half_thr, p.trans_thr)) ? 1u : 0u;
         }
     }
     __syncthreads ();
+    return true;
 }
 
-static __device__ void fin_result_to_state (const icp_fin_result *res, icp_reg_state *st, uint32_t pending)
+// cooperative publish: thread t of the block copies dword t (call with the whole first wave)
+static __device__ __forceinline__ void fin_result_to_state (const icp_fin_result *res, icp_reg_state *st, uint32_t pending)
 {
-    for (int k = 0; k < 8; ++k) { st->T[k] = res->T[k]; st->Tk[k] = res->Tk[k]; st->means[k] = res->means[k]; }
-    for (int k = 0; k < 9; ++k) { st->R[k] = res->R[k]; st->Rk[k] = res->Rk[k]; }
-    for (int k = 0; k < 11; ++k) st->S[k] = res->S[k];
-    st->sum_w = res->sum_w; st->pm_iters = res->iters; st->k = res->k; st->done = res->done; st->pending = pending;
+    static_assert (sizeof (icp_reg_state) / 4 <= 64, "the state is published by one wave");
+    const uint32_t t = threadIdx.x;
+    if (t < sizeof (icp_reg_state) / 4) {
+        uint32_t v = reinterpret_cast<const uint32_t *> (res)[t];
+        if (t == offsetof (icp_reg_state, pending) / 4) v = pending;
+        reinterpret_cast<uint32_t *> (st)[t] = v;
+    }
 }
 
 // CHAIN (fused mode only): launch j reads state slot j&1 and the moments buffer j&1, turns the previous
@@ -477,10 +521,15 @@ static __device__ void fin_result_to_state (const icp_fin_result *res, icp_reg_s
 // LPQ = lanes per query = waves per block: 16 when the grid is at most one block per CU (more waves per SIMD to
 // overlap the L2-cold loads), 8 when occupancy comes from the number of blocks.
 template <bool FUSED, bool CHAIN, int MINW, int LPQ>
-__global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (icp_params p)
+__global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, const float *gR, const uint32_t *gO_, const uint32_t *gN_,
+                                                              icp_reg_state *gst, uint32_t m, uint32_t nr, uint32_t side,
+                                                              uint32_t tpr_magic, icp_params p)
 {
+    // The first 14 dwords of the kernel arguments (everything the prologue's addresses need) are plain scalars so
+    // that they arrive preloaded in SGPRs / in one scalar load; the rest of icp_params is fetched while the first
+    // global loads are in flight.
     const uint32_t b = blockIdx.y;
-    icp_reg_state *st = CHAIN ? p.cst + (size_t) b * 2 + p.slot : p.st + b;
+    icp_reg_state *st = CHAIN ? p.cst + (size_t) b * 2 + p.slot : gst + b;
 #ifdef ICP_DBG_STAMPS
     { const uint32_t tid = threadIdx.x; unsigned long long t_; asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
       if (tid == 0 && p.dbg) p.dbg[(size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 16 + 8] = t_; }
@@ -492,7 +541,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (icp_params p)
                 reinterpret_cast<uint32_t *> (sout)[threadIdx.x] = reinterpret_cast<const uint32_t *> (st)[threadIdx.x];
             return;
         }
-    } else if (p.check && st->done) return;
+    }
 
     // representatives of the current tile, pair-interleaved for packed fp32 math:
     //   pair P = reps (2P, 2P+1) -> 3 float4: [x0 x1 y0 y1] [z0 z1 r0 r1] [g0 g1 b0 b1]
@@ -512,19 +561,20 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (icp_params p)
     const uint32_t qe = slice * KS_QPW + lane / KS_SPLIT, ss = lane & (KS_SPLIT - 1u);
     // reference-order mode: the 64 even (or odd) positions of one 128-query group (a closed sub-tree of
     // the weight reduction); fused mode: an 8 x 8 tile of the landmark grid (spatially coherent lists)
-    const uint32_t i = FUSED ? fused_query_index (p.m, p.side, blockIdx.x, qe)
+    const uint32_t i = FUSED ? fused_query_index (m, side, tpr_magic, blockIdx.x, qe)
                              : (blockIdx.x >> 1) * 128u + 2u * qe + (blockIdx.x & 1u);
-    const bool valid = i < p.m;
+    const bool valid = i < m;
 
-    const float4 *M4 = reinterpret_cast<const float4 *> (p.M + (size_t) b * p.m * 8);
-    const float4 *R4 = reinterpret_cast<const float4 *> (p.R + (size_t) b * p.nr * 8);
-    const float4 *XQ4 = reinterpret_cast<const float4 *> (p.XQ + (size_t) b * p.m * 8);
-    const uint32_t *gO = p.O + (size_t) b * p.nr, *gN = p.N + (size_t) b * p.nr;
+    const float4 *M4 = reinterpret_cast<const float4 *> (gM + (size_t) b * m * 8);
+    const float4 *R4 = reinterpret_cast<const float4 *> (gR + (size_t) b * nr * 8);
+    const uint32_t *gO = gO_ + (size_t) b * nr, *gN = gN_ + (size_t) b * nr;
 
-    // every independent global load of the prologue is issued before anything waits: first tile of
-    // representatives (+ list offsets / sizes), the query point, the transform
+    // every independent global load of the prologue is issued before anything waits: the state (one vector load,
+    // lane j = dword j: scalar loads of T would queue behind the waits of the vector loads), the first tile of
+    // representatives (+ list offsets / sizes), the query point (clamped address, selected afterwards)
+    const uint32_t sv = state_load_lanes (st);
     float *s_pairf = reinterpret_cast<float *> (s_pair);
-    const uint32_t tn0 = min (KS_TILE, p.nr);
+    const uint32_t tn0 = min (KS_TILE, nr);
     float4 rg[2], rc[2]; uint2 ron[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -532,21 +582,21 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (icp_params p)
         rg[u] = make_float4 (0.f, 0.f, 0.f, 0.f); rc[u] = rg[u]; ron[u] = make_uint2 (0u, 0u);
         if (k < tn0) { rg[u] = R4[2 * (size_t) k]; rc[u] = R4[2 * (size_t) k + 1]; ron[u] = make_uint2 (gO[k], gN[k]); }
     }
-    float4 mg = make_float4 (0.f, 0.f, 0.f, 1.f), mc = mg;
-    if (valid) { mg = M4[2 * (size_t) i]; mc = M4[2 * (size_t) i + 1]; }
+    const uint32_t ic = min (i, m - 1u);
+    float4 mg = M4[2 * (size_t) ic], mc = M4[2 * (size_t) ic + 1];
     float T[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) T[k] = st->T[k];
+    for (int k = 0; k < 8; ++k) T[k] = state_lane_f (sv, ICP_ST_DW (T) + k);
+    if constexpr (!CHAIN) { if (p.check && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))) return; }   // converged earlier
+    if (!valid) { mg = make_float4 (0.f, 0.f, 0.f, 1.f); mc = mg; }
+    const float4 *XQ4 = reinterpret_cast<const float4 *> (p.XQ + (size_t) b * m * 8);
     if constexpr (CHAIN) {
         const bool pending = st->pending != 0;
         if (pending) {
-            float Rp[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Rp[k] = st->R[k];
-            fused_finalize_block<32> (p, p.mom + ((size_t) b * 2 + p.slot) * ICP_NMOM * p.nb, T, Rp, st->k, &s_fin, s_l1, s_t);
+            fused_finalize_block<32, 64 * LPQ> (p, p.mom + ((size_t) b * 2 + p.slot) * ICP_NMOM * p.nb, p.nb, 0u, sv, &s_fin, s_l1, s_t);
 #pragma unroll
             for (int k = 0; k < 8; ++k) T[k] = s_fin.T[k];
-            if (blockIdx.x == 0 && tid == 0) fin_result_to_state (&s_fin, sout, s_fin.done ? 0u : 1u);
+            if (blockIdx.x == 0) fin_result_to_state (&s_fin, sout, s_fin.done ? 0u : 1u);
             KS_STAMP (9)
             if (s_fin.done) return;
         } else if (blockIdx.x == 0 && tid < sizeof (icp_reg_state) / 4) {
@@ -573,12 +623,12 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (icp_params p)
     // ---- stage 1: nearest representative, two representatives per packed instruction ----
     float best = __builtin_inff (); uint32_t bid = 0xFFFFFFFFu;
 #ifdef ICP_DBG_SKIP_S1
-    best = 0.f; bid = (i * 7u) % p.nr;
-    for (uint32_t t0 = p.nr; t0 < p.nr; t0 += KS_TILE) {
+    best = 0.f; bid = (i * 7u) % nr;
+    for (uint32_t t0 = nr; t0 < nr; t0 += KS_TILE) {
 #else
-    for (uint32_t t0 = 0; t0 < p.nr; t0 += KS_TILE) {
+    for (uint32_t t0 = 0; t0 < nr; t0 += KS_TILE) {
 #endif
-        const uint32_t tn = min (KS_TILE, p.nr - t0);
+        const uint32_t tn = min (KS_TILE, nr - t0);
         if (t0) {                                    // further tiles (nr > KS_TILE)
             __syncthreads ();
             for (uint32_t k = tid; k < tn; k += 64 * KS_SPLIT) {
@@ -600,7 +650,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (icp_params p)
         const float2v va = { alpha, alpha };
         // a lane's pairs ascend (P = ss, ss+8, ..) and an update needs a strict '<', so each lane keeps its lowest
         // index among equal distances; the 8-lane reduction below then takes the lowest index overall
-        if (p.nr >= 1024u && alpha > 0.f) {
+        if (nr >= 1024u && alpha > 0.f) {
             // throughput-bound sizes: exact early rejection.  d = fma (a, pho, geo) >= geo (a > 0), and an update needs
             // the strict d < best, so when no lane of the wave has geo < best the photometric half of the pair is
             // skipped (wave-uniform branch; the wave's queries are neighbours, so most far pairs are skipped).
@@ -641,7 +691,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (icp_params p)
     if (rstar == 0xFFFFFFFFu) rstar = 0u;            // every distance inf / NaN: representative 0, as the serial scan would
     KS_STAMP (3)
     uint32_t o, n;
-    if (p.nr <= KS_TILE) { uint2 on = s_on[rstar]; o = on.x; n = on.y; }
+    if (nr <= KS_TILE) { uint2 on = s_on[rstar]; o = on.x; n = on.y; }
     else { o = gO[rstar]; n = gN[rstar]; }
 
     // ---- stage 2: exhaustive scan of that representative's list: the eight lanes of a query read eight consecutive
@@ -679,7 +729,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (icp_params p)
         if (valid) {
             uint32_t id; float4 nn;
             if (n == 0) {            // empty list: fall back to the representative itself
-                d = dr; id = p.rep_src[(size_t) b * p.nr + rstar]; nn = R4[2 * (size_t) rstar];
+                d = dr; id = p.rep_src[(size_t) b * nr + rstar]; nn = R4[2 * (size_t) rstar];
             } else if (jmin == 0xFFFFFFFFu) {   // every distance inf / NaN: first list element, as the serial scan would
                 nn = XQ4[2 * (size_t) o]; id = __float_as_uint (nn.w);
             } else {
@@ -687,10 +737,10 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (icp_params p)
             }
             w = p.weighted ? 100.f / (100.f + d) : 1.f;                // icp_kernels.cl:232
             icp_dist_id di; di.dist = d; di.id = id;
-            p.nn_id[(size_t) b * p.m + i] = di;
-            p.PF[(size_t) b * p.m + i] = make_float4 (nn.x, nn.y, nn.z, w);
-            p.PM[(size_t) b * p.m + i] = make_float4 (qx, qy, qz, d);
-            p.rid[(size_t) b * p.m + i] = rstar;
+            p.nn_id[(size_t) b * m + i] = di;
+            p.PF[(size_t) b * m + i] = make_float4 (nn.x, nn.y, nn.z, w);
+            p.PM[(size_t) b * m + i] = make_float4 (qx, qy, qz, d);
+            p.rid[(size_t) b * m + i] = rstar;
             s_nn_x = nn.x; s_nn_y = nn.y; s_nn_z = nn.z;
         }
         if constexpr (FUSED) {
@@ -952,22 +1002,20 @@ __global__ __launch_bounds__ (192) void k_finalize (icp_params p)
 // (oracle orc_moments_fused / orc_moments_finish), then rotation, composition, convergence.
 // One block of 5 waves per registration: row k (of 20) reduces moment k.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__ (1024) void k_finalize_fused (icp_params p)
+__global__ __launch_bounds__ (1024) void k_finalize_fused (const double *gmom, icp_reg_state *gst, uint32_t nb, uint32_t check, icp_params p)
 {
+    // (the leading scalars: see k_search)
     const uint32_t b = blockIdx.x;
-    icp_reg_state *st = p.st + b;
+    icp_reg_state *st = gst + b;
     FF_STAMP (14)
-    if (p.check && st->done) return;
     __shared__ icp_fin_result s_fin;
     __shared__ double s_l1[ICP_NMOM][128];
     __shared__ double s_t[ICP_NMOM];
-    float T[8], Rp[9];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) T[k] = st->T[k];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Rp[k] = st->R[k];
-    fused_finalize_block<128> (p, p.mom + (size_t) b * 2 * ICP_NMOM * p.nb, T, Rp, st->k, &s_fin, s_l1, s_t);
-    if (threadIdx.x == 0) fin_result_to_state (&s_fin, st, 0u);
+    // the previous state travels with the moment loads (one vector load); a registration that has converged
+    // (done, checked mode) leaves as soon as it has arrived
+    const uint32_t sv = state_load_lanes (st);
+    if (!fused_finalize_block<128, 1024> (p, gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, check, sv, &s_fin, s_l1, s_t)) return;
+    fin_result_to_state (&s_fin, st, 0u);
 }
 
 // chain begin: user-visible state -> slot 0; chain end: finalize the last iteration's moments (slot given by
@@ -998,18 +1046,18 @@ __global__ __launch_bounds__ (320) void k_chain_end (icp_params p)
         }
         return;
     }
-    float T[8], Rp[9];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) T[k] = sin->T[k];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Rp[k] = sin->R[k];
-    fused_finalize_block<32> (p, p.mom + ((size_t) b * 2 + p.slot) * ICP_NMOM * p.nb, T, Rp, sin->k, &s_fin, s_l1, s_t);
-    if (threadIdx.x == 0) fin_result_to_state (&s_fin, st, 0u);
+    fused_finalize_block<32, 320> (p, p.mom + ((size_t) b * 2 + p.slot) * ICP_NMOM * p.nb, p.nb, 0u, state_load_lanes (sin), &s_fin, s_l1, s_t);
+    fin_result_to_state (&s_fin, st, 0u);
 }
 
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+static inline uint32_t icp_tpr_magic (uint32_t side)
+{   // floor (2^32 / tpr) + 1 for tpr = side / 8 tiles per row (tpr == 1: one block, b == 0, any value works)
+    const uint32_t tpr = side >> 3;
+    return tpr ? (uint32_t) ((1ull << 32) / tpr + 1ull) : 0u;
+}
 void icp_launch_reset_state (const icp_params &p, hipStream_t s, int reset_T)
 {
     hipLaunchKernelGGL (k_reset_state, dim3 ((p.batch + 63) / 64), dim3 (64), 0, s, p, reset_T);
@@ -1045,12 +1093,13 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 void icp_launch_search (const icp_params &p, hipStream_t s)
 {
     const bool dense = (size_t) p.batch * p.nb > 512u;          // more blocks than one per CU: trade registers for occupancy
+#define KS_ARGS p.M, p.R, p.O, p.N, p.st, p.m, p.nr, p.side, icp_tpr_magic (p.side), p
     if (p.fused) {
-        if (dense) hipLaunchKernelGGL ((k_search<true, false, 4, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p);
-        else hipLaunchKernelGGL ((k_search<true, false, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p);
+        if (dense) hipLaunchKernelGGL ((k_search<true, false, 4, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
+        else hipLaunchKernelGGL ((k_search<true, false, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_ARGS);
     } else {
-        if (dense) hipLaunchKernelGGL ((k_search<false, false, 4, 8>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, p);
-        else hipLaunchKernelGGL ((k_search<false, false, 2, 16>), dim3 (2 * p.nwg, p.batch), dim3 (1024), 0, s, p);
+        if (dense) hipLaunchKernelGGL ((k_search<false, false, 4, 8>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, KS_ARGS);
+        else hipLaunchKernelGGL ((k_search<false, false, 2, 16>), dim3 (2 * p.nwg, p.batch), dim3 (1024), 0, s, KS_ARGS);
     }
 }
 
@@ -1068,7 +1117,7 @@ void icp_launch_sij (const icp_params &p, hipStream_t s)
 
 void icp_launch_finalize (const icp_params &p, hipStream_t s)
 {
-    if (p.fused) hipLaunchKernelGGL (k_finalize_fused, dim3 (p.batch), dim3 (1024), 0, s, p);
+    if (p.fused) hipLaunchKernelGGL (k_finalize_fused, dim3 (p.batch), dim3 (1024), 0, s, (const double *) p.mom, p.st, p.nb, (uint32_t) p.check, p);
     else hipLaunchKernelGGL (k_finalize, dim3 (p.batch), dim3 (192), 0, s, p);
 }
 
@@ -1095,7 +1144,7 @@ void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations)
     hipLaunchKernelGGL (k_chain_begin, dim3 (p.batch), dim3 (64), 0, s, p);
     for (uint32_t j = 0; j < iterations; ++j) {
         p.slot = j & 1u;
-        hipLaunchKernelGGL ((k_search<true, true, 2, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p);
+        hipLaunchKernelGGL ((k_search<true, true, 2, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
     }
     p.slot = iterations & 1u;
     hipLaunchKernelGGL (k_chain_end, dim3 (p.batch), dim3 (320), 0, s, p);

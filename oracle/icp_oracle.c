@@ -481,6 +481,14 @@ static float distance4 (const float *a, const float *b)
     return sqrtf (s);
 }
 
+static float distance4_sq (const float *a, const float *b)
+{   /* the same sum without the root (squared-start stop rule) */
+    float s = 0.f, d;
+    d = a[0] - b[0]; s += d * d; d = a[1] - b[1]; s += d * d;
+    d = a[2] - b[2]; s += d * d; d = a[3] - b[3]; s += d * d;
+    return s;
+}
+
 static void build_N (const float *S, float *N)
 {   /* icp_kernels.cl:993-999 */
     float Sxx = S[0], Sxy = S[1], Sxz = S[2], Syx = S[3], Syy = S[4], Syz = S[5],
@@ -555,11 +563,17 @@ static int power_impl (const float *S, const float *means, float *Tk, int fast)
             normalize4 (xn);
             ++iters;
             error = error_new;
-            error_new = distance4 (x, xn);
             /* reference rule: stop when the step length repeats (:1019).  Squared start: x is already at the
-             * fixed point to ~1e-6, the step lengths fall to the rounding floor within two or three trips, so the
-             * loop stops as soon as they stop decreasing (a superset of "repeats"). */
-            if (fast ? (error_new >= error) : (error_new == error)) break;
+             * fixed point to ~1e-7 (the first step is at the rounding floor, <= 1 ulp of a unit vector), so the
+             * loop compares SQUARED step lengths (no root) and stops as soon as the step is below 2^-22 or
+             * stops decreasing. */
+            if (fast) {
+                error_new = distance4_sq (x, xn);
+                if (error_new >= error || error_new <= 0x1p-44f) break;
+            } else {
+                error_new = distance4 (x, xn);
+                if (error_new == error) break;
+            }
             memcpy (x, xn, sizeof x);
         }
         float lambda = dot4 (N, xn) / xn[0];                 /* :1024 */

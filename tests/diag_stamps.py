@@ -35,3 +35,6 @@ if t[0, 15] > 0 and t[0, 14] > 0:
           % (t[0, 10] - t[0, 14], t[0, 11] - t[0, 10], t[0, 12] - t[0, 11], t[0, 15] - t[0, 12], t[0, 15] - t[0, 14]))
 print("kernel span (first start -> last end): %d ticks; per-block mean %0.f" % (t[:, 7].max() - t0, (t[:, 7] - t[:, 8]).mean()))
 print("row0 raw:", [int(x) for x in t[0]])
+pm = t[1, :7]
+if pm[6] > pm[0] > 0:
+    print("power method (ticks): squarings %d  x0 %d  loop %d  lambda %d  final normalize %d  Tk %d" % tuple(int(pm[k + 1] - pm[k]) for k in range(6)))

@@ -308,6 +308,12 @@ __global__ __launch_bounds__ (1024) void k_place (icp_params p)
 #define KS_SPLIT LPQ
 #define KS_QPW (64 / KS_SPLIT)  // queries per wave
 #define KS_TILE 1024u            // representatives per LDS tile
+#ifndef ICP_S1_SEED
+#define ICP_S1_SEED 1                // stage 1: prune with the distance to the previous search's nearest representative
+#endif
+#ifndef ICP_S1_REJECT_MIN_NR
+#define ICP_S1_REJECT_MIN_NR 1024u   // stage 1: exact early rejection from this many representatives on
+#endif
 
 typedef float float2v __attribute__ ((ext_vector_type (2)));
 
@@ -584,6 +590,12 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     }
     const uint32_t ic = min (i, m - 1u);
     float4 mg = M4[2 * (size_t) ic], mc = M4[2 * (size_t) ic + 1];
+    // seed of the stage-1 pruning bound: this query's nearest representative of the previous search (any index < nr
+    // is a valid seed; the buffer starts zeroed)
+    // Pruning pays where stage 1 is throughput-bound: dense grids (MINW == 4: several blocks per CU) and large
+    // representative sets; a single small registration is latency-bound and keeps the branch-free loop.
+    const bool prune = p.a > 0.f && ICP_S1_SEED && (MINW == 4 || nr >= ICP_S1_REJECT_MIN_NR);
+    uint32_t seed = prune ? p.rid[(size_t) b * m + ic] : 0u;
     float T[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) T[k] = state_lane_f (sv, ICP_ST_DW (T) + k);
@@ -621,7 +633,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     KS_STAMP (0)
 
     // ---- stage 1: nearest representative, two representatives per packed instruction ----
-    float best = __builtin_inff (); uint32_t bid = 0xFFFFFFFFu;
+    float best = __builtin_inff (), s1_lim = __builtin_inff (); uint32_t bid = 0xFFFFFFFFu;
 #ifdef ICP_DBG_SKIP_S1
     best = 0.f; bid = (i * 7u) % nr;
     for (uint32_t t0 = nr; t0 < nr; t0 += KS_TILE) {
@@ -649,18 +661,36 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
         const float2v vqx = { qx, qx }, vqy = { qy, qy }, vqz = { qz, qz }, vqr = { qr, qr }, vqg = { qg, qg }, vqb = { qb, qb };
         const float2v va = { alpha, alpha };
         // a lane's pairs ascend (P = ss, ss+8, ..) and an update needs a strict '<', so each lane keeps its lowest
-        // index among equal distances; the 8-lane reduction below then takes the lowest index overall
-        if (nr >= 1024u && alpha > 0.f) {
-            // throughput-bound sizes: exact early rejection.  d = fma (a, pho, geo) >= geo (a > 0), and an update needs
-            // the strict d < best, so when no lane of the wave has geo < best the photometric half of the pair is
-            // skipped (wave-uniform branch; the wave's queries are neighbours, so most far pairs are skipped).
-#pragma unroll 4
+        // index among equal distances; the group reduction below then takes the lowest index overall.
+        //
+        // Exact pruning.  d = fma (a, pho, geo) >= geo for a > 0, so a pair whose two geo terms are not below `lim`
+        // cannot hold the nearest representative when lim <= max (own best, a known upper bound of the query's
+        // minimum): the photometric half, the third LDS read and the compare / select chain are skipped when no lane
+        // of the wave needs them (wave-uniform branch; the wave's queries are neighbours).  The upper bound is the
+        // distance to the seed (the previous search's nearest representative), bumped by one ulp so that a plain '<'
+        // keeps every representative that could tie with it.
+        float lim = __builtin_inff ();
+        if (t0 == 0 && prune) {
+            seed = min (seed, nr - 1u);
+            float sx, sy, sz, sr, sg, sb;
+            if (nr <= KS_TILE) {
+                const float *sp = s_pairf + (seed >> 1) * 12u + (seed & 1u);
+                sx = sp[0]; sy = sp[2]; sz = sp[4]; sr = sp[6]; sg = sp[8]; sb = sp[10];
+            } else {
+                const float4 g = R4[2 * (size_t) seed], c = R4[2 * (size_t) seed + 1];
+                sx = g.x; sy = g.y; sz = g.z; sr = c.x; sg = c.y; sb = c.z;
+            }
+            const float b0 = icp_metric8 (qx, qy, qz, qr, qg, qb, sx, sy, sz, sr, sg, sb, alpha);
+            if (b0 >= 0.f && b0 < __builtin_inff ()) lim = __uint_as_float (__float_as_uint (b0) + 1u);     // next float up
+            s1_lim = lim;
+        } else if (prune) lim = s1_lim;
+        if (prune) {
             for (uint32_t P = ss; P < npair; P += KS_SPLIT) {
                 float4 A = s_pair[3 * P], B = s_pair[3 * P + 1];
                 float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y };
                 float2v dx = vqx - x, dy = vqy - y, dz = vqz - z;
                 float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
-                if (!__any (geo.x < best || geo.y < best)) continue;
+                if (!__any (geo.x < lim || geo.y < lim)) continue;
                 float4 C = s_pair[3 * P + 2];
                 float2v r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
                 float2v dr = vqr - r, dg = vqg - g, db = vqb - bb;
@@ -669,7 +699,9 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
                 const uint32_t r0 = t0 + 2u * P;
                 if (d.x < best) { best = d.x; bid = r0; }
                 if (d.y < best) { best = d.y; bid = r0 + 1u; }
+                lim = fminf (lim, best);
             }
+            s1_lim = lim;
         } else {
 #pragma unroll 8
             for (uint32_t P = ss; P < npair; P += KS_SPLIT) {

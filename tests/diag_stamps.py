@@ -38,3 +38,11 @@ print("row0 raw:", [int(x) for x in t[0]])
 pm = t[1, :7]
 if pm[6] > pm[0] > 0:
     print("power method (ticks): squarings %d  x0 %d  loop %d  lambda %d  final normalize %d  Tk %d" % tuple(int(pm[k + 1] - pm[k]) for k in range(6)))
+try:
+    us = g.time_masked(1, 40, 20)
+    good = t[(t[:, 8] > 0) & (t[:, 7] > t[:, 8])]
+    span = int(good[:, 7].max() - good[:, 8].min())
+    print("calibration: masked search %.2f us per launch in this build (incl. ~1.74 us boundary); k_search span %d ticks -> %.3f ns/tick if boundary excluded"
+          % (us, span, (us - 1.74) * 1e3 / span))
+except Exception as e:
+    print("calibration failed:", e)

@@ -250,6 +250,8 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &M, B * m * 8))) return rc;
     h->dF = F; h->dM = M; p.F = F; p.M = M;
     if ((rc = dalloc (h, &p.R, B * nr * 8))) return rc;
+    p.n16 = (nr + 15u) / 16u; p.n32 = (nr + 31u) / 32u;
+    if ((rc = dalloc (h, &p.GB, B * 2 * (p.n16 + p.n32)))) return rc;
     if ((rc = dalloc (h, &p.XP, B * m * 8))) return rc;
     if ((rc = dalloc (h, &p.XQ, B * m * 8))) return rc;
     if ((rc = dalloc (h, &p.rep_src, B * nr))) return rc;

@@ -25,6 +25,8 @@ struct icp_params {
     // inputs / RBC
     const float *F, *M;          // [batch][m][8]
     float *R;                    // [batch][nr][8]
+    float4 *GB;                  // [batch][2*(n16+n32)] geometry bounding boxes (lo, hi) of 16 / 32 consecutive representatives
+    uint32_t n16, n32;           // ceil(nr/16), ceil(nr/32)
     float *XP;                   // [batch][m][8]  permuted database (RBCConstruct D_OUT_X_P)
     float *XQ;                   // [batch][m][8]  same, lane 3 = original index bits (search copy)
     uint32_t *rep_src, *owner, *N, *O, *perm, *chunk_hist;   // [batch][...]

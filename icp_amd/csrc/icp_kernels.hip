@@ -173,6 +173,25 @@ __global__ void k_get_reps (icp_params p)
     p.rep_src[(size_t) b * p.nr + r] = src;
 }
 
+// Geometry bounding boxes of every 16 and every 32 consecutive representatives (stage-1 group pruning of k_search).
+// fminf / fmaxf skip NaN coordinates: a representative with a NaN coordinate never wins a '<' anyway.
+__global__ void k_rep_boxes (icp_params p)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (t >= p.n16 + p.n32) return;
+    const uint32_t gs = t < p.n16 ? 16u : 32u, g = t < p.n16 ? t : t - p.n16;
+    const float4 *R4 = reinterpret_cast<const float4 *> (p.R + (size_t) b * p.nr * 8);
+    const float inf = __builtin_inff ();
+    float4 lo = make_float4 (inf, inf, inf, 0.f), hi = make_float4 (-inf, -inf, -inf, 0.f);
+    for (uint32_t r = g * gs; r < min (p.nr, (g + 1u) * gs); ++r) {
+        const float4 v = R4[2 * (size_t) r];
+        lo.x = fminf (lo.x, v.x); lo.y = fminf (lo.y, v.y); lo.z = fminf (lo.z, v.z);
+        hi.x = fmaxf (hi.x, v.x); hi.y = fmaxf (hi.y, v.y); hi.z = fmaxf (hi.z, v.z);
+    }
+    float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n32);
+    GB[2 * t] = lo; GB[2 * t + 1] = hi;
+}
+
 // nearest representative over [r0, r1): strict '<' in ascending r keeps the lowest index on ties
 static __device__ __forceinline__ void nearest_rep_range (const float4 *__restrict__ R4, uint32_t r0, uint32_t r1,
                                                           float qx, float qy, float qz, float qr, float qg, float qb,
@@ -553,6 +572,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     //   pair P = reps (2P, 2P+1) -> 3 float4: [x0 x1 y0 y1] [z0 z1 r0 r1] [g0 g1 b0 b1]
     __shared__ float4 s_pair[3 * KS_TILE / 2];
     __shared__ uint2 s_on[KS_TILE];                  // (offset, size) of every representative's list
+    __shared__ float4 s_box[2 * (KS_TILE / 16)];     // (lo, hi) of the tile's groups of 2 * LPQ representatives
     __shared__ float s_w[64];
     __shared__ double s_mom[FUSED ? ICP_NMOM : 1][64];
     __shared__ icp_fin_result s_fin;
@@ -592,10 +612,17 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     float4 mg = M4[2 * (size_t) ic], mc = M4[2 * (size_t) ic + 1];
     // seed of the stage-1 pruning bound: this query's nearest representative of the previous search (any index < nr
     // is a valid seed; the buffer starts zeroed)
-    // Pruning pays where stage 1 is throughput-bound: dense grids (MINW == 4: several blocks per CU) and large
-    // representative sets; a single small registration is latency-bound and keeps the branch-free loop.
-    const bool prune = p.a > 0.f && ICP_S1_SEED && (MINW == 4 || nr >= ICP_S1_REJECT_MIN_NR);
+    // Pruning pays where stage 1 is throughput-bound: the dense variant (MINW == 4: several blocks per CU, or a
+    // large representative set — see icp_launch_search); a single small registration is latency-bound and keeps
+    // the branch-free loop (compile-time: the pruning code costs 0.25 us there even when it is switched off).
+    constexpr bool PRUNE = ICP_S1_SEED && MINW == 4;
+    const bool prune = PRUNE && p.a > 0.f;
     uint32_t seed = prune ? p.rid[(size_t) b * m + ic] : 0u;
+    // (lo, hi) boxes of the groups of 2 * LPQ representatives: the 16-boxes (LPQ = 8) or the 32-boxes behind them
+    const float4 *GBt = p.GB + (size_t) b * 2 * (p.n16 + p.n32) + (KS_SPLIT == 8 ? 0u : 2u * p.n16);
+    const uint32_t nbox0 = 2u * ((tn0 + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
+    float4 boxv = make_float4 (0.f, 0.f, 0.f, 0.f);
+    if (prune && tid < nbox0) boxv = GBt[tid];
     float T[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) T[k] = state_lane_f (sv, ICP_ST_DW (T) + k);
@@ -626,6 +653,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
             s_on[k] = ron[u];
         }
     }
+    if (prune && tid < nbox0) s_box[tid] = boxv;
     float qx, qy, qz;
     icp_transform_point (T, mg.x, mg.y, mg.z, qx, qy, qz);
     const float qr = mc.x, qg = mc.y, qb = mc.z;
@@ -648,6 +676,10 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
                 float *dst = s_pairf + (k >> 1) * 12u + (k & 1u);
                 dst[0] = g.x; dst[2] = g.y; dst[4] = g.z; dst[6] = c.x; dst[8] = c.y; dst[10] = c.z;
                 s_on[k] = make_uint2 (gO[t0 + k], gN[t0 + k]);
+            }
+            if (prune) {
+                const uint32_t nbx = 2u * ((tn + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
+                for (uint32_t k = tid; k < nbx; k += 64 * KS_SPLIT) s_box[k] = GBt[2u * (t0 / (2u * KS_SPLIT)) + k];
             }
         }
         if ((tn & 1u) && tid == 0) {                 // odd tile (nr == 1): the pad slot never wins (NaN distance)
@@ -685,23 +717,43 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
             s1_lim = lim;
         } else if (prune) lim = s1_lim;
         if (prune) {
-            for (uint32_t P = ss; P < npair; P += KS_SPLIT) {
-                float4 A = s_pair[3 * P], B = s_pair[3 * P + 1];
-                float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y };
-                float2v dx = vqx - x, dy = vqy - y, dz = vqz - z;
-                float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
-                if (!__any (geo.x < lim || geo.y < lim)) continue;
-                float4 C = s_pair[3 * P + 2];
-                float2v r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
-                float2v dr = vqr - r, dg = vqg - g, db = vqb - bb;
-                float2v pho = __builtin_elementwise_fma (db, db, __builtin_elementwise_fma (dg, dg, dr * dr));
-                float2v d = __builtin_elementwise_fma (va, pho, geo);
-                const uint32_t r0 = t0 + 2u * P;
-                if (d.x < best) { best = d.x; bid = r0; }
-                if (d.y < best) { best = d.y; bid = r0 + 1u; }
-                lim = fminf (lim, best);
+            // coarse pass: a group = the 2 * LPQ representatives of one trip of the query's lanes; lane ss tests the
+            // groups ss, ss + LPQ, ..  The lower bound applies the metric's own operations to the per-axis distances
+            // to the group's bounding box; every operation is monotone under round-to-nearest, so
+            // bound <= geo <= d for every member, and a group whose bound is not below `lim` cannot hold the winner.
+            const uint32_t ngt = (npair + KS_SPLIT - 1u) / KS_SPLIT;
+            uint32_t cmask = 0u;
+            for (uint32_t t = 0, g = ss; g < ngt; ++t, g += KS_SPLIT) {
+                const float4 lo = s_box[2 * g], hi = s_box[2 * g + 1];
+                const float ex = fmaxf (fmaxf (lo.x - qx, qx - hi.x), 0.f);
+                const float ey = fmaxf (fmaxf (lo.y - qy, qy - hi.y), 0.f);
+                const float ez = fmaxf (fmaxf (lo.z - qz, qz - hi.z), 0.f);
+                const float bound = __builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex));
+                if (bound < lim) cmask |= 1u << t;
             }
-            s1_lim = lim;
+            // fine pass: the groups some query of the wave still needs, in ascending order (a lane's pairs must ascend
+            // for the tie rule), full evaluation
+            const unsigned long long rep = (KS_SPLIT == 8) ? 0x0101010101010101ull : 0x0001000100010001ull;
+            for (uint32_t t = 0; t * KS_SPLIT < ngt; ++t) {
+                const unsigned long long bal = __ballot ((cmask >> t) & 1u);
+                if (bal == 0ull) continue;
+                for (uint32_t sg = 0; sg < KS_SPLIT; ++sg) {
+                    if (!(bal & (rep << sg))) continue;
+                    const uint32_t P = (sg + KS_SPLIT * t) * KS_SPLIT + ss;
+                    if (P < npair) {
+                        float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];
+                        float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
+                        float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
+                        float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
+                        float2v pho = __builtin_elementwise_fma (db, db, __builtin_elementwise_fma (dg, dg, dr * dr));
+                        float2v d = __builtin_elementwise_fma (va, pho, geo);
+                        const uint32_t r0 = t0 + 2u * P;
+                        if (d.x < best) { best = d.x; bid = r0; }
+                        if (d.y < best) { best = d.y; bid = r0 + 1u; }
+                    }
+                }
+            }
+            s1_lim = fminf (lim, ks_grp_min_f<KS_SPLIT> (best));
         } else {
 #pragma unroll 8
             for (uint32_t P = ss; P < npair; P += KS_SPLIT) {
@@ -1115,6 +1167,7 @@ void icp_launch_transform_cloud (const float *in, float *out, const icp_reg_stat
 void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 {
     hipLaunchKernelGGL (k_get_reps, dim3 ((p.nr + 63) / 64, p.batch), dim3 (64), 0, s, p);
+    hipLaunchKernelGGL (k_rep_boxes, dim3 ((p.n16 + p.n32 + 63) / 64, p.batch), dim3 (64), 0, s, p);
     hipLaunchKernelGGL (k_owner, dim3 ((p.m + 255) / 256, p.batch), dim3 (256), 0, s, p);
     hipLaunchKernelGGL (k_chunk_hist, dim3 (p.nchunk, p.batch), dim3 (256), p.nr * sizeof (uint32_t), s, p);
     hipLaunchKernelGGL (k_count, dim3 ((p.nr + 63) / 64, p.batch), dim3 (64), 0, s, p);
@@ -1124,7 +1177,8 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 
 void icp_launch_search (const icp_params &p, hipStream_t s)
 {
-    const bool dense = (size_t) p.batch * p.nb > 512u;          // more blocks than one per CU: trade registers for occupancy
+    // more blocks than one per CU: trade registers for occupancy; many representatives: stage 1 is throughput-bound
+    const bool dense = (size_t) p.batch * p.nb > 512u || p.nr >= ICP_S1_REJECT_MIN_NR;
 #define KS_ARGS p.M, p.R, p.O, p.N, p.st, p.m, p.nr, p.side, icp_tpr_magic (p.side), p
     if (p.fused) {
         if (dense) hipLaunchKernelGGL ((k_search<true, false, 4, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);

@@ -220,6 +220,49 @@ def test_batched(engine, oracle):
     g.close()
 
 
+@pytest.mark.parametrize("side,nr,zero_fraction,steps", [(128, 1024, 0.1, 4), (256, 4096, 0.0, 2), (256, 2048, 0.05, 2)])
+def test_stage1_pruning_exact(engine, oracle, side, nr, zero_fraction, steps):
+    """The dense search variant prunes stage 1 (seed bound + bounding boxes of representative groups): ids, distances
+    and nearest representatives stay bit-exact, also with exact ties (10 % identical zero points), several tiles of
+    representatives (nr > 1024) and a seed that changes from one iteration to the next."""
+    g, o, F, M = make(engine, oracle, side, nr, zero_fraction=zero_fraction)
+    g.buildRBC()
+    o.build_rbc()
+    for _ in range(steps):
+        g.step()
+        o.step()
+        check_step(engine, g, o)
+    g.close()
+
+
+def test_stage1_pruning_batched_ties(engine, oracle):
+    """Dense by batch (9 x 64 blocks > 512): every registration equals its own oracle, zero points included."""
+    B, side, nr = 9, 64, 64
+    g = engine.ICP(0)
+    g.init(side * side, nr, A, C_, batch=B)
+    oracles = []
+    for b in range(B):
+        F, M = engine.synth_pair(side, seed=0x1C9D5EED + 7 * b, rot_deg=1.0 + 0.5 * b, zero_fraction=0.1 if b % 2 else 0.0)
+        g.write(engine.Memory.F, F, batch_index=b)
+        g.write(engine.Memory.M, M, batch_index=b)
+        o = oracle.OracleICP(side * side, nr, A, C_, threads=8)
+        o.write_f(F)
+        o.write_m(M)
+        o.build_rbc()
+        oracles.append(o)
+    g.buildRBC()
+    for it in range(3):
+        g.step()
+        for b, o in enumerate(oracles):
+            o.step()
+            assert np.array_equal(g.read(engine.Memory.RID, b), o.rid), (it, b)
+            gn = g.read(engine.Memory.NN_ID, b)
+            assert np.array_equal(gn["id"], o.nn_id["id"]), (it, b)
+            assert_bits(gn["dist"], o.nn_id["dist"], "distances of registration %d" % b)
+            assert_bits(g.read(engine.Memory.T, b), o.T, "T of registration %d" % b)
+    g.close()
+
+
 def test_config3_one_step(engine, oracle):
     """config 3: |F|=|M|=65536, |R|=1024 (the reference itself cannot run it: SURVEY §0.7)."""
     g, o, F, M = make(engine, oracle, 256, 1024)

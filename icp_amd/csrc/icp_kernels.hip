@@ -327,6 +327,9 @@ __global__ __launch_bounds__ (1024) void k_place (icp_params p)
 #define KS_SPLIT LPQ
 #define KS_QPW (64 / KS_SPLIT)  // queries per wave
 #define KS_TILE 1024u            // representatives per LDS tile
+#ifndef ICP_S2_DEPTH16
+#define ICP_S2_DEPTH16 8u            // stage 2, 16 lanes per query: candidates in flight per lane (8 x 16 = 128 covers every list at |R| = m/64)
+#endif
 #ifndef ICP_S1_SEED
 #define ICP_S1_SEED 1                // stage 1: prune with the distance to the previous search's nearest representative
 #endif
@@ -785,18 +788,22 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     float4 bnn = make_float4 (0.f, 0.f, 0.f, 0.f);
 #ifndef ICP_DBG_SKIP_S2
     if (valid) {
-        uint32_t j = o + ss;
+        // a batch = KS_DEPTH candidates per lane, all loads issued before the first distance (clamped addresses, the
+        // tail is masked): one memory round trip per batch, and one batch covers a list of KS_DEPTH * LPQ candidates
+        constexpr uint32_t KS_DEPTH = (KS_SPLIT == 16) ? ICP_S2_DEPTH16 : 4u;
         const uint32_t je = o + n;
-        for (; j + 3 * KS_SPLIT < je; j += 4 * KS_SPLIT) {      // four candidates in flight
-            float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
-            float4 g1 = XQ4[2 * (size_t) (j + KS_SPLIT)], c1 = XQ4[2 * (size_t) (j + KS_SPLIT) + 1];
-            float4 g2 = XQ4[2 * (size_t) (j + 2 * KS_SPLIT)], c2 = XQ4[2 * (size_t) (j + 2 * KS_SPLIT) + 1];
-            float4 g3 = XQ4[2 * (size_t) (j + 3 * KS_SPLIT)], c3 = XQ4[2 * (size_t) (j + 3 * KS_SPLIT) + 1];
-            KS_CAND (g0, c0, j); KS_CAND (g1, c1, j + KS_SPLIT); KS_CAND (g2, c2, j + 2 * KS_SPLIT); KS_CAND (g3, c3, j + 3 * KS_SPLIT);
-        }
-        for (; j < je; j += KS_SPLIT) {
-            float4 g0 = XQ4[2 * (size_t) j], c0 = XQ4[2 * (size_t) j + 1];
-            KS_CAND (g0, c0, j);
+        for (uint32_t j0 = o + ss; j0 < je; j0 += KS_DEPTH * KS_SPLIT) {
+            float4 g[KS_DEPTH], c[KS_DEPTH];
+#pragma unroll
+            for (uint32_t t = 0; t < KS_DEPTH; ++t) {
+                const uint32_t j = min (j0 + t * KS_SPLIT, je - 1u);
+                g[t] = XQ4[2 * (size_t) j]; c[t] = XQ4[2 * (size_t) j + 1];
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < KS_DEPTH; ++t) {
+                const uint32_t j = j0 + t * KS_SPLIT;
+                if (j < je) KS_CAND (g[t], c[t], j);
+            }
         }
     }
 #endif

@@ -14,7 +14,9 @@ data-path collective; value = iterations of all ranks / max-over-ranks time  ("s
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      dominant kernel (k_search): algorithmic bytes per launch (72 m + 32 |R| + 64) /
-                its average launch-to-launch time, measured with HIP events on the engine's own stream
+                its average launch-to-launch time, measured with HIP events on the engine's own stream.  In the
+                default (fused, chained) form an iteration IS one k_search launch (it first turns the previous
+                iteration's moments into T), so that time is the timed region / launches
   cpu_baseline  the CPU oracle ("port") timed on this host on a bounded sample (rank 0, N = 1 only)
 """
 import argparse
@@ -143,13 +145,22 @@ def main():
 
     total_t, total_iters = aggregate(dist, elapsed, args.steps * ITERS_PER_STEP * args.batch)
 
-    # dominant kernel (k_search): average launch-to-launch time of a graph holding only that kernel, HIP events on
-    # the engine's stream (rocprofv3's per-dispatch average for the same kernel: profiles/r01_final_*_kernel_stats.csv)
+    # dominant kernel (k_search): average launch-to-launch time, HIP events on the engine's stream (rocprofv3's
+    # per-dispatch average for the same kernel: profiles/r01_final_*_kernel_stats.csv).  Chained form: the timed
+    # region itself is `steps` graphs of ITERS_PER_STEP k_search launches (+ one begin / end kernel per graph);
+    # otherwise a graph holding only that kernel.
     fused = args.reduce_mode == "fused"
+    launches = g.launches_per_iteration()
     names = (("search", 1), ("finalize", 8)) if fused else (("search", 1), ("means", 2), ("sij", 4), ("finalize", 8))
-    kernel_us = {n: g.time_masked(mk, ITERS_PER_STEP, 20) for n, mk in names}
-    kernel_us["iteration (all kernels, from the timed region)"] = ev_ms * 1e3 / (args.steps * ITERS_PER_STEP)
-    search_us = kernel_us["search"]
+    kernel_us = {n + (" (separate launch)" if launches == 1 else ""): g.time_masked(mk, ITERS_PER_STEP, 20) for n, mk in names}
+    iter_us = ev_ms * 1e3 / (args.steps * ITERS_PER_STEP)
+    kernel_us["iteration (all kernels, from the timed region)"] = iter_us
+    if launches == 1:
+        search_us = iter_us
+        kernel_name = "k_search<chained> (finalize of the previous iteration in its prologue)"
+    else:
+        search_us = kernel_us["search"]
+        kernel_name = "k_search"
     achieved = ALGO_BYTES_PER_ITER / (search_us * 1e-6) / 1e9
     algo_flop = 18.0 * M_POINTS * (N_REPS + M_POINTS / N_REPS) + 100.0 * M_POINTS      # SURVEY.md §8d / BASELINE.md §3
     tflops = algo_flop / (search_us * 1e-6) / 1e12
@@ -180,8 +191,8 @@ def main():
                                    "a=2e2 c=1e-6; step = %d fixed iterations (one hipGraph), RBC prebuilt" % ITERS_PER_STEP,
                        "parallelism": "replicas" if world > 1 else "single", "registrations_per_gpu": args.batch,
                        "power_start": args.power_mode,
-                       "reduce_mode": args.reduce_mode},
-            "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                       "reduce_mode": args.reduce_mode, "launches_per_iteration": launches},
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "launches_per_iteration": launches, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ITER, "avg_launch_us": search_us,
                          "kernel_us": kernel_us,

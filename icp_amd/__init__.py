@@ -119,6 +119,7 @@ def lib():
     sig("icp_reset_transform", i32, vp)
     sig("icp_time_kernels", i32, vp, u32, C.POINTER(f32))
     sig("icp_time_masked", i32, vp, u32, u32, u32, C.POINTER(f32))
+    sig("icp_launches_per_iteration", i32, vp, C.POINTER(u32))
     sig("icp_reduce", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_scan", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_reduce_scan_last_error", C.c_char_p)
@@ -322,6 +323,12 @@ class ICPStep:
     def reset_transform(self):
         """T <- identity, k <- 0 (enqueue only)."""
         self._chk(self._L.icp_reset_transform(self._h))
+
+    def launches_per_iteration(self):
+        """Kernel launches per iteration of run() / run_fixed(): 4 (reference order), 2 (fused) or 1 (fused, chained)."""
+        n = C.c_uint32()
+        self._chk(self._L.icp_launches_per_iteration(self._h, C.byref(n)))
+        return n.value
 
     def time_masked(self, mask, iterations=40, reps=20):
         """us per iteration of a graph holding only the kernels in `mask` (diagnostic)."""

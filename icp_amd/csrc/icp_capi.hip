@@ -184,7 +184,7 @@ int icp_create (icp_handle *out, int device, int rot, int weighted)
     icp_context *h = new icp_context ();
     h->device = device;
     h->p.rot = rot; h->p.weighted = weighted; h->p.power_mode = ICP_POWER_LITERAL;
-    { const char *e = std::getenv ("ICP_AMD_CHAIN"); h->p.chain = (e && e[0] == '1') ? 1 : 0; }   // experimental, see icp_chain_supported
+    { const char *e = std::getenv ("ICP_AMD_CHAIN"); h->p.chain = !e ? 1 : (e[0] == '1') ? 2 : (e[0] == '0') ? 0 : 1; }   // see icp_chain_supported
     e = hipSetDevice (device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags (&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate (&h->ev0);
@@ -600,6 +600,14 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int fr
     HIPCHK (h, hipEventRecord (h->ev1, h->stream));
     HIPCHK (h, hipEventSynchronize (h->ev1));
     HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));
+    return ICP_OK;
+}
+
+int icp_launches_per_iteration (icp_handle h, uint32_t *n)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if (!n) return fail (h, ICP_EINVAL, "null output");
+    *n = icp_chain_supported (h->p) ? 1u : h->p.fused ? 2u : 4u;
     return ICP_OK;
 }
 

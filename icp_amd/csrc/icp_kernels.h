@@ -12,7 +12,7 @@ struct icp_params {
     uint32_t side, nrx, nry;     // landmark grid side and representative grid (getReps)
     float a, c;
     int weighted, rot, power_mode, check;
-    int chain;                   // fused mode: 1 = one launch per iteration (finalize in the next search's prologue)
+    int chain;                   // fused mode, one launch per iteration (finalize in the next search's prologue): 0 never, 1 automatic, 2 always
     int fused;                   // 0: reference-order reductions (3 global trees), 1: single-pass double moments
     double tan_half_thr, trans_thr;
     // derived sizes

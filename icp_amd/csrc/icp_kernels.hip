@@ -438,11 +438,13 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
         uint32_t k, g;
         if (ng == 1) { k = task; g = 0u; } else if (ng == 2) { k = task >> 1; g = task & 1u; } else { k = task / ng; g = task - k * ng; }
         const double *src = mom + (size_t) k * nb;
+        const bool live = ps * nrow + row < ntask;   // rows past the last task (whole waves when ntask % 4 == 0) load nothing
         double a[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {                // clamped address + select: eight loads back to back, no branches
             const uint32_t i = g * 128u + l + 16u * q;
-            const double t = src[min (i, nb - 1u)];
+            double t = 0.0;
+            if (live) t = src[min (i, nb - 1u)];
             a[q] = (i < nb) ? t : 0.0;
         }
         FF_STAMP (13)
@@ -549,27 +551,20 @@ static __device__ __forceinline__ void fin_result_to_state (const icp_fin_result
 // LPQ = lanes per query = waves per block: 16 when the grid is at most one block per CU (more waves per SIMD to
 // overlap the L2-cold loads), 8 when occupancy comes from the number of blocks.
 template <bool FUSED, bool CHAIN, int MINW, int LPQ>
-__global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, const float *gR, const uint32_t *gO_, const uint32_t *gN_,
-                                                              icp_reg_state *gst, uint32_t m, uint32_t nr, uint32_t side,
-                                                              uint32_t tpr_magic, icp_params p)
+__global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, const float *gR, icp_reg_state *gst, const double *gmom,
+                                                              uint32_t m, uint32_t nr, uint32_t side, uint32_t tpr_magic,
+                                                              uint32_t nb, uint32_t check, icp_params p)
 {
     // The first 14 dwords of the kernel arguments (everything the prologue's addresses need) are plain scalars so
     // that they arrive preloaded in SGPRs / in one scalar load; the rest of icp_params is fetched while the first
-    // global loads are in flight.
+    // global loads are in flight.  gst = the state this launch reads (CHAIN: slot p.slot of every pair of slots),
+    // gmom = the moments it turns into T first (CHAIN only: buffer p.slot).
     const uint32_t b = blockIdx.y;
-    icp_reg_state *st = CHAIN ? p.cst + (size_t) b * 2 + p.slot : gst + b;
+    icp_reg_state *st = CHAIN ? gst + (size_t) b * 2 : gst + b;
 #ifdef ICP_DBG_STAMPS
     { const uint32_t tid = threadIdx.x; unsigned long long t_; asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
       if (tid == 0 && p.dbg) p.dbg[(size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 16 + 8] = t_; }
 #endif
-    icp_reg_state *sout = CHAIN ? p.cst + (size_t) b * 2 + (p.slot ^ 1u) : st;
-    if constexpr (CHAIN) {
-        if (p.check && st->done) {                   // converged earlier: carry the state forward, nothing to do
-            if (blockIdx.x == 0 && threadIdx.x < sizeof (icp_reg_state) / 4)
-                reinterpret_cast<uint32_t *> (sout)[threadIdx.x] = reinterpret_cast<const uint32_t *> (st)[threadIdx.x];
-            return;
-        }
-    }
 
     // representatives of the current tile, pair-interleaved for packed fp32 math:
     //   pair P = reps (2P, 2P+1) -> 3 float4: [x0 x1 y0 y1] [z0 z1 r0 r1] [g0 g1 b0 b1]
@@ -596,7 +591,6 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
 
     const float4 *M4 = reinterpret_cast<const float4 *> (gM + (size_t) b * m * 8);
     const float4 *R4 = reinterpret_cast<const float4 *> (gR + (size_t) b * nr * 8);
-    const uint32_t *gO = gO_ + (size_t) b * nr, *gN = gN_ + (size_t) b * nr;
 
     // every independent global load of the prologue is issued before anything waits: the state (one vector load,
     // lane j = dword j: scalar loads of T would queue behind the waits of the vector loads), the first tile of
@@ -608,11 +602,19 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         uint32_t k = tid + (uint32_t) u * 64u * KS_SPLIT;
-        rg[u] = make_float4 (0.f, 0.f, 0.f, 0.f); rc[u] = rg[u]; ron[u] = make_uint2 (0u, 0u);
-        if (k < tn0) { rg[u] = R4[2 * (size_t) k]; rc[u] = R4[2 * (size_t) k + 1]; ron[u] = make_uint2 (gO[k], gN[k]); }
+        rg[u] = make_float4 (0.f, 0.f, 0.f, 0.f); rc[u] = rg[u];
+        if (k < tn0) { rg[u] = R4[2 * (size_t) k]; rc[u] = R4[2 * (size_t) k + 1]; }
     }
     const uint32_t ic = min (i, m - 1u);
     float4 mg = M4[2 * (size_t) ic], mc = M4[2 * (size_t) ic + 1];
+    // (list offsets / sizes: their base pointers come with the second batch of kernel arguments)
+    const uint32_t *gO = p.O + (size_t) b * nr, *gN = p.N + (size_t) b * nr;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        uint32_t k = tid + (uint32_t) u * 64u * KS_SPLIT;
+        ron[u] = make_uint2 (0u, 0u);
+        if (k < tn0) ron[u] = make_uint2 (gO[k], gN[k]);
+    }
     // seed of the stage-1 pruning bound: this query's nearest representative of the previous search (any index < nr
     // is a valid seed; the buffer starts zeroed)
     // Pruning pays where stage 1 is throughput-bound: the dense variant (MINW == 4: several blocks per CU, or a
@@ -629,24 +631,17 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     float T[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) T[k] = state_lane_f (sv, ICP_ST_DW (T) + k);
-    if constexpr (!CHAIN) { if (p.check && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))) return; }   // converged earlier
+    icp_reg_state *sout = CHAIN ? p.cst + (size_t) b * 2 + (p.slot ^ 1u) : st;
+    if (check && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))) {    // converged earlier
+        if constexpr (CHAIN) {                       // carry the state forward
+            if (blockIdx.x == 0 && tid < sizeof (icp_reg_state) / 4) reinterpret_cast<uint32_t *> (sout)[tid] = sv;
+        }
+        return;
+    }
     if (!valid) { mg = make_float4 (0.f, 0.f, 0.f, 1.f); mc = mg; }
     const float4 *XQ4 = reinterpret_cast<const float4 *> (p.XQ + (size_t) b * m * 8);
-    if constexpr (CHAIN) {
-        const bool pending = st->pending != 0;
-        if (pending) {
-            fused_finalize_block<32, 64 * LPQ> (p, p.mom + ((size_t) b * 2 + p.slot) * ICP_NMOM * p.nb, p.nb, 0u, sv, &s_fin, s_l1, s_t);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) T[k] = s_fin.T[k];
-            if (blockIdx.x == 0) fin_result_to_state (&s_fin, sout, s_fin.done ? 0u : 1u);
-            KS_STAMP (9)
-            if (s_fin.done) return;
-        } else if (blockIdx.x == 0 && tid < sizeof (icp_reg_state) / 4) {
-            uint32_t v = reinterpret_cast<const uint32_t *> (st)[tid];
-            if (tid == offsetof (icp_reg_state, pending) / 4) v = 1u;
-            reinterpret_cast<uint32_t *> (sout)[tid] = v;
-        }
-    }
+    // the first tile of representatives goes to LDS now: nothing in it depends on T, and in the chained variant the
+    // writes and their barrier disappear behind the power method of wave 0
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         uint32_t k = tid + (uint32_t) u * 64u * KS_SPLIT;
@@ -657,6 +652,19 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
         }
     }
     if (prune && tid < nbox0) s_box[tid] = boxv;
+    if constexpr (CHAIN) {
+        const bool pending = __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (pending)) != 0;
+        if (pending) {
+            fused_finalize_block<32, 64 * LPQ> (p, gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, 0u, sv, &s_fin, s_l1, s_t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) T[k] = s_fin.T[k];
+            if (blockIdx.x == 0) fin_result_to_state (&s_fin, sout, s_fin.done ? 0u : 1u);
+            KS_STAMP (9)
+            if (s_fin.done) return;
+        } else if (blockIdx.x == 0 && tid < sizeof (icp_reg_state) / 4) {
+            reinterpret_cast<uint32_t *> (sout)[tid] = (tid == offsetof (icp_reg_state, pending) / 4) ? 1u : sv;
+        }
+    }
     float qx, qy, qz;
     icp_transform_point (T, mg.x, mg.y, mg.z, qx, qy, qz);
     const float qr = mc.x, qg = mc.y, qb = mc.z;
@@ -1182,11 +1190,16 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
     hipLaunchKernelGGL (k_place, dim3 (p.nchunk, p.batch), dim3 (1024), p.nr * sizeof (uint32_t), s, p);
 }
 
+static inline bool icp_dense (const icp_params &p)
+{   // more blocks than one per CU: trade registers for occupancy; many representatives: stage 1 is throughput-bound
+    return (size_t) p.batch * p.nb > 512u || p.nr >= ICP_S1_REJECT_MIN_NR;
+}
+
 void icp_launch_search (const icp_params &p, hipStream_t s)
 {
-    // more blocks than one per CU: trade registers for occupancy; many representatives: stage 1 is throughput-bound
-    const bool dense = (size_t) p.batch * p.nb > 512u || p.nr >= ICP_S1_REJECT_MIN_NR;
-#define KS_ARGS p.M, p.R, p.O, p.N, p.st, p.m, p.nr, p.side, icp_tpr_magic (p.side), p
+    const bool dense = icp_dense (p);
+#define KS_ARGS p.M, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, (uint32_t) p.check, p
+#define KS_CHAIN_ARGS p.M, p.R, p.cst + p.slot, (const double *) p.mom + (size_t) p.slot * ICP_NMOM * p.nb, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, (uint32_t) p.check, p
     if (p.fused) {
         if (dense) hipLaunchKernelGGL ((k_search<true, false, 4, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
         else hipLaunchKernelGGL ((k_search<true, false, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_ARGS);
@@ -1229,7 +1242,12 @@ void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask)
 // chained fused run: begin, one launch per iteration, end (icp_chain_supported: second tree level fits 32 groups)
 // Measured at |F|=|M|=16384: the replicated prologue (every block fetching the 36 KB of fresh moment partials)
 // costs more than the launch boundary it removes (15.7 vs 14.9 us per iteration), so the chain is opt-in.
-bool icp_chain_supported (const icp_params &p) { return p.fused && p.chain && p.nb <= 4096u; }
+// One launch per iteration (fused mode): p.chain = 0 never, 1 automatic (latency-bound sizes: the launch boundary it
+// removes outweighs every block re-deriving T), 2 always (sizes the second tree level of the prologue can hold).
+bool icp_chain_supported (const icp_params &p)
+{
+    return p.fused && p.nb <= 4096u && (p.chain == 2 || (p.chain == 1 && !icp_dense (p)));
+}
 
 void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations)
 {
@@ -1237,7 +1255,7 @@ void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations)
     hipLaunchKernelGGL (k_chain_begin, dim3 (p.batch), dim3 (64), 0, s, p);
     for (uint32_t j = 0; j < iterations; ++j) {
         p.slot = j & 1u;
-        hipLaunchKernelGGL ((k_search<true, true, 2, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
+        hipLaunchKernelGGL ((k_search<true, true, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
     }
     p.slot = iterations & 1u;
     hipLaunchKernelGGL (k_chain_end, dim3 (p.batch), dim3 (320), 0, s, p);

@@ -208,6 +208,12 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int fr
  * iterations): out_ms[0..3] = mean ms of {search, means, sij, finalize}. */
 int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4);
 
+/* Kernel launches per iteration of the graphs behind icp_run / icp_run_fixed with the current modes and sizes:
+ * 4 (reference-order reductions), 2 (fused: search + finalize) or 1 (fused, chained: the finalize of iteration k
+ * runs in the prologue of the search of iteration k+1; chosen automatically for latency-bound sizes, environment
+ * ICP_AMD_CHAIN=0 / 1 forces it off / on at icp_create). */
+int icp_launches_per_iteration (icp_handle h, uint32_t *n);
+
 /* Diagnostic: a graph of `iterations` x (the kernels selected by mask: bit 0 search, 1 means, 2 sij,
  * 3 finalize, 4 an empty 256-block kernel), launched `reps` times; *ms_total = elapsed ms. */
 int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t reps, float *ms_total);

@@ -428,6 +428,17 @@ def test_fused_chain_fixed_run_and_limits(engine, oracle):
     g.close()
 
 
+def test_chain_is_automatic_only_for_latency_bound_sizes(engine, monkeypatch):
+    monkeypatch.delenv("ICP_AMD_CHAIN", raising=False)
+    for side, nr, batch, fused, want in ((128, 256, 1, True, 1), (128, 256, 4, True, 2), (256, 1024, 1, True, 2),
+                                         (128, 256, 1, False, 4), (64, 64, 8, True, 1), (64, 64, 9, True, 2)):
+        g = engine.ICP(0)
+        g.init(side * side, nr, A, C_, batch=batch)
+        g.setReduceMode(engine.ReduceMode.FUSED if fused else engine.ReduceMode.REFERENCE_ORDER)
+        assert g.launches_per_iteration() == want, (side, nr, batch, fused)
+        g.close()
+
+
 def test_fused_chain_batched(engine, oracle):
     B, side, nr = 3, 64, 64
     g = engine.ICP(0)
@@ -455,11 +466,17 @@ def test_fused_chain_batched(engine, oracle):
     g.close()
 
 
-def test_opt_in_chain_mode(engine, oracle, monkeypatch):
-    """ICP_AMD_CHAIN=1 (read at icp_create): one launch per iteration, finalize in the next search's prologue,
-    double-buffered state and moments — same bits as the two-launch fused path and as the oracle."""
-    monkeypatch.setenv("ICP_AMD_CHAIN", "1")
+@pytest.mark.parametrize("chain,launches", [(None, 1), ("1", 1), ("0", 2)])
+def test_chain_modes(engine, oracle, monkeypatch, chain, launches):
+    """Fused graphs run one launch per iteration (finalize in the next search's prologue, double-buffered state and
+    moments) where the size is latency-bound; ICP_AMD_CHAIN=0 / 1 (read at icp_create) forces the two-launch / chained
+    form.  Same bits either way, and the same as the oracle."""
+    if chain is None:
+        monkeypatch.delenv("ICP_AMD_CHAIN", raising=False)
+    else:
+        monkeypatch.setenv("ICP_AMD_CHAIN", chain)
     g, o, F, M = make(engine, oracle, 128, 256, power_fast=True, fused=True)
+    assert g.launches_per_iteration() == launches
     g.buildRBC()
     o.build_rbc()
     assert g.run() == o.run()

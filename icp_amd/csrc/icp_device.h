@@ -203,8 +203,10 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
     float x = 1.f, xn = 0.f;
     int iters = 0;
     PM_STAMP (0)
-    for (;;) {
-        if (squared_start) {
+    if (squared_start) {
+        // oracle power_fast: B = N^1024, u = B 1, x = normalize (u), xn = normalize (N u) (two independent chains),
+        // loop on squared step lengths, division-free sign test, no extra pass after the loop
+        for (;;) {
             float Brow[4] = { Nrow[0], Nrow[1], Nrow[2], Nrow[3] };
             pmq_rescale (Brow);
             for (int s = 0; s < ICP_PM_SQUARINGS; ++s) {
@@ -217,37 +219,51 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
                 if (s % 3 == 2) pmq_rescale (Brow);
             }
             PM_STAMP (1)
-            x = pmq_normalize (pmq_matvec (Brow, x));
-            PM_STAMP (2)
-        }
-        float error, error_new = __builtin_inff ();
-        for (uint32_t it = 0; it < 1000; ++it) {                      // icp_kernels.cl:1012-1022
-            xn = pmq_normalize (pmq_matvec (Nrow, x));
+            const float u = pmq_matvec (Brow, 1.f);
+            x = pmq_normalize (u);
+            xn = pmq_normalize (pmq_matvec (Nrow, u));
             ++iters;
-            error = error_new;
-            float d = x - xn;
-            if (squared_start) {                                      // oracle power_impl: squared step, floor 2^-22
-                error_new = pmq_seq4 (d * d);
-                if (error_new >= error || error_new <= 0x1p-44f) break;
-            } else {
+            PM_STAMP (2)
+            float e2_prev = __builtin_inff (), d = x - xn, e2 = pmq_seq4 (d * d);
+            while (e2 > 0x1p-44f && e2 < e2_prev && iters < 1000) {
+                x = xn;
+                xn = pmq_normalize (pmq_matvec (Nrow, x));
+                ++iters;
+                e2_prev = e2; d = x - xn; e2 = pmq_seq4 (d * d);
+            }
+            PM_STAMP (3)
+            const float lam_num = pmq_lane (pmq_matvec (Nrow, xn), 0), den = pmq_lane (xn, 0);
+            if ((lam_num < 0.f && den > 0.f) || (lam_num > 0.f && den < 0.f)) {
+                const float lambda = lam_num / den;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Nrow[k] = (i == (uint32_t) k) ? Nrow[k] - lambda : Nrow[k];
+            } else break;
+        }
+        PM_STAMP (4)
+        PM_STAMP (5)
+    } else {
+        for (;;) {
+            float error, error_new = __builtin_inff ();
+            for (uint32_t it = 0; it < 1000; ++it) {                  // icp_kernels.cl:1012-1022
+                xn = pmq_normalize (pmq_matvec (Nrow, x));
+                ++iters;
+                error = error_new;
+                float d = x - xn;
                 error_new = sqrtf (pmq_seq4 (d * d));
                 if (error_new == error) break;
+                x = xn;
             }
-            x = xn;
-        }
-        PM_STAMP (3)
-        float lam_num = pmq_lane (pmq_matvec (Nrow, xn), 0);
-        float lambda = lam_num / pmq_lane (xn, 0);                    // :1024
-        if (lambda < 0) {
+            float lam_num = pmq_lane (pmq_matvec (Nrow, xn), 0);
+            float lambda = lam_num / pmq_lane (xn, 0);                // :1024
+            if (lambda < 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) Nrow[k] = (i == (uint32_t) k) ? Nrow[k] - lambda : Nrow[k];
-            x = 1.f;
-        } else break;
+                for (int k = 0; k < 4; ++k) Nrow[k] = (i == (uint32_t) k) ? Nrow[k] - lambda : Nrow[k];
+                x = 1.f;
+            } else break;
+        }
+        x = xn;                                                       // :1039-1041
+        xn = pmq_normalize (pmq_matvec (Nrow, x));
     }
-    PM_STAMP (4)
-    x = xn;                                                           // :1039-1041
-    xn = pmq_normalize (pmq_matvec (Nrow, x));
-    PM_STAMP (5)
 
     float qx = pmq_lane (xn, 0), qy = pmq_lane (xn, 1), qz = pmq_lane (xn, 2), qw = pmq_lane (xn, 3);
     const float *mf = means, *mm = means + 4;

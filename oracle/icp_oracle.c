@@ -532,48 +532,21 @@ static void rescale16 (float *B)
 
 #define PM_SQUARINGS 10
 
-static int power_impl (const float *S, const float *means, float *Tk, int fast)
+/* The reference's power method, literally (icp_kernels.cl:977-1054). */
+static int power_literal (const float *S, const float *means, float *Tk)
 {
     float N[16]; build_N (S, N);
     float x[4] = { 1.f, 1.f, 1.f, 1.f }, xn[4];
     int iters = 0;
     for (;;) {
-        if (fast) {
-            /* build's accelerated start: B = N^(2^PM_SQUARINGS) by repeated
-             * squaring (fmaf chains, exact power-of-two rescaling every third squaring), x = normalize (B * 1).  The loop
-             * below is the reference's loop and polishes x with the un-squared N. */
-            float B[16], C[16]; memcpy (B, N, sizeof B); rescale16 (B);
-            for (int s = 0; s < PM_SQUARINGS; ++s) {
-                /* C = B B as a k-ordered fmaf chain (what v_mfma_f32_4x4x1 evaluates: one rounding per step) */
-                for (int i = 0; i < 4; ++i)
-                    for (int j = 0; j < 4; ++j) {
-                        float acc = 0.f;
-                        for (int k = 0; k < 4; ++k) acc = fmaf (B[i * 4 + k], B[k * 4 + j], acc);
-                        C[i * 4 + j] = acc;
-                    }
-                memcpy (B, C, sizeof B);
-                if (s % 3 == 2) rescale16 (B);      /* max|entry| < 2 after a rescale, < 2^22 three squarings later */
-            }
-            prod4 (B, x, xn); normalize4 (xn);
-            memcpy (x, xn, sizeof x);
-        }
         float error, error_new = INFINITY;
         for (uint32_t it = 0; it < 1000; ++it) {            /* icp_kernels.cl:1012-1022 */
             prod4 (N, x, xn);
             normalize4 (xn);
             ++iters;
             error = error_new;
-            /* reference rule: stop when the step length repeats (:1019).  Squared start: x is already at the
-             * fixed point to ~1e-7 (the first step is at the rounding floor, <= 1 ulp of a unit vector), so the
-             * loop compares SQUARED step lengths (no root) and stops as soon as the step is below 2^-22 or
-             * stops decreasing. */
-            if (fast) {
-                error_new = distance4_sq (x, xn);
-                if (error_new >= error || error_new <= 0x1p-44f) break;
-            } else {
-                error_new = distance4 (x, xn);
-                if (error_new == error) break;
-            }
+            error_new = distance4 (x, xn);
+            if (error_new == error) break;                  /* stop when the step length repeats (:1019) */
             memcpy (x, xn, sizeof x);
         }
         float lambda = dot4 (N, xn) / xn[0];                 /* :1024 */
@@ -588,6 +561,56 @@ static int power_impl (const float *S, const float *means, float *Tk, int fast)
     finish_Tk (S, means, xn, Tk);
     return iters;
 }
+
+/* The build's accelerated power method (the GPU twin is icp_power_method_quad, squared start).
+ *   B = N^(2^PM_SQUARINGS) by repeated squaring (k-ordered fmaf chains, exact power-of-two rescaling every third
+ *   squaring); u = B 1 (not normalised);  x = normalize (u) and xn = normalize (N u) (independent of each other);
+ *   then the reference's loop on SQUARED step lengths: it goes on only while the step is above 2^-22 (one ulp of a
+ *   unit vector) and still decreasing.  The sign test of :1024 divides only when it has to shift; the vector the
+ *   loop ends with is the result (the reference's extra pass after its loop, :1039-1041, is what the loop's last
+ *   trip already is here). */
+static int power_fast (const float *S, const float *means, float *Tk)
+{
+    float N[16]; build_N (S, N);
+    float x[4], xn[4], u[4];
+    const float ones[4] = { 1.f, 1.f, 1.f, 1.f };
+    int iters = 0;
+    for (;;) {
+        float B[16], C[16]; memcpy (B, N, sizeof B); rescale16 (B);
+        for (int s = 0; s < PM_SQUARINGS; ++s) {
+            /* C = B B as a k-ordered fmaf chain (what v_mfma_f32_4x4x1 evaluates: one rounding per step) */
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    float acc = 0.f;
+                    for (int k = 0; k < 4; ++k) acc = fmaf (B[i * 4 + k], B[k * 4 + j], acc);
+                    C[i * 4 + j] = acc;
+                }
+            memcpy (B, C, sizeof B);
+            if (s % 3 == 2) rescale16 (B);          /* max|entry| < 2 after a rescale, < 2^22 three squarings later */
+        }
+        prod4 (B, ones, u);
+        memcpy (x, u, sizeof x); normalize4 (x);
+        prod4 (N, u, xn); normalize4 (xn);
+        ++iters;
+        float e2_prev = INFINITY, e2 = distance4_sq (x, xn);
+        while (e2 > 0x1p-44f && e2 < e2_prev && iters < 1000) {       /* false on NaN: the loop ends */
+            memcpy (x, xn, sizeof x);
+            prod4 (N, x, xn); normalize4 (xn);
+            ++iters;
+            e2_prev = e2; e2 = distance4_sq (x, xn);
+        }
+        const float lam_num = dot4 (N, xn), den = xn[0];              /* :1024, lambda = lam_num / den */
+        if ((lam_num < 0.f && den > 0.f) || (lam_num > 0.f && den < 0.f)) {
+            const float lambda = lam_num / den;
+            N[0] -= lambda; N[5] -= lambda; N[10] -= lambda; N[15] -= lambda;
+        } else break;
+    }
+    finish_Tk (S, means, xn, Tk);
+    return iters;
+}
+
+static int power_impl (const float *S, const float *means, float *Tk, int fast)
+{ return fast ? power_fast (S, means, Tk) : power_literal (S, means, Tk); }
 
 int orc_power_method (const float *S11, const float *mean8, float *Tk8)
 { return power_impl (S11, mean8, Tk8, 0); }

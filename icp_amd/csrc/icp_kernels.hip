@@ -308,10 +308,11 @@ __global__ __launch_bounds__ (1024) void k_place (icp_params p)
         float4 g = F4[2 * (size_t) i], c = F4[2 * (size_t) i + 1];
         X4[2 * (size_t) pos] = g;
         X4[2 * (size_t) pos + 1] = c;
-        // search copy: the unused homogeneous lane carries the original index (saves the perm[] round trip)
+        // search copy, laid out for packed fp32 math: [x r y g | z b id 0] — (geometry, colour) pairs side by side, and
+        // the unused homogeneous lane carries the original index (saves the perm[] round trip)
         float4 *Q4 = reinterpret_cast<float4 *> (p.XQ + (size_t) b * p.m * 8);
-        Q4[2 * (size_t) pos] = make_float4 (g.x, g.y, g.z, __uint_as_float (i));
-        Q4[2 * (size_t) pos + 1] = c;
+        Q4[2 * (size_t) pos] = make_float4 (g.x, c.x, g.y, c.y);
+        Q4[2 * (size_t) pos + 1] = make_float4 (g.z, c.z, __uint_as_float (i), 0.f);
     }
 }
 
@@ -369,11 +370,16 @@ template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint
     return v;
 }
 
-// candidate j of a list: XQ = [x y z id | r g b -]; keeps the best (distance, position, point)
+// candidate j of a list: XQ = [x r y g | z b id 0].  The geometric and the photometric sum of the metric are
+// evaluated side by side, one packed instruction per step: (dx, dr), (dy, dg), (dz, db) -> (geo, pho) with exactly the
+// operations of icp_metric8 (mul, fma, fma per half), then d = fma (a, pho, geo).  Keeps the best (distance, position).
 #define KS_CAND(G, C, J)                                                                              \
     {                                                                                                 \
-        float d_ = icp_metric8 (qx, qy, qz, qr, qg, qb, (G).x, (G).y, (G).z, (C).x, (C).y, (C).z, alpha); \
-        if (d_ < best2) { best2 = d_; bj = (J); bnn = (G); }                                          \
+        const float2v d1_ = vq_xr - float2v { (G).x, (G).y }, d2_ = vq_yg - float2v { (G).z, (G).w }, \
+                      d3_ = vq_zb - float2v { (C).x, (C).y };                                         \
+        const float2v gp_ = __builtin_elementwise_fma (d3_, d3_, __builtin_elementwise_fma (d2_, d2_, d1_ * d1_)); \
+        const float d_ = __builtin_fmaf (alpha, gp_.y, gp_.x);                                        \
+        if (d_ < best2) { best2 = d_; bj = (J); }                                                     \
     }
 
 #define ICP_NMOM 18
@@ -793,23 +799,27 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     // candidates (256 contiguous bytes) per load.  (Staging the block's lists through LDS first was measured and is
     // slower: enumerating the distinct lists and the extra barrier cost more than the direct gathers.)
     float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
-    float4 bnn = make_float4 (0.f, 0.f, 0.f, 0.f);
+    const float2v vq_xr = { qx, qr }, vq_yg = { qy, qg }, vq_zb = { qz, qb };
 #ifndef ICP_DBG_SKIP_S2
     if (valid) {
         // a batch = KS_DEPTH candidates per lane, all loads issued before the first distance (clamped addresses, the
-        // tail is masked): one memory round trip per batch, and one batch covers a list of KS_DEPTH * LPQ candidates
+        // tail is masked): one memory round trip per batch, and one batch covers a list of KS_DEPTH * LPQ candidates;
+        // a trip no lane of the wave needs is skipped (wave-uniform branch)
         constexpr uint32_t KS_DEPTH = (KS_SPLIT == 16) ? ICP_S2_DEPTH16 : 4u;
         const uint32_t je = o + n;
         for (uint32_t j0 = o + ss; j0 < je; j0 += KS_DEPTH * KS_SPLIT) {
             float4 g[KS_DEPTH], c[KS_DEPTH];
 #pragma unroll
             for (uint32_t t = 0; t < KS_DEPTH; ++t) {
+                // (the scan is bound by the L1's 64 B / clock: a trip no lane needs is not loaded either)
+                if (t && !__any (j0 + t * KS_SPLIT < je)) break;
                 const uint32_t j = min (j0 + t * KS_SPLIT, je - 1u);
                 g[t] = XQ4[2 * (size_t) j]; c[t] = XQ4[2 * (size_t) j + 1];
             }
 #pragma unroll
             for (uint32_t t = 0; t < KS_DEPTH; ++t) {
                 const uint32_t j = j0 + t * KS_SPLIT;
+                if (!__any (j < je)) break;
                 if (j < je) KS_CAND (g[t], c[t], j);
             }
         }
@@ -829,10 +839,11 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
             uint32_t id; float4 nn;
             if (n == 0) {            // empty list: fall back to the representative itself
                 d = dr; id = p.rep_src[(size_t) b * nr + rstar]; nn = R4[2 * (size_t) rstar];
-            } else if (jmin == 0xFFFFFFFFu) {   // every distance inf / NaN: first list element, as the serial scan would
-                nn = XQ4[2 * (size_t) o]; id = __float_as_uint (nn.w);
-            } else {
-                nn = bnn; id = __float_as_uint (nn.w);
+            } else {                 // the winner's point (jmin), or, when every distance is inf / NaN, the first list
+                                     // element as the serial scan would: one reload instead of tracking it per candidate
+                const size_t jw = (jmin == 0xFFFFFFFFu) ? (size_t) o : (size_t) jmin;
+                const float4 wg = XQ4[2 * jw], wc = XQ4[2 * jw + 1];
+                nn = make_float4 (wg.x, wg.z, wc.x, 0.f); id = __float_as_uint (wc.z);
             }
             w = p.weighted ? 100.f / (100.f + d) : 1.f;                // icp_kernels.cl:232
             icp_dist_id di; di.dist = d; di.id = id;

@@ -171,11 +171,12 @@ __device__ __forceinline__ float pmq_normalize (float y)
 }
 __device__ __forceinline__ void pmq_rescale (float *Brow)
 {   // exact power-of-two rescale so that max|entry| lies in [1,2)
+    // (oracle rescale16; max is exact in any order: the quad's rows are combined with two DPP steps)
     float mx = fmaxf (fmaxf (fabsf (Brow[0]), fabsf (Brow[1])), fmaxf (fabsf (Brow[2]), fabsf (Brow[3])));
-    mx = fmaxf (fmaxf (pmq_lane (mx, 0), pmq_lane (mx, 1)), fmaxf (pmq_lane (mx, 2), pmq_lane (mx, 3)));
-    uint32_t e = (__float_as_uint (mx) >> 23) & 0xFFu;
-    if (e == 0u || e >= 254u) return;
-    float sc = __uint_as_float ((254u - e) << 23);
+    mx = fmaxf (mx, icp_dpp<0xB1> (mx));             // quad_perm [1,0,3,2]
+    mx = fmaxf (mx, icp_dpp<0x4E> (mx));             // quad_perm [2,3,0,1]
+    const uint32_t e = (__float_as_uint (mx) >> 23) & 0xFFu;
+    const float sc = (e == 0u || e >= 254u) ? 1.f : __uint_as_float ((254u - e) << 23);    // zero / subnormal / inf / nan: leave
     Brow[0] = Brow[0] * sc; Brow[1] = Brow[1] * sc; Brow[2] = Brow[2] * sc; Brow[3] = Brow[3] * sc;
 }
 
@@ -216,7 +217,7 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
                 acc = __builtin_amdgcn_mfma_f32_4x4x1f32 (Brow[2], Brow[2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_4x4x1f32 (Brow[3], Brow[3], acc, 0, 0, 0);
                 Brow[0] = acc[0]; Brow[1] = acc[1]; Brow[2] = acc[2]; Brow[3] = acc[3];
-                if (s % 3 == 2) pmq_rescale (Brow);
+                if (s % 5 == 4) pmq_rescale (Brow);              // max|entry| < 2 after a rescale, < 2^94 five squarings later
             }
             PM_STAMP (1)
             const float u = pmq_matvec (Brow, 1.f);

@@ -563,7 +563,7 @@ static int power_literal (const float *S, const float *means, float *Tk)
 }
 
 /* The build's accelerated power method (the GPU twin is icp_power_method_quad, squared start).
- *   B = N^(2^PM_SQUARINGS) by repeated squaring (k-ordered fmaf chains, exact power-of-two rescaling every third
+ *   B = N^(2^PM_SQUARINGS) by repeated squaring (k-ordered fmaf chains, exact power-of-two rescaling every fifth
  *   squaring); u = B 1 (not normalised);  x = normalize (u) and xn = normalize (N u) (independent of each other);
  *   then the reference's loop on SQUARED step lengths: it goes on only while the step is above 2^-22 (one ulp of a
  *   unit vector) and still decreasing.  The sign test of :1024 divides only when it has to shift; the vector the
@@ -586,7 +586,7 @@ static int power_fast (const float *S, const float *means, float *Tk)
                     C[i * 4 + j] = acc;
                 }
             memcpy (B, C, sizeof B);
-            if (s % 3 == 2) rescale16 (B);          /* max|entry| < 2 after a rescale, < 2^22 three squarings later */
+            if (s % 5 == 4) rescale16 (B);          /* max|entry| < 2 after a rescale, < 2^94 five squarings later */
         }
         prod4 (B, ones, u);
         memcpy (x, u, sizeof x); normalize4 (x);

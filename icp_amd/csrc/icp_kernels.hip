@@ -646,6 +646,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     }
     if (!valid) { mg = make_float4 (0.f, 0.f, 0.f, 1.f); mc = mg; }
     const float4 *XQ4 = reinterpret_cast<const float4 *> (p.XQ + (size_t) b * m * 8);
+    const char *XQb = reinterpret_cast<const char *> (XQ4);
     // the first tile of representatives goes to LDS now: nothing in it depends on T, and in the chained variant the
     // writes and their barrier disappear behind the power method of wave 0
 #pragma unroll
@@ -791,8 +792,11 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     uint32_t rstar = ks_grp_min_u<KS_SPLIT> (best == dr ? bid : 0xFFFFFFFFu);     // ties -> lowest index
     if (rstar == 0xFFFFFFFFu) rstar = 0u;            // every distance inf / NaN: representative 0, as the serial scan would
     KS_STAMP (3)
+    // list offset / size of the winner.  One tile (always the case for the MINW == 2 variants, see icp_launch_search):
+    // from LDS; the compile-time split keeps the compiler from merging the two sources into flat loads.
     uint32_t o, n;
-    if (nr <= KS_TILE) { uint2 on = s_on[rstar]; o = on.x; n = on.y; }
+    if constexpr (MINW == 2) { const uint2 on = s_on[rstar]; o = on.x; n = on.y; }
+    else if (nr <= KS_TILE) { const uint2 on = s_on[rstar]; o = on.x; n = on.y; asm volatile ("" : "+v"(o), "+v"(n)); }
     else { o = gO[rstar]; n = gN[rstar]; }
 
     // ---- stage 2: exhaustive scan of that representative's list: the eight lanes of a query read eight consecutive
@@ -814,7 +818,8 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
                 // (the scan is bound by the L1's 64 B / clock: a trip no lane needs is not loaded either)
                 if (t && !__any (j0 + t * KS_SPLIT < je)) break;
                 const uint32_t j = min (j0 + t * KS_SPLIT, je - 1u);
-                g[t] = XQ4[2 * (size_t) j]; c[t] = XQ4[2 * (size_t) j + 1];
+                const char *rec = XQb + (j << 5);     // 32-bit byte offset from a uniform base (m <= 2^20: < 2^25 bytes)
+                g[t] = *reinterpret_cast<const float4 *> (rec); c[t] = *reinterpret_cast<const float4 *> (rec + 16);
             }
 #pragma unroll
             for (uint32_t t = 0; t < KS_DEPTH; ++t) {
@@ -1257,7 +1262,7 @@ void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask)
 // removes outweighs every block re-deriving T), 2 always (sizes the second tree level of the prologue can hold).
 bool icp_chain_supported (const icp_params &p)
 {
-    return p.fused && p.nb <= 4096u && (p.chain == 2 || (p.chain == 1 && !icp_dense (p)));
+    return p.fused && p.nb <= 4096u && p.nr <= 1024u && (p.chain == 2 || (p.chain == 1 && !icp_dense (p)));
 }
 
 void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations)

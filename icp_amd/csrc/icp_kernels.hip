@@ -846,16 +846,19 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
                 d = dr; id = p.rep_src[(size_t) b * nr + rstar]; nn = R4[2 * (size_t) rstar];
             } else {                 // the winner's point (jmin), or, when every distance is inf / NaN, the first list
                                      // element as the serial scan would: one reload instead of tracking it per candidate
-                const size_t jw = (jmin == 0xFFFFFFFFu) ? (size_t) o : (size_t) jmin;
-                const float4 wg = XQ4[2 * jw], wc = XQ4[2 * jw + 1];
+                const char *rec = XQb + (((jmin == 0xFFFFFFFFu) ? o : jmin) << 5);
+                const float4 wg = *reinterpret_cast<const float4 *> (rec), wc = *reinterpret_cast<const float4 *> (rec + 16);
                 nn = make_float4 (wg.x, wg.z, wc.x, 0.f); id = __float_as_uint (wc.z);
             }
             w = p.weighted ? 100.f / (100.f + d) : 1.f;                // icp_kernels.cl:232
+            // per-query outputs: uniform bases + 32-bit byte offsets (i < 2^20)
             icp_dist_id di; di.dist = d; di.id = id;
-            p.nn_id[(size_t) b * m + i] = di;
-            p.PF[(size_t) b * m + i] = make_float4 (nn.x, nn.y, nn.z, w);
-            p.PM[(size_t) b * m + i] = make_float4 (qx, qy, qz, d);
-            p.rid[(size_t) b * m + i] = rstar;
+            char *o_nn = reinterpret_cast<char *> (p.nn_id + (size_t) b * m), *o_pf = reinterpret_cast<char *> (p.PF + (size_t) b * m);
+            char *o_pm = reinterpret_cast<char *> (p.PM + (size_t) b * m), *o_rid = reinterpret_cast<char *> (p.rid + (size_t) b * m);
+            *reinterpret_cast<icp_dist_id *> (o_nn + (i << 3)) = di;
+            *reinterpret_cast<float4 *> (o_pf + (i << 4)) = make_float4 (nn.x, nn.y, nn.z, w);
+            *reinterpret_cast<float4 *> (o_pm + (i << 4)) = make_float4 (qx, qy, qz, d);
+            *reinterpret_cast<uint32_t *> (o_rid + (i << 2)) = rstar;
             s_nn_x = nn.x; s_nn_y = nn.y; s_nn_z = nn.z;
         }
         if constexpr (FUSED) {

@@ -418,9 +418,21 @@ int icp_build_rbc (icp_handle h)
 {
     int rc = need (h, false); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
-    icp_launch_build_rbc (h->p, h->stream);
-    icp_launch_reset_state (h->p, h->stream, 0);                     // ICP::buildRBC: k = 0 (:4796)
-    HIPCHK (h, hipGetLastError ());
+    // the seven launches of the construction as one cached graph (key: all ones; dropped with the others when a
+    // parameter or a buffer changes)
+    const uint64_t key = ~0ull;
+    auto it = h->graphs.find (key);
+    if (it == h->graphs.end ()) {
+        graph_entry ge;
+        HIPCHK (h, hipStreamBeginCapture (h->stream, hipStreamCaptureModeThreadLocal));
+        icp_launch_build_rbc (h->p, h->stream);
+        icp_launch_reset_state (h->p, h->stream, 0);                 // ICP::buildRBC: k = 0 (:4796)
+        hipError_t e = hipStreamEndCapture (h->stream, &ge.graph);
+        if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("hipStreamEndCapture: ") + hipGetErrorString (e));
+        HIPCHK (h, hipGraphInstantiate (&ge.exec, ge.graph, nullptr, nullptr, 0));
+        it = h->graphs.emplace (key, ge).first;
+    }
+    HIPCHK (h, hipGraphLaunch (it->second.exec, h->stream));
     h->built = true;
     return ICP_OK;
 }

@@ -192,30 +192,7 @@ __global__ void k_rep_boxes (icp_params p)
     GB[2 * t] = lo; GB[2 * t + 1] = hi;
 }
 
-// nearest representative over [r0, r1): strict '<' in ascending r keeps the lowest index on ties
-static __device__ __forceinline__ void nearest_rep_range (const float4 *__restrict__ R4, uint32_t r0, uint32_t r1,
-                                                          float qx, float qy, float qz, float qr, float qg, float qb,
-                                                          float a, float &best, uint32_t &bid)
-{
-    for (uint32_t r = r0; r < r1; ++r) {
-        float4 g = R4[2 * r], c = R4[2 * r + 1];
-        float d = icp_metric8 (qx, qy, qz, qr, qg, qb, g.x, g.y, g.z, c.x, c.y, c.z, a);
-        if (d < best) { best = d; bid = r; }
-    }
-}
-
-// RBC construct, step 1: owner(x) = argmin_r d(x, R[r])
-__global__ __launch_bounds__ (256) void k_owner (icp_params p)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (i >= p.m) return;
-    const float4 *F4 = reinterpret_cast<const float4 *> (p.F + (size_t) b * p.m * 8);
-    const float4 *R4 = reinterpret_cast<const float4 *> (p.R + (size_t) b * p.nr * 8);
-    float4 g = F4[2 * (size_t) i], c = F4[2 * (size_t) i + 1];
-    float best = __builtin_inff (); uint32_t bid = 0;
-    nearest_rep_range (R4, 0, p.nr, g.x, g.y, g.z, c.x, c.y, c.z, p.a, best, bid);
-    p.owner[(size_t) b * p.m + i] = bid;
-}
+// RBC construct, step 1 (owner(x) = argmin_r d(x, R[r]), ties -> lowest r) is k_search<.., OWNER = true> below.
 
 // step 2: per-chunk histograms of the owners (integer LDS atomics: deterministic)
 __global__ __launch_bounds__ (256) void k_chunk_hist (icp_params p)
@@ -247,61 +224,55 @@ __global__ void k_count (icp_params p)
     p.N[(size_t) b * p.nr + r] = run;
 }
 
-// step 4: O = exclusive scan of N (exclusiveScan_i semantics, kernels/scan_kernels.cl:188). One block.
+// step 4: O = exclusive scan of N (exclusiveScan_i semantics, kernels/scan_kernels.cl:188). One block of 1024 threads:
+// per-thread runs, wave scans (shuffles), a scan of the 16 wave totals.
 __global__ __launch_bounds__ (1024) void k_offsets (icp_params p)
 {
-    __shared__ uint32_t s_sum[1024];
-    uint32_t b = blockIdx.y, t = threadIdx.x;
+    __shared__ uint32_t s_wave[16];
+    const uint32_t b = blockIdx.y, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t *N = p.N + (size_t) b * p.nr;
     uint32_t *O = p.O + (size_t) b * p.nr;
-    uint32_t per = (p.nr + 1023u) / 1024u, lo = t * per, hi = min (lo + per, p.nr);
-    uint32_t s = 0;
-    for (uint32_t r = lo; r < hi; ++r) s += N[r];
-    s_sum[t] = s;
+    const uint32_t per = (p.nr + 1023u) / 1024u, lo = t * per, hi = min (lo + per, p.nr);
+    uint32_t part = 0;
+    for (uint32_t r = lo; r < hi; ++r) part += N[r];
+    uint32_t inc = part;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t v = __shfl_up (inc, d); if (lane >= d) inc += v; }
+    if (lane == 63u) s_wave[wave] = inc;
     __syncthreads ();
-    if (t == 0) {
-        uint32_t run = 0;
-        for (uint32_t k = 0; k < 1024; ++k) { uint32_t v = s_sum[k]; s_sum[k] = run; run += v; }
-    }
-    __syncthreads ();
-    uint32_t run = s_sum[t];
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
+    uint32_t run = base + inc - part;
     for (uint32_t r = lo; r < hi; ++r) { O[r] = run; run += N[r]; }
 }
 
-// step 5: stable placement: position = O[owner] + #{j < i : owner[j] == owner[i]}; perm and X_P.
-// One block per chunk; its 16 waves take turns in index order so that ranks follow the index.
+// step 5: stable placement: position = O[owner] + #{j < i : owner[j] == owner[i]}; perm, X_P and the search copy.
+// One block per chunk of 1024 points; the rank inside the chunk is a plain count over the chunk's owners in LDS
+// (broadcast reads; every wave works at once), the rank base of the chunk comes from step 3.
 __global__ __launch_bounds__ (1024) void k_place (icp_params p)
 {
-    extern __shared__ __attribute__ ((aligned (16))) uint32_t s_base[];
-    uint32_t chunk = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t *O = p.O + (size_t) b * p.nr;
-    const uint32_t *H = p.chunk_hist + ((size_t) b * p.nchunk + chunk) * p.nr;
-    for (uint32_t r = t; r < p.nr; r += blockDim.x) s_base[r] = O[r] + H[r];
-    uint32_t i = chunk * ICP_CHUNK + t;
-    bool valid = i < p.m;
-    uint32_t own = valid ? p.owner[(size_t) b * p.m + i] : 0xFFFFFFFFu;
-    uint32_t pos = 0;
-    for (uint32_t w = 0; w < ICP_CHUNK / 64u; ++w) {
-        __syncthreads ();
-        if (wave == w) {
-            bool active = valid;
-            unsigned long long todo = __ballot (active);
-            while (todo) {
-                int leader = __ffsll ((long long) todo) - 1;
-                uint32_t oo = __shfl (own, leader);
-                unsigned long long same = __ballot (active && own == oo);
-                if (active && own == oo) {
-                    unsigned long long below = same & ((1ull << lane) - 1ull);
-                    pos = s_base[oo] + (uint32_t) __popcll (below);
-                    active = false;
-                }
-                __builtin_amdgcn_wave_barrier ();
-                if ((int) lane == leader) s_base[oo] += (uint32_t) __popcll (same);
-                todo &= ~same;
-            }
-        }
+    __shared__ uint4 s_own4[ICP_CHUNK / 4];
+    uint32_t *s_own = reinterpret_cast<uint32_t *> (s_own4);
+    const uint32_t chunk = blockIdx.x, b = blockIdx.y, t = threadIdx.x, wave = t >> 6;
+    const uint32_t i = chunk * ICP_CHUNK + t;
+    const bool valid = i < p.m;
+    const uint32_t own = valid ? p.owner[(size_t) b * p.m + i] : 0xFFFFFFFFu;
+    uint32_t base = 0;
+    if (valid) base = p.O[(size_t) b * p.nr + own] + p.chunk_hist[((size_t) b * p.nchunk + chunk) * p.nr + own];
+    s_own[t] = own;
+    __syncthreads ();
+    uint32_t rank = 0;
+    for (uint32_t j4 = 0; j4 < wave * 16u; ++j4) {                     // earlier waves: every element precedes t
+        const uint4 v = s_own4[j4];
+        rank += (v.x == own) + (v.y == own) + (v.z == own) + (v.w == own);
+    }
+    for (uint32_t j4 = wave * 16u; j4 < wave * 16u + 16u; ++j4) {      // own wave: elements below t
+        const uint4 v = s_own4[j4];
+        const uint32_t j = 4u * j4;
+        rank += (v.x == own && j < t) + (v.y == own && j + 1u < t) + (v.z == own && j + 2u < t) + (v.w == own && j + 3u < t);
     }
     if (valid) {
+        const uint32_t pos = base + rank;
         const float4 *F4 = reinterpret_cast<const float4 *> (p.F + (size_t) b * p.m * 8);
         float4 *X4 = reinterpret_cast<float4 *> (p.XP + (size_t) b * p.m * 8);
         p.perm[(size_t) b * p.m + pos] = i;
@@ -556,7 +527,10 @@ static __device__ __forceinline__ void fin_result_to_state (const icp_fin_result
 // nothing to hide latency behind, no spills) or 4 (two blocks per CU: batched registrations, +70 % throughput).
 // LPQ = lanes per query = waves per block: 16 when the grid is at most one block per CU (more waves per SIMD to
 // overlap the L2-cold loads), 8 when occupancy comes from the number of blocks.
-template <bool FUSED, bool CHAIN, int MINW, int LPQ>
+// OWNER: the kernel is RBC construct step 1 instead (owner(x) = nearest representative of the FIXED point x: gM = F,
+// no transform, stage 1 only, result to p.owner) — the same stage-1 code, pruning included, seeded with the
+// representative of the point's own grid cell.
+template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER = false>
 __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, const float *gR, icp_reg_state *gst, const double *gmom,
                                                               uint32_t m, uint32_t nr, uint32_t side, uint32_t tpr_magic,
                                                               uint32_t nb, uint32_t check, icp_params p)
@@ -601,7 +575,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     // every independent global load of the prologue is issued before anything waits: the state (one vector load,
     // lane j = dword j: scalar loads of T would queue behind the waits of the vector loads), the first tile of
     // representatives (+ list offsets / sizes), the query point (clamped address, selected afterwards)
-    const uint32_t sv = state_load_lanes (st);
+    const uint32_t sv = OWNER ? 0u : state_load_lanes (st);
     float *s_pairf = reinterpret_cast<float *> (s_pair);
     const uint32_t tn0 = min (KS_TILE, nr);
     float4 rg[2], rc[2]; uint2 ron[2];
@@ -619,7 +593,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     for (int u = 0; u < 2; ++u) {
         uint32_t k = tid + (uint32_t) u * 64u * KS_SPLIT;
         ron[u] = make_uint2 (0u, 0u);
-        if (k < tn0) ron[u] = make_uint2 (gO[k], gN[k]);
+        if (!OWNER && k < tn0) ron[u] = make_uint2 (gO[k], gN[k]);
     }
     // seed of the stage-1 pruning bound: this query's nearest representative of the previous search (any index < nr
     // is a valid seed; the buffer starts zeroed)
@@ -628,7 +602,13 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     // the branch-free loop (compile-time: the pruning code costs 0.25 us there even when it is switched off).
     constexpr bool PRUNE = ICP_S1_SEED && MINW == 4;
     const bool prune = PRUNE && p.a > 0.f;
-    uint32_t seed = prune ? p.rid[(size_t) b * m + ic] : 0u;
+    uint32_t seed = 0u;
+    if constexpr (OWNER) {
+        if (prune && side && side * side == m && p.nrx && p.nry) {     // the representative sampled from the point's own cell
+            const uint32_t y = ic / side, x = ic - y * side;
+            seed = (y / (side / p.nry)) * p.nrx + x / (side / p.nrx);
+        }
+    } else if (prune) seed = p.rid[(size_t) b * m + ic];
     // (lo, hi) boxes of the groups of 2 * LPQ representatives: the 16-boxes (LPQ = 8) or the 32-boxes behind them
     const float4 *GBt = p.GB + (size_t) b * 2 * (p.n16 + p.n32) + (KS_SPLIT == 8 ? 0u : 2u * p.n16);
     const uint32_t nbox0 = 2u * ((tn0 + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
@@ -638,7 +618,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
 #pragma unroll
     for (int k = 0; k < 8; ++k) T[k] = state_lane_f (sv, ICP_ST_DW (T) + k);
     icp_reg_state *sout = CHAIN ? p.cst + (size_t) b * 2 + (p.slot ^ 1u) : st;
-    if (check && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))) {    // converged earlier
+    if (!OWNER && check && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))) {    // converged earlier
         if constexpr (CHAIN) {                       // carry the state forward
             if (blockIdx.x == 0 && tid < sizeof (icp_reg_state) / 4) reinterpret_cast<uint32_t *> (sout)[tid] = sv;
         }
@@ -655,7 +635,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
         if (k < tn0) {
             float *dst = s_pairf + (k >> 1) * 12u + (k & 1u);
             dst[0] = rg[u].x; dst[2] = rg[u].y; dst[4] = rg[u].z; dst[6] = rc[u].x; dst[8] = rc[u].y; dst[10] = rc[u].z;
-            s_on[k] = ron[u];
+            if constexpr (!OWNER) s_on[k] = ron[u];
         }
     }
     if (prune && tid < nbox0) s_box[tid] = boxv;
@@ -672,8 +652,8 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
             reinterpret_cast<uint32_t *> (sout)[tid] = (tid == offsetof (icp_reg_state, pending) / 4) ? 1u : sv;
         }
     }
-    float qx, qy, qz;
-    icp_transform_point (T, mg.x, mg.y, mg.z, qx, qy, qz);
+    float qx = mg.x, qy = mg.y, qz = mg.z;
+    if constexpr (!OWNER) icp_transform_point (T, mg.x, mg.y, mg.z, qx, qy, qz);
     const float qr = mc.x, qg = mc.y, qb = mc.z;
     const float alpha = p.a;
     KS_STAMP (0)
@@ -693,7 +673,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
                 float4 g = R4[2 * (size_t) (t0 + k)], c = R4[2 * (size_t) (t0 + k) + 1];
                 float *dst = s_pairf + (k >> 1) * 12u + (k & 1u);
                 dst[0] = g.x; dst[2] = g.y; dst[4] = g.z; dst[6] = c.x; dst[8] = c.y; dst[10] = c.z;
-                s_on[k] = make_uint2 (gO[t0 + k], gN[t0 + k]);
+                if constexpr (!OWNER) s_on[k] = make_uint2 (gO[t0 + k], gN[t0 + k]);
             }
             if (prune) {
                 const uint32_t nbx = 2u * ((tn + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
@@ -791,6 +771,10 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     const float dr = ks_grp_min_f<KS_SPLIT> (best);           // the query's nearest representative: smallest distance,
     uint32_t rstar = ks_grp_min_u<KS_SPLIT> (best == dr ? bid : 0xFFFFFFFFu);     // ties -> lowest index
     if (rstar == 0xFFFFFFFFu) rstar = 0u;            // every distance inf / NaN: representative 0, as the serial scan would
+    if constexpr (OWNER) {
+        if (ss == 0u && valid) p.owner[(size_t) b * m + i] = rstar;
+        return;
+    }
     KS_STAMP (3)
     // list offset / size of the winner.  One tile (always the case for the MINW == 2 variants, see icp_launch_search):
     // from LDS; the compile-time split keeps the compiler from merging the two sources into flat loads.
@@ -1198,20 +1182,22 @@ void icp_launch_transform_cloud (const float *in, float *out, const icp_reg_stat
                         reinterpret_cast<const float4 *> (in), reinterpret_cast<float4 *> (out), st, n);
 }
 
+static inline bool icp_dense (const icp_params &p)
+{   // more blocks than one per CU: trade registers for occupancy; many representatives: stage 1 is throughput-bound
+    return (size_t) p.batch * p.nb > 512u || p.nr >= ICP_S1_REJECT_MIN_NR;
+}
+
 void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 {
     hipLaunchKernelGGL (k_get_reps, dim3 ((p.nr + 63) / 64, p.batch), dim3 (64), 0, s, p);
     hipLaunchKernelGGL (k_rep_boxes, dim3 ((p.n16 + p.n32 + 63) / 64, p.batch), dim3 (64), 0, s, p);
-    hipLaunchKernelGGL (k_owner, dim3 ((p.m + 255) / 256, p.batch), dim3 (256), 0, s, p);
+    // step 1, owner(x) = nearest representative: the search kernel's stage 1 over the fixed points
+    if (icp_dense (p)) hipLaunchKernelGGL ((k_search<true, false, 4, 8, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
+    else hipLaunchKernelGGL ((k_search<true, false, 2, 16, true>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
     hipLaunchKernelGGL (k_chunk_hist, dim3 (p.nchunk, p.batch), dim3 (256), p.nr * sizeof (uint32_t), s, p);
     hipLaunchKernelGGL (k_count, dim3 ((p.nr + 63) / 64, p.batch), dim3 (64), 0, s, p);
     hipLaunchKernelGGL (k_offsets, dim3 (1, p.batch), dim3 (1024), 0, s, p);
-    hipLaunchKernelGGL (k_place, dim3 (p.nchunk, p.batch), dim3 (1024), p.nr * sizeof (uint32_t), s, p);
-}
-
-static inline bool icp_dense (const icp_params &p)
-{   // more blocks than one per CU: trade registers for occupancy; many representatives: stage 1 is throughput-bound
-    return (size_t) p.batch * p.nb > 512u || p.nr >= ICP_S1_REJECT_MIN_NR;
+    hipLaunchKernelGGL (k_place, dim3 (p.nchunk, p.batch), dim3 (1024), 0, s, p);
 }
 
 void icp_launch_search (const icp_params &p, hipStream_t s)

@@ -145,6 +145,30 @@ def main():
 
     total_t, total_iters = aggregate(dist, elapsed, args.steps * ITERS_PER_STEP * args.batch)
 
+    # beside the metric (never part of `value`): latency of one whole registration = RBC construction + 40 iterations,
+    # inputs resident, and the same with the two clouds uploaded from host memory first
+    e2e = None
+    if rank == 0 and args.batch == 1:
+        reps = 20
+        g.buildRBC(); g.sync()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            g.buildRBC(); g.reset_transform(); g.run_fixed(ITERS_PER_STEP)
+        g.sync()
+        resident_ms = (time.perf_counter() - t1) / reps * 1e3
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            g.write(icp_amd.Memory.F, F); g.write(icp_amd.Memory.M, M)
+            g.buildRBC(); g.reset_transform(); g.run_fixed(ITERS_PER_STEP)
+        g.sync()
+        upload_ms = (time.perf_counter() - t1) / reps * 1e3
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            g.buildRBC()
+        g.sync()
+        e2e = {"build_rbc_ms": (time.perf_counter() - t1) / reps * 1e3, "build_plus_%d_iterations_ms" % ITERS_PER_STEP: resident_ms,
+               "with_upload_of_F_and_M_ms": upload_ms}
+
     # dominant kernel (k_search): average launch-to-launch time, HIP events on the engine's stream (rocprofv3's
     # per-dispatch average for the same kernel: profiles/r01_final_*_kernel_stats.csv).  Chained form: the timed
     # region itself is `steps` graphs of ITERS_PER_STEP k_search launches (+ one begin / end kernel per graph);
@@ -200,6 +224,8 @@ def main():
                                             "peak_tflops_fp32_vector": 157.3, "frac": tflops / 157.3},
                          "note": "cache-resident at this size (1.19 MB/iteration): latency/VALU-bound, see DESIGN.md §5"},
         }
+        if e2e is not None:
+            line["registration_latency"] = e2e
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(F, M, fused)
         print(json.dumps(line))

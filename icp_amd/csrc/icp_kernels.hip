@@ -481,10 +481,6 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
 #ifdef ICP_DBG_STAMPS
         if (lane < 8 && p.dbg && p.rot == 1) p.dbg[16 + lane] = icp_pm_stamps[lane];
 #endif
-#ifdef ICP_DBG_PM_TWICE
-        if (p.rot == 1) iters = icp_power_method_quad (S, means, Tk, p.power_mode, lane);
-        FF_STAMP (15)
-#endif
         float Tprev[8], Rprev[9];
 #pragma unroll
         for (int k = 0; k < 8; ++k) Tprev[k] = state_lane_f (sv, ICP_ST_DW (T) + k);
@@ -660,12 +656,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
 
     // ---- stage 1: nearest representative, two representatives per packed instruction ----
     float best = __builtin_inff (), s1_lim = __builtin_inff (); uint32_t bid = 0xFFFFFFFFu;
-#ifdef ICP_DBG_SKIP_S1
-    best = 0.f; bid = (i * 7u) % nr;
-    for (uint32_t t0 = nr; t0 < nr; t0 += KS_TILE) {
-#else
     for (uint32_t t0 = 0; t0 < nr; t0 += KS_TILE) {
-#endif
         const uint32_t tn = min (KS_TILE, nr - t0);
         if (t0) {                                    // further tiles (nr > KS_TILE)
             __syncthreads ();
@@ -783,12 +774,11 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     else if (nr <= KS_TILE) { const uint2 on = s_on[rstar]; o = on.x; n = on.y; asm volatile ("" : "+v"(o), "+v"(n)); }
     else { o = gO[rstar]; n = gN[rstar]; }
 
-    // ---- stage 2: exhaustive scan of that representative's list: the eight lanes of a query read eight consecutive
-    // candidates (256 contiguous bytes) per load.  (Staging the block's lists through LDS first was measured and is
+    // ---- stage 2: exhaustive scan of that representative's list: the LPQ lanes of a query read LPQ consecutive
+    // candidates (32 contiguous bytes each) per load.  (Staging the block's lists through LDS first was measured and is
     // slower: enumerating the distinct lists and the extra barrier cost more than the direct gathers.)
     float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
     const float2v vq_xr = { qx, qr }, vq_yg = { qy, qg }, vq_zb = { qz, qb };
-#ifndef ICP_DBG_SKIP_S2
     if (valid) {
         // a batch = KS_DEPTH candidates per lane, all loads issued before the first distance (clamped addresses, the
         // tail is masked): one memory round trip per batch, and one batch covers a list of KS_DEPTH * LPQ candidates;
@@ -799,7 +789,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
             float4 g[KS_DEPTH], c[KS_DEPTH];
 #pragma unroll
             for (uint32_t t = 0; t < KS_DEPTH; ++t) {
-                // (the scan is bound by the L1's 64 B / clock: a trip no lane needs is not loaded either)
+                // (the scan is bound by the vector-memory issue rate: a trip no lane needs is not loaded either)
                 if (t && !__any (j0 + t * KS_SPLIT < je)) break;
                 const uint32_t j = min (j0 + t * KS_SPLIT, je - 1u);
                 const char *rec = XQb + (j << 5);     // 32-bit byte offset from a uniform base (m <= 2^20: < 2^25 bytes)
@@ -813,7 +803,6 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
             }
         }
     }
-#endif
     KS_STAMP (4)
     // the query's winner among its eight lanes: smallest distance, ties -> lowest list position; that lane finishes
     // the query (lane ss == 0 when the list is empty or no candidate has a finite distance)
@@ -922,26 +911,28 @@ __global__ __launch_bounds__ (1024) void k_gmean (icp_params p)
 // K2  means: icpMean(_Weighted) — kernels/icp_kernels.cl:371-411, 455-495.
 //     One 16-lane row per 128-pair work-group (8 pairs per lane), 4 work-groups per wave.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__ (64) void k_means (icp_params p)
+// (leading scalars: preloaded with the dispatch, see k_search)
+__global__ __launch_bounds__ (64) void k_means (const float4 *gPF, const float4 *gPM, const float *gwpart, icp_reg_state *gst,
+                                                uint32_t m, uint32_t nwp, uint32_t weighted, uint32_t check, icp_params p)
 {
     const uint32_t b = blockIdx.y, lane = threadIdx.x, l = lane & 15u;
     const uint32_t g = blockIdx.x * 4u + (lane >> 4);
-    icp_reg_state *st = p.st + b;
-    if (p.check && st->done) return;
+    icp_reg_state *st = gst + b;
+    if (check && st->done) return;
 
-    const float4 *PF = p.PF + (size_t) b * p.m, *PM = p.PM + (size_t) b * p.m;
+    const float4 *PF = gPF + (size_t) b * m, *PM = gPM + (size_t) b * m;
     float4 pf[8], pm[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         uint32_t e = g * 128u + l + 16u * k;
-        bool ok = (e & ~1u) < p.m;                   // the pair's flag guards both points (icp_kernels.cl:390-392)
+        bool ok = (e & ~1u) < m;                   // the pair's flag guards both points (icp_kernels.cl:390-392)
         pf[k] = make_float4 (0.f, 0.f, 0.f, 0.f); pm[k] = pf[k];
         if (ok) { pf[k] = PF[e]; pm[k] = PM[e]; }
     }
     double sum_w = 1.0;
-    if (p.weighted) {
-        if (p.nwp <= 512) {
-            double sw = sum_w_row (p.wpart + (size_t) b * 2 * p.nwp, p.nwp, l);
+    if (weighted) {
+        if (nwp <= 512) {
+            double sw = sum_w_row (gwpart + (size_t) b * 2 * nwp, nwp, l);
             unsigned long long u = __builtin_bit_cast (unsigned long long, sw);
             uint32_t lo = __builtin_amdgcn_readfirstlane ((uint32_t) u), hi = __builtin_amdgcn_readfirstlane ((uint32_t) (u >> 32));
             sum_w = __builtin_bit_cast (double, ((unsigned long long) hi << 32) | lo);
@@ -949,12 +940,12 @@ __global__ __launch_bounds__ (64) void k_means (icp_params p)
         } else sum_w = st->sum_w;                    // written by k_sum_w
     }
     float fx[8], fy[8], fz[8], qx[8], qy[8], qz[8];
-    const float nf = (float) p.m;
+    const float nf = (float) m;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         uint32_t e = g * 128u + l + 16u * k;
-        bool ok = (e & ~1u) < p.m;
-        if (p.weighted) {
+        bool ok = (e & ~1u) < m;
+        if (weighted) {
             float kk = (float) ((double) pf[k].w / sum_w);               // icp_kernels.cl:475
             fx[k] = ok ? kk * pf[k].x : 0.f; fy[k] = ok ? kk * pf[k].y : 0.f; fz[k] = ok ? kk * pf[k].z : 0.f;
             qx[k] = ok ? kk * pm[k].x : 0.f; qy[k] = ok ? kk * pm[k].y : 0.f; qz[k] = ok ? kk * pm[k].z : 0.f;
@@ -979,28 +970,29 @@ __global__ __launch_bounds__ (64) void k_means (icp_params p)
 //     16 positions = r (mod 8) of a work-group (64 columns, one per lane, 4 strided points each) and
 //     runs the tree levels d = 64, 32, 16, 8, which stay inside that class.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__ (64) void k_sij (icp_params p)
+__global__ __launch_bounds__ (64) void k_sij (const float4 *gPF, const float4 *gPM, const float4 *gmpart, icp_reg_state *gst,
+                                              uint32_t m, uint32_t G, uint32_t nwg, uint32_t check, icp_params p)
 {
     const uint32_t b = blockIdx.y, lane = threadIdx.x, l = lane & 15u, row = lane >> 4;
-    icp_reg_state *st = p.st + b;
-    if (p.check && st->done) return;
+    icp_reg_state *st = gst + b;
+    if (check && st->done) return;
 
     __shared__ __attribute__ ((aligned (16))) float s_col[11][64];
 
     const uint32_t wg = blockIdx.x >> 3, res = blockIdx.x & 7u;
     const uint32_t col = wg * 512u + 4u * (res + 8u * (lane >> 2)) + (lane & 3u);
-    const float4 *PF = p.PF + (size_t) b * p.m, *PM = p.PM + (size_t) b * p.m;
+    const float4 *PF = gPF + (size_t) b * m, *PM = gPM + (size_t) b * m;
     float4 pf[4], pm[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {                                        // icp_kernels.cl:718: pi = gX + k gXdim
-        uint32_t pi = col + (uint32_t) k * p.G;
+        uint32_t pi = col + (uint32_t) k * G;
         pf[k] = make_float4 (0.f, 0.f, 0.f, 0.f); pm[k] = pf[k];
-        if (col < p.G && pi < p.m) { pf[k] = PF[pi]; pm[k] = PM[pi]; }
+        if (col < G && pi < m) { pf[k] = PF[pi]; pm[k] = PM[pi]; }
     }
     float4 mf, mm;
-    if (p.nwg <= 128) {                              // icpGMean in the prologue
-        float4 r0 = gmean_row (p.mpart + ((size_t) b * 2 + 0) * p.nwg, p.nwg, l);
-        float4 r1 = gmean_row (p.mpart + ((size_t) b * 2 + 1) * p.nwg, p.nwg, l);
+    if (nwg <= 128) {                              // icpGMean in the prologue
+        float4 r0 = gmean_row (gmpart + ((size_t) b * 2 + 0) * nwg, nwg, l);
+        float4 r1 = gmean_row (gmpart + ((size_t) b * 2 + 1) * nwg, nwg, l);
         mf.x = __builtin_bit_cast (float, __builtin_amdgcn_readfirstlane (__builtin_bit_cast (uint32_t, r0.x)));
         mf.y = __builtin_bit_cast (float, __builtin_amdgcn_readfirstlane (__builtin_bit_cast (uint32_t, r0.y)));
         mf.z = __builtin_bit_cast (float, __builtin_amdgcn_readfirstlane (__builtin_bit_cast (uint32_t, r0.z)));
@@ -1022,8 +1014,8 @@ __global__ __launch_bounds__ (64) void k_sij (icp_params p)
     for (int k = 0; k < 11; ++k) A[k] = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        uint32_t pi = col + (uint32_t) k * p.G;
-        if (col < p.G && pi < p.m) {
+        uint32_t pi = col + (uint32_t) k * G;
+        if (col < G && pi < m) {
             float Mp[3] = { c * (pm[k].x - mm.x), c * (pm[k].y - mm.y), c * (pm[k].z - mm.z) };
             float Fp[3] = { c * (pf[k].x - mf.x), c * (pf[k].y - mf.y), c * (pf[k].z - mf.z) };
             float ff = (Fp[0] * Fp[0] + Fp[1] * Fp[1]) + Fp[2] * Fp[2];
@@ -1063,16 +1055,16 @@ __global__ __launch_bounds__ (64) void k_sij (icp_params p)
 //     One block of 3 waves per registration: 11 rows reduce the 11 rows of S, then wave 0 runs the
 //     lane-parallel power method and lane 0 composes.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__ (192) void k_finalize (icp_params p)
+__global__ __launch_bounds__ (192) void k_finalize (const float *gspart, icp_reg_state *gst, uint32_t nsp, uint32_t check, icp_params p)
 {
     const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, l = tid & 15u, row = tid >> 4;
-    icp_reg_state *st = p.st + b;
-    if (p.check && st->done) return;
+    icp_reg_state *st = gst + b;
+    if (check && st->done) return;
 
     __shared__ float s_S[12];
     {
         const uint32_t a = min (row, 10u);
-        float v = s_reduce_row (p.spart + ((size_t) b * 11 + a) * p.nsp * 8u, p.nsp, l);
+        float v = s_reduce_row (gspart + ((size_t) b * 11 + a) * nsp * 8u, nsp, l);
         if (l == 0 && row < 11) s_S[row] = v;
     }
     __syncthreads ();
@@ -1217,19 +1209,21 @@ void icp_launch_search (const icp_params &p, hipStream_t s)
 void icp_launch_means (const icp_params &p, hipStream_t s)
 {
     if (p.weighted && p.nwp > 512) hipLaunchKernelGGL (k_sum_w, dim3 (1, p.batch), dim3 (64), 0, s, p);
-    hipLaunchKernelGGL (k_means, dim3 ((p.nwg + 3) / 4, p.batch), dim3 (64), 0, s, p);
+    hipLaunchKernelGGL (k_means, dim3 ((p.nwg + 3) / 4, p.batch), dim3 (64), 0, s, (const float4 *) p.PF, (const float4 *) p.PM, (const float *) p.wpart, p.st,
+                        p.m, p.nwp, (uint32_t) p.weighted, (uint32_t) p.check, p);
 }
 
 void icp_launch_sij (const icp_params &p, hipStream_t s)
 {
     if (p.nwg > 128) hipLaunchKernelGGL (k_gmean, dim3 (1, p.batch), dim3 (1024), 0, s, p);
-    hipLaunchKernelGGL (k_sij, dim3 (((p.G + 511) / 512) * 8, p.batch), dim3 (64), 0, s, p);
+    hipLaunchKernelGGL (k_sij, dim3 (((p.G + 511) / 512) * 8, p.batch), dim3 (64), 0, s, (const float4 *) p.PF, (const float4 *) p.PM, (const float4 *) p.mpart, p.st,
+                        p.m, p.G, p.nwg, (uint32_t) p.check, p);
 }
 
 void icp_launch_finalize (const icp_params &p, hipStream_t s)
 {
     if (p.fused) hipLaunchKernelGGL (k_finalize_fused, dim3 (p.batch), dim3 (1024), 0, s, (const double *) p.mom, p.st, p.nb, (uint32_t) p.check, p);
-    else hipLaunchKernelGGL (k_finalize, dim3 (p.batch), dim3 (192), 0, s, p);
+    else hipLaunchKernelGGL (k_finalize, dim3 (p.batch), dim3 (192), 0, s, (const float *) p.spart, p.st, p.nsp, (uint32_t) p.check, p);
 }
 
 __global__ void k_nop (icp_params p) { if (p.m == 0xFFFFFFFFu) p.st->k = 0; }

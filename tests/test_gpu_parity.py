@@ -228,6 +228,9 @@ def test_stage1_pruning_exact(engine, oracle, side, nr, zero_fraction, steps):
     g, o, F, M = make(engine, oracle, side, nr, zero_fraction=zero_fraction)
     g.buildRBC()
     o.build_rbc()
+    check_rbc(engine, g, o)                          # the owner search of the construction is the same pruned stage 1
+    g.buildRBC()                                     # (cached graph: a second construction gives the same structure)
+    check_rbc(engine, g, o)
     for _ in range(steps):
         g.step()
         o.step()

@@ -529,14 +529,16 @@ static __device__ __forceinline__ void fin_result_to_state (const icp_fin_result
 template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER = false>
 __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, const float *gR, icp_reg_state *gst, const double *gmom,
                                                               uint32_t m, uint32_t nr, uint32_t side, uint32_t tpr_magic,
-                                                              uint32_t nb, uint32_t check, icp_params p)
+                                                              uint32_t nb, uint32_t check_flags, icp_params p)
 {
     // The first 14 dwords of the kernel arguments (everything the prologue's addresses need) are plain scalars so
     // that they arrive preloaded in SGPRs / in one scalar load; the rest of icp_params is fetched while the first
     // global loads are in flight.  gst = the state this launch reads (CHAIN: slot p.slot of every pair of slots),
     // gmom = the moments it turns into T first (CHAIN only: buffer p.slot).
-    const uint32_t b = blockIdx.y;
-    icp_reg_state *st = CHAIN ? gst + (size_t) b * 2 : gst + b;
+    // check_flags: bit 0 = convergence checks on; bit 1 (CHAIN) = first launch of a chain: gst is the user-visible
+    // state array (stride 1) instead of a pair of slots.
+    const uint32_t b = blockIdx.y, check = check_flags & 1u;
+    icp_reg_state *st = (CHAIN && !(check_flags & 2u)) ? gst + (size_t) b * 2 : gst + b;
 #ifdef ICP_DBG_STAMPS
     { const uint32_t tid = threadIdx.x; unsigned long long t_; asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
       if (tid == 0 && p.dbg) p.dbg[(size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 16 + 8] = t_; }
@@ -1112,18 +1114,8 @@ __global__ __launch_bounds__ (1024) void k_finalize_fused (const double *gmom, i
     fin_result_to_state (&s_fin, st, 0u);
 }
 
-// chain begin: user-visible state -> slot 0; chain end: finalize the last iteration's moments (slot given by
-// p.slot) into the user-visible state.
-__global__ void k_chain_begin (icp_params p)
-{
-    const uint32_t b = blockIdx.x, t = threadIdx.x;
-    if (t < sizeof (icp_reg_state) / 4) {
-        uint32_t v = reinterpret_cast<const uint32_t *> (p.st + b)[t];
-        if (t == offsetof (icp_reg_state, pending) / 4) v = 0u;
-        reinterpret_cast<uint32_t *> (p.cst + (size_t) b * 2)[t] = v;
-    }
-}
-
+// chain end: finalize the last iteration's moments (slot given by p.slot) into the user-visible state.  (There is no
+// begin kernel: the first launch of a chain reads the user-visible state itself.)
 __global__ __launch_bounds__ (320) void k_chain_end (icp_params p)
 {
     const uint32_t b = blockIdx.x;
@@ -1251,10 +1243,13 @@ bool icp_chain_supported (const icp_params &p)
 void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations)
 {
     icp_params p = p0;
-    hipLaunchKernelGGL (k_chain_begin, dim3 (p.batch), dim3 (64), 0, s, p);
+    if (iterations == 0) return;
     for (uint32_t j = 0; j < iterations; ++j) {
         p.slot = j & 1u;
-        hipLaunchKernelGGL ((k_search<true, true, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
+        // the first launch reads the user-visible state directly (pending == 0 there: nothing to finalize yet)
+        if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, (const double *) p.mom,
+                                        p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, (uint32_t) p.check | 2u, p);
+        else hipLaunchKernelGGL ((k_search<true, true, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
     }
     p.slot = iterations & 1u;
     hipLaunchKernelGGL (k_chain_end, dim3 (p.batch), dim3 (320), 0, s, p);

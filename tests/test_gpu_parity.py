@@ -506,3 +506,67 @@ def test_tiny_and_odd_shapes(engine, oracle, side, nr, fused):
         o.step()
         check_step(engine, g, o, weighted=not fused)
     g.close()
+
+
+def _random_cases(n, seed=20261003):
+    rng = np.random.default_rng(seed)
+    cases = []
+    sides = [8, 12, 16, 24, 32, 40, 48, 64, 96, 128]
+    while len(cases) < n:
+        side = int(rng.choice(sides))
+        nr = int(2 ** rng.integers(0, 11))
+        p = nr.bit_length() - 1
+        nrx, nry = 1 << (p - p // 2), 1 << (p // 2)
+        if nr > side * side or side % nrx or side % nry:
+            continue
+        batch = int(rng.choice([1, 1, 1, 2, 5, 9])) if side <= 64 else 1
+        cases.append((side, nr, batch, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.integers(0, 2)),
+                      int(rng.integers(0, 2)), float(rng.choice([0.0, 0.0, 0.05, 0.3])), int(rng.integers(1, 5)),
+                      int(rng.integers(1, 1 << 30))))
+    return cases
+
+
+@pytest.mark.parametrize("side,nr,batch,fused,squared,weighted,rot,zero_fraction,steps,seed", _random_cases(28))
+def test_randomized_configurations(engine, oracle, side, nr, batch, fused, squared, weighted, rot, zero_fraction, steps, seed):
+    """Seeded random sweep over sizes, representative counts (1 .. 1024: one block per CU, dense, several LDS tiles' worth of
+    groups), batches, reduction / power-method modes, weighting, rotation solver and zero points: after every step the
+    nearest representatives, correspondences and the transform of every registration equal its own oracle bit for bit;
+    then a graph run (chained where the size allows) from that state does too."""
+    m = side * side
+    g = engine.ICP(0, rot, weighted)
+    g.init(m, nr, A, C_, batch=batch)
+    if squared:
+        g.setPowerMode(engine.PowerMode.SQUARED)
+    if fused:
+        g.setReduceMode(engine.ReduceMode.FUSED)
+    oracles = []
+    for b in range(batch):
+        F, M = engine.synth_pair(side, seed=seed + 13 * b, rot_deg=1.0 + b, zero_fraction=zero_fraction)
+        g.write(engine.Memory.F, F, batch_index=b)
+        g.write(engine.Memory.M, M, batch_index=b)
+        o = oracle.OracleICP(m, nr, A, C_, rot=rot, weighted=weighted, power_fast=squared, threads=8, fused=fused)
+        o.write_f(F)
+        o.write_m(M)
+        o.build_rbc()
+        oracles.append(o)
+    g.buildRBC()
+
+    def compare(tag):
+        for b, o in enumerate(oracles):
+            assert np.array_equal(g.read(engine.Memory.RID, b), o.rid), (tag, b, "rid")
+            gn = g.read(engine.Memory.NN_ID, b)
+            assert np.array_equal(gn["id"], o.nn_id["id"]), (tag, b, "ids")
+            assert_bits(gn["dist"], o.nn_id["dist"], "distances %s/%d" % (tag, b))
+            assert_bits(g.read(engine.Memory.T, b), o.T, "T %s/%d" % (tag, b))
+
+    for it in range(steps):
+        g.step()
+        for o in oracles:
+            o.step()
+        compare("step %d" % it)
+    g.run_fixed(3)
+    for o in oracles:
+        for _ in range(3):
+            o.step()
+    compare("graph")
+    g.close()

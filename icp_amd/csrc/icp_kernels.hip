@@ -4,12 +4,21 @@
 // un-vendored kernels/RBC/*.cl of the reference.  Per-iteration launch set (reference: >= 18 launches
 // plus a blocking 32-byte read and a 32-byte write, src/ICP/algorithms.cpp:4670-4698):
 //
+//   reference-order reductions (4 launches)
 //   k_search    transform (a3) + nearest representative + list scan (a4) + weights and their
-//               128-element tree partials (a5, first level)                         grid (m/128, B)
+//               128-element tree partials (a5, first level)
 //   k_means     sum of weights (a5, second level, in the prologue) + weighted block means (a6)
 //   k_sij       global means (a6 icpGMean, prologue) + deviations (a7) + S products and their
 //               512-column tree partials (a8)
 //   k_finalize  S final tree (a8) + power method / SVD (a9, a12) + composition (a10) + check (a11)
+//
+//   fused reductions (2 launches, or 1 chained launch where the size is latency-bound: DESIGN.md §5)
+//   k_search<FUSED>   the same search + the 18 double moments of every 64-pair block
+//   k_finalize_fused  moment trees, means / S, rotation, composition, check — or, chained, the prologue of the
+//                     next k_search<FUSED, CHAIN>
+//
+// RBC construction (once per fixed frame): k_get_reps, k_rep_boxes, k_search<.., OWNER>, k_chunk_hist, k_count,
+// k_offsets, k_place.
 //
 // Every reduction follows the canonical tree of DESIGN.md §3, so results are bit-identical to
 // oracle/icp_oracle.c.  blockIdx.y is the registration index of a batch.
@@ -290,10 +299,10 @@ __global__ __launch_bounds__ (1024) void k_place (icp_params p)
 // ------------------------------------------------------------------------------------------
 // K1  search: transform (a3) + RBC one-shot search (a4) + weights and their first tree levels (a5)
 //
-//   block  = 64 queries x 8 slices (512 threads); the 64 queries are the even (or odd) positions of one
-//            128-query group, so that the block owns a closed sub-tree of the weight reduction;
-//   wave s = slice s: 1/8 of the representatives (stage 1) and every 8th list position (stage 2);
-//   representatives are staged through LDS in tiles (coalesced float4 loads, broadcast ds_read_b128).
+//   block  = 64 queries x LPQ lanes (LPQ waves); reference order: the 64 even (or odd) positions of one 128-query
+//            group, so that the block owns a closed sub-tree of the weight reduction; fused: an 8 x 8 tile of the grid;
+//   wave   = 64 / LPQ queries end to end: the LPQ lanes of a query split the representatives (stage 1) and the list
+//            positions (stage 2); representatives are staged through LDS in tiles (broadcast ds_read_b128).
 // ------------------------------------------------------------------------------------------
 // KS_SPLIT = lanes per query = waves per block (8 or 16); inside k_search it names the template parameter LPQ
 #define KS_SPLIT LPQ
@@ -555,9 +564,9 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     __shared__ double s_l1[CHAIN ? ICP_NMOM : 1][CHAIN ? 32 : 1];
     __shared__ double s_t[ICP_NMOM];
 
-    // A wave serves KS_QPW (= 8) queries end to end, KS_SPLIT (= 8) lanes per query: lane (L & 7) takes the
-    // representative pairs = (L & 7) mod 8 in stage 1 and the list positions = (L & 7) mod 8 in stage 2, and the
-    // query's winner is an 8-lane DPP reduction — no cross-wave exchange, two block barriers in the whole kernel.
+    // A wave serves KS_QPW queries end to end, KS_SPLIT (= LPQ) lanes per query: lane ss of a query takes the
+    // representative pairs = ss mod LPQ in stage 1 and the list positions = ss mod LPQ in stage 2, and the
+    // query's winner is an LPQ-lane DPP reduction — no cross-wave exchange, two block barriers in the whole kernel.
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t slice = __builtin_amdgcn_readfirstlane (tid >> 6);
     const uint32_t qe = slice * KS_QPW + lane / KS_SPLIT, ss = lane & (KS_SPLIT - 1u);
@@ -806,7 +815,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
         }
     }
     KS_STAMP (4)
-    // the query's winner among its eight lanes: smallest distance, ties -> lowest list position; that lane finishes
+    // the query's winner among its lanes: smallest distance, ties -> lowest list position; that lane finishes
     // the query (lane ss == 0 when the list is empty or no candidate has a finite distance)
     const float dmin = ks_grp_min_f<KS_SPLIT> (best2);
     const uint32_t jmin = ks_grp_min_u<KS_SPLIT> (best2 == dmin ? bj : 0xFFFFFFFFu);

@@ -705,9 +705,11 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
         if (t0 == 0 && prune) {
             seed = min (seed, nr - 1u);
             float sx, sy, sz, sr, sg, sb;
-            if (nr <= KS_TILE) {
+            if (MINW == 2 || nr <= KS_TILE) {        // one tile: the seed is in LDS (MINW == 2: always, see icp_launch_search)
                 const float *sp = s_pairf + (seed >> 1) * 12u + (seed & 1u);
                 sx = sp[0]; sy = sp[2]; sz = sp[4]; sr = sp[6]; sg = sp[8]; sb = sp[10];
+                // (keeps the compiler from merging this with the global path below into flat loads)
+                asm volatile ("" : "+v"(sx), "+v"(sy), "+v"(sz), "+v"(sr), "+v"(sg), "+v"(sb));
             } else {
                 const float4 g = R4[2 * (size_t) seed], c = R4[2 * (size_t) seed + 1];
                 sx = g.x; sy = g.y; sz = g.z; sr = c.x; sg = c.y; sb = c.z;

@@ -735,12 +735,17 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
             }
             // fine pass: the groups some query of the wave still needs, in ascending order (a lane's pairs must ascend
             // for the tie rule), full evaluation
-            const unsigned long long rep = (KS_SPLIT == 8) ? 0x0101010101010101ull : 0x0001000100010001ull;
+            // (scalar control flow: the lane ballot of trip t is folded over the wave's queries into one bit per group
+            // and only the set bits are visited — a taken branch costs more than the arithmetic it guards)
             for (uint32_t t = 0; t * KS_SPLIT < ngt; ++t) {
-                const unsigned long long bal = __ballot ((cmask >> t) & 1u);
+                unsigned long long bal = __ballot ((cmask >> t) & 1u);
                 if (bal == 0ull) continue;
-                for (uint32_t sg = 0; sg < KS_SPLIT; ++sg) {
-                    if (!(bal & (rep << sg))) continue;
+                bal |= bal >> 32; bal |= bal >> 16;
+                if (KS_SPLIT == 8) bal |= bal >> 8;
+                uint32_t need = (uint32_t) bal & ((1u << KS_SPLIT) - 1u);
+                while (need) {
+                    const uint32_t sg = (uint32_t) __builtin_ctz (need);
+                    need &= need - 1u;
                     const uint32_t P = (sg + KS_SPLIT * t) * KS_SPLIT + ss;
                     if (P < npair) {
                         float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];

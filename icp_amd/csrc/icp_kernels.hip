@@ -559,6 +559,8 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     __shared__ uint2 s_on[KS_TILE];                  // (offset, size) of every representative's list
     __shared__ float4 s_box[2 * (KS_TILE / 16)];     // (lo, hi) of the tile's groups of 2 * LPQ representatives
     __shared__ float s_w[64];
+    __shared__ float4 s_qa[64];                      // per-query hand-off to the finishing wave: (q', distance)
+    __shared__ uint4 s_qb[64];                       //   (winner position or representative, representative, flags, query index)
     __shared__ double s_mom[FUSED ? ICP_NMOM : 1][64];
     __shared__ icp_fin_result s_fin;
     __shared__ double s_l1[CHAIN ? ICP_NMOM : 1][CHAIN ? 32 : 1];
@@ -826,49 +828,61 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     // the query (lane ss == 0 when the list is empty or no candidate has a finite distance)
     const float dmin = ks_grp_min_f<KS_SPLIT> (best2);
     const uint32_t jmin = ks_grp_min_u<KS_SPLIT> (best2 == dmin ? bj : 0xFFFFFFFFu);
-    const bool winner = (jmin == 0xFFFFFFFFu) ? (ss == 0u) : (bj == jmin && best2 == dmin);
     KS_STAMP (5)
-    if (winner) {
-        float d = dmin; float w = 0.f;
-        float s_nn_x = 0.f, s_nn_y = 0.f, s_nn_z = 0.f;
-        if (valid) {
-            uint32_t id; float4 nn;
-            if (n == 0) {            // empty list: fall back to the representative itself
-                d = dr; id = p.rep_src[(size_t) b * nr + rstar]; nn = R4[2 * (size_t) rstar];
-            } else {                 // the winner's point (jmin), or, when every distance is inf / NaN, the first list
-                                     // element as the serial scan would: one reload instead of tracking it per candidate
-                const char *rec = XQb + (((jmin == 0xFFFFFFFFu) ? o : jmin) << 5);
+    // Hand-off: lane 0 of every query leaves (q, distance, winner position, representative, flags) in LDS, and ONE wave
+    // finishes all 64 queries of the block with every lane active (lane e = query e): the winner's record, the weight,
+    // the per-query outputs and the 18 moment products are then issued once per block instead of once per wave for a
+    // handful of active lanes (an instruction costs the same whatever its lane count).
+    if (ss == 0u) {
+        const bool empty = (n == 0u);
+        s_qa[qe] = make_float4 (qx, qy, qz, empty ? dr : dmin);
+        s_qb[qe] = make_uint4 (empty ? rstar : ((jmin == 0xFFFFFFFFu) ? o : jmin), rstar, (valid ? 1u : 0u) | (empty ? 2u : 0u), i);
+    }
+    __syncthreads ();
+    if (slice == 0u) {
+        const float4 qa = s_qa[lane]; const uint4 qb = s_qb[lane];
+        const bool v = (qb.z & 1u) != 0u, empty = (qb.z & 2u) != 0u;
+        const float ex = qa.x, ey = qa.y, ez = qa.z, d = qa.w;
+        const uint32_t ei = qb.w;
+        float w = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f;
+        if (v) {
+            uint32_t id;
+            if (empty) {             // empty list: fall back to the representative itself
+                const float4 nn = R4[2 * (size_t) qb.x];
+                id = p.rep_src[(size_t) b * nr + qb.x]; f0 = nn.x; f1 = nn.y; f2 = nn.z;
+            } else {                 // the winner's point, or, when every distance is inf / NaN, the first list element as
+                                     // the serial scan would: one reload instead of tracking it per candidate
+                const char *rec = XQb + (qb.x << 5);
                 const float4 wg = *reinterpret_cast<const float4 *> (rec), wc = *reinterpret_cast<const float4 *> (rec + 16);
-                nn = make_float4 (wg.x, wg.z, wc.x, 0.f); id = __float_as_uint (wc.z);
+                f0 = wg.x; f1 = wg.z; f2 = wc.x; id = __float_as_uint (wc.z);
             }
             w = p.weighted ? 100.f / (100.f + d) : 1.f;                // icp_kernels.cl:232
             // per-query outputs: uniform bases + 32-bit byte offsets (i < 2^20)
             icp_dist_id di; di.dist = d; di.id = id;
             char *o_nn = reinterpret_cast<char *> (p.nn_id + (size_t) b * m), *o_pf = reinterpret_cast<char *> (p.PF + (size_t) b * m);
             char *o_pm = reinterpret_cast<char *> (p.PM + (size_t) b * m), *o_rid = reinterpret_cast<char *> (p.rid + (size_t) b * m);
-            *reinterpret_cast<icp_dist_id *> (o_nn + (i << 3)) = di;
-            *reinterpret_cast<float4 *> (o_pf + (i << 4)) = make_float4 (nn.x, nn.y, nn.z, w);
-            *reinterpret_cast<float4 *> (o_pm + (i << 4)) = make_float4 (qx, qy, qz, d);
-            *reinterpret_cast<uint32_t *> (o_rid + (i << 2)) = rstar;
-            s_nn_x = nn.x; s_nn_y = nn.y; s_nn_z = nn.z;
+            *reinterpret_cast<icp_dist_id *> (o_nn + (ei << 3)) = di;
+            *reinterpret_cast<float4 *> (o_pf + (ei << 4)) = make_float4 (f0, f1, f2, w);
+            *reinterpret_cast<float4 *> (o_pm + (ei << 4)) = make_float4 (ex, ey, ez, d);
+            *reinterpret_cast<uint32_t *> (o_rid + (ei << 2)) = qb.y;
         }
         if constexpr (FUSED) {
             // the 18 moments of this pair in double (oracle orc_moments_fused); invalid queries contribute 0
             double W = (double) w;
-            double f0 = valid ? (double) s_nn_x : 0.0, f1 = valid ? (double) s_nn_y : 0.0, f2 = valid ? (double) s_nn_z : 0.0;
-            double q0 = (double) qx, q1 = (double) qy, q2 = (double) qz;
-            if (!valid) { W = 0.0; q0 = q1 = q2 = 0.0; }
+            double g0 = v ? (double) f0 : 0.0, g1 = v ? (double) f1 : 0.0, g2 = v ? (double) f2 : 0.0;
+            double q0 = (double) ex, q1 = (double) ey, q2 = (double) ez;
+            if (!v) { W = 0.0; q0 = q1 = q2 = 0.0; }
             double wq0 = W * q0, wq1 = W * q1, wq2 = W * q2;
-            s_mom[0][qe] = W;
-            s_mom[1][qe] = W * f0; s_mom[2][qe] = W * f1; s_mom[3][qe] = W * f2;
-            s_mom[4][qe] = wq0; s_mom[5][qe] = wq1; s_mom[6][qe] = wq2;
-            s_mom[7][qe] = wq0 * f0; s_mom[8][qe] = wq0 * f1; s_mom[9][qe] = wq0 * f2;
-            s_mom[10][qe] = wq1 * f0; s_mom[11][qe] = wq1 * f1; s_mom[12][qe] = wq1 * f2;
-            s_mom[13][qe] = wq2 * f0; s_mom[14][qe] = wq2 * f1; s_mom[15][qe] = wq2 * f2;
-            s_mom[16][qe] = W * ((f0 * f0 + f1 * f1) + f2 * f2);
-            s_mom[17][qe] = W * ((q0 * q0 + q1 * q1) + q2 * q2);
+            s_mom[0][lane] = W;
+            s_mom[1][lane] = W * g0; s_mom[2][lane] = W * g1; s_mom[3][lane] = W * g2;
+            s_mom[4][lane] = wq0; s_mom[5][lane] = wq1; s_mom[6][lane] = wq2;
+            s_mom[7][lane] = wq0 * g0; s_mom[8][lane] = wq0 * g1; s_mom[9][lane] = wq0 * g2;
+            s_mom[10][lane] = wq1 * g0; s_mom[11][lane] = wq1 * g1; s_mom[12][lane] = wq1 * g2;
+            s_mom[13][lane] = wq2 * g0; s_mom[14][lane] = wq2 * g1; s_mom[15][lane] = wq2 * g2;
+            s_mom[16][lane] = W * ((g0 * g0 + g1 * g1) + g2 * g2);
+            s_mom[17][lane] = W * ((q0 * q0 + q1 * q1) + q2 * q2);
         } else
-            s_w[qe] = w;
+            s_w[lane] = w;
     }
     KS_STAMP (6)
     __syncthreads ();

@@ -559,6 +559,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     __shared__ uint2 s_on[KS_TILE];                  // (offset, size) of every representative's list
     __shared__ float4 s_box[2 * (KS_TILE / 16)];     // (lo, hi) of the tile's groups of 2 * LPQ representatives
     __shared__ float s_w[64];
+    __shared__ float4 s_qc[64];                      // query hand-in: (r, g, b, pruning seed); s_qa carries (q', index)
     __shared__ float4 s_qa[64];                      // per-query hand-off to the finishing wave: (q', distance)
     __shared__ uint4 s_qb[64];                       //   (winner position or representative, representative, flags, query index)
     __shared__ double s_mom[FUSED ? ICP_NMOM : 1][64];
@@ -574,9 +575,12 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     const uint32_t qe = slice * KS_QPW + lane / KS_SPLIT, ss = lane & (KS_SPLIT - 1u);
     // reference-order mode: the 64 even (or odd) positions of one 128-query group (a closed sub-tree of
     // the weight reduction); fused mode: an 8 x 8 tile of the landmark grid (spatially coherent lists)
-    const uint32_t i = FUSED ? fused_query_index (m, side, tpr_magic, blockIdx.x, qe)
-                             : (blockIdx.x >> 1) * 128u + 2u * qe + (blockIdx.x & 1u);
-    const bool valid = i < m;
+    // One wave (the last: wave 0 runs the power method in the chained variant) prepares the block's 64 queries —
+    // lane e = query e: index, load, transform, pruning seed — and hands them to the lanes of each query through LDS;
+    // the other 15 (7) waves neither compute the index nor load / transform the same point LPQ times over.
+    const bool qwave = slice == KS_SPLIT - 1u;
+    const uint32_t iq = FUSED ? fused_query_index (m, side, tpr_magic, blockIdx.x, lane)
+                              : (blockIdx.x >> 1) * 128u + 2u * lane + (blockIdx.x & 1u);
 
     const float4 *M4 = reinterpret_cast<const float4 *> (gM + (size_t) b * m * 8);
     const float4 *R4 = reinterpret_cast<const float4 *> (gR + (size_t) b * nr * 8);
@@ -594,8 +598,9 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
         rg[u] = make_float4 (0.f, 0.f, 0.f, 0.f); rc[u] = rg[u];
         if (k < tn0) { rg[u] = R4[2 * (size_t) k]; rc[u] = R4[2 * (size_t) k + 1]; }
     }
-    const uint32_t ic = min (i, m - 1u);
-    float4 mg = M4[2 * (size_t) ic], mc = M4[2 * (size_t) ic + 1];
+    const uint32_t ic = min (iq, m - 1u);
+    float4 mg = make_float4 (0.f, 0.f, 0.f, 1.f), mc = mg;
+    if (qwave) { mg = M4[2 * (size_t) ic]; mc = M4[2 * (size_t) ic + 1]; }
     // (list offsets / sizes: their base pointers come with the second batch of kernel arguments)
     const uint32_t *gO = p.O + (size_t) b * nr, *gN = p.N + (size_t) b * nr;
 #pragma unroll
@@ -613,11 +618,11 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     const bool prune = PRUNE && p.a > 0.f;
     uint32_t seed = 0u;
     if constexpr (OWNER) {
-        if (prune && side && side * side == m && p.nrx && p.nry) {     // the representative sampled from the point's own cell
+        if (qwave && prune && side && side * side == m && p.nrx && p.nry) {     // the representative sampled from the point's own cell
             const uint32_t y = ic / side, x = ic - y * side;
             seed = (y / (side / p.nry)) * p.nrx + x / (side / p.nrx);
         }
-    } else if (prune) seed = p.rid[(size_t) b * m + ic];
+    } else if (qwave && prune) seed = p.rid[(size_t) b * m + ic];
     // (lo, hi) boxes of the groups of 2 * LPQ representatives: the 16-boxes (LPQ = 8) or the 32-boxes behind them
     const float4 *GBt = p.GB + (size_t) b * 2 * (p.n16 + p.n32) + (KS_SPLIT == 8 ? 0u : 2u * p.n16);
     const uint32_t nbox0 = 2u * ((tn0 + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
@@ -633,7 +638,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
         }
         return;
     }
-    if (!valid) { mg = make_float4 (0.f, 0.f, 0.f, 1.f); mc = mg; }
+    if (iq >= m) { mg = make_float4 (0.f, 0.f, 0.f, 1.f); mc = mg; }
     const float4 *XQ4 = reinterpret_cast<const float4 *> (p.XQ + (size_t) b * m * 8);
     const char *XQb = reinterpret_cast<const char *> (XQ4);
     // the first tile of representatives goes to LDS now: nothing in it depends on T, and in the chained variant the
@@ -661,9 +666,14 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
             reinterpret_cast<uint32_t *> (sout)[tid] = (tid == offsetof (icp_reg_state, pending) / 4) ? 1u : sv;
         }
     }
-    float qx = mg.x, qy = mg.y, qz = mg.z;
-    if constexpr (!OWNER) icp_transform_point (T, mg.x, mg.y, mg.z, qx, qy, qz);
-    const float qr = mc.x, qg = mc.y, qb = mc.z;
+    if (qwave) {
+        float tx = mg.x, ty = mg.y, tz = mg.z;
+        if constexpr (!OWNER) icp_transform_point (T, mg.x, mg.y, mg.z, tx, ty, tz);
+        s_qa[lane] = make_float4 (tx, ty, tz, __uint_as_float (iq));
+        s_qc[lane] = make_float4 (mc.x, mc.y, mc.z, __uint_as_float (seed));
+    }
+    float qx = 0.f, qy = 0.f, qz = 0.f, qr = 0.f, qg = 0.f, qb = 0.f;
+    uint32_t i = 0u; bool valid = false;
     const float alpha = p.a;
     KS_STAMP (0)
 
@@ -690,6 +700,11 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
             dst[0] = qnan; dst[2] = qnan; dst[4] = qnan; dst[6] = qnan; dst[8] = qnan; dst[10] = qnan;
         }
         __syncthreads ();
+        if (t0 == 0) {                               // the query prepared by the query wave
+            const float4 a4 = s_qa[qe], c4 = s_qc[qe];
+            qx = a4.x; qy = a4.y; qz = a4.z; i = __float_as_uint (a4.w); valid = i < m;
+            qr = c4.x; qg = c4.y; qb = c4.z; seed = __float_as_uint (c4.w);
+        }
         KS_STAMP (1)
         const uint32_t npair = (tn + 1u) >> 1;
         const float2v vqx = { qx, qx }, vqy = { qy, qy }, vqz = { qz, qz }, vqr = { qr, qr }, vqg = { qg, qg }, vqb = { qb, qb };

@@ -408,31 +408,50 @@ static __device__ __forceinline__ float state_lane_f (uint32_t sv, uint32_t dwor
 }
 #define ICP_ST_DW(field) (offsetof (icp_reg_state, field) / 4)
 
+// First tree level of the moments, pass ps: one 16-lane row per (moment k, group g) task.  The loads are a separate
+// step so that a caller can issue them together with its other prologue loads (before anything waits).
+template <int NT>
+static __device__ __forceinline__ void fused_moment_task (uint32_t nb, uint32_t ps, uint32_t &k, uint32_t &g, bool &live)
+{
+    constexpr uint32_t nrow = NT / 16;
+    const uint32_t row = threadIdx.x >> 4, ng = (nb + 127u) / 128u, ntask = ICP_NMOM * ng;
+    const uint32_t task = min (ps * nrow + row, ntask - 1u);
+    if (ng == 1) { k = task; g = 0u; } else if (ng == 2) { k = task >> 1; g = task & 1u; } else { k = task / ng; g = task - k * ng; }
+    live = ps * nrow + row < ntask;                  // rows past the last task (whole waves when ntask % 4 == 0) load nothing
+}
+template <int NT>
+static __device__ __forceinline__ void fused_moment_loads (const double *mom, uint32_t nb, uint32_t ps, double *a)
+{
+    uint32_t k, g; bool live;
+    fused_moment_task<NT> (nb, ps, k, g, live);
+    const double *src = mom + (size_t) k * nb;
+    const uint32_t l = threadIdx.x & 15u;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = 0.0;
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {                // clamped address + select: eight loads back to back
+            const uint32_t i = g * 128u + l + 16u * q;
+            const double t = src[min (i, nb - 1u)];
+            a[q] = (i < nb) ? t : 0.0;
+        }
+    }
+}
+
 // Returns false (for every thread, before any barrier) when the registration had already converged (checked mode).
+// a0 = the values of pass 0 (fused_moment_loads (mom, nb, 0, a0), issued by the caller with its other loads).
 template <int NG, int NT>
 static __device__ bool fused_finalize_block (const icp_params &p, const double *mom, uint32_t nb, uint32_t check, uint32_t sv,
-                                             icp_fin_result *res, double (*s_l1)[NG], double *s_t)
+                                             const double *a0, icp_fin_result *res, double (*s_l1)[NG], double *s_t)
 {
     // NT = threads of the calling block (compile-time: reading blockDim costs a dependent cold load at kernel start)
     constexpr uint32_t nrow = NT / 16;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, l = tid & 15u, row = tid >> 4;
     const uint32_t ng = (nb + 127u) / 128u;
-    // first tree level: one 16-lane row per (moment k, group g) task; rows loop over the tasks (whole waves stay converged)
     const uint32_t ntask = ICP_NMOM * ng, npass = (ntask + nrow - 1u) / nrow;
-    auto pass = [&] (uint32_t ps) {
-        const uint32_t task = min (ps * nrow + row, ntask - 1u);
-        uint32_t k, g;
-        if (ng == 1) { k = task; g = 0u; } else if (ng == 2) { k = task >> 1; g = task & 1u; } else { k = task / ng; g = task - k * ng; }
-        const double *src = mom + (size_t) k * nb;
-        const bool live = ps * nrow + row < ntask;   // rows past the last task (whole waves when ntask % 4 == 0) load nothing
-        double a[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {                // clamped address + select: eight loads back to back, no branches
-            const uint32_t i = g * 128u + l + 16u * q;
-            double t = 0.0;
-            if (live) t = src[min (i, nb - 1u)];
-            a[q] = (i < nb) ? t : 0.0;
-        }
+    auto pass = [&] (uint32_t ps, const double *a) {
+        uint32_t k, g; bool live;
+        fused_moment_task<NT> (nb, ps, k, g, live);
         FF_STAMP (13)
         double v = row_tree8_d (a);
         if (nb == 1) v = a[0];
@@ -440,11 +459,15 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
             // the two groups of a moment sit in adjacent rows of one wave, and the second level (a 128-position
             // tree over [g0, g1, 0, ..]) is (g0 + 0) + (g1 + 0): no LDS round trip, no second barrier
             const double o = __shfl_down (v, 16);
-            if (l == 0 && !(row & 1u) && ps * nrow + row < ntask) s_t[k] = (v + 0.0) + (o + 0.0);
-        } else if (l == 0 && ps * nrow + row < ntask) { if (ng == 1) s_t[k] = v; else s_l1[k][g] = v; }
+            if (l == 0 && !(row & 1u) && live) s_t[k] = (v + 0.0) + (o + 0.0);
+        } else if (l == 0 && live) { if (ng == 1) s_t[k] = v; else s_l1[k][g] = v; }
     };
-    if (npass == 1) pass (0u);                       // straight-line for the common sizes (no loop-carried waits)
-    else for (uint32_t ps = 0; ps < npass; ++ps) pass (ps);
+    pass (0u, a0);
+    for (uint32_t ps = 1; ps < npass; ++ps) {        // small blocks / many groups only
+        double a[8];
+        fused_moment_loads<NT> (mom, nb, ps, a);
+        pass (ps, a);
+    }
     if (check && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))) return false;    // block-uniform
     FF_STAMP (9)
     if (ng > 2) {                                    // second level: rows 0..17, one moment each
@@ -589,6 +612,10 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     // lane j = dword j: scalar loads of T would queue behind the waits of the vector loads), the first tile of
     // representatives (+ list offsets / sizes), the query point (clamped address, selected afterwards)
     const uint32_t sv = OWNER ? 0u : state_load_lanes (st);
+    // chained variant: the previous iteration's block moments (first tree level of this block's finalize) travel with
+    // the other prologue loads
+    double ma0[8];
+    if constexpr (CHAIN) fused_moment_loads<64 * LPQ> (gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, 0u, ma0);
     float *s_pairf = reinterpret_cast<float *> (s_pair);
     const uint32_t tn0 = min (KS_TILE, nr);
     float4 rg[2], rc[2]; uint2 ron[2];
@@ -656,7 +683,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     if constexpr (CHAIN) {
         const bool pending = __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (pending)) != 0;
         if (pending) {
-            fused_finalize_block<32, 64 * LPQ> (p, gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, 0u, sv, &s_fin, s_l1, s_t);
+            fused_finalize_block<32, 64 * LPQ> (p, gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, 0u, sv, ma0, &s_fin, s_l1, s_t);
 #pragma unroll
             for (int k = 0; k < 8; ++k) T[k] = s_fin.T[k];
             if (blockIdx.x == 0) fin_result_to_state (&s_fin, sout, s_fin.done ? 0u : 1u);
@@ -1155,7 +1182,10 @@ __global__ __launch_bounds__ (1024) void k_finalize_fused (const double *gmom, i
     // the previous state travels with the moment loads (one vector load); a registration that has converged
     // (done, checked mode) leaves as soon as it has arrived
     const uint32_t sv = state_load_lanes (st);
-    if (!fused_finalize_block<128, 1024> (p, gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, check, sv, &s_fin, s_l1, s_t)) return;
+    const double *mom = gmom + (size_t) b * 2 * ICP_NMOM * nb;
+    double a0[8];
+    fused_moment_loads<1024> (mom, nb, 0u, a0);
+    if (!fused_finalize_block<128, 1024> (p, mom, nb, check, sv, a0, &s_fin, s_l1, s_t)) return;
     fin_result_to_state (&s_fin, st, 0u);
 }
 
@@ -1177,7 +1207,10 @@ __global__ __launch_bounds__ (320) void k_chain_end (icp_params p)
         }
         return;
     }
-    fused_finalize_block<32, 320> (p, p.mom + ((size_t) b * 2 + p.slot) * ICP_NMOM * p.nb, p.nb, 0u, state_load_lanes (sin), &s_fin, s_l1, s_t);
+    const double *mom = p.mom + ((size_t) b * 2 + p.slot) * ICP_NMOM * p.nb;
+    double a0[8];
+    fused_moment_loads<320> (mom, p.nb, 0u, a0);
+    fused_finalize_block<32, 320> (p, mom, p.nb, 0u, state_load_lanes (sin), a0, &s_fin, s_l1, s_t);
     fin_result_to_state (&s_fin, st, 0u);
 }
 

@@ -592,7 +592,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
 
     // A wave serves KS_QPW queries end to end, KS_SPLIT (= LPQ) lanes per query: lane ss of a query takes the
     // representative pairs = ss mod LPQ in stage 1 and the list positions = ss mod LPQ in stage 2, and the
-    // query's winner is an LPQ-lane DPP reduction — no cross-wave exchange, two block barriers in the whole kernel.
+    // query's winner is an LPQ-lane DPP reduction — no cross-wave exchange inside the two stages (block barriers only around the LDS hand-overs).
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t slice = __builtin_amdgcn_readfirstlane (tid >> 6);
     const uint32_t qe = slice * KS_QPW + lane / KS_SPLIT, ss = lane & (KS_SPLIT - 1u);

@@ -841,26 +841,33 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     // slower: enumerating the distinct lists and the extra barrier cost more than the direct gathers.)
     float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
     const float2v vq_xr = { qx, qr }, vq_yg = { qy, qg }, vq_zb = { qz, qb };
-    if (valid) {
+    {
         // a batch = KS_DEPTH candidates per lane, all loads issued before the first distance (clamped addresses, the
-        // tail is masked): one memory round trip per batch, and one batch covers a list of KS_DEPTH * LPQ candidates;
-        // a trip no lane of the wave needs is skipped (wave-uniform branch)
+        // tail is masked): one memory round trip per batch, and one batch covers a list of KS_DEPTH * LPQ candidates.
+        // The number of trips the wave needs (its longest list) is a scalar: a trip no lane needs is neither loaded
+        // nor evaluated, at the cost of scalar compares only (the scan is bound by the vector-memory issue rate).
         constexpr uint32_t KS_DEPTH = (KS_SPLIT == 16) ? ICP_S2_DEPTH16 : 4u;
-        const uint32_t je = o + n;
-        for (uint32_t j0 = o + ss; j0 < je; j0 += KS_DEPTH * KS_SPLIT) {
+        const uint32_t je = valid ? o + n : o;       // (invalid queries: an empty range)
+        uint32_t ntrips = 0u;
+#pragma unroll
+        for (uint32_t gq = 0; gq < KS_QPW; ++gq) {
+            const uint32_t ng_ = (uint32_t) __builtin_amdgcn_readlane ((int) (je - o), (int) (gq * KS_SPLIT));
+            ntrips = max (ntrips, (ng_ + KS_SPLIT - 1u) / KS_SPLIT);
+        }
+        for (uint32_t tb = 0; tb < ntrips; tb += KS_DEPTH) {
+            const uint32_t j0 = o + ss + tb * KS_SPLIT, nt = min (KS_DEPTH, ntrips - tb);
             float4 g[KS_DEPTH], c[KS_DEPTH];
 #pragma unroll
             for (uint32_t t = 0; t < KS_DEPTH; ++t) {
-                // (the scan is bound by the vector-memory issue rate: a trip no lane needs is not loaded either)
-                if (t && !__any (j0 + t * KS_SPLIT < je)) break;
-                const uint32_t j = min (j0 + t * KS_SPLIT, je - 1u);
+                if (t >= nt) break;
+                const uint32_t j = min (j0 + t * KS_SPLIT, max (je, 1u) - 1u);
                 const char *rec = XQb + (j << 5);     // 32-bit byte offset from a uniform base (m <= 2^20: < 2^25 bytes)
                 g[t] = *reinterpret_cast<const float4 *> (rec); c[t] = *reinterpret_cast<const float4 *> (rec + 16);
             }
 #pragma unroll
             for (uint32_t t = 0; t < KS_DEPTH; ++t) {
+                if (t >= nt) break;
                 const uint32_t j = j0 + t * KS_SPLIT;
-                if (!__any (j < je)) break;
                 if (j < je) KS_CAND (g[t], c[t], j);
             }
         }

@@ -147,6 +147,9 @@ __device__ __forceinline__ void icp_transform_point (const float *T, float px, f
 #define ICP_PM_SQUARINGS 10
 typedef float icp_f4 __attribute__ ((ext_vector_type (4)));
 
+// value of lane k of the quad, in every lane of the quad: one DPP quad broadcast (no SGPR round trip, no hazards)
+template <int K> __device__ __forceinline__ float pmq_q (float v) { return icp_dpp<ICP_QUAD_BCAST (K)> (v); }
+// the same as a wave-uniform scalar (control flow only)
 __device__ __forceinline__ float pmq_lane (float v, int k)
 {
     return __builtin_bit_cast (float, __builtin_amdgcn_readlane (__builtin_bit_cast (int, v), k));
@@ -154,14 +157,14 @@ __device__ __forceinline__ float pmq_lane (float v, int k)
 __device__ __forceinline__ float pmq_seq4 (float v)
 {
     float s = 0.f;
-    s = s + pmq_lane (v, 0); s = s + pmq_lane (v, 1); s = s + pmq_lane (v, 2); s = s + pmq_lane (v, 3);
+    s = s + pmq_q<0> (v); s = s + pmq_q<1> (v); s = s + pmq_q<2> (v); s = s + pmq_q<3> (v);
     return s;
 }
 __device__ __forceinline__ float pmq_matvec (const float *Nrow, float x)
 {
     float s = 0.f;
-    s = s + Nrow[0] * pmq_lane (x, 0); s = s + Nrow[1] * pmq_lane (x, 1);
-    s = s + Nrow[2] * pmq_lane (x, 2); s = s + Nrow[3] * pmq_lane (x, 3);
+    s = s + Nrow[0] * pmq_q<0> (x); s = s + Nrow[1] * pmq_q<1> (x);
+    s = s + Nrow[2] * pmq_q<2> (x); s = s + Nrow[3] * pmq_q<3> (x);
     return s;
 }
 __device__ __forceinline__ float pmq_normalize (float y)
@@ -266,7 +269,7 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
         xn = pmq_normalize (pmq_matvec (Nrow, x));
     }
 
-    float qx = pmq_lane (xn, 0), qy = pmq_lane (xn, 1), qz = pmq_lane (xn, 2), qw = pmq_lane (xn, 3);
+    float qx = pmq_q<0> (xn), qy = pmq_q<1> (xn), qz = pmq_q<2> (xn), qw = pmq_q<3> (xn);
     const float *mf = means, *mm = means + 4;
     float c1x = (qy * mm[2] - qz * mm[1]) + qw * mm[0];                // :1050
     float c1y = (qz * mm[0] - qx * mm[2]) + qw * mm[1];

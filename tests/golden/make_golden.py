@@ -52,6 +52,21 @@ def main():
     s.write_f(F); s.write_m(M); s.build_rbc()
     out["svd_k"] = np.array([s.run()])
     out["svd_T"] = s.T
+    # the bench's modes: single-pass double moments (fused) + squared-start power method, at 32 x 32 / 16 and at the
+    # benchmark size 128 x 128 / 256
+    for tag, sd, r in (("fs32", 32, 16), ("fs128", 128, 256)):
+        Ff, Mf = icp_amd.synth_pair(sd)
+        f = O.OracleICP(sd * sd, r, 2e2, 1e-6, power_fast=True, fused=True, threads=8)
+        f.write_f(Ff); f.write_m(Mf); f.build_rbc()
+        Ts, Ss, ms, its, ids = [], [], [], [], []
+        for _ in range(4):
+            f.step()
+            Ts.append(f.T); Ss.append(f.S); ms.append(f.means); its.append(f.power_iters)
+            ids.append(f.nn_id["id"][:64].copy())
+        out.update({tag + "_T": np.array(Ts), tag + "_S": np.array(Ss), tag + "_means": np.array(ms),
+                    tag + "_pm_iters": np.array(its), tag + "_ids": np.array(ids)})
+        out[tag + "_run_k"] = np.array([f.run()])
+        out[tag + "_run_T"] = f.T
     np.savez_compressed(os.path.join(HERE, "oracle_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "oracle_vectors.npz"), {k: np.asarray(v).shape for k, v in out.items()})
 

@@ -244,6 +244,25 @@ def test_golden_vectors(oracle, engine):
     assert o.k == g["run_k"][0] and np.array_equal(o.T, g["run_T"])
 
 
+@pytest.mark.parametrize("tag,side,nr", [("fs32", 32, 16), ("fs128", 128, 256)])
+def test_golden_vectors_fused_squared(oracle, engine, tag, side, nr):
+    """The bench's modes (single-pass double moments + squared-start power method) pinned the same way: four steps and
+    a run to convergence reproduce the committed vectors bit for bit."""
+    g = np.load(os.path.join(HERE, "golden", "oracle_vectors.npz"))
+    F, M = engine.synth_pair(side)
+    o = oracle.OracleICP(side * side, nr, 2e2, 1e-6, power_fast=True, fused=True, threads=8)
+    o.write_f(F)
+    o.write_m(M)
+    o.build_rbc()
+    for it in range(4):
+        o.step()
+        assert np.array_equal(o.T, g[tag + "_T"][it]) and np.array_equal(o.S, g[tag + "_S"][it])
+        assert np.array_equal(o.means, g[tag + "_means"][it])
+        assert o.power_iters == g[tag + "_pm_iters"][it]
+        assert np.array_equal(o.nn_id["id"][:64], g[tag + "_ids"][it])
+    assert o.run() == g[tag + "_run_k"][0] and np.array_equal(o.T, g[tag + "_run_T"])
+
+
 def test_config1_svd_path_recovers_motion(oracle, engine):
     """BASELINE config 1 (plumbing, no GPU): kg-like pair, |F|=|M|=16384, |R|=256, SVD rotation path."""
     F, M = engine.synth_pair(128)

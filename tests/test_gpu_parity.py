@@ -3,6 +3,8 @@
 Bar: bit-exact for indices AND for every float the iteration produces (the canonical arithmetic of
 DESIGN.md §3 makes the fp32 reductions reproducible), so comparisons are on the raw bit patterns.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -569,4 +571,28 @@ def test_randomized_configurations(engine, oracle, side, nr, batch, fused, squar
         for _ in range(3):
             o.step()
     compare("graph")
+    g.close()
+
+
+@pytest.mark.parametrize("tag,side,nr", [("fs32", 32, 16), ("fs128", 128, 256)])
+def test_engine_against_committed_golden_vectors(engine, tag, side, nr):
+    """The HIP path against the committed fixture itself (tests/golden/oracle_vectors.npz, no oracle in the loop):
+    the bench's modes, four steps and a run to convergence, bit for bit."""
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.npz"))
+    F, M = engine.synth_pair(side)
+    g = engine.ICP(0)
+    g.init(side * side, nr, A, C_)
+    g.setPowerMode(engine.PowerMode.SQUARED)
+    g.setReduceMode(engine.ReduceMode.FUSED)
+    g.write(engine.Memory.F, F)
+    g.write(engine.Memory.M, M)
+    g.buildRBC()
+    for it in range(4):
+        g.step()
+        assert_bits(g.read(engine.Memory.T), gold[tag + "_T"][it], "T at step %d" % it)
+        assert_bits(g.read(engine.Memory.S), gold[tag + "_S"][it], "S at step %d" % it)
+        assert np.array_equal(g.read(engine.Memory.NN_ID)["id"][:64], gold[tag + "_ids"][it])
+    g.buildRBC()                                     # the reference's contract: buildRBC (k <- 0, T kept) before every run
+    assert g.run() == gold[tag + "_run_k"][0]
+    assert_bits(g.read(engine.Memory.T), gold[tag + "_run_T"], "T after the run")
     g.close()

@@ -139,7 +139,10 @@ int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *o
     graph_entry ge;
     HIPCHK (h, hipStreamBeginCapture (h->stream, hipStreamCaptureModeThreadLocal));
     if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations);        // one launch per iteration
-    else for (uint32_t k = 0; k < iterations; ++k) icp_launch_iteration (p, h->stream);
+    else for (uint32_t k = 0; k < iterations; ++k) {
+        p.emit = (check || k + 1 == iterations) ? 1 : 0;            // (with checks on, any iteration may be the last executed)
+        icp_launch_iteration (p, h->stream);
+    }
     hipError_t e = hipStreamEndCapture (h->stream, &ge.graph);
     if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("hipStreamEndCapture: ") + hipGetErrorString (e));
     HIPCHK (h, hipGraphInstantiate (&ge.exec, ge.graph, nullptr, nullptr, 0));
@@ -230,7 +233,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     free_all (h);
     icp_params &p = h->p;
     p = icp_params {};
-    p.rot = rot; p.weighted = weighted; p.power_mode = pmode; p.check = 0; p.fused = fused; p.chain = chain;
+    p.rot = rot; p.weighted = weighted; p.power_mode = pmode; p.check = 0; p.fused = fused; p.chain = chain; p.emit = 1;
     p.m = m; p.nr = nr; p.batch = batch; p.side = side; p.nrx = nrx; p.nry = nry;
     p.a = a; p.c = c;
     h->max_iterations = max_iterations; h->angle_threshold = angle_threshold; h->translation_threshold = translation_threshold;

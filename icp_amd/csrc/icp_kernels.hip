@@ -568,7 +568,8 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     // global loads are in flight.  gst = the state this launch reads (CHAIN: slot p.slot of every pair of slots),
     // gmom = the moments it turns into T first (CHAIN only: buffer p.slot).
     // check_flags: bit 0 = convergence checks on; bit 1 (CHAIN) = first launch of a chain: gst is the user-visible
-    // state array (stride 1) instead of a pair of slots.
+    // state array (stride 1) instead of a pair of slots; bit 3 = store the matched / transformed points too (fused
+    // mode needs them only after the last iteration of a graph; the reference-order kernels read them every time).
     const uint32_t b = blockIdx.y, check = check_flags & 1u;
     icp_reg_state *st = (CHAIN && !(check_flags & 2u)) ? gst + (size_t) b * 2 : gst + b;
 #ifdef ICP_DBG_STAMPS
@@ -911,8 +912,10 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
             char *o_nn = reinterpret_cast<char *> (p.nn_id + (size_t) b * m), *o_pf = reinterpret_cast<char *> (p.PF + (size_t) b * m);
             char *o_pm = reinterpret_cast<char *> (p.PM + (size_t) b * m), *o_rid = reinterpret_cast<char *> (p.rid + (size_t) b * m);
             *reinterpret_cast<icp_dist_id *> (o_nn + (ei << 3)) = di;
-            *reinterpret_cast<float4 *> (o_pf + (ei << 4)) = make_float4 (f0, f1, f2, w);
-            *reinterpret_cast<float4 *> (o_pm + (ei << 4)) = make_float4 (ex, ey, ez, d);
+            if (!FUSED || (check_flags & 8u)) {
+                *reinterpret_cast<float4 *> (o_pf + (ei << 4)) = make_float4 (f0, f1, f2, w);
+                *reinterpret_cast<float4 *> (o_pm + (ei << 4)) = make_float4 (ex, ey, ez, d);
+            }
             *reinterpret_cast<uint32_t *> (o_rid + (ei << 2)) = qb.y;
         }
         if constexpr (FUSED) {
@@ -1272,8 +1275,9 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 void icp_launch_search (const icp_params &p, hipStream_t s)
 {
     const bool dense = icp_dense (p);
-#define KS_ARGS p.M, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, (uint32_t) p.check, p
-#define KS_CHAIN_ARGS p.M, p.R, p.cst + p.slot, (const double *) p.mom + (size_t) p.slot * ICP_NMOM * p.nb, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, (uint32_t) p.check, p
+#define KS_FLAGS(p) ((uint32_t) ((p).check ? 1u : 0u) | ((p).emit ? 8u : 0u))
+#define KS_ARGS p.M, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
+#define KS_CHAIN_ARGS p.M, p.R, p.cst + p.slot, (const double *) p.mom + (size_t) p.slot * ICP_NMOM * p.nb, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
     if (p.fused) {
         if (dense) hipLaunchKernelGGL ((k_search<true, false, 4, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
         else hipLaunchKernelGGL ((k_search<true, false, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_ARGS);
@@ -1331,9 +1335,10 @@ void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations)
     if (iterations == 0) return;
     for (uint32_t j = 0; j < iterations; ++j) {
         p.slot = j & 1u;
+        p.emit = (p.check || j + 1 == iterations) ? 1 : 0;          // (with checks on, any iteration may be the last executed)
         // the first launch reads the user-visible state directly (pending == 0 there: nothing to finalize yet)
         if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, (const double *) p.mom,
-                                        p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, (uint32_t) p.check | 2u, p);
+                                        p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | 2u, p);
         else hipLaunchKernelGGL ((k_search<true, true, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
     }
     p.slot = iterations & 1u;

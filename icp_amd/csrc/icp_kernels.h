@@ -14,7 +14,7 @@ struct icp_params {
     int weighted, rot, power_mode, check;
     int chain;                   // fused mode, one launch per iteration (finalize in the next search's prologue): 0 never, 1 automatic, 2 always
     int fused;                   // 0: reference-order reductions (3 global trees), 1: single-pass double moments
-    int emit;                    // fused mode: this search also stores the matched / transformed points (PF, PM); graphs of a
+    int emit;                    // fused mode: this search also stores the per-query outputs (nn_id, PF, PM; rid unless pruning needs it anyway); graphs of a
                                  // fixed length switch it off for all but their last iteration (nothing in between can read them)
     double tan_half_thr, trans_thr;
     // derived sizes

@@ -911,12 +911,15 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
             icp_dist_id di; di.dist = d; di.id = id;
             char *o_nn = reinterpret_cast<char *> (p.nn_id + (size_t) b * m), *o_pf = reinterpret_cast<char *> (p.PF + (size_t) b * m);
             char *o_pm = reinterpret_cast<char *> (p.PM + (size_t) b * m), *o_rid = reinterpret_cast<char *> (p.rid + (size_t) b * m);
-            *reinterpret_cast<icp_dist_id *> (o_nn + (ei << 3)) = di;
-            if (!FUSED || (check_flags & 8u)) {
+            // (fused mode consumes none of these itself: inside a graph of a fixed length only the last iteration
+            // stores them — except the nearest representative where the next search seeds its pruning with it)
+            const bool emit = !FUSED || (check_flags & 8u);
+            if (emit) {
+                *reinterpret_cast<icp_dist_id *> (o_nn + (ei << 3)) = di;
                 *reinterpret_cast<float4 *> (o_pf + (ei << 4)) = make_float4 (f0, f1, f2, w);
                 *reinterpret_cast<float4 *> (o_pm + (ei << 4)) = make_float4 (ex, ey, ez, d);
             }
-            *reinterpret_cast<uint32_t *> (o_rid + (ei << 2)) = qb.y;
+            if (emit || PRUNE) *reinterpret_cast<uint32_t *> (o_rid + (ei << 2)) = qb.y;
         }
         if constexpr (FUSED) {
             // the 18 moments of this pair in double (oracle orc_moments_fused); invalid queries contribute 0

@@ -1,0 +1,29 @@
+// icpreg_test.cpp — the reference's demo flow (examples/registration.cpp:285-337 + src/ocl_icp_reg.cpp) through ICPReg:
+// two synthetic VGA clouds, init, registerPC.  Prints k, [q | t, s] and a checksum of the transformed cloud so that
+// tests/test_gpu_facade.py can compare them with the Python / oracle flow.
+#include <cstdio>
+#include <ocl_icp_reg.hpp>
+
+int main ()
+{
+    try
+    {
+        std::vector<icp_float8> pc1 (640 * 480), pc2 (640 * 480);
+        if (icp_synth_cloud_vga (0x1C9D5EEDull, 0, pc1[0].data ()) || icp_synth_cloud_vga (0x1C9D5EEDull, 1, pc2[0].data ())) return 2;
+        ICPReg<cl_algo::ICP::ICPStepConfigT::POWER_METHOD, cl_algo::ICP::ICPStepConfigW::WEIGHTED> app (0);
+        app.init (pc1, pc2);
+        app.registerPC ();
+        auto &reg = app.registration ();
+        printf ("k %u\n", reg.k);             // (Staging::NONE as in the reference: results through the public members)
+        printf ("T %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", reg.q.x (), reg.q.y (), reg.q.z (), reg.q.w (), reg.t (0), reg.t (1), reg.t (2), reg.s);
+        double cs[3] = { 0, 0, 0 };
+        for (const auto &p : app.transformed ()) { cs[0] += p[0]; cs[1] += p[1]; cs[2] += p[2]; }
+        printf ("C %.17g %.17g %.17g\n", cs[0], cs[1], cs[2]);
+    }
+    catch (const std::exception &e)
+    {
+        fprintf (stderr, "%s\n", e.what ());
+        return 1;
+    }
+    return 0;
+}

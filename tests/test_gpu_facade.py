@@ -30,6 +30,27 @@ def test_cpp_facade_matches_oracle(engine, oracle):
     assert "alpha parameter cannot be equal to zero" in " ".join(lines["ERR"])
 
 
+def test_cpp_icpreg_matches_oracle(engine, oracle):
+    """`ICPReg<POWER_METHOD, WEIGHTED>` (include/ocl_icp_reg.hpp: the reference's demo registration class without
+    the GL plumbing): init (two VGA clouds) + registerPC = landmarks, RBC, run, full-cloud transform."""
+    exe = os.path.join(ROOT, "tests", "cpp", "icpreg_test")
+    subprocess.check_call(["make", "-C", ROOT, "-s", "icpreg_test"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Iterations" in out.stdout and "Rotation angle" in out.stdout and "Translation vector" in out.stdout
+    lines = {l.split()[0]: l.split()[1:] for l in out.stdout.strip().splitlines() if l[:2] in ("k ", "T ", "C ")}
+    cloud_f = engine.synth_cloud_vga(moved=False)
+    cloud_m = engine.synth_cloud_vga(moved=True)
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8)
+    o.write_f(oracle.get_lms(cloud_f)); o.write_m(oracle.get_lms(cloud_m)); o.build_rbc()
+    assert int(lines["k"][0]) == o.run()
+    T = np.array([float(x) for x in lines["T"]], np.float32)
+    assert np.array_equal(T.view(np.uint32), o.T.view(np.uint32))
+    want = oracle.transform_q(cloud_m, o.T).astype(np.float64)[:, :3].sum(0)
+    got = np.array([float(x) for x in lines["C"]])
+    assert np.allclose(got, want, rtol=1e-9)
+
+
 def test_get_lms_and_cloud_transform(engine, oracle):
     cloud_f = engine.synth_cloud_vga(moved=False)
     cloud_m = engine.synth_cloud_vga(moved=True)

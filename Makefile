@@ -18,7 +18,7 @@ oracle:
 facade_test: $(LIB) tests/cpp/facade_test.cpp include/ICP/algorithms.hpp
 	g++ -O2 -std=c++17 -Iinclude -o tests/cpp/facade_test tests/cpp/facade_test.cpp -Licp_amd -licp_amd -Wl,-rpath,'$$ORIGIN/../../icp_amd'
 
-icpreg_test: $(LIB) tests/cpp/icpreg_test.cpp include/ocl_icp_reg.hpp include/ICP/algorithms.hpp
+icpreg_test: $(LIB) tests/cpp/icpreg_test.cpp include/ocl_icp_reg.hpp include/ocl_icp_sbs.hpp include/ICP/algorithms.hpp
 	g++ -O2 -std=c++17 -Iinclude -o tests/cpp/icpreg_test tests/cpp/icpreg_test.cpp -Licp_amd -licp_amd -Wl,-rpath,'$$ORIGIN/../../icp_amd'
 
 capi_example: $(LIB) tests/cpp/capi_example.c include/icp_amd.h

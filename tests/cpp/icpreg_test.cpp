@@ -3,6 +3,7 @@
 // tests/test_gpu_facade.py can compare them with the Python / oracle flow.
 #include <cstdio>
 #include <ocl_icp_reg.hpp>
+#include <ocl_icp_sbs.hpp>
 
 int main ()
 {
@@ -19,6 +20,13 @@ int main ()
         double cs[3] = { 0, 0, 0 };
         for (const auto &p : app.transformed ()) { cs[0] += p[0]; cs[1] += p[1]; cs[2] += p[2]; }
         printf ("C %.17g %.17g %.17g\n", cs[0], cs[1], cs[2]);
+
+        // the step-by-step application (src/ocl_icp_sbs.cpp): three steps
+        ICPSBS<cl_algo::ICP::ICPStepConfigT::POWER_METHOD, cl_algo::ICP::ICPStepConfigW::WEIGHTED> sbs (0);
+        sbs.init (pc1, pc2);
+        sbs.step (); sbs.step (); sbs.step ();
+        auto &st = sbs.stepper ();
+        printf ("S %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", st.q.x (), st.q.y (), st.q.z (), st.q.w (), st.t (0), st.t (1), st.t (2), st.s);
     }
     catch (const std::exception &e)
     {

@@ -38,7 +38,7 @@ def test_cpp_icpreg_matches_oracle(engine, oracle):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "Iterations" in out.stdout and "Rotation angle" in out.stdout and "Translation vector" in out.stdout
-    lines = {l.split()[0]: l.split()[1:] for l in out.stdout.strip().splitlines() if l[:2] in ("k ", "T ", "C ")}
+    lines = {l.split()[0]: l.split()[1:] for l in out.stdout.strip().splitlines() if l[:2] in ("k ", "T ", "C ", "S ")}
     cloud_f = engine.synth_cloud_vga(moved=False)
     cloud_m = engine.synth_cloud_vga(moved=True)
     o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8)
@@ -49,6 +49,14 @@ def test_cpp_icpreg_matches_oracle(engine, oracle):
     want = oracle.transform_q(cloud_m, o.T).astype(np.float64)[:, :3].sum(0)
     got = np.array([float(x) for x in lines["C"]])
     assert np.allclose(got, want, rtol=1e-9)
+    # ICPSBS (include/ocl_icp_sbs.hpp): three single steps
+    assert out.stdout.count("Iteration k = ") == 3 and "Change in translation" in out.stdout
+    s3 = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8)
+    s3.write_f(oracle.get_lms(cloud_f)); s3.write_m(oracle.get_lms(cloud_m)); s3.build_rbc()
+    for _ in range(3):
+        s3.step()
+    S = np.array([float(x) for x in lines["S"]], np.float32)
+    assert np.array_equal(S.view(np.uint32), s3.T.view(np.uint32))
 
 
 def test_get_lms_and_cloud_transform(engine, oracle):

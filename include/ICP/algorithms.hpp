@@ -73,6 +73,76 @@ namespace ICP
     /*! \brief Staging buffers to instantiate — reference include/ICP/common.hpp. */
     enum class Staging : uint8_t { NONE, I, O, IO };
 
+    /*! \brief reference include/ICP/algorithms.hpp:52-58 */
+    enum class ReduceConfig : uint8_t { MIN, MAX, SUM };
+    /*! \brief reference include/ICP/algorithms.hpp:169-174 */
+    enum class ScanConfig : uint8_t { INCLUSIVE, EXCLUSIVE };
+
+    /*! \brief Row-wise reduction — mirrors `Reduce<C, T>` (reference include/ICP/algorithms.hpp:83-166,
+     *         src/ICP/algorithms.cpp:131-322): MIN over floats, MAX over unsigned ints, SUM over floats (the SUM
+     *         reproduces `reduce_sum_f`'s tree bit for bit).  Host staging buffers as with `Staging::IO`:
+     *         `write` copies `cols x rows` elements in, `run` reduces every row, `read` returns `rows` results.
+     */
+    template <ReduceConfig C, typename T = float>
+    class Reduce
+    {
+    public:
+        enum class Memory : uint8_t { H_IN, H_OUT, D_IN, D_RED, D_OUT };
+        static_assert ((C == ReduceConfig::MAX && sizeof (T) == 4) || C != ReduceConfig::MAX, "MAX reduces 32-bit unsigned integers");
+
+        explicit Reduce (icp::Env _env) : env (_env), cols (0), rows (0) {}
+        void init (unsigned int _cols, unsigned int _rows, Staging = Staging::IO)
+        {
+            if (_cols == 0 || _rows == 0 || _cols % 4) throw std::runtime_error ("Reduce::init: cols must be a positive multiple of 4");
+            cols = _cols; rows = _rows; in.assign ((size_t) cols * rows, T ()); out.assign (rows, T ());
+        }
+        void write (Memory = Memory::D_IN, void *ptr = nullptr, bool = false)
+        { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (T)); }
+        void* read (Memory = Memory::H_OUT, bool = true) { return out.data (); }
+        void run ()
+        {
+            const int op = C == ReduceConfig::MIN ? ICP_REDUCE_MIN_F : C == ReduceConfig::MAX ? ICP_REDUCE_MAX_UI : ICP_REDUCE_SUM_F;
+            if (icp_reduce (env.device, op, in.data (), cols, rows, out.data ()) != ICP_OK)
+                throw std::runtime_error (std::string ("Reduce: ") + icp_reduce_scan_last_error ());
+        }
+        T *hPtrIn () { return in.data (); }
+        T *hPtrOut () { return out.data (); }
+
+    private:
+        icp::Env env;
+        unsigned int cols, rows;
+        std::vector<T> in, out;
+    };
+
+    /*! \brief Row-wise prefix sum of ints — mirrors `Scan<C>` (reference include/ICP/algorithms.hpp:200-290,
+     *         src/ICP/algorithms.cpp:403-600). */
+    template <ScanConfig C>
+    class Scan
+    {
+    public:
+        enum class Memory : uint8_t { H_IN, H_OUT, D_IN, D_SUMS, D_OUT };
+
+        explicit Scan (icp::Env _env) : env (_env), cols (0), rows (0) {}
+        void init (unsigned int _cols, unsigned int _rows, Staging = Staging::IO)
+        {
+            if (_cols == 0 || _rows == 0 || _cols % 4) throw std::runtime_error ("Scan::init: cols must be a positive multiple of 4");
+            cols = _cols; rows = _rows; in.assign ((size_t) cols * rows, 0); out.assign ((size_t) cols * rows, 0);
+        }
+        void write (Memory = Memory::D_IN, void *ptr = nullptr, bool = false)
+        { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (int32_t)); }
+        void* read (Memory = Memory::H_OUT, bool = true) { return out.data (); }
+        void run ()
+        {
+            if (icp_scan (env.device, C == ScanConfig::INCLUSIVE ? 1 : 0, in.data (), cols, rows, out.data ()) != ICP_OK)
+                throw std::runtime_error (std::string ("Scan: ") + icp_reduce_scan_last_error ());
+        }
+
+    private:
+        icp::Env env;
+        unsigned int cols, rows;
+        std::vector<int32_t> in, out;
+    };
+
     /*! \brief One ICP iteration — mirrors the four specialisations of the reference's
      *         `ICPStep<CR, CW>` (include/ICP/algorithms.hpp:1613, 1825, 2038, 2234).
      */

@@ -1,6 +1,7 @@
 // facade_test.cpp — drives the engine through the C++ facade the way a user of the reference drives
 // cl_algo::ICP::ICP<POWER_METHOD, WEIGHTED> (compare src/ocl_icp_reg.cpp:103-120, 165-210).
 // Prints k and the final [q | t, s] so that tests/test_gpu_facade.py can compare them with the oracle.
+#include <algorithm>
 #include <cstdio>
 #include <vector>
 #include <ICP/algorithms.hpp>
@@ -38,6 +39,31 @@ int main (int argc, char **argv)
         sbs.buildRBC ();
         sbs.run (true); sbs.run ();
         printf ("S %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", sbs.q.x (), sbs.q.y (), sbs.q.z (), sbs.q.w (), sbs.t (0), sbs.t (1), sbs.t (2), sbs.s);
+
+        // standalone Reduce / Scan classes (tests/testsReduce.cpp, tests/testsScan.cpp of the reference)
+        {
+            const unsigned cols = 1024, rows = 3;
+            std::vector<float> v ((size_t) cols * rows);
+            for (size_t i = 0; i < v.size (); ++i) v[i] = (float) ((i * 2654435761u) % 1000u) * 0.25f - 100.f;
+            Reduce<ReduceConfig::MIN, float> rmin (env); rmin.init (cols, rows); rmin.write (decltype (rmin)::Memory::D_IN, v.data ()); rmin.run ();
+            Reduce<ReduceConfig::SUM, float> rsum (env); rsum.init (cols, rows); rsum.write (decltype (rsum)::Memory::D_IN, v.data ()); rsum.run ();
+            const float *mn = (const float *) rmin.read (), *sm = (const float *) rsum.read ();
+            std::vector<int32_t> w ((size_t) cols * rows);
+            for (size_t i = 0; i < w.size (); ++i) w[i] = (int32_t) (i % 7u) - 3;
+            Scan<ScanConfig::EXCLUSIVE> sc (env); sc.init (cols, rows); sc.write (decltype (sc)::Memory::D_IN, w.data ()); sc.run ();
+            const int32_t *so = (const int32_t *) sc.read ();
+            int bad = 0;
+            for (unsigned r = 0; r < rows; ++r) {
+                float m0 = v[(size_t) r * cols]; long long run = 0;
+                for (unsigned c = 0; c < cols; ++c) {
+                    m0 = std::min (m0, v[(size_t) r * cols + c]);
+                    if (so[(size_t) r * cols + c] != run) ++bad;
+                    run += w[(size_t) r * cols + c];
+                }
+                if (mn[r] != m0) ++bad;
+            }
+            printf ("RS %d %.9g %.9g %.9g\n", bad, sm[0], sm[1], sm[2]);
+        }
 
         // argument errors surface as exceptions, not exit()
         try { ICP<ICPStepConfigT::POWER_METHOD, ICPStepConfigW::WEIGHTED> bad (env); bad.init (m, r, 0.f); printf ("ERR missing\n"); }

@@ -28,6 +28,12 @@ def test_cpp_facade_matches_oracle(engine, oracle):
     S = np.array([float(x) for x in lines["S"]], np.float32)
     assert np.array_equal(S.view(np.uint32), s.T.view(np.uint32))
     assert "alpha parameter cannot be equal to zero" in " ".join(lines["ERR"])
+    # Reduce<MIN>, Reduce<SUM>, Scan<EXCLUSIVE> class mirrors: min and scan checked in the program, the sums here
+    assert int(lines["RS"][0]) == 0
+    v = ((np.arange(3 * 1024, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1000)).astype(np.float32) * np.float32(0.25) - np.float32(100)
+    want = oracle.reduce_sum_f(v.reshape(3, 1024))
+    got = np.array([float(x) for x in lines["RS"][1:]], np.float32)
+    assert np.array_equal(got.view(np.uint32), np.asarray(want, np.float32).view(np.uint32))
 
 
 def test_cpp_icpreg_matches_oracle(engine, oracle):

@@ -8,8 +8,9 @@
  * It is a plain-C restatement of the reference's per-iteration algorithm
  * (nlamprian/ICP, /root/reference): every function cites the reference file:line it
  * follows.  Arithmetic is the canonical spec of DESIGN.md §3: fp32, round-to-nearest,
- * NO fused multiply-add (build with -ffp-contract=off), IEEE divide and sqrt, reduction
- * trees of the reference's shape for a 64-wide wavefront (W = 64).
+ * NO implicit fused multiply-add (build with -ffp-contract=off; the only fmaf calls are the
+ * explicit ones of the metric and of the squared-start power method), IEEE divide and sqrt,
+ * reduction trees of the reference's shape for a 64-wide wavefront (W = 64).
  *
  * PINNING STATUS (details: DESIGN.md §2)
  *   - The reference cannot be built or run in this image (CLUtils, RandomBallCover, Eigen and an

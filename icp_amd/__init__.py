@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["ICP", "ICPStep", "ICPError", "Memory", "ICPStepConfigT", "ICPStepConfigW",
-           "PowerMode", "ReduceMode", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
+           "PowerMode", "ReduceMode", "TransformKind", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("ICP_AMD_LIB", os.path.join(_HERE, "libicp_amd.so"))   # override: A/B builds of the same ABI
@@ -45,6 +45,12 @@ class PowerMode:
 class ReduceMode:
     REFERENCE_ORDER = 0
     FUSED = 1
+
+
+class TransformKind:             # ICPTransformConfig (include/ICP/algorithms.hpp:1189) + the second quaternion kernel
+    QUATERNION = 0
+    QUATERNION_2 = 1
+    MATRIX = 2
 
 
 class Memory:                    # icp_mem in include/icp_amd.h
@@ -115,6 +121,7 @@ def lib():
     sig("icp_state_b", i32, vp, u32, C.POINTER(_State))
     sig("icp_write_cloud", i32, vp, i32, vp, i32)
     sig("icp_transform_cloud", i32, vp, vp, vp, u32)
+    sig("icp_transform_cloud_ex", i32, vp, i32, vp, vp, vp, u32)
     sig("icp_time_run_fixed", i32, vp, u32, u32, i32, C.POINTER(f32))
     sig("icp_reset_transform", i32, vp)
     sig("icp_time_kernels", i32, vp, u32, C.POINTER(f32))
@@ -309,10 +316,20 @@ class ICPStep:
             raise ValueError("expected a 640x480 float8 cloud")
         self._chk(self._L.icp_write_cloud(self._h, which, _p(cloud), 1))
 
-    def transform_cloud(self, cloud):
+    def transform_cloud(self, cloud, T=None, kind=TransformKind.QUATERNION):
+        """ICPTransform: the handle's current T (default), or an explicit one — [q | t, s] for the quaternion kinds,
+        a row-major 4x4 for TransformKind.MATRIX."""
         cloud = np.ascontiguousarray(cloud, np.float32).reshape(-1, 8)
         out = np.empty_like(cloud)
-        self._chk(self._L.icp_transform_cloud(self._h, _p(cloud), _p(out), cloud.shape[0]))
+        if T is None:
+            if kind != TransformKind.QUATERNION:
+                raise ValueError("an explicit T is required for this kind")
+            self._chk(self._L.icp_transform_cloud(self._h, _p(cloud), _p(out), cloud.shape[0]))
+        else:
+            T = np.ascontiguousarray(T, np.float32).reshape(-1)
+            if T.size != (16 if kind == TransformKind.MATRIX else 8):
+                raise ValueError("T has %d floats" % T.size)
+            self._chk(self._L.icp_transform_cloud_ex(self._h, kind, _p(T), _p(cloud), _p(out), cloud.shape[0]))
         return out
 
     def time_run_fixed(self, iterations, reps, from_identity=False):

@@ -128,6 +128,30 @@ int set_device (icp_context *h)
     return ICP_OK;
 }
 
+// Captures the launches `launches ()` enqueues on the handle's stream into an instantiated graph.  Whatever fails,
+// the stream has left capture mode and nothing is leaked when this returns.
+template <typename Fn>
+int capture_graph (icp_context *h, Fn &&launches, graph_entry *out)
+{
+    graph_entry ge;
+    HIPCHK (h, hipStreamBeginCapture (h->stream, hipStreamCaptureModeThreadLocal));
+    launches ();
+    const hipError_t le = hipGetLastError ();                        // launch-configuration errors of the captured kernels
+    hipError_t e = hipStreamEndCapture (h->stream, &ge.graph);      // always: ends the capture also on the error path
+    if (e == hipSuccess && le != hipSuccess) e = le;
+    if (e != hipSuccess) {
+        if (ge.graph) (void) hipGraphDestroy (ge.graph);
+        return fail (h, ICP_EHIP, std::string ("graph capture: ") + hipGetErrorString (e));
+    }
+    e = hipGraphInstantiate (&ge.exec, ge.graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void) hipGraphDestroy (ge.graph);
+        return fail (h, ICP_EHIP, std::string ("hipGraphInstantiate: ") + hipGetErrorString (e));
+    }
+    *out = ge;
+    return ICP_OK;
+}
+
 // Capture `iterations` iterations into a graph (cached until a parameter changes).
 int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *out)
 {
@@ -137,15 +161,14 @@ int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *o
     icp_params p = h->p;
     p.check = check;
     graph_entry ge;
-    HIPCHK (h, hipStreamBeginCapture (h->stream, hipStreamCaptureModeThreadLocal));
-    if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations);        // one launch per iteration
-    else for (uint32_t k = 0; k < iterations; ++k) {
-        p.emit = (check || k + 1 == iterations) ? 1 : 0;            // (with checks on, any iteration may be the last executed)
-        icp_launch_iteration (p, h->stream);
-    }
-    hipError_t e = hipStreamEndCapture (h->stream, &ge.graph);
-    if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("hipStreamEndCapture: ") + hipGetErrorString (e));
-    HIPCHK (h, hipGraphInstantiate (&ge.exec, ge.graph, nullptr, nullptr, 0));
+    int rc = capture_graph (h, [&] {
+        if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations);        // one launch per iteration
+        else for (uint32_t k = 0; k < iterations; ++k) {
+            p.emit = (check || k + 1 == iterations) ? 1 : 0;            // (with checks on, any iteration may be the last executed)
+            icp_launch_iteration (p, h->stream);
+        }
+    }, &ge);
+    if (rc) return rc;
     h->graphs[key] = ge;
     *out = ge.exec;
     return ICP_OK;
@@ -161,6 +184,7 @@ const char *icp_last_error (icp_handle h) { return h ? h->err.c_str () : g_creat
 
 int icp_device_count (int *n)
 {
+    if (!n) return fail (nullptr, ICP_EINVAL, "icp_device_count: null output");
     int c = 0;
     hipError_t e = hipGetDeviceCount (&c);
     if (e != hipSuccess) { *n = 0; return fail (nullptr, ICP_ENODEVICE, std::string ("hipGetDeviceCount: ") + hipGetErrorString (e)); }
@@ -186,7 +210,11 @@ int icp_create (icp_handle *out, int device, int rot, int weighted)
         return fail (nullptr, ICP_ENODEVICE, std::string ("icp_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     icp_context *h = new icp_context ();
     h->device = device;
-    h->p.rot = rot; h->p.weighted = weighted; h->p.power_mode = ICP_POWER_LITERAL;
+    // Default modes = the benchmarked path: single-pass double moments + squared power start.
+    // ICP_AMD_MODE=reference (read here) starts the handle in the reference-order / literal modes instead, whose
+    // intermediates restate the reference's arithmetic order; icp_set_reduce_mode / icp_set_power_mode switch later.
+    h->p.rot = rot; h->p.weighted = weighted; h->p.power_mode = ICP_POWER_SQUARED; h->p.fused = ICP_REDUCE_FUSED;
+    { const char *e = std::getenv ("ICP_AMD_MODE"); if (e && (e[0] == 'r' || e[0] == 'R')) { h->p.power_mode = ICP_POWER_LITERAL; h->p.fused = ICP_REDUCE_REFERENCE_ORDER; } }
     { const char *e = std::getenv ("ICP_AMD_CHAIN"); h->p.chain = !e ? 1 : (e[0] == '1') ? 2 : (e[0] == '0') ? 0 : 1; }   // see icp_chain_supported
     e = hipSetDevice (device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags (&h->stream, hipStreamNonBlocking);
@@ -427,12 +455,10 @@ int icp_build_rbc (icp_handle h)
     auto it = h->graphs.find (key);
     if (it == h->graphs.end ()) {
         graph_entry ge;
-        HIPCHK (h, hipStreamBeginCapture (h->stream, hipStreamCaptureModeThreadLocal));
-        icp_launch_build_rbc (h->p, h->stream);
-        icp_launch_reset_state (h->p, h->stream, 0);                 // ICP::buildRBC: k = 0 (:4796)
-        hipError_t e = hipStreamEndCapture (h->stream, &ge.graph);
-        if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("hipStreamEndCapture: ") + hipGetErrorString (e));
-        HIPCHK (h, hipGraphInstantiate (&ge.exec, ge.graph, nullptr, nullptr, 0));
+        if ((rc = capture_graph (h, [&] {
+                 icp_launch_build_rbc (h->p, h->stream);
+                 icp_launch_reset_state (h->p, h->stream, 0);        // ICP::buildRBC: k = 0 (:4796)
+             }, &ge))) return rc;
         it = h->graphs.emplace (key, ge).first;
     }
     HIPCHK (h, hipGraphLaunch (it->second.exec, h->stream));
@@ -591,6 +617,29 @@ int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint
     return ICP_OK;
 }
 
+int icp_transform_cloud_ex (icp_handle h, int kind, const float *T, const void *host_in, void *host_out, uint32_t n)
+{
+    if (!h) return ICP_EINVAL;
+    if (kind != ICP_TRANSFORM_QUATERNION && kind != ICP_TRANSFORM_QUATERNION_2 && kind != ICP_TRANSFORM_MATRIX)
+        return fail (h, ICP_EINVAL, "icp_transform_cloud_ex: unknown transformation kind");
+    if (!T || !host_in || !host_out || n == 0) return fail (h, ICP_EINVAL, "bad arguments");
+    int rc = set_device (h); if (rc) return rc;
+    if (h->cloud_cap < n) {
+        if (h->dCloud) (void) hipFree (h->dCloud);
+        if (h->dCloudOut) (void) hipFree (h->dCloudOut);
+        h->dCloud = h->dCloudOut = nullptr; h->cloud_cap = 0;
+        HIPCHK (h, hipMalloc ((void **) &h->dCloud, (size_t) n * 32));
+        HIPCHK (h, hipMalloc ((void **) &h->dCloudOut, (size_t) n * 32));
+        h->cloud_cap = n;
+    }
+    HIPCHK (h, hipMemcpyAsync (h->dCloud, host_in, (size_t) n * 32, hipMemcpyHostToDevice, h->stream));
+    icp_launch_transform_cloud_ex (kind, h->dCloud, h->dCloudOut, T, n, h->stream);
+    HIPCHK (h, hipGetLastError ());
+    HIPCHK (h, hipMemcpyAsync (host_out, h->dCloudOut, (size_t) n * 32, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    return ICP_OK;
+}
+
 int icp_reset_transform (icp_handle h)
 {   // T <- identity, k <- 0 (what ICPStep::init uploads, src/ICP/algorithms.cpp:4486-4493); enqueue only
     int rc = need (h, false); if (rc) return rc;
@@ -632,18 +681,16 @@ int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t 
     if (!ms_total || iterations == 0 || reps == 0 || mask == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
     icp_params p = h->p; p.check = 0;
-    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-    HIPCHK (h, hipStreamBeginCapture (h->stream, hipStreamCaptureModeThreadLocal));
-    for (uint32_t k = 0; k < iterations; ++k) icp_launch_masked (p, h->stream, mask);
-    HIPCHK (h, hipStreamEndCapture (h->stream, &graph));
-    HIPCHK (h, hipGraphInstantiate (&exec, graph, nullptr, nullptr, 0));
-    HIPCHK (h, hipGraphLaunch (exec, h->stream));                       // warm-up
-    HIPCHK (h, hipEventRecord (h->ev0, h->stream));
-    for (uint32_t r = 0; r < reps; ++r) HIPCHK (h, hipGraphLaunch (exec, h->stream));
-    HIPCHK (h, hipEventRecord (h->ev1, h->stream));
-    HIPCHK (h, hipEventSynchronize (h->ev1));
-    HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));
-    (void) hipGraphExecDestroy (exec); (void) hipGraphDestroy (graph);
+    graph_entry ge;
+    if ((rc = capture_graph (h, [&] { for (uint32_t k = 0; k < iterations; ++k) icp_launch_masked (p, h->stream, mask); }, &ge))) return rc;
+    hipError_t e = hipGraphLaunch (ge.exec, h->stream);                 // warm-up
+    if (e == hipSuccess) e = hipEventRecord (h->ev0, h->stream);
+    for (uint32_t r = 0; r < reps && e == hipSuccess; ++r) e = hipGraphLaunch (ge.exec, h->stream);
+    if (e == hipSuccess) e = hipEventRecord (h->ev1, h->stream);
+    if (e == hipSuccess) e = hipEventSynchronize (h->ev1);
+    if (e == hipSuccess) e = hipEventElapsedTime (ms_total, h->ev0, h->ev1);
+    (void) hipGraphExecDestroy (ge.exec); (void) hipGraphDestroy (ge.graph);
+    if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("icp_time_masked: ") + hipGetErrorString (e));
     return ICP_OK;
 }
 

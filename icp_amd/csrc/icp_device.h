@@ -303,6 +303,18 @@ __device__ __forceinline__ void icp_quat_to_rot (const float *q, float *R)
     R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
 }
 
+// Eigen's matrix -> quaternion (oracle orc_rot_to_quat).  The largest-diagonal branch is written out per axis
+// (compile-time indices): a runtime index into m[] would put the matrix in scratch memory.
+template <int I> __device__ __forceinline__ void icp_rot_to_quat_axis (const float *m, float *q)
+{
+    constexpr int J = (I + 1) % 3, K = (J + 1) % 3;
+    float t = sqrtf (((m[I * 4] - m[J * 4]) - m[K * 4]) + 1.f);
+    q[I] = 0.5f * t;
+    t = 0.5f / t;
+    q[3] = (m[K * 3 + J] - m[J * 3 + K]) * t;
+    q[J] = (m[J * 3 + I] + m[I * 3 + J]) * t;
+    q[K] = (m[K * 3 + I] + m[I * 3 + K]) * t;
+}
 __device__ inline void icp_rot_to_quat (const float *m, float *q)
 {
     float t = (m[0] + m[4]) + m[8];
@@ -314,69 +326,74 @@ __device__ inline void icp_rot_to_quat (const float *m, float *q)
         q[1] = (m[2] - m[6]) * t;
         q[2] = (m[3] - m[1]) * t;
     } else {
-        int i = 0;
-        if (m[4] > m[0]) i = 1;
-        if (m[8] > m[i * 4]) i = 2;
-        int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrtf (((m[i * 4] - m[j * 4]) - m[k * 4]) + 1.f);
-        float qi = 0.5f * t;
-        t = 0.5f / t;
-        float qw = (m[k * 3 + j] - m[j * 3 + k]) * t;
-        float qj = (m[j * 3 + i] + m[i * 3 + j]) * t;
-        float qk = (m[k * 3 + i] + m[i * 3 + k]) * t;
-        q[3] = qw;
-        // scatter without dynamic register indexing
-        q[0] = (i == 0) ? qi : ((j == 0) ? qj : qk);
-        q[1] = (i == 1) ? qi : ((j == 1) ? qj : qk);
-        q[2] = (i == 2) ? qi : ((j == 2) ? qj : qk);
+        const bool i1 = m[4] > m[0];
+        const bool i2 = m[8] > (i1 ? m[4] : m[0]);
+        if (i2) icp_rot_to_quat_axis<2> (m, q);
+        else if (i1) icp_rot_to_quat_axis<1> (m, q);
+        else icp_rot_to_quat_axis<0> (m, q);
     }
 }
 
 // a12  EIGEN branch (src/ICP/algorithms.cpp:3867-3909) — one-sided Jacobi SVD, oracle orc_svd_rotation.
+// One rotation of the sweep on the column pair (P, Q), compile-time indices (no scratch memory).
+template <int P, int Q> __device__ __forceinline__ void icp_svd_rotate_pair (float *A, float *V, float &off)
+{
+    float alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        alpha = alpha + A[i * 3 + P] * A[i * 3 + P];
+        beta  = beta  + A[i * 3 + Q] * A[i * 3 + Q];
+        gamma = gamma + A[i * 3 + P] * A[i * 3 + Q];
+    }
+    if (gamma == 0.f) return;
+    off = fmaxf (off, fabsf (gamma) / sqrtf (alpha * beta));
+    float zeta = (beta - alpha) / (2.f * gamma);
+    float t = (zeta >= 0.f ? 1.f : -1.f) / (fabsf (zeta) + sqrtf (1.f + zeta * zeta));
+    float cs = 1.f / sqrtf (1.f + t * t), sn = cs * t;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float ap = A[i * 3 + P], aq = A[i * 3 + Q];
+        A[i * 3 + P] = cs * ap - sn * aq; A[i * 3 + Q] = sn * ap + cs * aq;
+        float vp = V[i * 3 + P], vq = V[i * 3 + Q];
+        V[i * 3 + P] = cs * vp - sn * vq; V[i * 3 + Q] = sn * vp + cs * vq;
+    }
+}
 __device__ inline void icp_svd_rotation (const float *S11, const float *means, float *Rk, float *Tk)
 {
     float A[9], V[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+#pragma unroll
     for (int i = 0; i < 9; ++i) A[i] = S11[i];
     for (int sweep = 0; sweep < 30; ++sweep) {
         float off = 0.f;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                float alpha = 0, beta = 0, gamma = 0;
-                for (int i = 0; i < 3; ++i) {
-                    alpha = alpha + A[i * 3 + p] * A[i * 3 + p];
-                    beta  = beta  + A[i * 3 + q] * A[i * 3 + q];
-                    gamma = gamma + A[i * 3 + p] * A[i * 3 + q];
-                }
-                if (gamma == 0.f) continue;
-                off = fmaxf (off, fabsf (gamma) / sqrtf (alpha * beta));
-                float zeta = (beta - alpha) / (2.f * gamma);
-                float t = (zeta >= 0.f ? 1.f : -1.f) / (fabsf (zeta) + sqrtf (1.f + zeta * zeta));
-                float cs = 1.f / sqrtf (1.f + t * t), sn = cs * t;
-                for (int i = 0; i < 3; ++i) {
-                    float ap = A[i * 3 + p], aq = A[i * 3 + q];
-                    A[i * 3 + p] = cs * ap - sn * aq; A[i * 3 + q] = sn * ap + cs * aq;
-                    float vp = V[i * 3 + p], vq = V[i * 3 + q];
-                    V[i * 3 + p] = cs * vp - sn * vq; V[i * 3 + q] = sn * vp + cs * vq;
-                }
-            }
+        icp_svd_rotate_pair<0, 1> (A, V, off);
+        icp_svd_rotate_pair<0, 2> (A, V, off);
+        icp_svd_rotate_pair<1, 2> (A, V, off);
         if (off < 1e-7f) break;
     }
     float U[9], sig[3];
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
         sig[j] = sqrtf ((A[j] * A[j] + A[3 + j] * A[3 + j]) + A[6 + j] * A[6 + j]);
+#pragma unroll
         for (int i = 0; i < 3; ++i) U[i * 3 + j] = sig[j] > 0.f ? A[i * 3 + j] / sig[j] : 0.f;
     }
-    int smin = 0;
-    for (int j = 1; j < 3; ++j) if (sig[j] < sig[smin]) smin = j;
+    int smin = 0; float sminv = sig[0];                                // first smallest singular value
+    if (sig[1] < sminv) { smin = 1; sminv = sig[1]; }
+    if (sig[2] < sminv) { smin = 2; sminv = sig[2]; }
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j)
             Rk[i * 3 + j] = (V[i * 3] * U[j * 3] + V[i * 3 + 1] * U[j * 3 + 1]) + V[i * 3 + 2] * U[j * 3 + 2];
     float det = Rk[0] * (Rk[4] * Rk[8] - Rk[5] * Rk[7]) - Rk[1] * (Rk[3] * Rk[8] - Rk[5] * Rk[6])
               + Rk[2] * (Rk[3] * Rk[7] - Rk[4] * Rk[6]);
     if (det < 0.f) {
+#pragma unroll
         for (int i = 0; i < 3; ++i)
+#pragma unroll
             for (int j = 0; j < 3; ++j) {
                 float acc = 0.f;
+#pragma unroll
                 for (int k = 0; k < 3; ++k)
                     acc = acc + V[i * 3 + k] * (k == smin ? det : 1.f) * U[j * 3 + k];
                 Rk[i * 3 + j] = acc;
@@ -386,6 +403,7 @@ __device__ inline void icp_svd_rotation (const float *S11, const float *means, f
     float sk = sqrtf (S11[9] / S11[10]);
     const float *mf = means, *mm = means + 4;
     Tk[0] = qk[0]; Tk[1] = qk[1]; Tk[2] = qk[2]; Tk[3] = qk[3];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
         Tk[4 + i] = mf[i] - ((sk * Rk[i * 3]) * mm[0] + (sk * Rk[i * 3 + 1]) * mm[1] + (sk * Rk[i * 3 + 2]) * mm[2]);
     Tk[7] = sk;

@@ -61,3 +61,5 @@ void icp_launch_reset_state (const icp_params &p, hipStream_t s, int reset_T);
 void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStream_t s);
 void icp_launch_get_lms (const float *cloud, float *lms, hipStream_t s);
 void icp_launch_transform_cloud (const float *in, float *out, const icp_reg_state *st, uint32_t n, hipStream_t s);
+// kind 0 / 1: T = [q | t, s] (8 floats), 2: T = row-major 4x4 (16 floats); host pointer, passed by value
+void icp_launch_transform_cloud_ex (int kind, const float *in, float *out, const float *T, uint32_t n, hipStream_t s);

@@ -161,6 +161,44 @@ __global__ void k_transform_cloud (const float4 *in, float4 *out, const icp_reg_
     out[2 * (size_t) i + 1] = c;
 }
 
+// ICPTransform<QUATERNION | MATRIX> with an explicit transformation (the cloud kernels of the reference that take
+// their parameters from a buffer of their own): KIND 0 icpTransform_Quaternion (kernels/icp_kernels.cl:772-802),
+// 1 icpTransform_Quaternion_2 (:842-879: the two quaternion products as 4x4 matrix-vector products), 2
+// icpTransform_Matrix (:904-933: rows 0..2 of a row-major 4x4 applied to the homogeneous point as stored).
+// dot (a, b) = (((0 + a0 b0) + a1 b1) + a2 b2) + a3 b3, the CPU twins' order (oracle orc_transform_q2 / orc_transform_m).
+struct icp_T16 { float v[16]; };
+static __device__ __forceinline__ float dot4_seq (float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3)
+{
+    float s = 0.f;
+    s = s + a0 * b0; s = s + a1 * b1; s = s + a2 * b2; s = s + a3 * b3;
+    return s;
+}
+template <int KIND>
+__global__ __launch_bounds__ (256) void k_transform_cloud_ex (const float4 *in, float4 *out, icp_T16 T, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 g = in[2 * (size_t) i], c = in[2 * (size_t) i + 1];
+    float x, y, z;
+    if constexpr (KIND == 0) icp_transform_point (T.v, g.x, g.y, g.z, x, y, z);
+    else if constexpr (KIND == 1) {
+        const float qx = T.v[0], qy = T.v[1], qz = T.v[2], qw = T.v[3];
+        const float p0 = dot4_seq ( qw, -qz,  qy, qx, g.x, g.y, g.z, 0.f);
+        const float p1 = dot4_seq ( qz,  qw, -qx, qy, g.x, g.y, g.z, 0.f);
+        const float p2 = dot4_seq (-qy,  qx,  qw, qz, g.x, g.y, g.z, 0.f);
+        const float p3 = dot4_seq (-qx, -qy, -qz, qw, g.x, g.y, g.z, 0.f);
+        x = T.v[7] * dot4_seq ( qw, -qz,  qy, -qx, p0, p1, p2, p3) + T.v[4];
+        y = T.v[7] * dot4_seq ( qz,  qw, -qx, -qy, p0, p1, p2, p3) + T.v[5];
+        z = T.v[7] * dot4_seq (-qy,  qx,  qw, -qz, p0, p1, p2, p3) + T.v[6];
+    } else {
+        x = dot4_seq (T.v[0], T.v[1], T.v[2],  T.v[3],  g.x, g.y, g.z, g.w);
+        y = dot4_seq (T.v[4], T.v[5], T.v[6],  T.v[7],  g.x, g.y, g.z, g.w);
+        z = dot4_seq (T.v[8], T.v[9], T.v[10], T.v[11], g.x, g.y, g.z, g.w);
+    }
+    out[2 * (size_t) i] = make_float4 (x, y, z, g.w);
+    out[2 * (size_t) i + 1] = c;
+}
+
 // ------------------------------------------------------------------------------------------
 // buildRBC
 // ------------------------------------------------------------------------------------------
@@ -440,7 +478,7 @@ static __device__ __forceinline__ void fused_moment_loads (const double *mom, ui
 
 // Returns false (for every thread, before any barrier) when the registration had already converged (checked mode).
 // a0 = the values of pass 0 (fused_moment_loads (mom, nb, 0, a0), issued by the caller with its other loads).
-template <int NG, int NT>
+template <int NG, int NT, int ROT>
 static __device__ bool fused_finalize_block (const icp_params &p, const double *mom, uint32_t nb, uint32_t check, uint32_t sv,
                                              const double *a0, icp_fin_result *res, double (*s_l1)[NG], double *s_t)
 {
@@ -507,11 +545,12 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
         float Tk[8], Rk[9], Rkin[9];
         int iters = 0;
         FF_STAMP (11)
-        if (p.rot == 1) iters = icp_power_method_quad (S, means, Tk, p.power_mode, lane);
+        // ROT = rotation solver, compile-time: a power-method kernel carries no SVD code (registers, instruction cache)
+        if constexpr (ROT == 1) iters = icp_power_method_quad (S, means, Tk, p.power_mode, lane);
         else icp_svd_rotation (S, means, Rkin, Tk);
         FF_STAMP (12)
 #ifdef ICP_DBG_STAMPS
-        if (lane < 8 && p.dbg && p.rot == 1) p.dbg[16 + lane] = icp_pm_stamps[lane];
+        if (lane < 8 && p.dbg && ROT == 1) p.dbg[16 + lane] = icp_pm_stamps[lane];
 #endif
         float Tprev[8], Rprev[9];
 #pragma unroll
@@ -521,7 +560,7 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
         const uint32_t kprev = (uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (k));
         if (lane == 0) {
             float Tn[8], Rn[9];
-            icp_compose_pure (Tprev, Rprev, Tk, Rkin, p.rot != 1, Tn, Rn, Rk);
+            icp_compose_pure (Tprev, Rprev, Tk, Rkin, ROT != 1, Tn, Rn, Rk);
 #pragma unroll
             for (int k = 0; k < 8; ++k) { res->T[k] = Tn[k]; res->Tk[k] = Tk[k]; res->means[k] = means[k]; }
 #pragma unroll
@@ -558,7 +597,7 @@ static __device__ __forceinline__ void fin_result_to_state (const icp_fin_result
 // OWNER: the kernel is RBC construct step 1 instead (owner(x) = nearest representative of the FIXED point x: gM = F,
 // no transform, stage 1 only, result to p.owner) — the same stage-1 code, pruning included, seeded with the
 // representative of the point's own grid cell.
-template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER = false>
+template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER = false, int ROT = 1>
 __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, const float *gR, icp_reg_state *gst, const double *gmom,
                                                               uint32_t m, uint32_t nr, uint32_t side, uint32_t tpr_magic,
                                                               uint32_t nb, uint32_t check_flags, icp_params p)
@@ -684,7 +723,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     if constexpr (CHAIN) {
         const bool pending = __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (pending)) != 0;
         if (pending) {
-            fused_finalize_block<32, 64 * LPQ> (p, gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, 0u, sv, ma0, &s_fin, s_l1, s_t);
+            fused_finalize_block<32, 64 * LPQ, ROT> (p, gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, 0u, sv, ma0, &s_fin, s_l1, s_t);
 #pragma unroll
             for (int k = 0; k < 8; ++k) T[k] = s_fin.T[k];
             if (blockIdx.x == 0) fin_result_to_state (&s_fin, sout, s_fin.done ? 0u : 1u);
@@ -1142,6 +1181,7 @@ __global__ __launch_bounds__ (64) void k_sij (const float4 *gPF, const float4 *g
 //     One block of 3 waves per registration: 11 rows reduce the 11 rows of S, then wave 0 runs the
 //     lane-parallel power method and lane 0 composes.
 // ------------------------------------------------------------------------------------------
+template <int ROT>
 __global__ __launch_bounds__ (192) void k_finalize (const float *gspart, icp_reg_state *gst, uint32_t nsp, uint32_t check, icp_params p)
 {
     const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, l = tid & 15u, row = tid >> 4;
@@ -1165,11 +1205,11 @@ __global__ __launch_bounds__ (192) void k_finalize (const float *gspart, icp_reg
 
     float Tk[8], Rk[9];
     int iters = 0;
-    if (p.rot == 1) iters = icp_power_method_quad (S, means, Tk, p.power_mode, lane);
+    if constexpr (ROT == 1) iters = icp_power_method_quad (S, means, Tk, p.power_mode, lane);
     else icp_svd_rotation (S, means, Rk, Tk);
 
     if (lane == 0) {
-        icp_compose (st, Tk, Rk, p.rot != 1);
+        icp_compose (st, Tk, Rk, ROT != 1);
 #pragma unroll
         for (int k = 0; k < 11; ++k) st->S[k] = S[k];
         st->pm_iters = (uint32_t) iters;
@@ -1183,6 +1223,7 @@ __global__ __launch_bounds__ (192) void k_finalize (const float *gspart, icp_reg
 // (oracle orc_moments_fused / orc_moments_finish), then rotation, composition, convergence.
 // One block of 5 waves per registration: row k (of 20) reduces moment k.
 // ------------------------------------------------------------------------------------------
+template <int ROT>
 __global__ __launch_bounds__ (1024) void k_finalize_fused (const double *gmom, icp_reg_state *gst, uint32_t nb, uint32_t check, icp_params p)
 {
     // (the leading scalars: see k_search)
@@ -1198,12 +1239,13 @@ __global__ __launch_bounds__ (1024) void k_finalize_fused (const double *gmom, i
     const double *mom = gmom + (size_t) b * 2 * ICP_NMOM * nb;
     double a0[8];
     fused_moment_loads<1024> (mom, nb, 0u, a0);
-    if (!fused_finalize_block<128, 1024> (p, mom, nb, check, sv, a0, &s_fin, s_l1, s_t)) return;
+    if (!fused_finalize_block<128, 1024, ROT> (p, mom, nb, check, sv, a0, &s_fin, s_l1, s_t)) return;
     fin_result_to_state (&s_fin, st, 0u);
 }
 
 // chain end: finalize the last iteration's moments (slot given by p.slot) into the user-visible state.  (There is no
 // begin kernel: the first launch of a chain reads the user-visible state itself.)
+template <int ROT>
 __global__ __launch_bounds__ (320) void k_chain_end (icp_params p)
 {
     const uint32_t b = blockIdx.x;
@@ -1223,7 +1265,7 @@ __global__ __launch_bounds__ (320) void k_chain_end (icp_params p)
     const double *mom = p.mom + ((size_t) b * 2 + p.slot) * ICP_NMOM * p.nb;
     double a0[8];
     fused_moment_loads<320> (mom, p.nb, 0u, a0);
-    fused_finalize_block<32, 320> (p, mom, p.nb, 0u, state_load_lanes (sin), a0, &s_fin, s_l1, s_t);
+    fused_finalize_block<32, 320, ROT> (p, mom, p.nb, 0u, state_load_lanes (sin), a0, &s_fin, s_l1, s_t);
     fin_result_to_state (&s_fin, st, 0u);
 }
 
@@ -1255,6 +1297,17 @@ void icp_launch_transform_cloud (const float *in, float *out, const icp_reg_stat
 {
     hipLaunchKernelGGL (k_transform_cloud, dim3 ((n + 255) / 256), dim3 (256), 0, s,
                         reinterpret_cast<const float4 *> (in), reinterpret_cast<float4 *> (out), st, n);
+}
+
+void icp_launch_transform_cloud_ex (int kind, const float *in, float *out, const float *T, uint32_t n, hipStream_t s)
+{
+    icp_T16 t {};
+    for (int i = 0; i < (kind == 2 ? 16 : 8); ++i) t.v[i] = T[i];
+    const float4 *i4 = reinterpret_cast<const float4 *> (in); float4 *o4 = reinterpret_cast<float4 *> (out);
+    const dim3 grid ((n + 255) / 256), block (256);
+    if (kind == 0) hipLaunchKernelGGL (k_transform_cloud_ex<0>, grid, block, 0, s, i4, o4, t, n);
+    else if (kind == 1) hipLaunchKernelGGL (k_transform_cloud_ex<1>, grid, block, 0, s, i4, o4, t, n);
+    else hipLaunchKernelGGL (k_transform_cloud_ex<2>, grid, block, 0, s, i4, o4, t, n);
 }
 
 static inline bool icp_dense (const icp_params &p)
@@ -1306,8 +1359,14 @@ void icp_launch_sij (const icp_params &p, hipStream_t s)
 
 void icp_launch_finalize (const icp_params &p, hipStream_t s)
 {
-    if (p.fused) hipLaunchKernelGGL (k_finalize_fused, dim3 (p.batch), dim3 (1024), 0, s, (const double *) p.mom, p.st, p.nb, (uint32_t) p.check, p);
-    else hipLaunchKernelGGL (k_finalize, dim3 (p.batch), dim3 (192), 0, s, (const float *) p.spart, p.st, p.nsp, (uint32_t) p.check, p);
+    // the rotation solver is a template parameter (p.rot: 1 power method, else SVD)
+    if (p.fused) {
+        if (p.rot == 1) hipLaunchKernelGGL (k_finalize_fused<1>, dim3 (p.batch), dim3 (1024), 0, s, (const double *) p.mom, p.st, p.nb, (uint32_t) p.check, p);
+        else hipLaunchKernelGGL (k_finalize_fused<0>, dim3 (p.batch), dim3 (1024), 0, s, (const double *) p.mom, p.st, p.nb, (uint32_t) p.check, p);
+    } else {
+        if (p.rot == 1) hipLaunchKernelGGL (k_finalize<1>, dim3 (p.batch), dim3 (192), 0, s, (const float *) p.spart, p.st, p.nsp, (uint32_t) p.check, p);
+        else hipLaunchKernelGGL (k_finalize<0>, dim3 (p.batch), dim3 (192), 0, s, (const float *) p.spart, p.st, p.nsp, (uint32_t) p.check, p);
+    }
 }
 
 __global__ void k_nop (icp_params p) { if (p.m == 0xFFFFFFFFu) p.st->k = 0; }
@@ -1340,12 +1399,19 @@ void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations)
         p.slot = j & 1u;
         p.emit = (p.check || j + 1 == iterations) ? 1 : 0;          // (with checks on, any iteration may be the last executed)
         // the first launch reads the user-visible state directly (pending == 0 there: nothing to finalize yet)
-        if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, (const double *) p.mom,
-                                        p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | 2u, p);
-        else hipLaunchKernelGGL ((k_search<true, true, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
+        if (p.rot == 1) {
+            if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 1>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, (const double *) p.mom,
+                                            p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | 2u, p);
+            else hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 1>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
+        } else {
+            if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 0>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, (const double *) p.mom,
+                                            p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | 2u, p);
+            else hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 0>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
+        }
     }
     p.slot = iterations & 1u;
-    hipLaunchKernelGGL (k_chain_end, dim3 (p.batch), dim3 (320), 0, s, p);
+    if (p.rot == 1) hipLaunchKernelGGL (k_chain_end<1>, dim3 (p.batch), dim3 (320), 0, s, p);
+    else hipLaunchKernelGGL (k_chain_end<0>, dim3 (p.batch), dim3 (320), 0, s, p);
 }
 
 void icp_launch_iteration (const icp_params &p, hipStream_t s)

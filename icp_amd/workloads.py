@@ -1,0 +1,37 @@
+"""Synthetic workloads of BASELINE.json's configs, shared by bench.py, the parity tests and the golden
+fixtures.  Host-side only.
+
+Config 4 — independent frame pairs, 64 per GPU: registration i of a job has seed base + i; rotation and translation vary
+with i so that registrations stop at different iterations."""
+import zlib
+
+import numpy as np
+
+# name -> (landmark grid side, |R|): |F| = |M| = side^2.  A = configs[1] (the headline), B = configs[2], C = configs[4].
+CONFIGS = {"A": (128, 256), "B": (256, 1024), "C": (1024, 4096)}
+
+SIDE, NR, M_POINTS, PER_GPU = 128, 256, 16384, 64
+A, C_ = 2e2, 1e-6
+BASE_SEED = 0x1C9D5EED
+CHECKED = (0, 9, 18, 27, 36, 45, 54, 63)          # the registrations the parity tests and the fixture check
+
+
+def pair(engine, i):
+    """Fixed / moving landmark sets of registration i of config 4 (host arrays); `engine` = the icp_amd module."""
+    return engine.synth_pair(SIDE, seed=BASE_SEED + i, rot_deg=1.0 + 0.125 * (i % 32), t=(25.0 - (i % 7), -10.0 + (i % 5), 15.0))
+
+
+def ids_digest(ids):
+    """(crc32, sum) of a correspondence-id array: the fixture's size-independent check of all 16384 ids."""
+    ids = np.ascontiguousarray(ids, np.uint32)
+    return np.array([zlib.crc32(ids.tobytes()), int(ids.astype(np.uint64).sum())], np.uint64)
+
+
+def algorithmic_bytes(m, nr):
+    """Per registration-iteration: read M, read the permuted fixed set once, read R, write {dist, id}, T."""
+    return 72 * m + 32 * nr + 64
+
+
+def algorithmic_flop(m, nr):
+    """Per registration-iteration (SURVEY.md §8d / BASELINE.md §3): 18 flop per distance, Q x R + balanced list scans."""
+    return 18.0 * m * (nr + m / nr) + 100.0 * m

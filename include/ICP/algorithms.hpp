@@ -34,6 +34,13 @@ namespace icp
     /*! \brief Replaces the clutils::CLEnv / CLEnvInfo pair: which GPU the object lives on. */
     struct Env { int device; explicit Env (int d = 0) : device (d) {} };
 
+    /*! \brief How an iteration is evaluated (include/icp_amd.h: icp_reduce_mode / icp_power_mode).
+     *  FAST (default): single-pass double moments + squared power start — the benchmarked path, one launch per
+     *  iteration at the reference's size.  REFERENCE_ORDER: the reference's three reductions in its own order and its
+     *  literal power loop — every intermediate restates the reference's arithmetic, four launches per iteration.
+     *  Final [q | t, s] of the two agree within 1e-5 relative (|q| = 1, scene scale for t, s itself). */
+    enum class Mode : uint8_t { FAST, REFERENCE_ORDER };
+
     struct Vector3f
     {
         float v[3] = { 0.f, 0.f, 0.f };
@@ -143,6 +150,59 @@ namespace ICP
         std::vector<int32_t> in, out;
     };
 
+    /*! \brief reference include/ICP/algorithms.hpp:1189-1207 */
+    enum class ICPTransformConfig : uint8_t { QUATERNION, MATRIX };
+
+    /*! \brief Transforms a set of points — mirrors `ICPTransform<QUATERNION>` (`icpTransform_Quaternion`, reference
+     *         include/ICP/algorithms.hpp:1240-1330, src/ICP/algorithms.cpp:2554-2753) and `ICPTransform<MATRIX>`
+     *         (`icpTransform_Matrix`, :1348-1430, :2760-2960).  Same staging members (`hPtrInM`, `hPtrInT`, `hPtrOut`);
+     *         the transformation is 8 floats `[q | t, s]` (QUATERNION) or a row-major 4x4 (MATRIX). */
+    template <ICPTransformConfig C>
+    class ICPTransform
+    {
+    public:
+        enum class Memory : uint8_t { H_IN_M, H_IN_T, H_OUT, D_IN_M, D_IN_T, D_OUT };
+
+        explicit ICPTransform (icp::Env _env) : hPtrInM (nullptr), hPtrInT (nullptr), hPtrOut (nullptr), env (_env), h (nullptr), m (0)
+        {
+            if (icp_create (&h, env.device, ICP_ROT_POWER_METHOD, ICP_W_WEIGHTED) != ICP_OK)
+                throw std::runtime_error (std::string ("ICPTransform: ") + icp_last_error (nullptr));
+        }
+        ICPTransform (const ICPTransform&) = delete;
+        ICPTransform& operator= (const ICPTransform&) = delete;
+        ~ICPTransform () { if (h) icp_destroy (h); }
+
+        void init (unsigned int _m, Staging = Staging::IO)
+        {
+            if (_m == 0) throw std::runtime_error ("ICPTransform::init: the set cannot have zero points");
+            m = _m; in.assign ((size_t) m * 8, 0.f); out.assign ((size_t) m * 8, 0.f); T.assign (C == ICPTransformConfig::MATRIX ? 16 : 8, 0.f);
+            hPtrInM = in.data (); hPtrInT = T.data (); hPtrOut = out.data ();
+        }
+        void write (Memory mem = Memory::D_IN_M, void *ptr = nullptr, bool = false)
+        {
+            if (!ptr) return;                       // (data written through the staging pointers is used as it stands)
+            if (mem == Memory::D_IN_M) std::memcpy (in.data (), ptr, in.size () * sizeof (float));
+            else if (mem == Memory::D_IN_T) std::memcpy (T.data (), ptr, T.size () * sizeof (float));
+        }
+        void* read (Memory = Memory::H_OUT, bool = true) { return out.data (); }
+        void run ()
+        {
+            const int kind = C == ICPTransformConfig::MATRIX ? ICP_TRANSFORM_MATRIX : ICP_TRANSFORM_QUATERNION;
+            if (icp_transform_cloud_ex (h, kind, T.data (), in.data (), out.data (), m) != ICP_OK)
+                throw std::runtime_error (std::string ("ICPTransform: ") + icp_last_error (h));
+        }
+
+        float *hPtrInM;  /*!< Staging buffer of the set of points. */
+        float *hPtrInT;  /*!< Staging buffer of the transformation. */
+        float *hPtrOut;  /*!< Staging buffer of the transformed set. */
+
+    private:
+        icp::Env env;
+        icp_handle h;
+        unsigned int m;
+        std::vector<float> in, out, T;
+    };
+
     /*! \brief One ICP iteration — mirrors the four specialisations of the reference's
      *         `ICPStep<CR, CW>` (include/ICP/algorithms.hpp:1613, 1825, 2038, 2234).
      */
@@ -153,20 +213,23 @@ namespace ICP
         /*! \brief reference include/ICP/algorithms.hpp:2241-2267 */
         enum class Memory : uint8_t { H_IN_F, H_IN_M, H_IO_T, D_IN_F, D_IN_M, D_IO_T };
 
-        ICPStep (icp::Env _env) : env (_env), h (nullptr), m (0), nr (0), a (1e2f), c (1e-6f)
+        ICPStep (icp::Env _env, icp::Mode _mode = icp::Mode::FAST) : env (_env), h (nullptr), a (1e2f), c (1e-6f), m (0), nr (0)
         {
             static_assert (CR != ICPStepConfigT::JACOBI, "JACOBI is a \\todo in the reference as well");
             int rc = icp_create (&h, env.device, CR == ICPStepConfigT::POWER_METHOD ? ICP_ROT_POWER_METHOD : ICP_ROT_EIGEN,
                                  CW == ICPStepConfigW::WEIGHTED ? ICP_W_WEIGHTED : ICP_W_REGULAR);
             if (rc != ICP_OK) throw std::runtime_error (std::string ("ICPStep: ") + icp_last_error (nullptr));
             hPtrInF = hPtrInM = hPtrIOT = nullptr; sk = 1.f; s = 1.f;
+            setMode (_mode);
         }
         ICPStep (const ICPStep&) = delete;
         ICPStep& operator= (const ICPStep&) = delete;
         virtual ~ICPStep () { if (h) icp_destroy (h); }
 
         /*! \brief Device pointer of a buffer (reference: cl::Memory& get (Memory), algorithms.cpp:4366-4383).
-         *  \note Assigning a pointer before `init` makes the object adopt that buffer, as the reference does. */
+         *  \note Assigning a pointer before `init` makes the object adopt that buffer, as the reference does
+         *        (src/ocl_icp_reg.cpp:111-113); the buffer stays the caller's.  After `init` the references hold the
+         *        buffers in use (the engine's own ones unless adopted), valid until the next `init`. */
         void*& get (Memory mem)
         {
             switch (mem)
@@ -214,6 +277,15 @@ namespace ICP
         /*! \brief One iteration; updates Rk qk tk sk R q t s like the reference (src/ICP/algorithms.cpp:4670-4698). */
         void run (bool config = false) { check (icp_step (h, config ? 1 : 0)); pull (); }
 
+        /*! \brief Switches between the benchmarked evaluation and the reference-order one (see icp::Mode). */
+        void setMode (icp::Mode _mode)
+        {
+            mode = _mode;
+            check (icp_set_reduce_mode (h, mode == icp::Mode::FAST ? ICP_REDUCE_FUSED : ICP_REDUCE_REFERENCE_ORDER));
+            check (icp_set_power_mode (h, mode == icp::Mode::FAST ? ICP_POWER_SQUARED : ICP_POWER_LITERAL));
+        }
+        icp::Mode getMode () const { return mode; }
+
         float getAlpha () { return a; }
         void setAlpha (float _a) { check (icp_set_alpha (h, _a)); a = _a; }
         float getScaling () { return c; }
@@ -234,12 +306,16 @@ namespace ICP
         void init_ (unsigned int _m, unsigned int _nr, float _a, float _c, unsigned int max_it, double ang, double tra, Staging _staging)
         {
             m = _m; nr = _nr; a = _a; c = _c; staging = _staging;
+            // A pointer found in dPtr[] is the caller's only if it is not one this object fetched from the engine after
+            // an earlier init: those belong to the handle, and icp_init is about to free them (re-init).
+            for (int i = 0; i < 2; ++i) { user[i] = dPtr[i] != nullptr && dPtr[i] != engine[i]; if (!user[i]) dPtr[i] = nullptr; }
             check (icp_init (h, m, nr, a, c, max_it, ang, tra));
-            if (dPtr[0]) check (icp_adopt_device_buffer (h, ICP_MEM_F, dPtr[0]));
-            if (dPtr[1]) check (icp_adopt_device_buffer (h, ICP_MEM_M, dPtr[1]));
+            if (user[0]) check (icp_adopt_device_buffer (h, ICP_MEM_F, dPtr[0]));
+            if (user[1]) check (icp_adopt_device_buffer (h, ICP_MEM_M, dPtr[1]));
             check (icp_device_ptr (h, ICP_MEM_F, &dPtr[0]));
             check (icp_device_ptr (h, ICP_MEM_M, &dPtr[1]));
             check (icp_device_ptr (h, ICP_MEM_T, &dPtr[2]));
+            for (int i = 0; i < 2; ++i) engine[i] = user[i] ? nullptr : dPtr[i];
             stageF.assign (staging == Staging::I || staging == Staging::IO ? (size_t) m * 8 : 0, 0.f);
             stageM.assign (stageF.size (), 0.f);
             hPtrInF = stageF.empty () ? nullptr : stageF.data ();
@@ -265,6 +341,9 @@ namespace ICP
         unsigned int m, nr;
         unsigned int k_ = 0;
         void *dPtr[3] = { nullptr, nullptr, nullptr };
+        void *engine[2] = { nullptr, nullptr };   // F / M buffers owned by the handle (as fetched after the last init)
+        bool user[2] = { false, false };          // F / M adopted from the caller at the last init
+        icp::Mode mode = icp::Mode::FAST;
         std::vector<float> stageF, stageM;
         float stageT[8];
     };
@@ -276,7 +355,7 @@ namespace ICP
     class ICP : public ICPStep<CR, CW>
     {
     public:
-        ICP (icp::Env _env) : ICPStep<CR, CW> (_env), k (0), max_iterations (40), angle_threshold (0.001), translation_threshold (0.01) {}
+        ICP (icp::Env _env, icp::Mode _mode = icp::Mode::FAST) : ICPStep<CR, CW> (_env, _mode), k (0), max_iterations (40), angle_threshold (0.001), translation_threshold (0.01) {}
 
         void init (unsigned int _m, unsigned int _nr, float _a = 1e2f, float _c = 1e-6f, unsigned int _max_iterations = 40,
                    double _angle_threshold = 0.001, double _translation_threshold = 0.01, Staging _staging = Staging::IO)

@@ -42,10 +42,15 @@ typedef enum { ICP_ROT_EIGEN = 0, ICP_ROT_POWER_METHOD = 1 } icp_rot;
 typedef enum { ICP_W_REGULAR = 0, ICP_W_WEIGHTED = 1 } icp_weighting;
 
 /* How the power method starts.  LITERAL = the reference loop from x=(1,1,1,1)
- * (kernels/icp_kernels.cl:1003-1022); SQUARED = same loop started from normalize(N^1024 * 1). */
+ * (kernels/icp_kernels.cl:1003-1022); SQUARED = same loop started from normalize(N^1024 * 1).
+ * Default of icp_create: SQUARED (the benchmarked path). */
 typedef enum { ICP_POWER_LITERAL = 0, ICP_POWER_SQUARED = 1 } icp_power_mode;
 
-/* How the three reductions of an iteration are evaluated.
+/* How the three reductions of an iteration are evaluated.  Default of icp_create: FUSED (the
+ * benchmarked path: 1 launch per iteration at latency-bound sizes, 2 otherwise); REFERENCE_ORDER (4 launches per
+ * iteration) is the opt-in for intermediates that restate the reference's arithmetic order.  The environment variable
+ * ICP_AMD_MODE=reference, read by icp_create, starts handles in REFERENCE_ORDER + LITERAL without a code change.
+ * Contract between the two: final [q | t, s] within 1e-5 relative (|q| = 1, scene scale for t, s itself).
  * REFERENCE_ORDER: sum of weights -> means -> S as three global trees in the reference's order
  * (kernels/icp_kernels.cl:213-329, 455-566, 588-743); every intermediate matches the literal oracle.
  * FUSED: one pass accumulating 18 moments in double, means and S derived from them; one global tree;
@@ -93,7 +98,8 @@ typedef struct {
 /* ---- life cycle ------------------------------------------------------------------------- */
 
 /* ICPStep<CR,CW>::ICPStep (env, infoRBC, infoICP) — include/ICP/algorithms.hpp:2269,
- * src/ICP/algorithms.cpp:4348-4358.  `device` replaces the CLEnv/CLEnvInfo pair. */
+ * src/ICP/algorithms.cpp:4348-4358.  `device` replaces the CLEnv/CLEnvInfo pair.  The handle starts in the modes
+ * ICP_REDUCE_FUSED + ICP_POWER_SQUARED (see above). */
 int icp_create (icp_handle *h, int device, int rot, int weighted);
 int icp_destroy (icp_handle h);
 
@@ -125,8 +131,10 @@ size_t icp_mem_size (icp_handle h, int mem);
 
 /* cl::Memory& ICPStep::get (Memory) — include/ICP/algorithms.hpp:2270,
  * src/ICP/algorithms.cpp:4366-4383: the device buffer itself, for zero-copy chaining.
- * adopt: the caller's device buffer replaces the handle's (must be called after init and stay
- * valid for the handle's lifetime; F/M only). */
+ * The pointers icp_device_ptr returns are valid until the next icp_init* / icp_destroy on the handle (init frees and
+ * re-creates every buffer the handle owns).
+ * adopt: the caller's device buffer replaces the handle's (F/M only; call after init, again after every re-init; the
+ * buffer stays the caller's — never freed by the handle — and must outlive its use by the handle). */
 int icp_device_ptr (icp_handle h, int mem, void **dptr);
 int icp_adopt_device_buffer (icp_handle h, int mem, void *dptr);
 
@@ -142,7 +150,9 @@ int icp_build_rbc (icp_handle h);
 int icp_step (icp_handle h, int config);
 
 /* ICP::run () — include/ICP/algorithms.hpp:2446, src/ICP/algorithms.cpp:4806-4834: iterate until
- * check() stops; blocking.  *k receives the iteration count (ICP::k) of registration 0. */
+ * check() stops; blocking.  *k receives the iteration count (ICP::k) of registration 0 (a batch: icp_state_b gives every
+ * registration's own k and converged flag; a registration that has converged is skipped by the remaining launches of
+ * the graph, which is always max_iterations launches long). */
 int icp_run (icp_handle h, uint32_t *k);
 
 /* ICP::run (timer) — include/ICP/algorithms.hpp:2482-2494: exactly `iterations` steps, no
@@ -184,6 +194,14 @@ int icp_write_cloud (icp_handle h, int which, const void *host_cloud_640x480x8, 
 /* ICPTransform<QUATERNION> on an arbitrary cloud with the handle's current T —
  * src/ocl_icp_reg.cpp:175 (full-cloud transform after run()).  Host in, host out; n points. */
 int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint32_t n);
+
+/* ICPTransform<QUATERNION> / ICPTransform<MATRIX> with an explicit transformation — include/ICP/algorithms.hpp:1189-1211,
+ * 1240, 1348; src/ICP/algorithms.cpp:2554-2753 (quaternion), :2760-2960 (matrix); kernels/icp_kernels.cl:772-802
+ * (icpTransform_Quaternion), :842-879 (icpTransform_Quaternion_2: the same mapping through two 4x4 products),
+ * :904-933 (icpTransform_Matrix).  T: 8 floats [q | t, s] for the quaternion kinds, 16 floats (row-major 4x4, the
+ * scaling already in the rotation block) for MATRIX.  Host in, host out; n points of 8 floats; needs no icp_init. */
+typedef enum { ICP_TRANSFORM_QUATERNION = 0, ICP_TRANSFORM_QUATERNION_2 = 1, ICP_TRANSFORM_MATRIX = 2 } icp_transform_kind;
+int icp_transform_cloud_ex (icp_handle h, int kind, const float *T, const void *host_in, void *host_out, uint32_t n);
 
 /* ---- standalone Reduce / Scan classes of the reference ------------------------------ */
 

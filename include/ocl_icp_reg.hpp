@@ -28,10 +28,10 @@ public:
     /*! \brief reference: `ICPReg (GLuint *glPC4DBuffer, GLuint *glRGBABuffer)`, src/ocl_icp_reg.cpp:81-120 —
      *         sizes and parameters as there (:82, :88): 640 x 480 clouds, 16384 landmarks, 256 representatives,
      *         a = 2e2, c = 1e-6, 40 iterations, 0.001 degrees, 0.01 mm. */
-    explicit ICPReg (int device = 0) :
+    explicit ICPReg (int device = 0, icp::Mode mode = icp::Mode::FAST) :
         width (640), height (480), n (640 * 480), m (16384), r (256),
         a (2e2f), c (1e-6f), max_iterations (40), angle_threshold (0.001), translation_threshold (0.01),
-        env (device), reg (env), latency_ms (0.0)
+        env (device), reg (env, mode), latency_ms (0.0)
     {
         reg.init (m, r, a, c, max_iterations, angle_threshold, translation_threshold, cl_algo::ICP::Staging::NONE);
     }

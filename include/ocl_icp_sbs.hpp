@@ -24,9 +24,9 @@ class ICPSBS
 {
 public:
     /*! \brief reference: `ICPSBS (GLuint*, GLuint*)`, src/ocl_icp_sbs.cpp:81-118 (sizes and parameters :82, :88). */
-    explicit ICPSBS (int device = 0) :
+    explicit ICPSBS (int device = 0, icp::Mode mode = icp::Mode::FAST) :
         width (640), height (480), n (640 * 480), m (16384), r (256), a (2e2f), c (1e-6f),
-        env (device), icpStep (env), config (true), k (0)
+        env (device), icpStep (env, mode), config (true), k (0)
     {
         icpStep.init (m, r, a, c, cl_algo::ICP::Staging::NONE);
     }

@@ -4,8 +4,10 @@
 #include <stdlib.h>
 #include "icp_amd.h"
 
-int main (void)
+int main (int argc, char **argv)
 {
+    /* argument "reference": the reference-order / literal modes instead of the defaults (fused / squared) */
+    const int reference = argc > 1 && argv[1][0] == 'r';
     const uint32_t side = 64, m = side * side, nr = 64;
     float *F = (float *) malloc ((size_t) m * 32), *M = (float *) malloc ((size_t) m * 32);
     const float axis[3] = { 0.3f, 0.9f, 0.1f }, t[3] = { 25.f, -10.f, 15.f };
@@ -15,6 +17,7 @@ int main (void)
             icp_handle h = NULL;
             if (icp_create (&h, 0, rot, w) != ICP_OK) { fprintf (stderr, "%s\n", icp_last_error (NULL)); return 1; }
             uint32_t k = 0; float T[8];
+            if (reference && (icp_set_reduce_mode (h, ICP_REDUCE_REFERENCE_ORDER) || icp_set_power_mode (h, ICP_POWER_LITERAL))) return 1;
             if (icp_init (h, m, nr, 2e2f, 1e-6f, 40, 0.001, 0.01) || icp_write (h, ICP_MEM_F, F, 0) || icp_write (h, ICP_MEM_M, M, 0) ||
                 icp_build_rbc (h) || icp_run (h, &k) || icp_read (h, ICP_MEM_T, T, sizeof T)) {
                 fprintf (stderr, "%s\n", icp_last_error (h)); return 1;

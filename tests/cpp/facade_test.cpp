@@ -13,6 +13,8 @@ int main (int argc, char **argv)
     const unsigned int side = argc > 1 ? (unsigned) atoi (argv[1]) : 64, r = argc > 2 ? (unsigned) atoi (argv[2]) : 64;
     const unsigned int m = side * side;
     const float a = 2e2f, c = 1e-6f;                                  // src/ocl_icp_reg.cpp:88
+    // third argument "reference": the reference-order / literal modes (default: the benchmarked fused / squared ones)
+    const icp::Mode mode = (argc > 3 && argv[3][0] == 'r') ? icp::Mode::REFERENCE_ORDER : icp::Mode::FAST;
     try
     {
         std::vector<float> F ((size_t) m * 8), M ((size_t) m * 8);
@@ -20,7 +22,7 @@ int main (int argc, char **argv)
         icp_synth_pair (0x1C9D5EEDull, side, 3.f, axis, t, 1.f, 0.01f, 0.f, F.data (), M.data ());
 
         icp::Env env (0);
-        ICP<ICPStepConfigT::POWER_METHOD, ICPStepConfigW::WEIGHTED> reg (env);
+        ICP<ICPStepConfigT::POWER_METHOD, ICPStepConfigW::WEIGHTED> reg (env, mode);
         reg.init (m, r, a, c, 40, 0.001, 0.01, Staging::IO);
         reg.write (decltype (reg)::Memory::D_IN_F, F.data ());
         reg.write (decltype (reg)::Memory::D_IN_M, M.data ());
@@ -32,13 +34,34 @@ int main (int argc, char **argv)
         printf ("q %.9g %.9g %.9g %.9g s %.9g\n", reg.q.x (), reg.q.y (), reg.q.z (), reg.q.w (), reg.s);
 
         // step-by-step object (src/ocl_icp_sbs.cpp:167-181): two iterations
-        ICPStep<ICPStepConfigT::POWER_METHOD, ICPStepConfigW::WEIGHTED> sbs (env);
+        ICPStep<ICPStepConfigT::POWER_METHOD, ICPStepConfigW::WEIGHTED> sbs (env, mode);
         sbs.init (m, r, a, c);
         sbs.write (decltype (sbs)::Memory::D_IN_F, F.data ());
         sbs.write (decltype (sbs)::Memory::D_IN_M, M.data ());
         sbs.buildRBC ();
         sbs.run (true); sbs.run ();
         printf ("S %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", sbs.q.x (), sbs.q.y (), sbs.q.z (), sbs.q.w (), sbs.t (0), sbs.t (1), sbs.t (2), sbs.s);
+
+        // re-init of the same object at another size, then at the first size again (the buffers fetched through get ()
+        // after the first init belong to the engine and are re-created, never adopted): same result as a fresh object
+        {
+            const unsigned int side2 = side / 2, m2 = side2 * side2, r2 = r / 4 ? r / 4 : 1;
+            std::vector<float> F2 ((size_t) m2 * 8), M2 ((size_t) m2 * 8);
+            icp_synth_pair (0x1C9D5EEDull, side2, 3.f, axis, t, 1.f, 0.01f, 0.f, F2.data (), M2.data ());
+            reg.init (m2, r2, a, c, 40, 0.001, 0.01, Staging::IO);
+            reg.write (decltype (reg)::Memory::D_IN_F, F2.data ());
+            reg.write (decltype (reg)::Memory::D_IN_M, M2.data ());
+            reg.buildRBC ();
+            reg.run ();
+            reg.init (m, r, a, c, 40, 0.001, 0.01, Staging::IO);
+            reg.write (decltype (reg)::Memory::D_IN_F, F.data ());
+            reg.write (decltype (reg)::Memory::D_IN_M, M.data ());
+            reg.buildRBC ();
+            reg.run ();
+            float *T2 = (float *) reg.read ();
+            printf ("k2 %u\n", reg.k);
+            printf ("T2 %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", T2[0], T2[1], T2[2], T2[3], T2[4], T2[5], T2[6], T2[7]);
+        }
 
         // standalone Reduce / Scan classes (tests/testsReduce.cpp, tests/testsScan.cpp of the reference)
         {
@@ -63,6 +86,27 @@ int main (int argc, char **argv)
                 if (mn[r] != m0) ++bad;
             }
             printf ("RS %d %.9g %.9g %.9g\n", bad, sm[0], sm[1], sm[2]);
+        }
+
+        // ICPTransform<QUATERNION> and <MATRIX> on the reference test's rotation (tests/testsICP.cpp:917-922: 36.21 degrees
+        // about (1,1,1)/sqrt(3)): the two must agree within that test's tolerance, 42000 eps
+        {
+            const unsigned int n = 4096;
+            ICPTransform<ICPTransformConfig::QUATERNION> tq (env); tq.init (n);
+            ICPTransform<ICPTransformConfig::MATRIX> tm (env); tm.init (n);
+            for (unsigned int i = 0; i < n * 8; ++i) tq.hPtrInM[i] = tm.hPtrInM[i] = (float) ((i * 2654435761u) % 25500u) * 0.01f;
+            const double half = 36.21 * M_PI / 360.0, ax = 1.0 / std::sqrt (3.0);
+            const float Tq[8] = { (float) (ax * std::sin (half)), (float) (ax * std::sin (half)), (float) (ax * std::sin (half)), (float) std::cos (half), 7.f, -3.f, 11.f, 1.f };
+            const float Tm[16] = { 0.871238f, -0.276687f, 0.405449f, 7.f, 0.405449f, 0.871238f, -0.276687f, -3.f, -0.276687f, 0.405449f, 0.871238f, 11.f, 0.f, 0.f, 0.f, 1.f };
+            std::memcpy (tq.hPtrInT, Tq, sizeof Tq); std::memcpy (tm.hPtrInT, Tm, sizeof Tm);
+            tq.write (); tm.write (); tq.run (); tm.run ();
+            const float *a = (const float *) tq.read (), *b = (const float *) tm.read ();
+            float worst = 0.f; int copied = 1;
+            for (unsigned int i = 0; i < n; ++i) {
+                for (int k = 0; k < 3; ++k) worst = std::max (worst, std::fabs (a[i * 8 + k] - b[i * 8 + k]));
+                for (int k = 3; k < 8; ++k) copied &= (a[i * 8 + k] == tq.hPtrInM[i * 8 + k]) && (b[i * 8 + k] == tm.hPtrInM[i * 8 + k]);
+            }
+            printf ("TR %.9g %d\n", worst, copied);
         }
 
         // argument errors surface as exceptions, not exit()

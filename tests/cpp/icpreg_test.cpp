@@ -5,13 +5,14 @@
 #include <ocl_icp_reg.hpp>
 #include <ocl_icp_sbs.hpp>
 
-int main ()
+int main (int argc, char **argv)
 {
+    const icp::Mode mode = (argc > 1 && argv[1][0] == 'r') ? icp::Mode::REFERENCE_ORDER : icp::Mode::FAST;
     try
     {
         std::vector<icp_float8> pc1 (640 * 480), pc2 (640 * 480);
         if (icp_synth_cloud_vga (0x1C9D5EEDull, 0, pc1[0].data ()) || icp_synth_cloud_vga (0x1C9D5EEDull, 1, pc2[0].data ())) return 2;
-        ICPReg<cl_algo::ICP::ICPStepConfigT::POWER_METHOD, cl_algo::ICP::ICPStepConfigW::WEIGHTED> app (0);
+        ICPReg<cl_algo::ICP::ICPStepConfigT::POWER_METHOD, cl_algo::ICP::ICPStepConfigW::WEIGHTED> app (0, mode);
         app.init (pc1, pc2);
         app.registerPC ();
         auto &reg = app.registration ();
@@ -22,7 +23,7 @@ int main ()
         printf ("C %.17g %.17g %.17g\n", cs[0], cs[1], cs[2]);
 
         // the step-by-step application (src/ocl_icp_sbs.cpp): three steps
-        ICPSBS<cl_algo::ICP::ICPStepConfigT::POWER_METHOD, cl_algo::ICP::ICPStepConfigW::WEIGHTED> sbs (0);
+        ICPSBS<cl_algo::ICP::ICPStepConfigT::POWER_METHOD, cl_algo::ICP::ICPStepConfigW::WEIGHTED> sbs (0, mode);
         sbs.init (pc1, pc2);
         sbs.step (); sbs.step (); sbs.step ();
         auto &st = sbs.stepper ();

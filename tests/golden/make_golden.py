@@ -69,6 +69,34 @@ def main():
         out[tag + "_run_T"] = f.T
     np.savez_compressed(os.path.join(HERE, "oracle_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "oracle_vectors.npz"), {k: np.asarray(v).shape for k, v in out.items()})
+    config4()
+
+
+def config4():
+    """BASELINE config 4 at its real per-GPU shape (64 pairs of 16384 / 256): for the checked registrations of
+    icp_amd/workloads.py, the default modes' (fused + squared) run to convergence and the 40-iteration fixed run from the
+    identity: k, converged, T, the first 256 correspondence ids and a digest of all of them."""
+    from icp_amd import workloads as C4
+    out = {"checked": np.array(C4.CHECKED)}
+    for i in C4.CHECKED:
+        F, M = C4.pair(icp_amd, i)
+        o = O.OracleICP(C4.M_POINTS, C4.NR, C4.A, C4.C_, power_fast=True, fused=True, threads=8)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        k = o.run()
+        ids = o.nn_id["id"]
+        out["r%d_run" % i] = np.array([k, int(o.converged)])
+        out["r%d_run_T" % i] = o.T
+        out["r%d_run_ids_head" % i] = ids[:256].copy()
+        out["r%d_run_ids_digest" % i] = C4.ids_digest(ids)
+        o.write_t([0, 0, 0, 1, 0, 0, 0, 1])
+        for _ in range(40):
+            o.step()
+        ids = o.nn_id["id"]
+        out["r%d_fixed40_T" % i] = o.T
+        out["r%d_fixed40_ids_head" % i] = ids[:256].copy()
+        out["r%d_fixed40_ids_digest" % i] = C4.ids_digest(ids)
+    np.savez_compressed(os.path.join(HERE, "config4_vectors.npz"), **out)
+    print("wrote config4_vectors.npz; k of the checked registrations:", [int(out["r%d_run" % i][0]) for i in C4.CHECKED])
 
 
 if __name__ == "__main__":

@@ -13,21 +13,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cpp_facade_matches_oracle(engine, oracle):
     exe = os.path.join(ROOT, "tests", "cpp", "facade_test")
     subprocess.check_call(["make", "-C", ROOT, "-s", "facade_test"])
-    out = subprocess.run([exe, "64", "64"], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr
-    lines = {l.split()[0]: l.split()[1:] for l in out.stdout.strip().splitlines()}
     F, M = engine.synth_pair(64)
-    o = oracle.OracleICP(4096, 64, 2e2, 1e-6, threads=8)
-    o.write_f(F); o.write_m(M); o.build_rbc()
-    k = o.run()
-    assert int(lines["k"][0]) == k
-    T = np.array([float(x) for x in lines["T"]], np.float32)
-    assert np.array_equal(T.view(np.uint32), o.T.view(np.uint32))
-    s = oracle.OracleICP(4096, 64, 2e2, 1e-6, threads=8)
-    s.write_f(F); s.write_m(M); s.build_rbc(); s.step(); s.step()
-    S = np.array([float(x) for x in lines["S"]], np.float32)
-    assert np.array_equal(S.view(np.uint32), s.T.view(np.uint32))
+    # both evaluation modes of the facade (icp::Mode): the default, benchmarked one and the reference-order one
+    for mode, fast in (("fast", True), ("reference", False)):
+        out = subprocess.run([exe, "64", "64", mode], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        lines = {l.split()[0]: l.split()[1:] for l in out.stdout.strip().splitlines()}
+        o = oracle.OracleICP(4096, 64, 2e2, 1e-6, threads=8, power_fast=fast, fused=fast)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        k = o.run()
+        assert int(lines["k"][0]) == k, mode
+        T = np.array([float(x) for x in lines["T"]], np.float32)
+        assert np.array_equal(T.view(np.uint32), o.T.view(np.uint32)), mode
+        # the same object re-initialised at another size and back (no stale device pointers): same result
+        assert int(lines["k2"][0]) == k and lines["T2"] == lines["T"], mode
+        s = oracle.OracleICP(4096, 64, 2e2, 1e-6, threads=8, power_fast=fast, fused=fast)
+        s.write_f(F); s.write_m(M); s.build_rbc(); s.step(); s.step()
+        S = np.array([float(x) for x in lines["S"]], np.float32)
+        assert np.array_equal(S.view(np.uint32), s.T.view(np.uint32)), mode
     assert "alpha parameter cannot be equal to zero" in " ".join(lines["ERR"])
+    # ICPTransform<QUATERNION> vs <MATRIX> on the reference test's 36.21 degree rotation: within 42000 eps, lanes 3..7 copied
+    assert float(lines["TR"][0]) < 42000 * np.finfo(np.float32).eps and int(lines["TR"][1]) == 1
     # Reduce<MIN>, Reduce<SUM>, Scan<EXCLUSIVE> class mirrors: min and scan checked in the program, the sums here
     assert int(lines["RS"][0]) == 0
     v = ((np.arange(3 * 1024, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1000)).astype(np.float32) * np.float32(0.25) - np.float32(100)
@@ -41,13 +47,18 @@ def test_cpp_icpreg_matches_oracle(engine, oracle):
     the GL plumbing): init (two VGA clouds) + registerPC = landmarks, RBC, run, full-cloud transform."""
     exe = os.path.join(ROOT, "tests", "cpp", "icpreg_test")
     subprocess.check_call(["make", "-C", ROOT, "-s", "icpreg_test"])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    cloud_f = engine.synth_cloud_vga(moved=False)
+    cloud_m = engine.synth_cloud_vga(moved=True)
+    for mode, fast in (("fast", True), ("reference", False)):
+        _icpreg_one_mode(engine, oracle, exe, mode, fast, cloud_f, cloud_m)
+
+
+def _icpreg_one_mode(engine, oracle, exe, mode, fast, cloud_f, cloud_m):
+    out = subprocess.run([exe, mode], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "Iterations" in out.stdout and "Rotation angle" in out.stdout and "Translation vector" in out.stdout
     lines = {l.split()[0]: l.split()[1:] for l in out.stdout.strip().splitlines() if l[:2] in ("k ", "T ", "C ", "S ")}
-    cloud_f = engine.synth_cloud_vga(moved=False)
-    cloud_m = engine.synth_cloud_vga(moved=True)
-    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8)
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=fast, fused=fast)
     o.write_f(oracle.get_lms(cloud_f)); o.write_m(oracle.get_lms(cloud_m)); o.build_rbc()
     assert int(lines["k"][0]) == o.run()
     T = np.array([float(x) for x in lines["T"]], np.float32)
@@ -57,7 +68,7 @@ def test_cpp_icpreg_matches_oracle(engine, oracle):
     assert np.allclose(got, want, rtol=1e-9)
     # ICPSBS (include/ocl_icp_sbs.hpp): three single steps
     assert out.stdout.count("Iteration k = ") == 3 and "Change in translation" in out.stdout
-    s3 = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8)
+    s3 = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=fast, fused=fast)
     s3.write_f(oracle.get_lms(cloud_f)); s3.write_m(oracle.get_lms(cloud_m)); s3.build_rbc()
     for _ in range(3):
         s3.step()
@@ -76,7 +87,7 @@ def test_get_lms_and_cloud_transform(engine, oracle):
     assert np.array_equal(g.read(engine.Memory.M), oracle.get_lms(cloud_m))
     g.buildRBC()
     k = g.run()
-    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8)
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)      # the handle's default modes
     o.write_f(oracle.get_lms(cloud_f)); o.write_m(oracle.get_lms(cloud_m)); o.build_rbc()
     assert k == o.run()
     T = g.read(engine.Memory.T)
@@ -116,7 +127,7 @@ def test_set_alpha_changes_the_metric(engine, oracle):
     g.write(engine.Memory.F, F); g.write(engine.Memory.M, M)
     g.setAlpha(1e-9)                                         # "really small a": colour ignored (data/README.md:12)
     g.buildRBC(); g.step()
-    o = oracle.OracleICP(1024, 16, 1e-9, 1e-6)
+    o = oracle.OracleICP(1024, 16, 1e-9, 1e-6, power_fast=True, fused=True)
     o.write_f(F); o.write_m(M); o.build_rbc(); o.step()
     assert np.array_equal(g.read(engine.Memory.NN_ID)["id"], o.nn_id["id"])
     assert np.array_equal(g.read(engine.Memory.T).view(np.uint32), o.T.view(np.uint32))
@@ -166,19 +177,20 @@ def test_plain_c_program_all_specialisations(engine, oracle):
     """tests/cpp/capi_example.c (gcc -std=c99): the four ICPStep specialisations through the bare C-ABI."""
     exe = os.path.join(ROOT, "tests", "cpp", "capi_example")
     subprocess.check_call(["make", "-C", ROOT, "-s", "capi_example"])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr
     F, M = engine.synth_pair(64)
-    lines = out.stdout.strip().splitlines()
-    assert len(lines) == 4
-    for line in lines:
-        tok = line.split()
-        rot, w, k = int(tok[1]), int(tok[3]), int(tok[5])
-        T = np.array([float(x) for x in tok[7:15]], np.float32)
-        o = oracle.OracleICP(4096, 64, 2e2, 1e-6, rot=rot, weighted=w, threads=8)
-        o.write_f(F); o.write_m(M); o.build_rbc()
-        assert k == o.run(), line
-        assert np.array_equal(T.view(np.uint32), o.T.view(np.uint32)), line
+    for args, fast in (([], True), (["reference"], False)):           # default modes, then the reference-order ones
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        lines = out.stdout.strip().splitlines()
+        assert len(lines) == 4
+        for line in lines:
+            tok = line.split()
+            rot, w, k = int(tok[1]), int(tok[3]), int(tok[5])
+            T = np.array([float(x) for x in tok[7:15]], np.float32)
+            o = oracle.OracleICP(4096, 64, 2e2, 1e-6, rot=rot, weighted=w, threads=8, power_fast=fast, fused=fast)
+            o.write_f(F); o.write_m(M); o.build_rbc()
+            assert k == o.run(), line
+            assert np.array_equal(T.view(np.uint32), o.T.view(np.uint32)), line
 
 
 def test_handles_are_independent_and_reusable(engine, oracle):
@@ -192,7 +204,8 @@ def test_handles_are_independent_and_reusable(engine, oracle):
     a.buildRBC(); b.buildRBC()
     for _ in range(3):
         a.step(); b.step()
-    oa = oracle.OracleICP(4096, 64, 2e2, 1e-6, threads=8); ob = oracle.OracleICP(1024, 16, 2e2, 1e-6)
+    oa = oracle.OracleICP(4096, 64, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+    ob = oracle.OracleICP(1024, 16, 2e2, 1e-6, power_fast=True, fused=True)
     for o_, F_, M_ in ((oa, F1, M1), (ob, F2, M2)):
         o_.write_f(F_); o_.write_m(M_); o_.build_rbc()
         for _ in range(3):
@@ -220,3 +233,83 @@ def test_handles_are_independent_and_reusable(engine, oracle):
         c.step()
     assert np.array_equal(c.read(engine.Memory.T).view(np.uint32), ob.T.view(np.uint32))
     c.close(); a.close(); b.close()
+
+
+def test_transform_kernels_bit_exact_and_reference_tolerances(engine, oracle):
+    """icpTransform_Quaternion, icpTransform_Quaternion_2 and icpTransform_Matrix in HIP (kernels/icp_kernels.cl:772-933)
+    against the oracle's restatements bit for bit, and the reference's own checks on its literals
+    (tests/testsICP.cpp:796-875: q = (0.5144, 0.5743, 0.5632, 0.2973), 4200 eps; :890-932: the 36.21 degree matrix, 42000 eps)."""
+    import json
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kat.json")))
+    eps = np.finfo(np.float32).eps
+    r = np.random.default_rng(5)
+    n = 16384
+    cloud = r.uniform(0, 255, (n, 8)).astype(np.float32)                       # ICP::rNum_0_255
+    g = engine.ICP(0)                                                           # (no init needed for the transforms)
+    K = engine.TransformKind
+    q = np.array(kat["transform_quaternion"]["q"], np.float32)
+    Tq = np.concatenate([q, r.uniform(0, 255, 3).astype(np.float32), [np.float32(r.uniform(0, 1))]]).astype(np.float32)
+    out_q = g.transform_cloud(cloud, Tq, K.QUATERNION)
+    out_q2 = g.transform_cloud(cloud, Tq, K.QUATERNION_2)
+    assert np.array_equal(out_q.view(np.uint32), oracle.transform_q(cloud, Tq).view(np.uint32))
+    assert np.array_equal(out_q2.view(np.uint32), oracle.transform_q(cloud, Tq, variant=2).view(np.uint32))
+    # the reference's check of the quaternion kernel: against a float64 evaluation of s R(q) p + t within 4200 eps * |p'|
+    qd = q.astype(np.float64)
+    x, y, z, w = qd
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]) / (qd @ qd)
+    want = Tq[7].astype(np.float64) * (cloud[:, :3].astype(np.float64) @ Rm.T) * (qd @ qd) + Tq[4:7].astype(np.float64)
+    assert np.abs(out_q[:, :3] - want).max() < 4200 * eps * 8, np.abs(out_q[:, :3] - want).max()
+    assert np.abs(out_q2[:, :3] - out_q[:, :3]).max() < 4200 * eps * 8
+    assert np.array_equal(out_q[:, 3:], cloud[:, 3:]) and np.array_equal(out_q2[:, 3:], cloud[:, 3:])
+    # matrix kernel: the reference test's literal rotation (times a scale), translation in column 3
+    s = np.float32(r.uniform(0, 1))
+    Rl = np.array(kat["transform_matrix"]["R"], np.float32).reshape(3, 3)
+    T16 = np.zeros((4, 4), np.float32)
+    T16[:3, :3] = s * Rl
+    T16[:3, 3] = r.uniform(0, 255, 3).astype(np.float32)
+    T16[3, 3] = 1.0
+    out_m = g.transform_cloud(cloud, T16, K.MATRIX)
+    assert np.array_equal(out_m.view(np.uint32), oracle.transform_m(cloud, T16.reshape(-1)).view(np.uint32))
+    wantm = cloud[:, :4].astype(np.float64) @ T16.astype(np.float64)[:3].T
+    assert np.abs(out_m[:, :3] - wantm).max() < 42000 * eps
+    # the same rotation as a quaternion: both kernels agree within the matrix test's tolerance
+    half = np.deg2rad(kat["transform_matrix"]["angle_deg"]) / 2
+    ax = np.array(kat["transform_matrix"]["axis"])
+    Tq2 = np.concatenate([ax * np.sin(half), [np.cos(half)], T16[:3, 3], [s]]).astype(np.float32)
+    # (cloud lane 3 is random here, the matrix kernel multiplies the translation column by it: use homogeneous points)
+    hom = cloud.copy()
+    hom[:, 3] = 1.0
+    assert np.abs(g.transform_cloud(hom, Tq2, K.QUATERNION)[:, :3] - g.transform_cloud(hom, T16, K.MATRIX)[:, :3]).max() < 42000 * eps
+    # ragged sizes (grid tail) and the error paths
+    for nn in (1, 255, 257, 1000):
+        assert np.array_equal(g.transform_cloud(cloud[:nn], T16, K.MATRIX).view(np.uint32), oracle.transform_m(cloud[:nn], T16.reshape(-1)).view(np.uint32))
+    with pytest.raises(ValueError):
+        g.transform_cloud(cloud, Tq, K.MATRIX)
+    with pytest.raises(engine.ICPError):
+        g._chk(g._L.icp_transform_cloud_ex(g._h, 7, Tq.ctypes.data, cloud.ctypes.data, out_q.ctypes.data, n))
+    g.close()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path end to end the way the driver launches it (torch.distributed.run, one process per rank), here
+    with both ranks on GPU 0 and the gloo backend: replicas only — every rank registers its own batch, rank 0 prints one
+    JSON line whose value counts the iterations of both ranks."""
+    import json
+    import socket
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ICP_BENCH_DEVICE="0", ICP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "replicas"
+    assert d["config"]["registrations_per_gpu"] == 2 and d["roofline"]["registrations_per_launch"] == 2
+    # 2 ranks x 2 registrations x 3 steps x 40 iterations over the max-over-ranks time
+    assert d["value"] == pytest.approx(2 * 2 * 3 * 40 / (d["ms_per_step"] * 3 * 1e-3), rel=1e-6)
+    assert "cpu_baseline" not in d and "other_configs" not in d

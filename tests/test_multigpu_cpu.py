@@ -50,4 +50,9 @@ def test_aggregate_single_process():
     sys.path.insert(0, ROOT)
     import bench
     assert bench.aggregate(None, 0.5, 40) == (0.5, 40)
-    assert bench.ALGO_BYTES_PER_ITER == 72 * 16384 + 32 * 256 + 64 == 1187904
+    from icp_amd import workloads as W
+    assert W.algorithmic_bytes(16384, 256) == 72 * 16384 + 32 * 256 + 64 == 1187904
+    assert W.algorithmic_bytes(65536, 1024) == 4751424 and W.algorithmic_bytes(1 << 20, 4096) == 75628608
+    # registrations per GPU: the headline on one GPU, BASELINE config 4 (64 per GPU) on several, --batch wins
+    assert bench.default_batch(1, 0) == 1 and bench.default_batch(8, 0) == 64 and bench.default_batch(8, 3) == 3
+    assert bench.default_batch(1, 64) == 64

@@ -360,3 +360,21 @@ def test_fused_moments_against_float64(oracle):
     assert np.all(np.abs(S[:9] - Sref) <= 4 * EPS * np.abs(Sref).max())
     assert abs(S[9] - c * c * (w * ((f - mf) ** 2).sum(1)).sum()) <= 4 * EPS * S[9]
     assert abs(S[10] - c * c * (w * ((q - mq) ** 2).sum(1)).sum()) <= 4 * EPS * S[10]
+
+
+@pytest.mark.parametrize("i", [0, 36])
+def test_config4_fixture_pins_the_oracle(oracle, engine, i):
+    """tests/golden/config4_vectors.npz (BASELINE config 4's real shape; script tests/golden/make_golden.py): the oracle
+    reproduces it (two of the eight checked registrations here, to keep the CPU suite short; the GPU test checks all)."""
+    from icp_amd import workloads as C4
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config4_vectors.npz"))
+    assert i in gold["checked"]
+    F, M = C4.pair(engine, i)
+    o = oracle.OracleICP(C4.M_POINTS, C4.NR, C4.A, C4.C_, power_fast=True, fused=True, threads=8)
+    o.write_f(F); o.write_m(M); o.build_rbc()
+    k = o.run()
+    assert (k, int(o.converged)) == tuple(int(v) for v in gold["r%d_run" % i])
+    assert np.array_equal(o.T.view(np.uint32), gold["r%d_run_T" % i].view(np.uint32))
+    ids = o.nn_id["id"]
+    assert np.array_equal(ids[:256], gold["r%d_run_ids_head" % i])
+    assert np.array_equal(C4.ids_digest(ids), gold["r%d_run_ids_digest" % i])

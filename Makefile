@@ -2,8 +2,8 @@
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 # -ffp-contract=off: the canonical arithmetic has no fused multiply-add
-HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -mllvm -amdgpu-kernarg-preload-count=14
-SRC      := icp_amd/csrc/icp_kernels.hip icp_amd/csrc/icp_capi.hip icp_amd/csrc/icp_reduce_scan.hip icp_amd/csrc/icp_synth.cpp
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -pthread -mllvm -amdgpu-kernarg-preload-count=14
+SRC      := icp_amd/csrc/icp_kernels.hip icp_amd/csrc/icp_capi.hip icp_amd/csrc/icp_reduce_scan.hip icp_amd/csrc/icp_synth.cpp icp_amd/csrc/icp_batch.cpp
 HDR      := icp_amd/csrc/icp_device.h icp_amd/csrc/icp_kernels.h include/icp_amd.h
 LIB      := icp_amd/libicp_amd.so
 
@@ -24,8 +24,19 @@ icpreg_test: $(LIB) tests/cpp/icpreg_test.cpp include/ocl_icp_reg.hpp include/oc
 capi_example: $(LIB) tests/cpp/capi_example.c include/icp_amd.h
 	gcc -O2 -std=c99 -Wall -Iinclude -o tests/cpp/capi_example tests/cpp/capi_example.c -Licp_amd -licp_amd -Wl,-rpath,'$$ORIGIN/../../icp_amd'
 
+# Host-side sanitizer build (GPU ASan is not available on this pool): the CPU oracle, the synthetic
+# generator and a driver over every oracle entry point at small / ragged / degenerate sizes, AddressSanitizer + UBSan.
+# No OpenMP (its runtime is not instrumented).  `make asan` builds and runs it; tests/test_oracle_golden.py does too.
+ASANFLAGS := -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -ffp-contract=off -fno-fast-math -mfma -Wall -Wno-unknown-pragmas
+tests/cpp/asan_host: tests/cpp/asan_host.cpp oracle/icp_oracle.c oracle/icp_oracle.h icp_amd/csrc/icp_synth.cpp include/icp_amd.h
+	gcc $(ASANFLAGS) -std=gnu11 -c oracle/icp_oracle.c -o tests/cpp/asan_oracle.o
+	g++ $(ASANFLAGS) -std=c++17 -o $@ tests/cpp/asan_host.cpp icp_amd/csrc/icp_synth.cpp tests/cpp/asan_oracle.o -lm
+
+asan: tests/cpp/asan_host
+	ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 tests/cpp/asan_host
+
 clean:
-	rm -f $(LIB) tests/cpp/facade_test tests/cpp/capi_example tests/cpp/icpreg_test
+	rm -f $(LIB) tests/cpp/facade_test tests/cpp/capi_example tests/cpp/icpreg_test tests/cpp/asan_host tests/cpp/asan_oracle.o
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean asan

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["ICP", "ICPStep", "ICPError", "Memory", "ICPStepConfigT", "ICPStepConfigW",
-           "PowerMode", "ReduceMode", "TransformKind", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
+           "PowerMode", "ReduceMode", "TransformKind", "ICPBatch", "batch_partition", "ReduceScan", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("ICP_AMD_LIB", os.path.join(_HERE, "libicp_amd.so"))   # override: A/B builds of the same ABI
@@ -122,14 +122,38 @@ def lib():
     sig("icp_write_cloud", i32, vp, i32, vp, i32)
     sig("icp_transform_cloud", i32, vp, vp, vp, u32)
     sig("icp_transform_cloud_ex", i32, vp, i32, vp, vp, vp, u32)
+    sig("icp_track_next", i32, vp, vp, i32, C.POINTER(u32), C.POINTER(i32))
+    sig("icp_track_reset", i32, vp)
+    sig("icp_batch_create", i32, C.POINTER(vp), C.POINTER(i32), i32, i32, i32)
+    sig("icp_batch_destroy", i32, vp)
+    sig("icp_batch_init", i32, vp, u32, u32, u32, f32, f32, u32, f64, f64)
+    sig("icp_batch_set_modes", i32, vp, i32, i32)
+    sig("icp_batch_write", i32, vp, u32, i32, vp)
+    sig("icp_batch_build_rbc", i32, vp)
+    sig("icp_batch_run", i32, vp)
+    sig("icp_batch_run_fixed", i32, vp, u32, i32)
+    sig("icp_batch_state", i32, vp, u32, C.POINTER(_State))
+    sig("icp_batch_read", i32, vp, u32, i32, vp, C.c_size_t)
+    sig("icp_batch_size", i32, vp, C.POINTER(u32), C.POINTER(u32))
+    sig("icp_batch_time_run_fixed", i32, vp, u32, u32, C.POINTER(f64))
+    sig("icp_batch_partition", i32, u32, u32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32))
+    sig("icp_batch_last_error", C.c_char_p, vp)
     sig("icp_time_run_fixed", i32, vp, u32, u32, i32, C.POINTER(f32))
     sig("icp_reset_transform", i32, vp)
     sig("icp_time_kernels", i32, vp, u32, C.POINTER(f32))
+    sig("icp_profile_run", i32, vp, u32, vp, C.POINTER(f32))
     sig("icp_time_masked", i32, vp, u32, u32, u32, C.POINTER(f32))
     sig("icp_launches_per_iteration", i32, vp, C.POINTER(u32))
     sig("icp_reduce", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_scan", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_reduce_scan_last_error", C.c_char_p)
+    sig("icp_rs_create", i32, C.POINTER(vp), i32, i32, u32, u32)
+    sig("icp_rs_write", i32, vp, vp)
+    sig("icp_rs_run", i32, vp)
+    sig("icp_rs_read", i32, vp, vp)
+    sig("icp_rs_device_ptr", i32, vp, i32, C.POINTER(vp))
+    sig("icp_rs_time", i32, vp, u32, C.POINTER(f32))
+    sig("icp_rs_destroy", i32, vp)
     sig("icp_last_error", C.c_char_p, vp)
     sig("icp_version", C.c_char_p)
     sig("icp_device_count", i32, C.POINTER(i32))
@@ -168,6 +192,56 @@ def scan(a, inclusive=True, device=0):
     return out
 
 
+class ReduceScan:
+    """Resident Reduce / Scan object (icp_rs_*): kind = ReduceConfig.MIN / MAX / SUM, or "inclusive" / "exclusive" scan.
+    Device buffers live with the object; run() enqueues kernels only; time(reps) = mean microseconds per run."""
+
+    def __init__(self, kind, cols, rows, device=0):
+        self._L = lib()
+        self._kind = {"inclusive": 3, "exclusive": 4}.get(kind, kind)
+        self._dt = np.int32 if self._kind >= 3 else (np.uint32 if self._kind == ReduceConfig.MAX else np.float32)
+        self.cols, self.rows = cols, rows
+        self._r = C.c_void_p()
+        rc = self._L.icp_rs_create(C.byref(self._r), device, self._kind, cols, rows)
+        if rc:
+            self._r = None
+            raise ICPError(rc, self._L.icp_reduce_scan_last_error().decode())
+
+    def _chk(self, rc):
+        if rc:
+            raise ICPError(rc, self._L.icp_reduce_scan_last_error().decode())
+
+    def write(self, a):
+        a = np.ascontiguousarray(a, self._dt)
+        if a.shape != (self.rows, self.cols):
+            raise ValueError("expected a %d x %d array" % (self.rows, self.cols))
+        self._chk(self._L.icp_rs_write(self._r, _p(a)))
+
+    def run(self):
+        self._chk(self._L.icp_rs_run(self._r))
+
+    def read(self):
+        out = np.empty((self.rows, self.cols) if self._kind >= 3 else self.rows, self._dt)
+        self._chk(self._L.icp_rs_read(self._r, _p(out)))
+        return out
+
+    def time(self, reps=100):
+        us = C.c_float()
+        self._chk(self._L.icp_rs_time(self._r, reps, C.byref(us)))
+        return us.value
+
+    def close(self):
+        if getattr(self, "_r", None):
+            self._L.icp_rs_destroy(self._r)
+            self._r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def device_count():
     n = C.c_int(0)
     lib().icp_device_count(C.byref(n))
@@ -192,6 +266,7 @@ def synth_pair(side, seed=0x1C9D5EED, rot_deg=3.0, axis=(0.3, 0.9, 0.1), t=(25.0
 
 
 def synth_cloud_vga(seed=0x1C9D5EED, moved=False):
+    """Synthetic 640x480 float8 cloud; `moved` = frame number of a sequence (False / 0: the scene, True / 1: one step)."""
     cloud = np.empty((480 * 640, 8), np.float32)
     rc = lib().icp_synth_cloud_vga(seed, int(moved), _p(cloud))
     if rc:
@@ -316,6 +391,19 @@ class ICPStep:
             raise ValueError("expected a 640x480 float8 cloud")
         self._chk(self._L.icp_write_cloud(self._h, which, _p(cloud), 1))
 
+    def track_next(self, cloud, warm_start=False):
+        """Frame-to-frame tracking: feeds the next 640x480 float8 frame; returns k (iterations) once there is a previous
+        frame to register against, else None.  One upload per frame; the previous landmarks stay on the device."""
+        cloud = np.ascontiguousarray(cloud, np.float32)
+        if cloud.size != 640 * 480 * 8:
+            raise ValueError("expected a 640x480 float8 cloud")
+        k, reg = C.c_uint32(), C.c_int()
+        self._chk(self._L.icp_track_next(self._h, _p(cloud), int(warm_start), C.byref(k), C.byref(reg)))
+        return k.value if reg.value else None
+
+    def track_reset(self):
+        self._chk(self._L.icp_track_reset(self._h))
+
     def transform_cloud(self, cloud, T=None, kind=TransformKind.QUATERNION):
         """ICPTransform: the handle's current T (default), or an explicit one — [q | t, s] for the quaternion kinds,
         a row-major 4x4 for TransformKind.MATRIX."""
@@ -352,6 +440,23 @@ class ICPStep:
         ms = C.c_float()
         self._chk(self._L.icp_time_masked(self._h, mask, iterations, reps, C.byref(ms)))
         return ms.value * 1e3 / (iterations * reps)
+
+    def profile_run(self, iterations=40, print_table=False):
+        """ICP::run(timer) (include/ICP/algorithms.hpp:2482-2494): `iterations` steps with per-step, per-stage times.
+        Returns (table[iterations][4] in ms: search, means, sij, finalize; total ms); print_table: the reference's
+        ProfilingInfo-style summary (mean / min / max / total per stage)."""
+        t = np.zeros((iterations, 4), np.float32)
+        tot = C.c_float()
+        self._chk(self._L.icp_profile_run(self._h, iterations, _p(t), C.byref(tot)))
+        if print_table:
+            print(" ICP::run (timer): %d steps, %.3f ms in all" % (iterations, tot.value))
+            print(" %-10s %10s %10s %10s %10s" % ("stage", "mean [us]", "min [us]", "max [us]", "total [ms]"))
+            for k, name in enumerate(("search", "means", "sij", "finalize")):
+                c = t[:, k] * 1e3
+                print(" %-10s %10.2f %10.2f %10.2f %10.3f" % (name, c.mean(), c.min(), c.max(), c.sum() / 1e3))
+            s = t.sum(1) * 1e3
+            print(" %-10s %10.2f %10.2f %10.2f %10.3f" % ("step", s.mean(), s.min(), s.max(), s.sum() / 1e3))
+        return t, tot.value
 
     def time_kernels(self, reps):
         out = (C.c_float * 4)()
@@ -421,3 +526,86 @@ class ICP(ICPStep):
     def setTranslationThreshold(self, mm):
         self._chk(self._L.icp_set_translation_threshold(self._h, mm))
         self._tra = mm
+
+
+def batch_partition(registrations, n_slots, i):
+    """(slot, index inside the slot, registrations of that slot) of registration i — icp_batch_partition (no device needed)."""
+    slot, idx, cnt = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = lib().icp_batch_partition(registrations, n_slots, i, C.byref(slot), C.byref(idx), C.byref(cnt))
+    if rc:
+        raise ICPError(rc, "icp_batch_partition: bad arguments")
+    return slot.value, idx.value, cnt.value
+
+
+class ICPBatch:
+    """B independent registrations over a list of devices inside the library (icp_batch_*, include/icp_amd.h):
+    registration i -> device slot i mod n, one host thread and one stream per slot, no collective."""
+
+    def __init__(self, devices, CR=ICPStepConfigT.POWER_METHOD, CW=ICPStepConfigW.WEIGHTED):
+        self._L = lib()
+        self._b = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        rc = self._L.icp_batch_create(C.byref(self._b), devs, len(devices), CR, CW)
+        if rc:
+            msg = self._L.icp_batch_last_error(None).decode()
+            self._b = None
+            raise ICPError(rc, msg)
+        self.m = 0
+
+    def _chk(self, rc):
+        if rc:
+            raise ICPError(rc, self._L.icp_batch_last_error(self._b).decode())
+
+    def close(self):
+        if getattr(self, "_b", None):
+            self._L.icp_batch_destroy(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def init(self, registrations, m, nr, a=1e2, c=1e-6, max_iterations=40, angle_threshold=0.001, translation_threshold=0.01):
+        self._chk(self._L.icp_batch_init(self._b, registrations, m, nr, a, c, max_iterations, angle_threshold, translation_threshold))
+        self.m, self.registrations = m, registrations
+
+    def set_modes(self, reduce_mode, power_mode):
+        self._chk(self._L.icp_batch_set_modes(self._b, reduce_mode, power_mode))
+
+    def write(self, i, mem, ptr):
+        arr = np.ascontiguousarray(ptr, dtype=np.float32)
+        want = 8 if mem == Memory.T else self.m * 8
+        if arr.size != want:
+            raise ValueError("write(%d): expected %d floats, got %d" % (mem, want, arr.size))
+        self._chk(self._L.icp_batch_write(self._b, i, mem, _p(arr)))
+
+    def buildRBC(self):
+        self._chk(self._L.icp_batch_build_rbc(self._b))
+
+    def run(self):
+        self._chk(self._L.icp_batch_run(self._b))
+
+    def run_fixed(self, iterations, from_identity=True):
+        self._chk(self._L.icp_batch_run_fixed(self._b, iterations, int(from_identity)))
+
+    def time_run_fixed(self, iterations, reps):
+        """Wall-clock seconds of `reps` passes on all slots at once."""
+        s = C.c_double()
+        self._chk(self._L.icp_batch_time_run_fixed(self._b, iterations, reps, C.byref(s)))
+        return s.value
+
+    def state(self, i):
+        st = _State()
+        self._chk(self._L.icp_batch_state(self._b, i, C.byref(st)))
+        return st
+
+    def read(self, i, mem):
+        dt, cols = _MEM_DTYPE[mem]
+        sizes = {Memory.T: 32, Memory.TK: 32, Memory.MEANS: 32, Memory.S: 44, Memory.NN_ID: self.m * 8, Memory.R: 36, Memory.RK: 36,
+                 Memory.F: self.m * 32, Memory.M: self.m * 32, Memory.W: self.m * 4, Memory.RID: self.m * 4}
+        nbytes = sizes[mem]
+        out = np.empty(nbytes // np.dtype(dt).itemsize, dt)
+        self._chk(self._L.icp_batch_read(self._b, i, mem, _p(out), nbytes))
+        return out.reshape(-1, cols) if cols else out

@@ -1,0 +1,201 @@
+// icp_batch.cpp — icp_batch_*: B independent registrations spread over a list of devices, inside the library.
+//
+// SURVEY.md §8b ("batched twins icp_batch_* (B registrations, device list)") / §8e: a frame pair does not shard, so
+// multi-GPU = replicas only.  Registration i lives on device slot i mod n as batch entry i / n of that slot's engine
+// handle (icp_init_batched: one launch set per slot serves all its registrations); one host thread and one HIP stream
+// per slot, pinned staging inside each handle, no collective, no peer access, no RCCL.  The reference has no
+// counterpart (single context, single in-order queue: src/ICP/algorithms.cpp:4351-4352).
+// Host code only: everything goes through the C-ABI of include/icp_amd.h.
+#include "../../include/icp_amd.h"
+
+#include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct icp_batch_context {
+    std::vector<int> devices;                    // device ordinal of every slot (ordinals may repeat)
+    std::vector<icp_handle> slots;               // one engine handle per slot
+    std::vector<uint32_t> count;                 // registrations of every slot
+    uint32_t registrations = 0;
+    int rot = 1, weighted = 1;
+    bool inited = false;
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_batch_create_error;
+
+int bfail (icp_batch_context *b, int code, const std::string &msg)
+{
+    if (b) b->err = msg; else g_batch_create_error = msg;
+    return code;
+}
+
+// runs fn (slot) on one host thread per slot that holds registrations; returns the first failing status
+template <typename Fn>
+int for_each_slot (icp_batch_context *b, Fn &&fn)
+{
+    const size_t n = b->slots.size ();
+    std::vector<int> rc (n, ICP_OK);
+    std::vector<std::thread> th;
+    for (size_t s = 0; s < n; ++s)
+        if (b->count[s]) th.emplace_back ([&, s] { rc[s] = fn (s); });
+    for (auto &t : th) t.join ();
+    for (size_t s = 0; s < n; ++s)
+        if (rc[s] != ICP_OK) return bfail (b, rc[s], "slot " + std::to_string (s) + " (device " + std::to_string (b->devices[s]) + "): " + icp_last_error (b->slots[s]));
+    return ICP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int icp_batch_partition (uint32_t registrations, uint32_t n_slots, uint32_t i, uint32_t *slot, uint32_t *index, uint32_t *slot_count)
+{
+    if (n_slots == 0 || i >= registrations) return ICP_EINVAL;
+    const uint32_t s = i % n_slots;
+    if (slot) *slot = s;
+    if (index) *index = i / n_slots;
+    if (slot_count) *slot_count = (registrations - s + n_slots - 1u) / n_slots;    // registrations s, s + n, s + 2n, ..
+    return ICP_OK;
+}
+
+const char *icp_batch_last_error (icp_batch_handle b) { return b ? b->err.c_str () : g_batch_create_error.c_str (); }
+
+int icp_batch_create (icp_batch_handle *out, const int *devices, int n_devices, int rot, int weighted)
+{
+    if (!out) return ICP_EINVAL;
+    *out = nullptr;
+    if (!devices || n_devices <= 0) return bfail (nullptr, ICP_EINVAL, "icp_batch_create: empty device list");
+    icp_batch_context *b = new icp_batch_context ();
+    b->rot = rot; b->weighted = weighted;
+    for (int d = 0; d < n_devices; ++d) {
+        icp_handle h = nullptr;
+        int rc = icp_create (&h, devices[d], rot, weighted);
+        if (rc != ICP_OK) {
+            std::string m = icp_last_error (nullptr);
+            for (icp_handle q : b->slots) icp_destroy (q);
+            delete b;
+            return bfail (nullptr, rc, "icp_batch_create: device " + std::to_string (devices[d]) + ": " + m);
+        }
+        b->devices.push_back (devices[d]); b->slots.push_back (h);
+    }
+    b->count.assign (b->slots.size (), 0u);
+    *out = b;
+    return ICP_OK;
+}
+
+int icp_batch_destroy (icp_batch_handle b)
+{
+    if (!b) return ICP_EINVAL;
+    for (icp_handle h : b->slots) icp_destroy (h);
+    delete b;
+    return ICP_OK;
+}
+
+int icp_batch_size (icp_batch_handle b, uint32_t *registrations, uint32_t *n_slots)
+{
+    if (!b) return ICP_EINVAL;
+    if (registrations) *registrations = b->registrations;
+    if (n_slots) *n_slots = (uint32_t) b->slots.size ();
+    return ICP_OK;
+}
+
+int icp_batch_init (icp_batch_handle b, uint32_t registrations, uint32_t m, uint32_t nr, float a, float c,
+                    uint32_t max_iterations, double angle_threshold, double translation_threshold)
+{
+    if (!b) return ICP_EINVAL;
+    if (registrations == 0) return bfail (b, ICP_EINVAL, "icp_batch_init: no registrations");
+    const uint32_t n = (uint32_t) b->slots.size ();
+    b->inited = false;
+    for (uint32_t s = 0; s < n; ++s) b->count[s] = s < registrations ? (registrations - s + n - 1u) / n : 0u;
+    b->registrations = registrations;
+    int rc = for_each_slot (b, [&] (size_t s) {
+        return icp_init_batched (b->slots[s], b->count[s], m, nr, a, c, max_iterations, angle_threshold, translation_threshold);
+    });
+    if (rc == ICP_OK) b->inited = true;
+    return rc;
+}
+
+#define BATCH_SLOT(b, i)                                                                              \
+    if (!(b)) return ICP_EINVAL;                                                                      \
+    if (!(b)->inited) return bfail ((b), ICP_ESTATE, "icp_batch_init has not been called");           \
+    if ((i) >= (b)->registrations) return bfail ((b), ICP_EINVAL, "registration index out of range"); \
+    const uint32_t slot_ = (i) % (uint32_t) (b)->slots.size (), idx_ = (i) / (uint32_t) (b)->slots.size (); \
+    icp_handle h_ = (b)->slots[slot_];
+
+#define BATCH_CALL(b, expr)                                                                           \
+    do { int rc_ = (expr); if (rc_ != ICP_OK) return bfail ((b), rc_, icp_last_error (h_)); } while (0)
+
+int icp_batch_write (icp_batch_handle b, uint32_t i, int mem, const void *host_ptr)
+{
+    BATCH_SLOT (b, i)
+    BATCH_CALL (b, icp_write_b (h_, idx_, mem, host_ptr, 0));
+    return ICP_OK;
+}
+
+int icp_batch_read (icp_batch_handle b, uint32_t i, int mem, void *host_dst, size_t bytes)
+{
+    BATCH_SLOT (b, i)
+    BATCH_CALL (b, icp_read_b (h_, idx_, mem, host_dst, bytes));
+    return ICP_OK;
+}
+
+int icp_batch_state (icp_batch_handle b, uint32_t i, icp_state_t *out)
+{
+    BATCH_SLOT (b, i)
+    BATCH_CALL (b, icp_state_b (h_, idx_, out));
+    return ICP_OK;
+}
+
+int icp_batch_set_modes (icp_batch_handle b, int reduce_mode, int power_mode)
+{
+    if (!b) return ICP_EINVAL;
+    for (icp_handle h : b->slots) {
+        int rc = icp_set_reduce_mode (h, reduce_mode); if (rc == ICP_OK) rc = icp_set_power_mode (h, power_mode);
+        if (rc != ICP_OK) return bfail (b, rc, icp_last_error (h));
+    }
+    return ICP_OK;
+}
+
+int icp_batch_build_rbc (icp_batch_handle b)
+{
+    if (!b || !b->inited) return b ? bfail (b, ICP_ESTATE, "icp_batch_init has not been called") : ICP_EINVAL;
+    return for_each_slot (b, [&] (size_t s) { int rc = icp_build_rbc (b->slots[s]); return rc ? rc : icp_sync (b->slots[s]); });
+}
+
+int icp_batch_run (icp_batch_handle b)
+{
+    if (!b || !b->inited) return b ? bfail (b, ICP_ESTATE, "icp_batch_init has not been called") : ICP_EINVAL;
+    return for_each_slot (b, [&] (size_t s) { return icp_run (b->slots[s], nullptr); });
+}
+
+int icp_batch_run_fixed (icp_batch_handle b, uint32_t iterations, int from_identity)
+{
+    if (!b || !b->inited) return b ? bfail (b, ICP_ESTATE, "icp_batch_init has not been called") : ICP_EINVAL;
+    return for_each_slot (b, [&] (size_t s) {
+        int rc = from_identity ? icp_reset_transform (b->slots[s]) : ICP_OK;
+        if (rc == ICP_OK) rc = icp_run_fixed (b->slots[s], iterations);
+        return rc ? rc : icp_sync (b->slots[s]);
+    });
+}
+
+int icp_batch_time_run_fixed (icp_batch_handle b, uint32_t iterations, uint32_t reps, double *seconds)
+{
+    if (!b || !b->inited) return b ? bfail (b, ICP_ESTATE, "icp_batch_init has not been called") : ICP_EINVAL;
+    if (!seconds || iterations == 0 || reps == 0) return bfail (b, ICP_EINVAL, "bad arguments");
+    // warm-up (graph capture and instantiation), then the timed passes: wall time around all slots = max over devices
+    int rc = icp_batch_run_fixed (b, iterations, 1);
+    if (rc != ICP_OK) return rc;
+    const auto t0 = std::chrono::steady_clock::now ();
+    rc = for_each_slot (b, [&] (size_t s) {
+        float ms = 0.f;
+        return icp_time_run_fixed (b->slots[s], iterations, reps, 1, &ms);
+    });
+    *seconds = std::chrono::duration<double> (std::chrono::steady_clock::now () - t0).count ();
+    return rc;
+}
+
+}  // extern "C"

@@ -41,7 +41,9 @@ struct icp_context {
     float *hF = nullptr, *hM = nullptr, *hT = nullptr;   // pinned staging (H_IN_F / H_IN_M / H_IO_T)
     float *dTin = nullptr;                       // device scratch for write(T)
     float *dCloud = nullptr, *dCloudOut = nullptr; uint32_t cloud_cap = 0;
-    std::map<uint64_t, graph_entry> graphs;      // key: iterations << 1 | check
+    std::map<uint64_t, graph_entry> graphs;      // key: iterations << 2 | check << 1 | parity
+    uint32_t parity = 0;                         // tracking: which of the two landmark buffers is the fixed set (graphs hold pointers)
+    uint32_t track_frames = 0;                   // frames fed to icp_track_next since init / icp_track_reset
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -81,7 +83,7 @@ void free_all (icp_context *h)
     if (h->dCloudOut) (void) hipFree (h->dCloudOut);
     h->hF = h->hM = h->hT = nullptr; h->dCloud = h->dCloudOut = nullptr; h->cloud_cap = 0;
     h->dF = h->dM = nullptr; h->ownF = h->ownM = true;
-    h->inited = h->built = false;
+    h->inited = h->built = false; h->parity = 0; h->track_frames = 0;
 }
 
 template <typename T>
@@ -155,7 +157,7 @@ int capture_graph (icp_context *h, Fn &&launches, graph_entry *out)
 // Capture `iterations` iterations into a graph (cached until a parameter changes).
 int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *out)
 {
-    uint64_t key = ((uint64_t) iterations << 1) | (uint64_t) (check ? 1 : 0);
+    uint64_t key = ((uint64_t) iterations << 2) | (uint64_t) (check ? 2 : 0) | (uint64_t) h->parity;
     auto it = h->graphs.find (key);
     if (it != h->graphs.end ()) { *out = it->second.exec; return ICP_OK; }
     icp_params p = h->p;
@@ -451,7 +453,7 @@ int icp_build_rbc (icp_handle h)
     if ((rc = set_device (h))) return rc;
     // the seven launches of the construction as one cached graph (key: all ones; dropped with the others when a
     // parameter or a buffer changes)
-    const uint64_t key = ~0ull;
+    const uint64_t key = ~0ull - h->parity;
     auto it = h->graphs.find (key);
     if (it == h->graphs.end ()) {
         graph_entry ge;
@@ -617,6 +619,42 @@ int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint
     return ICP_OK;
 }
 
+int icp_track_reset (icp_handle h)
+{
+    if (!h) return ICP_EINVAL;
+    h->track_frames = 0;
+    return ICP_OK;
+}
+
+int icp_track_next (icp_handle h, const void *cloud, int warm_start, uint32_t *k, int *registered)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if (h->p.m != 16384u || h->p.batch != 1u) return fail (h, ICP_EINVAL, "tracking needs m == 16384 (getLMs) and a single registration");
+    if (!cloud) return fail (h, ICP_EINVAL, "null pointer");
+    if (k) *k = 0;
+    if (registered) *registered = 0;
+    const bool have_prev = h->track_frames > 0;
+    if (have_prev) {
+        // the previous frame's landmarks (the moving set so far) become the fixed set: pointer swap on the device.  Graphs
+        // hold the pointers as kernel arguments: one set of graphs per parity, both stay cached.
+        std::swap (h->dF, h->dM); std::swap (h->ownF, h->ownM);
+        h->p.F = h->dF; h->p.M = h->dM;
+        h->parity ^= 1u;
+        h->built = false;
+    }
+    if ((rc = icp_write_cloud (h, ICP_MEM_M, cloud, 1))) return rc;       // upload + getLMs into the moving set
+    h->track_frames++;
+    if (!have_prev) return ICP_OK;
+    if ((rc = icp_build_rbc (h))) return rc;
+    if (warm_start) { icp_launch_set_T (h->p, 0, h->p.st->T, h->stream); HIPCHK (h, hipGetLastError ()); }   // as write (D_IO_T) of the previous T
+    else if ((rc = icp_reset_transform (h))) return rc;
+    uint32_t kk = 0;
+    if ((rc = icp_run (h, &kk))) return rc;
+    if (k) *k = kk;
+    if (registered) *registered = 1;
+    return ICP_OK;
+}
+
 int icp_transform_cloud_ex (icp_handle h, int kind, const float *T, const void *host_in, void *host_out, uint32_t n)
 {
     if (!h) return ICP_EINVAL;
@@ -682,7 +720,10 @@ int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t 
     if ((rc = set_device (h))) return rc;
     icp_params p = h->p; p.check = 0;
     graph_entry ge;
-    if ((rc = capture_graph (h, [&] { for (uint32_t k = 0; k < iterations; ++k) icp_launch_masked (p, h->stream, mask); }, &ge))) return rc;
+    // (the per-query outputs follow the policy of the fixed-length graphs: stored by the last iteration only in fused mode)
+    if ((rc = capture_graph (h, [&] {
+             for (uint32_t k = 0; k < iterations; ++k) { p.emit = (k + 1 == iterations) ? 1 : 0; icp_launch_masked (p, h->stream, mask); }
+         }, &ge))) return rc;
     hipError_t e = hipGraphLaunch (ge.exec, h->stream);                 // warm-up
     if (e == hipSuccess) e = hipEventRecord (h->ev0, h->stream);
     for (uint32_t r = 0; r < reps && e == hipSuccess; ++r) e = hipGraphLaunch (ge.exec, h->stream);
@@ -710,32 +751,50 @@ int icp_debug_stamps (icp_handle h, unsigned long long *out, uint32_t nblocks)
     return ICP_OK;
 }
 
-int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4)
+int icp_profile_run (icp_handle h, uint32_t iterations, float *out_ms, float *total_ms)
 {
     int rc = need (h, true); if (rc) return rc;
-    if (!out_ms4 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
+    if (!out_ms || iterations == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
-    icp_params p = h->p; p.check = 0;
-    std::vector<hipEvent_t> ev ((size_t) reps * 5);
-    for (auto &e : ev) HIPCHK (h, hipEventCreate (&e));
-    for (uint32_t r = 0; r < reps; ++r) {
-        hipEvent_t *e = &ev[(size_t) r * 5];
-        HIPCHK (h, hipEventRecord (e[0], h->stream)); icp_launch_search (p, h->stream);
-        HIPCHK (h, hipEventRecord (e[1], h->stream)); icp_launch_means (p, h->stream);
-        HIPCHK (h, hipEventRecord (e[2], h->stream)); icp_launch_sij (p, h->stream);
-        HIPCHK (h, hipEventRecord (e[3], h->stream)); icp_launch_finalize (p, h->stream);
-        HIPCHK (h, hipEventRecord (e[4], h->stream));
+    icp_params p = h->p; p.check = 0; p.emit = 1;
+    std::vector<hipEvent_t> ev ((size_t) iterations * 5, nullptr);
+    hipError_t e = hipSuccess;
+    for (auto &x : ev) if (e == hipSuccess) e = hipEventCreate (&x);
+    // the stages as separate launches (the chained form has no stage boundaries to time), events around each
+    for (uint32_t r = 0; r < iterations && e == hipSuccess; ++r) {
+        hipEvent_t *x = &ev[(size_t) r * 5];
+        e = hipEventRecord (x[0], h->stream); icp_launch_search (p, h->stream);
+        if (e == hipSuccess) e = hipEventRecord (x[1], h->stream);
+        if (!p.fused) icp_launch_means (p, h->stream);
+        if (e == hipSuccess) e = hipEventRecord (x[2], h->stream);
+        if (!p.fused) icp_launch_sij (p, h->stream);
+        if (e == hipSuccess) e = hipEventRecord (x[3], h->stream);
+        icp_launch_finalize (p, h->stream);
+        if (e == hipSuccess) e = hipEventRecord (x[4], h->stream);
     }
-    HIPCHK (h, hipStreamSynchronize (h->stream));
-    double acc[4] = { 0, 0, 0, 0 };
-    for (uint32_t r = 0; r < reps; ++r)
-        for (int k = 0; k < 4; ++k) {
-            float ms = 0.f;
-            HIPCHK (h, hipEventElapsedTime (&ms, ev[(size_t) r * 5 + k], ev[(size_t) r * 5 + k + 1]));
-            acc[k] += ms;
-        }
-    for (int k = 0; k < 4; ++k) out_ms4[k] = (float) (acc[k] / reps);
-    for (auto &e : ev) (void) hipEventDestroy (e);
+    if (e == hipSuccess) e = hipGetLastError ();
+    if (e == hipSuccess) e = hipStreamSynchronize (h->stream);
+    for (uint32_t r = 0; r < iterations && e == hipSuccess; ++r)
+        for (int k = 0; k < 4 && e == hipSuccess; ++k)
+            e = hipEventElapsedTime (&out_ms[(size_t) r * 4 + k], ev[(size_t) r * 5 + k], ev[(size_t) r * 5 + k + 1]);
+    if (e == hipSuccess && total_ms) e = hipEventElapsedTime (total_ms, ev[0], ev[(size_t) iterations * 5 - 1]);
+    for (auto &x : ev) if (x) (void) hipEventDestroy (x);
+    if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("icp_profile_run: ") + hipGetErrorString (e));
+    return ICP_OK;
+}
+
+int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4)
+{
+    if (!h) return ICP_EINVAL;
+    if (!out_ms4 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
+    std::vector<float> t ((size_t) reps * 4);
+    int rc = icp_profile_run (h, reps, t.data (), nullptr);
+    if (rc) return rc;
+    for (int k = 0; k < 4; ++k) {
+        double acc = 0.0;
+        for (uint32_t r = 0; r < reps; ++r) acc += t[(size_t) r * 4 + k];
+        out_ms4[k] = (float) (acc / reps);
+    }
     return ICP_OK;
 }
 

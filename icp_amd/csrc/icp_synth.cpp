@@ -107,11 +107,15 @@ extern "C" int icp_synth_pair (uint64_t seed, uint32_t side, float rot_deg, cons
 
 extern "C" int icp_synth_cloud_vga (uint64_t seed, int moved, float *cloud)
 {
-    if (!cloud) return ICP_EINVAL;
-    rng g (seed);
+    // `moved` = frame number of a synthetic sequence: frame 0 is the scene itself, frame f > 0 the scene moved rigidly by
+    // f times the step (3 degrees about (0.3, 0.9, 0.1), t = (25, -10, 15) mm), sampled at a half-pixel offset, with
+    // 1 mm noise (noise stream of frame f: seed for f = 1, seed + f beyond)
+    if (!cloud || moved < 0) return ICP_EINVAL;
+    rng g (moved > 1 ? seed + (uint64_t) moved : seed);
     const float axis[3] = { 0.3f, 0.9f, 0.1f };
-    double R[9]; rotation (moved ? 3.0 : 0.0, axis, R);
-    const double t[3] = { moved ? 25.0 : 0.0, moved ? -10.0 : 0.0, moved ? 15.0 : 0.0 };
+    const double f = (double) moved;
+    double R[9]; rotation (3.0 * f, axis, R);
+    const double t[3] = { 25.0 * f, -10.0 * f, 15.0 * f };
     for (uint32_t v = 0; v < 480; ++v)
         for (uint32_t u = 0; u < 640; ++u) {
             // scene() is parametrised on a square grid: map the VGA pixel onto a 640-wide one

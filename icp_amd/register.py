@@ -31,23 +31,19 @@ def register_clouds(fixed, moving, device=0, a=2e2, c=1e-6, max_iterations=40, a
     return T, k, ms, out
 
 
-def track(frames, device=0, a=2e2, c=1e-6, **kw):
+def track(frames, device=0, a=2e2, c=1e-6, warm_start=False, **kw):
     """Frame-to-frame registration (README.md:4 of the reference): frame i is the fixed set of frame i+1.
-    Yields (T_i, k_i) mapping frame i+1 onto frame i; one handle, landmarks re-extracted per frame."""
+    Yields (T_i, k_i) mapping frame i+1 onto frame i.  One handle; every frame is uploaded once, its landmarks are
+    extracted on the device and stay there to serve as the next hop's fixed set (icp_track_next); warm_start: each hop
+    starts from the previous hop's transform instead of the identity."""
     reg = ICP(device)
     reg.init(16384, 256, a, c, kw.get("max_iterations", 40), kw.get("angle_threshold", 0.001), kw.get("translation_threshold", 0.01))
     reg.setPowerMode(PowerMode.SQUARED)
     reg.setReduceMode(kw.get("reduce_mode", ReduceMode.FUSED))
-    prev = None
     for f in frames:
-        if prev is not None:
-            reg.write_cloud(Memory.F, prev)
-            reg.write_cloud(Memory.M, f)
-            reg.write(Memory.T, np.array([0, 0, 0, 1, 0, 0, 0, 1], np.float32))
-            reg.buildRBC()
-            k = reg.run()
+        k = reg.track_next(f, warm_start)
+        if k is not None:
             yield reg.read(Memory.T), k
-        prev = f
     reg.close()
 
 

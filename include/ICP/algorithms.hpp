@@ -22,6 +22,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -48,6 +49,28 @@ namespace icp
         float operator() (int i) const { return v[i]; }
         float x () const { return v[0]; } float y () const { return v[1]; } float z () const { return v[2]; }
         float norm () const { return std::sqrt ((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
+    };
+
+    /*! \brief Per-step, per-stage times of a profiling run (stands in for clutils::ProfilingInfo<N>, Appendix C of the
+     *         survey: `operator[]`, `print`, `total`).  ms; stage = icp_stage (search, means, sij, finalize). */
+    struct ProfilingInfo
+    {
+        std::vector<float> ms;      /*!< [step * 4 + stage] */
+        float total_ms = 0.f;
+        unsigned int steps () const { return (unsigned int) (ms.size () / 4); }
+        float operator() (unsigned int step, int stage) const { return ms[(size_t) step * 4 + stage]; }
+        double total (int stage) const { double s = 0; for (unsigned int i = 0; i < steps (); ++i) s += (*this) (i, stage); return s; }
+        double total () const { return total_ms; }
+        void print (const char *title = "ICP") const
+        {
+            static const char *names[4] = { "search", "means", "sij", "finalize" };
+            std::printf (" %s: %u steps, %.3f ms\n %-10s %10s %10s %10s %10s\n", title, steps (), total_ms, "stage", "mean [us]", "min [us]", "max [us]", "total [ms]");
+            for (int s = 0; s < 4; ++s) {
+                float mn = 1e30f, mx = 0.f;
+                for (unsigned int i = 0; i < steps (); ++i) { mn = std::fmin (mn, (*this) (i, s)); mx = std::fmax (mx, (*this) (i, s)); }
+                std::printf (" %-10s %10.2f %10.2f %10.2f %10.3f\n", names[s], total (s) / steps () * 1e3, mn * 1e3, mx * 1e3, total (s));
+            }
+        }
     };
 
     /*! \brief Unit quaternion stored like Eigen::Quaternionf::coeffs (): x, y, z, w. */
@@ -97,26 +120,37 @@ namespace ICP
         enum class Memory : uint8_t { H_IN, H_OUT, D_IN, D_RED, D_OUT };
         static_assert ((C == ReduceConfig::MAX && sizeof (T) == 4) || C != ReduceConfig::MAX, "MAX reduces 32-bit unsigned integers");
 
-        explicit Reduce (icp::Env _env) : env (_env), cols (0), rows (0) {}
+        explicit Reduce (icp::Env _env) : env (_env), h (nullptr), cols (0), rows (0) {}
+        Reduce (const Reduce&) = delete;
+        Reduce& operator= (const Reduce&) = delete;
+        ~Reduce () { if (h) icp_rs_destroy (h); }
+        /*! \brief Creates the device buffers (they live until the next init / destruction). */
         void init (unsigned int _cols, unsigned int _rows, Staging = Staging::IO)
         {
             if (_cols == 0 || _rows == 0 || _cols % 4) throw std::runtime_error ("Reduce::init: cols must be a positive multiple of 4");
+            if (h) { icp_rs_destroy (h); h = nullptr; }
+            const int kind = C == ReduceConfig::MIN ? ICP_RS_MIN_F : C == ReduceConfig::MAX ? ICP_RS_MAX_UI : ICP_RS_SUM_F;
+            chk (icp_rs_create (&h, env.device, kind, _cols, _rows));
             cols = _cols; rows = _rows; in.assign ((size_t) cols * rows, T ()); out.assign (rows, T ());
         }
+        /*! \brief Device buffer (reference: cl::Memory& get (Memory)): D_IN, or D_OUT = the result of the last run. */
+        void* get (Memory mem) { void *p = nullptr; chk (icp_rs_device_ptr (h, mem == Memory::D_OUT || mem == Memory::D_RED ? 1 : 0, &p)); return p; }
+        /*! \brief Host -> device (ptr == nullptr: the staging buffer hPtrIn () as it stands). */
         void write (Memory = Memory::D_IN, void *ptr = nullptr, bool = false)
-        { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (T)); }
-        void* read (Memory = Memory::H_OUT, bool = true) { return out.data (); }
-        void run ()
-        {
-            const int op = C == ReduceConfig::MIN ? ICP_REDUCE_MIN_F : C == ReduceConfig::MAX ? ICP_REDUCE_MAX_UI : ICP_REDUCE_SUM_F;
-            if (icp_reduce (env.device, op, in.data (), cols, rows, out.data ()) != ICP_OK)
-                throw std::runtime_error (std::string ("Reduce: ") + icp_reduce_scan_last_error ());
-        }
+        { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (T)); chk (icp_rs_write (h, in.data ())); }
+        /*! \brief Device -> host staging; blocking. */
+        void* read (Memory = Memory::H_OUT, bool = true) { chk (icp_rs_read (h, out.data ())); return out.data (); }
+        /*! \brief Enqueues the kernels; nothing is allocated or copied. */
+        void run () { chk (icp_rs_run (h)); }
+        /*! \brief The reference's run (timer): mean microseconds of `reps` runs (HIP events on the object's stream). */
+        double run (unsigned int reps, bool) { float us = 0.f; chk (icp_rs_time (h, reps, &us)); return us; }
         T *hPtrIn () { return in.data (); }
         T *hPtrOut () { return out.data (); }
 
     private:
+        void chk (int rc) { if (rc != ICP_OK) throw std::runtime_error (std::string ("Reduce: ") + icp_reduce_scan_last_error ()); }
         icp::Env env;
+        icp_rs_handle h;
         unsigned int cols, rows;
         std::vector<T> in, out;
     };
@@ -129,23 +163,28 @@ namespace ICP
     public:
         enum class Memory : uint8_t { H_IN, H_OUT, D_IN, D_SUMS, D_OUT };
 
-        explicit Scan (icp::Env _env) : env (_env), cols (0), rows (0) {}
+        explicit Scan (icp::Env _env) : env (_env), h (nullptr), cols (0), rows (0) {}
+        Scan (const Scan&) = delete;
+        Scan& operator= (const Scan&) = delete;
+        ~Scan () { if (h) icp_rs_destroy (h); }
         void init (unsigned int _cols, unsigned int _rows, Staging = Staging::IO)
         {
             if (_cols == 0 || _rows == 0 || _cols % 4) throw std::runtime_error ("Scan::init: cols must be a positive multiple of 4");
+            if (h) { icp_rs_destroy (h); h = nullptr; }
+            chk (icp_rs_create (&h, env.device, C == ScanConfig::INCLUSIVE ? ICP_RS_SCAN_INCLUSIVE : ICP_RS_SCAN_EXCLUSIVE, _cols, _rows));
             cols = _cols; rows = _rows; in.assign ((size_t) cols * rows, 0); out.assign ((size_t) cols * rows, 0);
         }
+        void* get (Memory mem) { void *p = nullptr; chk (icp_rs_device_ptr (h, mem == Memory::D_OUT ? 1 : 0, &p)); return p; }
         void write (Memory = Memory::D_IN, void *ptr = nullptr, bool = false)
-        { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (int32_t)); }
-        void* read (Memory = Memory::H_OUT, bool = true) { return out.data (); }
-        void run ()
-        {
-            if (icp_scan (env.device, C == ScanConfig::INCLUSIVE ? 1 : 0, in.data (), cols, rows, out.data ()) != ICP_OK)
-                throw std::runtime_error (std::string ("Scan: ") + icp_reduce_scan_last_error ());
-        }
+        { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (int32_t)); chk (icp_rs_write (h, in.data ())); }
+        void* read (Memory = Memory::H_OUT, bool = true) { chk (icp_rs_read (h, out.data ())); return out.data (); }
+        void run () { chk (icp_rs_run (h)); }
+        double run (unsigned int reps, bool) { float us = 0.f; chk (icp_rs_time (h, reps, &us)); return us; }
 
     private:
+        void chk (int rc) { if (rc != ICP_OK) throw std::runtime_error (std::string ("Scan: ") + icp_reduce_scan_last_error ()); }
         icp::Env env;
+        icp_rs_handle h;
         unsigned int cols, rows;
         std::vector<int32_t> in, out;
     };
@@ -373,6 +412,19 @@ namespace ICP
             this->check (icp_run (this->h, &kk));
             this->pull ();
             k = kk;
+        }
+
+        /*! \brief The reference's profiling run, `double run (clutils::GPUTimer<period>&)` (include/ICP/algorithms.hpp:
+         *         2482-2494): exactly 40 steps (or `steps`), no convergence test, per-step / per-stage table; prints it
+         *         like `steps.print ("ICP")` there and returns the total time in ms. */
+        double run (icp::ProfilingInfo &info, unsigned int steps = 40, bool print = true)
+        {
+            info.ms.assign ((size_t) steps * 4, 0.f);
+            this->check (icp_profile_run (this->h, steps, info.ms.data (), &info.total_ms));
+            this->pull ();
+            k = this->k_;
+            if (print) info.print ("ICP");
+            return info.total ();
         }
 
         unsigned int getMaxIterations () { return max_iterations; }

@@ -195,6 +195,18 @@ int icp_write_cloud (icp_handle h, int which, const void *host_cloud_640x480x8, 
  * src/ocl_icp_reg.cpp:175 (full-cloud transform after run()).  Host in, host out; n points. */
 int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint32_t n);
 
+/* Frame-to-frame tracking — README.md:4 ("real-time frame-to-frame registration"); per pair the demo's flow
+ * src/ocl_icp_reg.cpp:128-172 (init: getLMs of both clouds; registerPC: buildRBC + run).  Feeds the next 640x480 float8
+ * frame of a sequence: its landmarks are extracted on the device into the moving set (ONE upload of 9.8 MB per frame);
+ * the previous frame's landmarks, already resident, become the fixed set by a pointer swap (no copy, no host trip);
+ * then buildRBC and ICP::run.  warm_start != 0: the registration starts from the previous hop's transform (written
+ * back as by icp_write (ICP_MEM_T): the rotation state is re-derived from it) instead of the identity.
+ * *registered = 0 for the first frame after icp_init / icp_track_reset (nothing to register against; *k = 0), else 1
+ * and *k = iterations executed; afterwards T (icp_read, icp_state) maps the new frame onto the previous one.
+ * m must be 16384 (getLMs), batch 1.  Blocking (the source is pageable host memory). */
+int icp_track_next (icp_handle h, const void *host_cloud_640x480x8, int warm_start, uint32_t *k, int *registered);
+int icp_track_reset (icp_handle h);
+
 /* ICPTransform<QUATERNION> / ICPTransform<MATRIX> with an explicit transformation — include/ICP/algorithms.hpp:1189-1211,
  * 1240, 1348; src/ICP/algorithms.cpp:2554-2753 (quaternion), :2760-2960 (matrix); kernels/icp_kernels.cl:772-802
  * (icpTransform_Quaternion), :842-879 (icpTransform_Quaternion_2: the same mapping through two 4x4 products),
@@ -216,14 +228,63 @@ int icp_reduce (int device, int op, const void *host_in, uint32_t cols, uint32_t
 int icp_scan (int device, int inclusive, const int32_t *host_in, uint32_t cols, uint32_t rows, int32_t *host_out);
 const char *icp_reduce_scan_last_error (void);
 
+/* The same as resident objects, the shape of the reference's classes (ctor / init / write / run / read / get,
+ * include/ICP/algorithms.hpp:83-166, 200-290): the device buffers live as long as the object, run enqueues kernels only
+ * (no allocation, no copy), device_ptr is `get (Memory::D_IN / D_OUT)` for zero-copy chaining, time brackets `reps` runs
+ * with HIP events on the object's stream (the reference's run (timer): 44 us for a 1024 x 1024 sum, 151 us for a scan on its
+ * R9 270X, tests/testsReduce.cpp:252, tests/testsScan.cpp:175). */
+typedef enum { ICP_RS_MIN_F = 0, ICP_RS_MAX_UI = 1, ICP_RS_SUM_F = 2, ICP_RS_SCAN_INCLUSIVE = 3, ICP_RS_SCAN_EXCLUSIVE = 4 } icp_rs_kind;
+typedef struct icp_rs_context *icp_rs_handle;
+int icp_rs_create (icp_rs_handle *r, int device, int kind, uint32_t cols, uint32_t rows);
+int icp_rs_write (icp_rs_handle r, const void *host_in);            /* cols x rows elements (4 bytes each) */
+int icp_rs_run (icp_rs_handle r);                                   /* enqueue only */
+int icp_rs_read (icp_rs_handle r, void *host_out);                  /* rows results (reduce) / cols x rows (scan); blocking */
+int icp_rs_device_ptr (icp_rs_handle r, int output, void **dptr);   /* 0: input buffer, 1: result of the last run */
+int icp_rs_time (icp_rs_handle r, uint32_t reps, float *us_per_run);
+int icp_rs_destroy (icp_rs_handle r);
+
+/* ---- batches across devices (SURVEY.md §8b "icp_batch_*", §8e "replicas only") ---------------------------------------------
+ * B independent registrations over a device list, inside the library: registration i lives on slot i mod n (slot s =
+ * devices[s]; an ordinal may appear more than once) as batch entry i / n of that slot's engine handle, so every slot
+ * serves its registrations with one launch set (icp_init_batched).  One host thread + one HIP stream per slot, pinned
+ * staging per handle, no collective / peer access / RCCL.  The reference has no counterpart: one context, one in-order
+ * queue (src/ICP/algorithms.cpp:4351-4352); per registration the calls mean what ICP<CR,CW>::init / write / buildRBC / run
+ * mean (include/ICP/algorithms.hpp:2437-2462).  All calls block until every slot is done. */
+typedef struct icp_batch_context *icp_batch_handle;
+int icp_batch_create (icp_batch_handle *b, const int *devices, int n_devices, int rot, int weighted);
+int icp_batch_destroy (icp_batch_handle b);
+int icp_batch_init (icp_batch_handle b, uint32_t registrations, uint32_t m, uint32_t nr, float a, float c,
+                    uint32_t max_iterations, double angle_threshold, double translation_threshold);
+int icp_batch_set_modes (icp_batch_handle b, int reduce_mode, int power_mode);
+int icp_batch_write (icp_batch_handle b, uint32_t i, int mem, const void *host_ptr);       /* mem: F, M or T of registration i */
+int icp_batch_build_rbc (icp_batch_handle b);
+int icp_batch_run (icp_batch_handle b);                                                      /* ICP::run of every registration */
+int icp_batch_run_fixed (icp_batch_handle b, uint32_t iterations, int from_identity);
+int icp_batch_state (icp_batch_handle b, uint32_t i, icp_state_t *out);
+int icp_batch_read (icp_batch_handle b, uint32_t i, int mem, void *host_dst, size_t bytes);
+int icp_batch_size (icp_batch_handle b, uint32_t *registrations, uint32_t *n_slots);
+/* wall-clock seconds of `reps` fixed-length passes (from the identity) on all slots at once = max over devices */
+int icp_batch_time_run_fixed (icp_batch_handle b, uint32_t iterations, uint32_t reps, double *seconds);
+/* the partition rule as a pure function (no device needed): slot, index inside the slot, registrations of that slot */
+int icp_batch_partition (uint32_t registrations, uint32_t n_slots, uint32_t i, uint32_t *slot, uint32_t *index, uint32_t *slot_count);
+const char *icp_batch_last_error (icp_batch_handle b);   /* b may be NULL: error of the last failed create */
+
 /* ---- measurement (bench.py, HIP events on the handle's stream) --------------------------------- */
 
 /* Times `reps` back-to-back icp_run_fixed(iterations) passes with hipEvents recorded on the
  * handle's own stream; *ms_total = elapsed ms over all reps.  from_identity != 0: every pass starts from
  * the identity transform (a fresh registration, like the reference's 40-step profiling run). */
 int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int from_identity, float *ms_total);
-/* Times each kernel class of the iteration separately (events around each launch, `reps`
- * iterations): out_ms[0..3] = mean ms of {search, means, sij, finalize}. */
+/* ICP::run (timer) — include/ICP/algorithms.hpp:2482-2494: the reference's profiling run, exactly `iterations` steps
+ * (40 there) from the current state, no convergence test, with a per-step, per-stage table (the reference fills a
+ * ProfilingInfo<40> per kernel class through the run (timer) overloads, e.g. :2359-2399).  The stages run as separate
+ * launches with HIP events around each: out_ms[it * 4 + s], s = icp_stage; fused reductions have no means / Sij
+ * stage (those entries read ~0: two events back to back).  *total_ms (may be NULL) = first event to last.  Blocking.
+ * (The graphs behind icp_run / icp_run_fixed fuse stages further — icp_launches_per_iteration — and are timed whole by
+ * icp_time_run_fixed.) */
+typedef enum { ICP_STAGE_SEARCH = 0, ICP_STAGE_MEANS = 1, ICP_STAGE_SIJ = 2, ICP_STAGE_FINALIZE = 3, ICP_STAGE_COUNT_ = 4 } icp_stage;
+int icp_profile_run (icp_handle h, uint32_t iterations, float *out_ms, float *total_ms);
+/* Means of the same over `reps` iterations: out_ms[0..3] = mean ms of {search, means, sij, finalize}. */
 int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4);
 
 /* Kernel launches per iteration of the graphs behind icp_run / icp_run_fixed with the current modes and sizes:
@@ -247,7 +308,8 @@ int icp_device_count (int *n);
 int icp_synth_pair (uint64_t seed, uint32_t side, float rot_deg, const float *axis3,
                     const float *t3, float noise_mm, float noise_rgb, float zero_fraction,
                     float *F, float *M);
-/* Synthetic 640x480 float8 cloud for the getLMs path. */
+/* Synthetic 640x480 float8 cloud for the getLMs path; `moved` = frame number of a sequence (0: the scene, f: moved
+ * rigidly by f steps of 3 degrees / (25, -10, 15) mm, with noise). */
 int icp_synth_cloud_vga (uint64_t seed, int moved, float *cloud);
 
 #ifdef __cplusplus

@@ -1,0 +1,74 @@
+// asan_host.cpp — host-side sanitizer run ("-fsanitize=address on the host build"; GPU ASan is not
+// available on this pool).  Built by `make asan` with -fsanitize=address,undefined together with the CPU oracle
+// (oracle/icp_oracle.c) and the synthetic generator (icp_amd/csrc/icp_synth.cpp), no GPU involved: every oracle entry
+// point on small, ragged and degenerate sizes — out-of-bounds reads of the trees' padding, misaligned accesses and
+// signed overflows would abort the run.  Exit code 0 = clean.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../include/icp_amd.h"
+#include "../../oracle/icp_oracle.h"
+
+static int run_pipeline (uint32_t side, uint32_t nr, int rot, int weighted, int fast, int fused, float zero_fraction, uint32_t max_it)
+{
+    const uint32_t m = side * side;
+    std::vector<float> F ((size_t) m * 8), M ((size_t) m * 8);
+    const float axis[3] = { 0.3f, 0.9f, 0.1f }, t[3] = { 25.f, -10.f, 15.f };
+    if (icp_synth_pair (0x1C9D5EEDull + side, side, 3.f, axis, t, 1.f, 0.01f, zero_fraction, F.data (), M.data ())) return 1;
+    orc_icp *o = orc_icp_create (rot, weighted);
+    if (!o) return 1;
+    if (orc_icp_init (o, m, nr, 2e2f, 1e-6f, max_it, 0.001, 0.01)) { orc_icp_destroy (o); return 1; }
+    orc_icp_set_power_fast (o, fast); orc_icp_set_fused (o, fused); orc_icp_set_threads (o, 1);
+    orc_icp_write_f (o, F.data ()); orc_icp_write_m (o, M.data ());
+    orc_icp_build_rbc (o);
+    orc_icp_step (o);
+    const uint32_t k = orc_icp_run (o);
+    double acc = 0.0;
+    for (int i = 0; i < 8; ++i) acc += orc_icp_T (o)[i];
+    for (uint32_t i = 0; i < m; ++i) acc += orc_icp_nn_id (o)[i].id + orc_icp_W (o)[i] + orc_icp_rid (o)[i];
+    for (uint32_t r = 0; r < nr; ++r) acc += orc_icp_rbc_N (o)[r] + orc_icp_rbc_O (o)[r];
+    std::printf ("side %4u nr %4u rot %d w %d fast %d fused %d zeros %.2f -> k %2u checksum %.6g\n", side, nr, rot, weighted, fast, fused, zero_fraction, k, acc);
+    orc_icp_destroy (o);
+    return acc == acc ? 0 : 1;
+}
+
+int main ()
+{
+    int bad = 0;
+    // sizes: the smallest sets, one representative, every point a representative, sides that are not multiples of 8,
+    // partially filled 64-pair blocks and 128-element groups, zero points (one huge list)
+    const uint32_t shapes[][2] = { { 2, 1 }, { 2, 4 }, { 4, 2 }, { 6, 4 }, { 8, 64 }, { 10, 4 }, { 14, 4 }, { 16, 256 }, { 30, 4 }, { 32, 16 }, { 64, 64 } };
+    for (auto &s : shapes)
+        for (int mode = 0; mode < 4; ++mode)
+            bad += run_pipeline (s[0], s[1], 1, 1, mode & 1, mode >> 1, 0.f, 6);
+    for (int rot = 0; rot < 2; ++rot)
+        for (int w = 0; w < 2; ++w) bad += run_pipeline (32, 16, rot, w, 1, 1, 0.1f, 8) + run_pipeline (30, 4, rot, w, 0, 0, 0.3f, 8);
+    // getLMs on a VGA cloud, the three transforms, the standalone reduction
+    {
+        std::vector<float> cloud ((size_t) 640 * 480 * 8), lms ((size_t) 16384 * 8), out ((size_t) 16384 * 8);
+        if (icp_synth_cloud_vga (1, 2, cloud.data ())) ++bad;
+        orc_get_lms (cloud.data (), lms.data ());
+        const float T8[8] = { 0.5144f, 0.5743f, 0.5632f, 0.2973f, 1.f, 2.f, 3.f, 0.5f };
+        float T16[16] = { 0 }; T16[0] = T16[5] = T16[10] = T16[15] = 1.f; T16[3] = 4.f;
+        orc_transform_q (lms.data (), out.data (), T8, 16384);
+        orc_transform_q2 (lms.data (), out.data (), T8, 16384);
+        orc_transform_m (lms.data (), out.data (), T16, 16384);
+        std::vector<float> a ((size_t) 11 * 516), r (11);
+        for (size_t i = 0; i < a.size (); ++i) a[i] = (float) (i % 17) * 0.5f;
+        orc_reduce_sum_f (a.data (), 516, 11, r.data ());
+        std::vector<uint32_t> n (257, 3), ex (257);
+        orc_exscan_u32 (n.data (), 257, ex.data ());
+        if (ex[256] != 768u) ++bad;
+    }
+    // rejected arguments must not touch memory
+    {
+        orc_icp *o = orc_icp_create (1, 1);
+        if (!orc_icp_init (o, 15, 4, 2e2f, 1e-6f, 40, 0.001, 0.01)) ++bad;
+        if (!orc_icp_init (o, 16, 3, 2e2f, 1e-6f, 40, 0.001, 0.01)) ++bad;
+        if (!orc_icp_init (o, 16, 4, 0.f, 1e-6f, 40, 0.001, 0.01)) ++bad;
+        orc_icp_destroy (o);
+    }
+    std::printf ("asan_host: %s\n", bad ? "FAILED" : "clean");
+    return bad ? 1 : 0;
+}

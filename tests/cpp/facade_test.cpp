@@ -94,7 +94,7 @@ int main (int argc, char **argv)
             const unsigned int n = 4096;
             ICPTransform<ICPTransformConfig::QUATERNION> tq (env); tq.init (n);
             ICPTransform<ICPTransformConfig::MATRIX> tm (env); tm.init (n);
-            for (unsigned int i = 0; i < n * 8; ++i) tq.hPtrInM[i] = tm.hPtrInM[i] = (float) ((i * 2654435761u) % 25500u) * 0.01f;
+            for (unsigned int i = 0; i < n * 8; ++i) tq.hPtrInM[i] = tm.hPtrInM[i] = (i % 8 == 3) ? 1.f : (float) ((i * 2654435761u) % 25500u) * 0.01f;   // homogeneous points
             const double half = 36.21 * M_PI / 360.0, ax = 1.0 / std::sqrt (3.0);
             const float Tq[8] = { (float) (ax * std::sin (half)), (float) (ax * std::sin (half)), (float) (ax * std::sin (half)), (float) std::cos (half), 7.f, -3.f, 11.f, 1.f };
             const float Tm[16] = { 0.871238f, -0.276687f, 0.405449f, 7.f, 0.405449f, 0.871238f, -0.276687f, -3.f, -0.276687f, 0.405449f, 0.871238f, 11.f, 0.f, 0.f, 0.f, 1.f };
@@ -107,6 +107,18 @@ int main (int argc, char **argv)
                 for (int k = 3; k < 8; ++k) copied &= (a[i * 8 + k] == tq.hPtrInM[i * 8 + k]) && (b[i * 8 + k] == tm.hPtrInM[i * 8 + k]);
             }
             printf ("TR %.9g %d\n", worst, copied);
+        }
+
+        // the reference's profiling run: 40 steps, per-stage table (include/ICP/algorithms.hpp:2482-2494)
+        {
+            ICP<ICPStepConfigT::POWER_METHOD, ICPStepConfigW::WEIGHTED> prof (env, mode);
+            prof.init (m, r, a, c, 40, 0.001, 0.01, Staging::IO);
+            prof.write (decltype (prof)::Memory::D_IN_F, F.data ());
+            prof.write (decltype (prof)::Memory::D_IN_M, M.data ());
+            prof.buildRBC ();
+            icp::ProfilingInfo info;
+            const double ms = prof.run (info, 40, false);
+            printf ("PROF %u %u %.6f %.6f %.6f\n", info.steps (), prof.k, ms, info.total (ICP_STAGE_SEARCH), info.total (ICP_STAGE_FINALIZE));
         }
 
         // argument errors surface as exceptions, not exit()

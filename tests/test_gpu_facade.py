@@ -25,6 +25,9 @@ def test_cpp_facade_matches_oracle(engine, oracle):
         assert int(lines["k"][0]) == k, mode
         T = np.array([float(x) for x in lines["T"]], np.float32)
         assert np.array_equal(T.view(np.uint32), o.T.view(np.uint32)), mode
+        # ICP::run (timer): 40 steps, k = 40, search and finalize times positive and inside the total
+        pr = lines["PROF"]
+        assert (int(pr[0]), int(pr[1])) == (40, 40) and 0 < float(pr[3]) < float(pr[2]) and 0 < float(pr[4]) < float(pr[2]), pr
         # the same object re-initialised at another size and back (no stale device pointers): same result
         assert int(lines["k2"][0]) == k and lines["T2"] == lines["T"], mode
         s = oracle.OracleICP(4096, 64, 2e2, 1e-6, threads=8, power_fast=fast, fused=fast)
@@ -313,3 +316,129 @@ def test_bench_two_ranks_on_one_gpu():
     # 2 ranks x 2 registrations x 3 steps x 40 iterations over the max-over-ranks time
     assert d["value"] == pytest.approx(2 * 2 * 3 * 40 / (d["ms_per_step"] * 3 * 1e-3), rel=1e-6)
     assert "cpu_baseline" not in d and "other_configs" not in d
+
+
+@pytest.mark.parametrize("warm", [False, True])
+def test_tracking_on_device_four_frames(engine, oracle, warm):
+    """icp_track_next: a 4-frame synthetic sequence; every hop's T, k and correspondences equal the oracle's bit for bit,
+    cold (identity) and warm (previous hop's transform) start.  The previous frame's landmarks become the fixed set by a
+    pointer swap on the device: what the engine holds as F / M after each hop is checked too."""
+    frames = [engine.synth_cloud_vga(moved=f) for f in range(4)]
+    lms = [oracle.get_lms(c) for c in frames]
+    g = engine.ICP(0)
+    g.init(16384, 256, 2e2, 1e-6)
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+    assert g.track_next(frames[0], warm) is None                   # nothing to register against yet
+    ks = []
+    for i in range(1, 4):
+        k = g.track_next(frames[i], warm)
+        o.write_f(lms[i - 1]); o.write_m(lms[i])
+        o.write_t(o.T if (warm and i > 1) else [0, 0, 0, 1, 0, 0, 0, 1])
+        o.build_rbc()
+        assert k == o.run(), (i, k, o.k)
+        assert np.array_equal(g.read(engine.Memory.T).view(np.uint32), o.T.view(np.uint32)), i
+        assert np.array_equal(g.read(engine.Memory.NN_ID)["id"], o.nn_id["id"]), i
+        assert np.array_equal(g.read(engine.Memory.F), lms[i - 1]) and np.array_equal(g.read(engine.Memory.M), lms[i])
+        ks.append(k)
+    # each hop recovers roughly the sequence's step: 3 degrees (|q_v| = sin 1.5 deg)
+    assert abs(np.linalg.norm(g.read(engine.Memory.T)[:3]) - np.sin(np.deg2rad(1.5))) < 2e-3
+    # a new sequence on the same handle; plain write / buildRBC / run still work after the swaps
+    g.track_reset()
+    assert g.track_next(frames[2], warm) is None
+    F, M = engine.synth_pair(128)
+    g.write(engine.Memory.F, F); g.write(engine.Memory.M, M)
+    g.reset_transform(); g.buildRBC()
+    o2 = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+    o2.write_f(F); o2.write_m(M); o2.build_rbc()
+    assert g.run() == o2.run()
+    assert np.array_equal(g.read(engine.Memory.T).view(np.uint32), o2.T.view(np.uint32))
+    g.close()
+
+
+def test_batch_api_across_device_slots(engine, oracle):
+    """icp_batch_* with the device list [0, 0] (two slots = two handles, streams and host threads on the one GPU of this
+    box): 5 registrations land on slots 0,1,0,1,0; every one equals its own oracle; gather by registration index."""
+    from icp_amd import workloads as W
+    B = 5
+    b = engine.ICPBatch([0, 0])
+    b.init(B, W.M_POINTS, W.NR, W.A, W.C_)
+    pairs = [W.pair(engine, 7 * i) for i in range(B)]
+    for i, (F, M) in enumerate(pairs):
+        b.write(i, engine.Memory.F, F)
+        b.write(i, engine.Memory.M, M)
+    b.buildRBC()
+    b.run()
+    for i, (F, M) in enumerate(pairs):
+        o = oracle.OracleICP(W.M_POINTS, W.NR, W.A, W.C_, threads=8, power_fast=True, fused=True)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        ko = o.run()
+        st = b.state(i)
+        assert (st.k, bool(st.converged)) == (ko, o.converged), i
+        assert np.array_equal(b.read(i, engine.Memory.T).view(np.uint32), o.T.view(np.uint32)), i
+        assert np.array_equal(b.read(i, engine.Memory.NN_ID)["id"], o.nn_id["id"]), i
+    b.run_fixed(3)
+    assert all(b.state(i).k == 3 for i in range(B))
+    assert b.time_run_fixed(10, 2) > 0
+    with pytest.raises(engine.ICPError):
+        b.write(B, engine.Memory.F, pairs[0][0])
+    b.close()
+    with pytest.raises(engine.ICPError):
+        engine.ICPBatch([0, 99])
+
+
+def test_profile_run_table(engine, oracle, capsys):
+    """icp_profile_run = ICP::run (timer) (include/ICP/algorithms.hpp:2482-2494): 40 steps from the current state with a
+    per-step, per-stage table; the state afterwards equals 40 oracle steps; the table is consistent."""
+    for fused in (True, False):
+        F, M = engine.synth_pair(64)
+        g = engine.ICP(0)
+        g.init(4096, 64, 2e2, 1e-6)
+        g.setReduceMode(engine.ReduceMode.FUSED if fused else engine.ReduceMode.REFERENCE_ORDER)
+        g.write(engine.Memory.F, F); g.write(engine.Memory.M, M); g.buildRBC()
+        t, total = g.profile_run(40, print_table=True)
+        o = oracle.OracleICP(4096, 64, 2e2, 1e-6, threads=8, power_fast=True, fused=fused)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        for _ in range(40):
+            o.step()
+        assert g.k == 40
+        assert np.array_equal(g.read(engine.Memory.T).view(np.uint32), o.T.view(np.uint32))
+        assert t.shape == (40, 4) and np.all(t[:, 0] > 0) and np.all(t[:, 3] > 0) and t.sum() <= total * 1.001
+        if fused:
+            assert t[:, 1:3].max() < 0.02                    # no means / Sij stage: two events back to back
+        else:
+            assert np.all(t[:, 1] > 0) and np.all(t[:, 2] > 0)
+        out = capsys.readouterr().out
+        assert "ICP::run (timer): 40 steps" in out and "finalize" in out
+        g.close()
+
+
+def test_resident_reduce_scan_objects_and_timing(engine, oracle):
+    """icp_rs_*: device buffers stay with the object, run() launches kernels only, results chain across runs; timed at the
+    reference's own size, 1024 x 1024 (tests/testsReduce.cpp:252: 44 us, tests/testsScan.cpp:175: 151 us on an R9 270X)."""
+    r = np.random.default_rng(3)
+    a = r.uniform(0, 1, (1024, 1024)).astype(np.float32)
+    i = r.integers(0, 256, (1024, 1024)).astype(np.int32)
+    rs = engine.ReduceScan(engine.ReduceConfig.SUM, 1024, 1024)
+    rs.write(a)
+    rs.run(); rs.run()                                         # repeated runs on the resident input: same result
+    assert np.array_equal(rs.read().view(np.uint32), oracle.reduce_sum_f(a).view(np.uint32))
+    b = r.uniform(0, 1, (1024, 1024)).astype(np.float32)
+    rs.write(b); rs.run()
+    assert np.array_equal(rs.read().view(np.uint32), oracle.reduce_sum_f(b).view(np.uint32))
+    us_sum = rs.time(200)
+    rs.close()
+    sc = engine.ReduceScan("exclusive", 1024, 1024)
+    sc.write(i); sc.run()
+    inc = np.cumsum(i, axis=1, dtype=np.int32)
+    assert np.array_equal(sc.read(), inc - i)
+    us_scan = sc.time(200)
+    sc.close()
+    mn = engine.ReduceScan(engine.ReduceConfig.MIN, 1024, 1024)
+    mn.write(a); mn.run()
+    assert np.array_equal(mn.read(), a.min(1))
+    us_min = mn.time(200)
+    mn.close()
+    print("1024 x 1024: reduce_sum_f %.1f us, reduce_min_f %.1f us, exclusive scan %.1f us (reference, R9 270X: 44 / 45 / 151 us)" % (us_sum, us_min, us_scan))
+    assert 0 < us_sum < 44 and 0 < us_min < 45 and 0 < us_scan < 151
+    with pytest.raises(engine.ICPError):
+        engine.ReduceScan(engine.ReduceConfig.SUM, 6, 2)

@@ -46,6 +46,26 @@ def test_aggregate_world_size_2():
         assert u == pytest.approx(300.0)     # SUM over ranks
 
 
+def test_batch_partition_rule():
+    """icp_batch_*: registration i -> slot i mod n, entry i / n; the slots' counts add up; gather order = index order.
+    Pure host function of the library (no device needed)."""
+    import icp_amd
+    for B, n in ((512, 8), (64, 8), (5, 8), (7, 2), (1, 1), (9, 4)):
+        seen = {}
+        for i in range(B):
+            slot, idx, cnt = icp_amd.batch_partition(B, n, i)
+            assert slot == i % n and idx == i // n
+            assert cnt == len(range(slot, B, n))
+            assert (slot, idx) not in seen
+            seen[(slot, idx)] = i
+        assert sum(icp_amd.batch_partition(B, n, s)[2] for s in range(min(B, n))) == B
+    assert icp_amd.batch_partition(512, 8, 511) == (7, 63, 64)               # BASELINE config 4: 64 per GPU
+    with pytest.raises(icp_amd.ICPError):
+        icp_amd.batch_partition(4, 0, 0)
+    with pytest.raises(icp_amd.ICPError):
+        icp_amd.batch_partition(4, 2, 4)
+
+
 def test_aggregate_single_process():
     sys.path.insert(0, ROOT)
     import bench

@@ -378,3 +378,13 @@ def test_config4_fixture_pins_the_oracle(oracle, engine, i):
     ids = o.nn_id["id"]
     assert np.array_equal(ids[:256], gold["r%d_run_ids_head" % i])
     assert np.array_equal(C4.ids_digest(ids), gold["r%d_run_ids_digest" % i])
+
+
+def test_host_sanitizer_build_is_clean():
+    """`make asan`: the oracle + the synthetic generator under AddressSanitizer / UBSan over every oracle
+    entry point at small, ragged and degenerate sizes; any report aborts the program."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    r = subprocess.run(["make", "-C", root, "-s", "asan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "asan_host: clean" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr

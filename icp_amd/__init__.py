@@ -109,6 +109,8 @@ def lib():
     sig("icp_set_alpha", i32, vp, f32)
     sig("icp_get_scaling", i32, vp, C.POINTER(f32))
     sig("icp_set_scaling", i32, vp, f32)
+    sig("icp_set_metric_scale", i32, vp, f32)
+    sig("icp_get_metric_scale", i32, vp, C.POINTER(f32))
     sig("icp_get_max_iterations", i32, vp, C.POINTER(u32))
     sig("icp_set_max_iterations", i32, vp, u32)
     sig("icp_get_angle_threshold", i32, vp, C.POINTER(f64))
@@ -370,6 +372,15 @@ class ICPStep:
 
     def setScaling(self, c):
         self._chk(self._L.icp_set_scaling(self._h, c))
+
+    def setMetricScale(self, f_g):
+        """Absolute scale of the metric: reported dist = f_g (geo + a pho); matters for the weights only."""
+        self._chk(self._L.icp_set_metric_scale(self._h, f_g))
+
+    def getMetricScale(self):
+        v = C.c_float()
+        self._chk(self._L.icp_get_metric_scale(self._h, C.byref(v)))
+        return v.value
 
     # -- extensions ------------------------------------------------------------------------
     def setPowerMode(self, mode):

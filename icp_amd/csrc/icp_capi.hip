@@ -216,6 +216,7 @@ int icp_create (icp_handle *out, int device, int rot, int weighted)
     // ICP_AMD_MODE=reference (read here) starts the handle in the reference-order / literal modes instead, whose
     // intermediates restate the reference's arithmetic order; icp_set_reduce_mode / icp_set_power_mode switch later.
     h->p.rot = rot; h->p.weighted = weighted; h->p.power_mode = ICP_POWER_SQUARED; h->p.fused = ICP_REDUCE_FUSED;
+    h->p.dist_scale = 1.f;
     { const char *e = std::getenv ("ICP_AMD_MODE"); if (e && (e[0] == 'r' || e[0] == 'R')) { h->p.power_mode = ICP_POWER_LITERAL; h->p.fused = ICP_REDUCE_REFERENCE_ORDER; } }
     { const char *e = std::getenv ("ICP_AMD_CHAIN"); h->p.chain = !e ? 1 : (e[0] == '1') ? 2 : (e[0] == '0') ? 0 : 1; }   // see icp_chain_supported
     e = hipSetDevice (device);
@@ -260,10 +261,12 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     int rc = set_device (h); if (rc) return rc;
     if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
     int rot = h->p.rot, weighted = h->p.weighted, pmode = h->p.power_mode, fused = h->p.fused, chain = h->p.chain;
+    const float dist_scale = h->p.dist_scale;
     free_all (h);
     icp_params &p = h->p;
     p = icp_params {};
     p.rot = rot; p.weighted = weighted; p.power_mode = pmode; p.check = 0; p.fused = fused; p.chain = chain; p.emit = 1;
+    p.dist_scale = dist_scale;
     p.m = m; p.nr = nr; p.batch = batch; p.side = side; p.nrx = nrx; p.nry = nry;
     p.a = a; p.c = c;
     h->max_iterations = max_iterations; h->angle_threshold = angle_threshold; h->translation_threshold = translation_threshold;
@@ -521,6 +524,13 @@ int icp_set_alpha (icp_handle h, float a)
     if (a == 0.f) return fail (h, ICP_EINVAL, "The alpha parameter cannot be equal to zero");
     h->p.a = a; drop_graphs (h); return ICP_OK;
 }
+int icp_set_metric_scale (icp_handle h, float f_g)
+{
+    if (!h) return ICP_EINVAL;
+    if (!(f_g > 0.f) || !std::isfinite (f_g)) return fail (h, ICP_EINVAL, "the metric scale must be positive and finite");
+    h->p.dist_scale = f_g; drop_graphs (h); return ICP_OK;
+}
+int icp_get_metric_scale (icp_handle h, float *f_g) { if (!h || !f_g) return ICP_EINVAL; *f_g = h->p.dist_scale; return ICP_OK; }
 int icp_get_scaling (icp_handle h, float *c) { if (!h || !c) return ICP_EINVAL; *c = h->p.c; return ICP_OK; }
 int icp_set_scaling (icp_handle h, float c) { if (!h) return ICP_EINVAL; h->p.c = c; drop_graphs (h); return ICP_OK; }
 int icp_get_max_iterations (icp_handle h, uint32_t *n) { if (!h || !n) return ICP_EINVAL; *n = h->max_iterations; return ICP_OK; }

@@ -11,6 +11,7 @@ struct icp_params {
     uint32_t m, nr, batch;
     uint32_t side, nrx, nry;     // landmark grid side and representative grid (getReps)
     float a, c;
+    float dist_scale;            // f_g of the metric text: reported distance (NN_ID.dist, the weights' input) = dist_scale * (geo + a pho); default 1
     int weighted, rot, power_mode, check;
     int chain;                   // fused mode, one launch per iteration (finalize in the next search's prologue): 0 never, 1 automatic, 2 always
     int fused;                   // 0: reference-order reductions (3 global trees), 1: single-pass double moments

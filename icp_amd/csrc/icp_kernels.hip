@@ -931,7 +931,9 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     if (slice == 0u) {
         const float4 qa = s_qa[lane]; const uint4 qb = s_qb[lane];
         const bool v = (qb.z & 1u) != 0u, empty = (qb.z & 2u) != 0u;
-        const float ex = qa.x, ey = qa.y, ez = qa.z, d = qa.w;
+        // the search ran on geo + a pho (a positive common factor changes neither the argmin nor the ties, and the pruning
+        // bound d >= geo stays as it is); the distance reported and fed to the weights carries the metric's absolute scale
+        const float ex = qa.x, ey = qa.y, ez = qa.z, d = p.dist_scale * qa.w;
         const uint32_t ei = qb.w;
         float w = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f;
         if (v) {

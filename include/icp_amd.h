@@ -171,6 +171,14 @@ int icp_sync (icp_handle h);
 int icp_get_alpha (icp_handle h, float *a);
 int icp_set_alpha (icp_handle h, float a);
 int icp_get_scaling (icp_handle h, float *c);
+/* Absolute scale of the photogeometric metric.  The reference only states d = f_g(a) |x_g - x'_g|^2 + f_p(a) |x_p - x'_p|^2
+ * (src/ICP/algorithms.cpp:4393-4398); euclideanSquaredMetric8 itself lives in the un-vendored RandomBallCover.  The engine
+ * searches on geo + a pho (i.e. f_p / f_g = a: the correspondences depend only on that ratio) and reports
+ * dist = f_g (geo + a pho), f_g = 1 by default.  f_g matters in WEIGHTED mode only, through w = 100 / (100 + dist)
+ * (kernels/icp_kernels.cl:232): a normalised metric, e.g. f_g = 1 / (1 + a), f_p = a / (1 + a), is selected with
+ * icp_set_alpha (h, a) + icp_set_metric_scale (h, 1 / (1 + a)).  Positive and finite. */
+int icp_set_metric_scale (icp_handle h, float f_g);
+int icp_get_metric_scale (icp_handle h, float *f_g);
 int icp_set_scaling (icp_handle h, float c);
 int icp_get_max_iterations (icp_handle h, uint32_t *n);
 int icp_set_max_iterations (icp_handle h, uint32_t n);

@@ -829,6 +829,7 @@ void orc_moments_finish (const double *t, float c, double *sum_w, float *mean8, 
 /* ======================================================================================= */
 struct orc_icp {
     int rot, weighted, fast, threads, fused;
+    float dist_scale;            /* f_g of the metric text (src/ICP/algorithms.cpp:4393-4398): reported dist = f_g (geo + a pho) */
     uint32_t side;
     uint32_t m, nr, max_it, k;
     float a, c;
@@ -844,7 +845,7 @@ struct orc_icp {
 orc_icp *orc_icp_create (int rot, int weighted)
 {
     orc_icp *h = (orc_icp *) calloc (1, sizeof *h);
-    h->rot = rot; h->weighted = weighted; h->threads = 1;
+    h->rot = rot; h->weighted = weighted; h->threads = 1; h->dist_scale = 1.f;
     return h;
 }
 
@@ -949,6 +950,9 @@ void orc_icp_step (orc_icp *h)
     orc_transform_q (h->M, h->tM, h->T, h->m);                                     /* transform.run */
     orc_rbc_search (h->tM, h->m, h->R, h->nr, h->XP, h->perm, h->O, h->N, h->rep_src, h->a,
                     h->nn_id, h->NN, h->rid);                                      /* rbcS.run      */
+    /* absolute scale of the metric (ASSUMPTION-METRIC, second half): the search runs on geo + a pho (argmin and ties do not
+     * depend on a positive common factor f_g); the distance it reports, which feeds the weights, is f_g times that */
+    for (uint32_t i = 0; i < h->m; ++i) h->nn_id[i].dist = h->dist_scale * h->nn_id[i].dist;
     if (h->fused) {
         if (h->weighted) for (uint32_t i = 0; i < h->m; ++i) h->W[i] = 100.f / (100.f + h->nn_id[i].dist);
         orc_moments_fused (h->NN, h->tM, h->weighted ? h->W : NULL, h->m, h->side, h->c, &h->sum_w, h->means, h->S);
@@ -982,6 +986,7 @@ uint32_t orc_icp_run (orc_icp *h)
     return h->k;
 }
 
+void               orc_icp_set_dist_scale (orc_icp *h, float f_g) { h->dist_scale = f_g; }
 int                orc_icp_converged (const orc_icp *h) { return h->converged; }
 const float       *orc_icp_T (const orc_icp *h) { return h->T; }
 const float       *orc_icp_Tk (const orc_icp *h) { return h->Tk; }

@@ -74,6 +74,7 @@ def lib():
     sig("orc_icp_set_fused", None, vp, C.c_int)
     sig("orc_moments_fused", None, vp, vp, vp, u32, u32, C.c_float, C.POINTER(C.c_double), vp, vp)
     sig("orc_icp_set_threads", None, vp, C.c_int)
+    sig("orc_icp_set_dist_scale", None, vp, C.c_float)
     sig("orc_icp_write_f", None, vp, vp)
     sig("orc_icp_write_m", None, vp, vp)
     sig("orc_icp_write_t", None, vp, vp)
@@ -294,7 +295,7 @@ class OracleICP:
 
     def __init__(self, m, nr, a=2e2, c=1e-6, rot=ROT_POWER, weighted=W_WEIGHTED,
                  max_iterations=40, angle_threshold=0.001, translation_threshold=0.01,
-                 power_fast=False, threads=1, fused=False):
+                 power_fast=False, threads=1, fused=False, dist_scale=1.0):
         self.L = lib()
         self.h = self.L.orc_icp_create(rot, weighted)
         self.m, self.nr = m, nr
@@ -306,6 +307,7 @@ class OracleICP:
         self.L.orc_icp_set_power_fast(self.h, int(power_fast))
         self.L.orc_icp_set_threads(self.h, threads)
         self.L.orc_icp_set_fused(self.h, int(fused))
+        self.L.orc_icp_set_dist_scale(self.h, dist_scale)
 
     def __del__(self):
         if getattr(self, "h", None):

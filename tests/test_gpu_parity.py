@@ -688,3 +688,32 @@ def test_config4_real_shape_batch64(engine, oracle):
         assert_bits(T, gold["r%d_fixed40_T" % i], "fixed-40 T of registration %d vs fixture" % i)
         assert np.array_equal(ids[:256], gold["r%d_fixed40_ids_head" % i]) and np.array_equal(C4.ids_digest(ids), gold["r%d_fixed40_ids_digest" % i]), i
     g.close()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_metric_absolute_scale(engine, oracle, fused):
+    """icp_set_metric_scale: dist = f_g (geo + a pho).  Same correspondences as f_g = 1 (the argmin depends on the ratio
+    f_p / f_g = a only), distances scaled, and the WEIGHTED pipeline (weights, means, S, T) follows the scaled distances:
+    bit for bit against the oracle with the same scale (normalised form f_g = 1 / (1 + a))."""
+    fg = np.float32(1.0) / np.float32(1.0 + A)
+    g, o, F, M = make(engine, oracle, 64, 64, power_fast=True, fused=fused)
+    o.L.orc_icp_set_dist_scale(o.h, float(fg))
+    g.setMetricScale(float(fg))
+    assert g.getMetricScale() == pytest.approx(float(fg))
+    g1, o1, _, _ = make(engine, oracle, 64, 64, power_fast=True, fused=fused)
+    for x in (g, g1):
+        x.buildRBC()
+    o.build_rbc()
+    g.step(); g1.step(); o.step()
+    n, n1 = g.read(engine.Memory.NN_ID), g1.read(engine.Memory.NN_ID)
+    assert np.array_equal(n["id"], n1["id"])
+    assert_bits(n["dist"], (fg * n1["dist"]).astype(np.float32), "scaled distances")
+    assert not np.array_equal(g.read(engine.Memory.T).view(np.uint32), g1.read(engine.Memory.T).view(np.uint32))   # the weights changed
+    for _ in range(3):
+        g.step(); o.step()
+    check_step(engine, g, o, weighted=not fused)
+    assert g.run() == o.run()
+    assert_bits(g.read(engine.Memory.T), o.T, "final T with a scaled metric")
+    with pytest.raises(engine.ICPError):
+        g.setMetricScale(0.0)
+    g.close(); g1.close()

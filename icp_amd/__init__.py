@@ -146,6 +146,8 @@ def lib():
     sig("icp_profile_run", i32, vp, u32, vp, C.POINTER(f32))
     sig("icp_time_masked", i32, vp, u32, u32, u32, C.POINTER(f32))
     sig("icp_launches_per_iteration", i32, vp, C.POINTER(u32))
+    sig("icp_run_form", i32, vp, C.POINTER(i32))
+    sig("icp_debug_inject_fault", i32, vp)
     sig("icp_reduce", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_scan", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_reduce_scan_last_error", C.c_char_p)
@@ -445,6 +447,12 @@ class ICPStep:
         n = C.c_uint32()
         self._chk(self._L.icp_launches_per_iteration(self._h, C.byref(n)))
         return n.value
+
+    def run_form(self):
+        """0 separate launches per stage, 1 chained (one launch per iteration), 2 persistent (one launch per run)."""
+        f = C.c_int()
+        self._chk(self._L.icp_run_form(self._h, C.byref(f)))
+        return f.value
 
     def time_masked(self, mask, iterations=40, reps=20):
         """us per iteration of a graph holding only the kernels in `mask` (diagnostic)."""

@@ -10,6 +10,7 @@
 #include "../../include/icp_amd.h"
 #include "icp_kernels.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,7 +23,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-struct graph_entry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+struct graph_entry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool persistent = false; };
 
 }  // namespace
 
@@ -42,12 +43,33 @@ struct icp_context {
     float *dTin = nullptr;                       // device scratch for write(T)
     float *dCloud = nullptr, *dCloudOut = nullptr; uint32_t cloud_cap = 0;
     std::map<uint64_t, graph_entry> graphs;      // key: iterations << 2 | check << 1 | parity
+    bool persist_inflight = false;               // a persistent run was enqueued since the last fault check
+    uint32_t last_iterations = 0; int last_check = 0;    // the last graph run (re-issued on the chained path if a persistent run gave up)
+    uint32_t enqueued_after_persist = 0;         // state-changing calls enqueued behind the oldest unchecked persistent run
     uint32_t parity = 0;                         // tracking: which of the two landmark buffers is the fixed set (graphs hold pointers)
     uint32_t track_frames = 0;                   // frames fed to icp_track_next since init / icp_track_reset
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 namespace {
+
+// A persistent run needs every block of its grid resident at once; two of them on one device could each hold half of the
+// CUs and wait for the other half forever (until their bounded spins give up).  So at most one handle per device runs
+// persistently: the first that asks gets the right and keeps it until it is re-initialised or destroyed.
+std::atomic<icp_context *> g_persist_owner[64];
+
+bool persist_acquire (icp_context *h)
+{
+    if (h->device < 0 || h->device >= 64) return false;
+    icp_context *expected = nullptr;
+    return g_persist_owner[h->device].compare_exchange_strong (expected, h) || expected == h;
+}
+void persist_release (icp_context *h)
+{
+    if (h->device < 0 || h->device >= 64) return;
+    icp_context *expected = h;
+    g_persist_owner[h->device].compare_exchange_strong (expected, nullptr);
+}
 
 int fail (icp_context *h, int code, const std::string &msg)
 {
@@ -74,6 +96,8 @@ void drop_graphs (icp_context *h)
 void free_all (icp_context *h)
 {
     drop_graphs (h);
+    persist_release (h);
+    h->persist_inflight = false;
     for (void *q : h->dev_allocs) (void) hipFree (q);
     h->dev_allocs.clear ();
     if (h->hF) (void) hipHostFree (h->hF);
@@ -155,26 +179,74 @@ int capture_graph (icp_context *h, Fn &&launches, graph_entry *out)
 }
 
 // Capture `iterations` iterations into a graph (cached until a parameter changes).
-int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *out)
+int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *out, bool *is_persistent = nullptr)
 {
     uint64_t key = ((uint64_t) iterations << 2) | (uint64_t) (check ? 2 : 0) | (uint64_t) h->parity;
     auto it = h->graphs.find (key);
-    if (it != h->graphs.end ()) { *out = it->second.exec; return ICP_OK; }
+    if (it != h->graphs.end ()) { *out = it->second.exec; if (is_persistent) *is_persistent = it->second.persistent; return ICP_OK; }
     icp_params p = h->p;
     p.check = check;
     graph_entry ge;
+    const bool persistent = icp_persistent_supported (p) && persist_acquire (h);
     int rc = capture_graph (h, [&] {
-        if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations);        // one launch per iteration
+        if (persistent) icp_launch_persistent (p, h->stream, iterations);                 // one launch per run
+        else if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations);   // one launch per iteration
         else for (uint32_t k = 0; k < iterations; ++k) {
             p.emit = (check || k + 1 == iterations) ? 1 : 0;            // (with checks on, any iteration may be the last executed)
             icp_launch_iteration (p, h->stream);
         }
     }, &ge);
     if (rc) return rc;
+    ge.persistent = persistent;
     h->graphs[key] = ge;
     *out = ge.exec;
+    if (is_persistent) *is_persistent = persistent;
     return ICP_OK;
 }
+
+// Launches the graph of a run and records what a fault of a persistent run needs to know later (settle).
+int launch_run (icp_context *h, uint32_t iterations, int check)
+{
+    hipGraphExec_t exec; bool persistent = false;
+    int rc = get_graph (h, iterations, check, &exec, &persistent);
+    if (rc) return rc;
+    if (h->persist_inflight) h->enqueued_after_persist++;
+    HIPCHK (h, hipGraphLaunch (exec, h->stream));
+    if (persistent && !h->persist_inflight) { h->persist_inflight = true; h->enqueued_after_persist = 0; }
+    if (persistent) { h->last_iterations = iterations; h->last_check = check; }
+    return ICP_OK;
+}
+
+// Waits for the stream and resolves a persistent run that gave up waiting for another block (the grid was not fully
+// resident: the kernel leaves the registration state untouched and raises `fault`).  If that run was the last thing
+// enqueued it is re-issued on the chained path, transparently; persistent runs are switched off for the handle.
+int settle (icp_context *h)
+{
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    if (!h->persist_inflight) return ICP_OK;
+    h->persist_inflight = false;
+    std::vector<icp_reg_state> st (h->p.batch);
+    HIPCHK (h, hipMemcpy (st.data (), h->p.st, sizeof (icp_reg_state) * st.size (), hipMemcpyDeviceToHost));
+    bool fault = false;
+    for (const auto &s : st) fault = fault || s.fault != 0u;
+    if (!fault) return ICP_OK;
+    h->p.persistent = 0;
+    drop_graphs (h);
+    persist_release (h);
+    icp_launch_clear_fault (h->p, h->stream);
+    HIPCHK (h, hipGetLastError ());
+    if (h->enqueued_after_persist)
+        return fail (h, ICP_EHIP, "a persistent run gave up (its blocks were not all resident) and further work had been enqueued behind it: "
+                                  "the results since are void; persistent runs are now off for this handle, repeat the calls");
+    hipGraphExec_t exec;
+    int rc = get_graph (h, h->last_iterations, h->last_check, &exec);
+    if (rc) return rc;
+    HIPCHK (h, hipGraphLaunch (exec, h->stream));
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    return ICP_OK;
+}
+
+void note_enqueue (icp_context *h) { if (h->persist_inflight) h->enqueued_after_persist++; }
 
 }  // namespace
 
@@ -219,6 +291,10 @@ int icp_create (icp_handle *out, int device, int rot, int weighted)
     h->p.dist_scale = 1.f;
     { const char *e = std::getenv ("ICP_AMD_MODE"); if (e && (e[0] == 'r' || e[0] == 'R')) { h->p.power_mode = ICP_POWER_LITERAL; h->p.fused = ICP_REDUCE_REFERENCE_ORDER; } }
     { const char *e = std::getenv ("ICP_AMD_CHAIN"); h->p.chain = !e ? 1 : (e[0] == '1') ? 2 : (e[0] == '0') ? 0 : 1; }   // see icp_chain_supported
+    // persistent runs (one launch per run) are opt-in: measured 10.7 us per iteration at the reference's size against 9.8 us
+    // for the chain — the in-launch exchange costs more than the launch boundary it replaces
+    { const char *e = std::getenv ("ICP_AMD_PERSISTENT"); h->p.persistent = (e && e[0] == '1') ? 1 : 0; }                  // see icp_persistent_supported
+    h->p.ncu = (uint32_t) prop.multiProcessorCount;
     e = hipSetDevice (device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags (&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate (&h->ev0);
@@ -261,12 +337,13 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     int rc = set_device (h); if (rc) return rc;
     if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
     int rot = h->p.rot, weighted = h->p.weighted, pmode = h->p.power_mode, fused = h->p.fused, chain = h->p.chain;
+    const int persistent = h->p.persistent; const uint32_t ncu = h->p.ncu;
     const float dist_scale = h->p.dist_scale;
     free_all (h);
     icp_params &p = h->p;
     p = icp_params {};
     p.rot = rot; p.weighted = weighted; p.power_mode = pmode; p.check = 0; p.fused = fused; p.chain = chain; p.emit = 1;
-    p.dist_scale = dist_scale;
+    p.dist_scale = dist_scale; p.persistent = persistent; p.ncu = ncu;
     p.m = m; p.nr = nr; p.batch = batch; p.side = side; p.nrx = nrx; p.nry = nry;
     p.a = a; p.c = c;
     h->max_iterations = max_iterations; h->angle_threshold = angle_threshold; h->translation_threshold = translation_threshold;
@@ -306,6 +383,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &p.spart, B * 11 * p.nsp * 8))) return rc;    // 8 sub-trees per work-group; padding stays 0.f
     if ((rc = dalloc (h, &p.mom, B * 2 * 18 * p.nb))) return rc;
     if ((rc = dalloc (h, &p.cst, B * 2))) return rc;
+    if ((rc = dalloc (h, reinterpret_cast<unsigned char **> (&p.xch), icp_xch_bytes (batch)))) return rc;
     if ((rc = dalloc (h, &p.st, B))) return rc;
     if (!h->dTin) HIPCHK (h, hipMalloc ((void **) &h->dTin, 8 * sizeof (float)));
     HIPCHK (h, hipHostMalloc ((void **) &h->hF, B * m * 8 * sizeof (float), hipHostMallocDefault));
@@ -329,6 +407,7 @@ int icp_write_b (icp_handle h, uint32_t b, int mem, const void *host_ptr, int bl
     int rc = need (h, false); if (rc) return rc;
     if (b >= h->p.batch) return fail (h, ICP_EINVAL, "batch index out of range");
     if ((rc = set_device (h))) return rc;
+    if (h->persist_inflight && (rc = settle (h))) return rc;       // (a write synchronises the stream anyway)
     const size_t fm = (size_t) h->p.m * 8 * sizeof (float);
     switch (mem) {
         case ICP_MEM_F:
@@ -416,6 +495,7 @@ int icp_read_b (icp_handle h, uint32_t b, int mem, void *host_dst, size_t bytes)
     if (full == 0) return fail (h, ICP_EINVAL, "unknown icp_mem value");
     if (bytes > full) return fail (h, ICP_EINVAL, "icp_read: more bytes requested than the object holds");
     if ((rc = set_device (h))) return rc;
+    if (h->persist_inflight && (rc = settle (h))) return rc;
     const void *src = nullptr;
     if ((rc = mem_ptr (h, b, mem, &src))) return rc;
     if (mem == ICP_MEM_W) {                        // weights live in the .w lane of the matched points
@@ -466,6 +546,7 @@ int icp_build_rbc (icp_handle h)
              }, &ge))) return rc;
         it = h->graphs.emplace (key, ge).first;
     }
+    note_enqueue (h);
     HIPCHK (h, hipGraphLaunch (it->second.exec, h->stream));
     h->built = true;
     return ICP_OK;
@@ -477,6 +558,7 @@ int icp_step (icp_handle h, int config)
     int rc = need (h, true); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
     icp_params p = h->p; p.check = 0;
+    note_enqueue (h);
     icp_launch_iteration (p, h->stream);
     HIPCHK (h, hipGetLastError ());
     return ICP_OK;
@@ -487,20 +569,15 @@ int icp_run_fixed (icp_handle h, uint32_t iterations)
     int rc = need (h, true); if (rc) return rc;
     if (iterations == 0) return ICP_OK;
     if ((rc = set_device (h))) return rc;
-    hipGraphExec_t exec;
-    if ((rc = get_graph (h, iterations, 0, &exec))) return rc;
-    HIPCHK (h, hipGraphLaunch (exec, h->stream));
-    return ICP_OK;
+    return launch_run (h, iterations, 0);
 }
 
 int icp_run (icp_handle h, uint32_t *k)
 {
     int rc = need (h, true); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
-    hipGraphExec_t exec;
-    if ((rc = get_graph (h, h->max_iterations, 1, &exec))) return rc;
-    HIPCHK (h, hipGraphLaunch (exec, h->stream));
-    HIPCHK (h, hipStreamSynchronize (h->stream));                    // queue.finish () — :4813
+    if ((rc = launch_run (h, h->max_iterations, 1))) return rc;
+    if ((rc = settle (h))) return rc;                                // queue.finish () — :4813
     if (k) {
         icp_reg_state st;
         HIPCHK (h, hipMemcpy (&st, h->p.st, sizeof st, hipMemcpyDeviceToHost));
@@ -513,8 +590,7 @@ int icp_sync (icp_handle h)
 {
     if (!h) return ICP_EINVAL;
     int rc = set_device (h); if (rc) return rc;
-    HIPCHK (h, hipStreamSynchronize (h->stream));
-    return ICP_OK;
+    return settle (h);
 }
 
 int icp_get_alpha (icp_handle h, float *a) { if (!h || !a) return ICP_EINVAL; *a = h->p.a; return ICP_OK; }
@@ -572,6 +648,7 @@ int icp_state_b (icp_handle h, uint32_t b, icp_state_t *out)
     if (!out) return fail (h, ICP_EINVAL, "null pointer");
     if (b >= h->p.batch) return fail (h, ICP_EINVAL, "batch index out of range");
     if ((rc = set_device (h))) return rc;
+    if (h->persist_inflight && (rc = settle (h))) return rc;
     icp_reg_state st;
     HIPCHK (h, hipMemcpyAsync (&st, h->p.st + b, sizeof st, hipMemcpyDeviceToHost, h->stream));
     HIPCHK (h, hipStreamSynchronize (h->stream));
@@ -692,6 +769,7 @@ int icp_reset_transform (icp_handle h)
 {   // T <- identity, k <- 0 (what ICPStep::init uploads, src/ICP/algorithms.cpp:4486-4493); enqueue only
     int rc = need (h, false); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
+    note_enqueue (h);
     icp_launch_reset_state (h->p, h->stream, 1);
     HIPCHK (h, hipGetLastError ());
     return ICP_OK;
@@ -702,8 +780,9 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int fr
     int rc = need (h, true); if (rc) return rc;
     if (!ms_total || iterations == 0 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
-    hipGraphExec_t exec;
-    if ((rc = get_graph (h, iterations, 0, &exec))) return rc;
+    hipGraphExec_t exec; bool persistent = false;
+    if ((rc = get_graph (h, iterations, 0, &exec, &persistent))) return rc;
+    if (persistent && (rc = settle (h))) return rc;                     // (earlier persistent runs checked before the timed ones start)
     HIPCHK (h, hipEventRecord (h->ev0, h->stream));
     for (uint32_t r = 0; r < reps; ++r) {
         if (from_identity) icp_launch_reset_state (h->p, h->stream, 1);   // every pass is a fresh registration
@@ -712,6 +791,31 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int fr
     HIPCHK (h, hipEventRecord (h->ev1, h->stream));
     HIPCHK (h, hipEventSynchronize (h->ev1));
     HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));
+    if (persistent) {                                                   // a run that gave up makes the timing void: say so
+        h->persist_inflight = true; h->enqueued_after_persist = reps > 1 || from_identity ? 1u : 0u;
+        h->last_iterations = iterations; h->last_check = 0;
+        if ((rc = settle (h))) return rc;
+    }
+    return ICP_OK;
+}
+
+int icp_debug_inject_fault (icp_handle h)
+{   // test hook: what a persistent run leaves behind when it gives up (the next persistent run returns at once, settle () re-runs it chained)
+    int rc = need (h, false); if (rc) return rc;
+    if ((rc = set_device (h))) return rc;
+    icp_launch_inject_fault (h->p, h->stream);
+    HIPCHK (h, hipGetLastError ());
+    return ICP_OK;
+}
+
+int icp_run_form (icp_handle h, int *form)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if (!form) return fail (h, ICP_EINVAL, "null output");
+    const icp_context *owner = (h->device >= 0 && h->device < 64) ? g_persist_owner[h->device].load () : nullptr;
+    if (icp_persistent_supported (h->p) && (owner == nullptr || owner == h)) *form = ICP_FORM_PERSISTENT;
+    else if (icp_chain_supported (h->p)) *form = ICP_FORM_CHAINED;
+    else *form = ICP_FORM_SEPARATE;
     return ICP_OK;
 }
 
@@ -719,7 +823,9 @@ int icp_launches_per_iteration (icp_handle h, uint32_t *n)
 {
     int rc = need (h, false); if (rc) return rc;
     if (!n) return fail (h, ICP_EINVAL, "null output");
-    *n = icp_chain_supported (h->p) ? 1u : h->p.fused ? 2u : 4u;
+    int form = ICP_FORM_SEPARATE;
+    if ((rc = icp_run_form (h, &form))) return rc;
+    *n = form != ICP_FORM_SEPARATE ? 1u : h->p.fused ? 2u : 4u;
     return ICP_OK;
 }
 
@@ -753,7 +859,8 @@ int icp_debug_stamps (icp_handle h, unsigned long long *out, uint32_t nblocks)
     HIPCHK (h, hipMalloc ((void **) &d, (size_t) nblocks * 16 * 8));
     HIPCHK (h, hipMemset (d, 0, (size_t) nblocks * 16 * 8));
     icp_params p = h->p; p.check = 0; p.dbg = d;
-    if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, 2);
+    if (icp_persistent_supported (p)) icp_launch_persistent (p, h->stream, 40);
+    else if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, 2);
     else { icp_launch_search (p, h->stream); if (p.fused) icp_launch_finalize (p, h->stream); }
     HIPCHK (h, hipStreamSynchronize (h->stream));
     HIPCHK (h, hipMemcpy (out, d, (size_t) nblocks * 16 * 8, hipMemcpyDeviceToHost));

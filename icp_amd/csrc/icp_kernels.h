@@ -42,6 +42,9 @@ struct icp_params {
     float4 *mscr;                // [batch][2][ceil(nwg/128)]  scratch of the multi-level icpGMean
     float *spart;                // [batch][11][nsp*8] 8 residue sub-trees per work-group
     double *mom;                 // [batch][2][18][nb]  fused mode: per-block moment partials (double-buffered for the chain)
+    unsigned long long *xch;     // [batch][2][18][256] 16-byte exchange records + one abort word: in-launch moment exchange of persistent runs
+    int persistent;              // 0 never, 1 where the size allows (icp_persistent_supported) and this handle holds the device's right to it
+    uint32_t ncu;                // compute units of the device (co-residency bound of a persistent grid)
     icp_reg_state *cst;          // [batch][2]  chained fused mode: state slots, launch j reads slot j&1 and writes the other
     uint32_t slot;               // chained fused mode: slot this launch reads
     icp_reg_state *st;           // [batch]
@@ -58,6 +61,11 @@ void icp_launch_iteration (const icp_params &p, hipStream_t s);
 void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask);
 void icp_launch_chain (const icp_params &p, hipStream_t s, uint32_t iterations);
 bool icp_chain_supported (const icp_params &p);
+bool icp_persistent_supported (const icp_params &p);
+void icp_launch_persistent (const icp_params &p, hipStream_t s, uint32_t iterations);
+size_t icp_xch_bytes (uint32_t batch);
+void icp_launch_clear_fault (const icp_params &p, hipStream_t s);
+void icp_launch_inject_fault (const icp_params &p, hipStream_t s);
 void icp_launch_reset_state (const icp_params &p, hipStream_t s, int reset_T);
 void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStream_t s);
 void icp_launch_get_lms (const float *cloud, float *lms, hipStream_t s);

@@ -296,10 +296,28 @@ int icp_profile_run (icp_handle h, uint32_t iterations, float *out_ms, float *to
 int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4);
 
 /* Kernel launches per iteration of the graphs behind icp_run / icp_run_fixed with the current modes and sizes:
- * 4 (reference-order reductions), 2 (fused: search + finalize) or 1 (fused, chained: the finalize of iteration k
- * runs in the prologue of the search of iteration k+1; chosen automatically for latency-bound sizes, environment
- * ICP_AMD_CHAIN=0 / 1 forces it off / on at icp_create). */
+ * 4 (reference-order reductions), 2 (fused: search + finalize) or 1 (fused, latency-bound sizes: at most one launch per
+ * iteration — chained or persistent, see icp_run_form). */
 int icp_launches_per_iteration (icp_handle h, uint32_t *n);
+
+/* How icp_run / icp_run_fixed execute with the current modes and sizes:
+ *   SEPARATE    one launch per stage (2 fused, 4 reference order);
+ *   CHAINED     fused, one launch per iteration: the finalize of iteration k runs in the prologue of the search of
+ *               iteration k+1 (latency-bound sizes; ICP_AMD_CHAIN=0 / 1 at icp_create forces it off / on);
+ *   PERSISTENT  fused, ONE launch per run: representatives in LDS and the moving points in registers for all iterations,
+ *               the per-iteration moment exchange between the blocks in-launch (agent-scope tagged records), convergence
+ *               ends the loop in place.  Needs the whole grid resident: |F| / 64 x batch <= number of CUs, |R| <= 1024; one
+ *               handle per device at a time holds the right to it (the first that runs; released by re-init / destroy).
+ *               OPT-IN (ICP_AMD_PERSISTENT=1 at icp_create): on MI355X the in-launch exchange costs more than the launch
+ *               boundaries it removes (10.7 against 9.8 us per iteration at |F| = 16384), so the default is
+ *               CHAINED.  A run whose blocks turn out not to be co-resident gives up after a bounded wait, leaves the
+ *               state untouched and is repeated on the chained path.
+ * Same bits in all three forms. */
+typedef enum { ICP_FORM_SEPARATE = 0, ICP_FORM_CHAINED = 1, ICP_FORM_PERSISTENT = 2 } icp_run_form_t;
+int icp_run_form (icp_handle h, int *form);
+/* Test hook: marks the registration as a persistent run does when it gives up waiting (fault raised, state untouched);
+ * the next blocking call repeats the last run on the chained path and switches persistent runs off for the handle. */
+int icp_debug_inject_fault (icp_handle h);
 
 /* Diagnostic: a graph of `iterations` x (the kernels selected by mask: bit 0 search, 1 means, 2 sij,
  * 3 finalize, 4 an empty 256-block kernel), launched `reps` times; *ms_total = elapsed ms. */

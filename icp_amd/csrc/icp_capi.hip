@@ -363,8 +363,10 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &M, B * m * 8))) return rc;
     h->dF = F; h->dM = M; p.F = F; p.M = M;
     if ((rc = dalloc (h, &p.R, B * nr * 8))) return rc;
-    p.n16 = (nr + 15u) / 16u; p.n32 = (nr + 31u) / 32u;
-    if ((rc = dalloc (h, &p.GB, B * 2 * (p.n16 + p.n32)))) return rc;
+    p.n16 = (nr + 15u) / 16u; p.n1k = (nr + 1023u) / 1024u;
+    p.gtile = 0u;                                                    // 4 x 4 tile groups where the representative grid allows
+    if (nrx % 4u == 0u && nry % 4u == 0u && !std::getenv ("ICP_AMD_STRIP_GROUPS")) { uint32_t lg = 0; while ((4u << lg) < nrx) ++lg; p.gtile = lg + 1u; }
+    if ((rc = dalloc (h, &p.GB, B * 2 * (p.n16 + p.n1k)))) return rc;
     if ((rc = dalloc (h, &p.XP, B * m * 8))) return rc;
     if ((rc = dalloc (h, &p.XQ, B * m * 8))) return rc;
     if ((rc = dalloc (h, &p.rep_src, B * nr))) return rc;
@@ -382,6 +384,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &p.mscr, B * 2 * ((p.nwg + 127u) / 128u)))) return rc;
     if ((rc = dalloc (h, &p.spart, B * 11 * p.nsp * 8))) return rc;    // 8 sub-trees per work-group; padding stays 0.f
     if ((rc = dalloc (h, &p.mom, B * 2 * 18 * p.nb))) return rc;
+    if ((rc = dalloc (h, &p.ml1, B * 18 * ((p.nb + 127u) / 128u)))) return rc;
     if ((rc = dalloc (h, &p.cst, B * 2))) return rc;
     if ((rc = dalloc (h, reinterpret_cast<unsigned char **> (&p.xch), icp_xch_bytes (batch)))) return rc;
     if ((rc = dalloc (h, &p.st, B))) return rc;

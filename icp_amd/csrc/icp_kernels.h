@@ -28,8 +28,9 @@ struct icp_params {
     // inputs / RBC
     const float *F, *M;          // [batch][m][8]
     float *R;                    // [batch][nr][8]
-    float4 *GB;                  // [batch][2*(n16+n32)] geometry bounding boxes (lo, hi) of 16 / 32 consecutive representatives
-    uint32_t n16, n32;           // ceil(nr/16), ceil(nr/32)
+    float4 *GB;                  // [batch][2*(n16+n32)] geometry bounding boxes (lo, hi) of the groups of 16 representatives, then of the tiles of 1024
+    uint32_t n16, n1k;           // ceil(nr/16), ceil(nr/1024)
+    uint32_t gtile;              // stage-1 pruning groups of 16: 0 = 16 consecutive representatives, 1 + log2 (nrx / 4) = 4 x 4 tiles of the representative grid
     float *XP;                   // [batch][m][8]  permuted database (RBCConstruct D_OUT_X_P)
     float *XQ;                   // [batch][m][8]  same, lane 3 = original index bits (search copy)
     uint32_t *rep_src, *owner, *N, *O, *perm, *chunk_hist;   // [batch][...]
@@ -42,6 +43,7 @@ struct icp_params {
     float4 *mscr;                // [batch][2][ceil(nwg/128)]  scratch of the multi-level icpGMean
     float *spart;                // [batch][11][nsp*8] 8 residue sub-trees per work-group
     double *mom;                 // [batch][2][18][nb]  fused mode: per-block moment partials (double-buffered for the chain)
+    double *ml1;                 // [batch][18][ceil(nb/128)]  fused mode, large sets: first tree level of the moments (k_moment_level1)
     unsigned long long *xch;     // [batch][2][18][256] 16-byte exchange records + one abort word: in-launch moment exchange of persistent runs
     int persistent;              // 0 never, 1 where the size allows (icp_persistent_supported) and this handle holds the device's right to it
     uint32_t ncu;                // compute units of the device (co-residency bound of a persistent grid)

@@ -220,23 +220,53 @@ __global__ void k_get_reps (icp_params p)
     p.rep_src[(size_t) b * p.nr + r] = src;
 }
 
-// Geometry bounding boxes of every 16 and every 32 consecutive representatives (stage-1 group pruning of k_search).
+// Geometry bounding boxes of the stage-1 pruning groups of k_search: groups of 16 representatives (then, unused by the
+// current launch set, of 32 consecutive ones).  A group of 16 is a 4 x 4 tile of the representative grid where the grid
+// allows (p.gtile: the representatives are a regular sample of the landmark grid, so a tile is compact in space: 1.8 - 2.9
+// groups per wave survive the bound instead of 3.3 - 8.8 with 16 x 1 strips), else 16 consecutive representatives.
 // fminf / fmaxf skip NaN coordinates: a representative with a NaN coordinate never wins a '<' anyway.
 __global__ void k_rep_boxes (icp_params p)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (t >= p.n16 + p.n32) return;
-    const uint32_t gs = t < p.n16 ? 16u : 32u, g = t < p.n16 ? t : t - p.n16;
+    if (t >= p.n16) return;                          // (the boxes of whole LDS tiles: k_tile_boxes)
+    const uint32_t gs = 16u, g = t;
     const float4 *R4 = reinterpret_cast<const float4 *> (p.R + (size_t) b * p.nr * 8);
     const float inf = __builtin_inff ();
     float4 lo = make_float4 (inf, inf, inf, 0.f), hi = make_float4 (-inf, -inf, -inf, 0.f);
-    for (uint32_t r = g * gs; r < min (p.nr, (g + 1u) * gs); ++r) {
+    const bool tiled = gs == 16u && p.gtile != 0u;
+    const uint32_t lg = p.gtile - 1u, ty = tiled ? g >> lg : 0u, tx = tiled ? g & ((1u << lg) - 1u) : 0u;
+    for (uint32_t e = 0; e < gs; ++e) {
+        const uint32_t r = tiled ? (4u * ty + (e >> 2)) * p.nrx + 4u * tx + (e & 3u) : g * gs + e;
+        if (r >= p.nr) continue;
         const float4 v = R4[2 * (size_t) r];
         lo.x = fminf (lo.x, v.x); lo.y = fminf (lo.y, v.y); lo.z = fminf (lo.z, v.z);
         hi.x = fmaxf (hi.x, v.x); hi.y = fmaxf (hi.y, v.y); hi.z = fmaxf (hi.z, v.z);
     }
-    float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n32);
+    float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n1k);
     GB[2 * t] = lo; GB[2 * t + 1] = hi;
+}
+
+// Geometry bounding box of every LDS tile of k_search (1024 consecutive representatives): one wave per tile
+// (min / max are exact in any order).
+__global__ __launch_bounds__ (64) void k_tile_boxes (icp_params p)
+{
+    const uint32_t tile = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const float4 *R4 = reinterpret_cast<const float4 *> (p.R + (size_t) b * p.nr * 8);
+    const float inf = __builtin_inff ();
+    float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+    for (uint32_t r = tile * 1024u + lane; r < min (p.nr, (tile + 1u) * 1024u); r += 64u) {
+        const float4 v = R4[2 * (size_t) r];
+        lo[0] = fminf (lo[0], v.x); lo[1] = fminf (lo[1], v.y); lo[2] = fminf (lo[2], v.z);
+        hi[0] = fmaxf (hi[0], v.x); hi[1] = fmaxf (hi[1], v.y); hi[2] = fmaxf (hi[2], v.z);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo[k] = fminf (lo[k], __shfl_xor (lo[k], d)); hi[k] = fmaxf (hi[k], __shfl_xor (hi[k], d)); }
+    if (lane == 0) {
+        float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16;
+        GB[2 * tile] = make_float4 (lo[0], lo[1], lo[2], 0.f); GB[2 * tile + 1] = make_float4 (hi[0], hi[1], hi[2], 0.f);
+    }
 }
 
 // RBC construct, step 1 (owner(x) = argmin_r d(x, R[r]), ties -> lowest r) is k_search<.., OWNER = true> below.
@@ -401,6 +431,9 @@ template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint
     }
 
 #define ICP_NMOM 18
+#ifndef ICP_L1_MIN_GROUPS
+#define ICP_L1_MIN_GROUPS 16u        // fused finalize: beyond this many 128-block groups the first tree level gets a kernel of its own
+#endif
 
 #ifdef ICP_DBG_STAMPS
 #define FF_STAMP(k)                                                                                       \
@@ -478,9 +511,11 @@ static __device__ __forceinline__ void fused_moment_loads (const double *mom, ui
 
 // Returns false (for every thread, before any barrier) when the registration had already converged (checked mode).
 // a0 = the values of pass 0 (fused_moment_loads (mom, nb, 0, a0), issued by the caller with its other loads).
+// gl1 != nullptr: the first tree level was evaluated by k_moment_level1 (many blocks: large sets); gl1[k * ng + g].
 template <int NG, int NT, int ROT>
 static __device__ bool fused_finalize_block (const icp_params &p, const double *mom, uint32_t nb, uint32_t check, uint32_t sv,
-                                             const double *a0, icp_fin_result *res, double (*s_l1)[NG], double *s_t)
+                                             const double *a0, icp_fin_result *res, double (*s_l1)[NG], double *s_t,
+                                             const double *gl1 = nullptr)
 {
     // NT = threads of the calling block (compile-time: reading blockDim costs a dependent cold load at kernel start)
     constexpr uint32_t nrow = NT / 16;
@@ -500,11 +535,13 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
             if (l == 0 && !(row & 1u) && live) s_t[k] = (v + 0.0) + (o + 0.0);
         } else if (l == 0 && live) { if (ng == 1) s_t[k] = v; else s_l1[k][g] = v; }
     };
-    pass (0u, a0);
-    for (uint32_t ps = 1; ps < npass; ++ps) {        // small blocks / many groups only
-        double a[8];
-        fused_moment_loads<NT> (mom, nb, ps, a);
-        pass (ps, a);
+    if (gl1 == nullptr) {
+        pass (0u, a0);
+        for (uint32_t ps = 1; ps < npass; ++ps) {    // small blocks / many groups only
+            double a[8];
+            fused_moment_loads<NT> (mom, nb, ps, a);
+            pass (ps, a);
+        }
     }
     if (check && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))) return false;    // block-uniform
     FF_STAMP (9)
@@ -516,7 +553,7 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 uint32_t i = l + 16u * q;
-                a[q] = (i < ng) ? s_l1[k][i] : 0.0;
+                a[q] = (i < ng) ? (gl1 ? gl1[(size_t) k * ng + i] : s_l1[k][i]) : 0.0;
             }
             double r = row_tree8_d (a);
             if (l == 0 && row < ICP_NMOM) s_t[row] = r;
@@ -684,6 +721,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     // the branch-free loop (compile-time: the pruning code costs 0.25 us there even when it is switched off).
     constexpr bool PRUNE = ICP_S1_SEED && MINW == 4;
     const bool prune = PRUNE && p.a > 0.f;
+    const uint32_t gt_lg1 = p.gtile;                 // 0: strip groups; 1 + log2 (nrx / 4): 4 x 4 tile groups (k_rep_boxes)
     uint32_t seed = 0u;
     if constexpr (OWNER) {
         if (qwave && prune && side && side * side == m && p.nrx && p.nry) {     // the representative sampled from the point's own cell
@@ -692,7 +730,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
         }
     } else if (qwave && prune) seed = p.rid[(size_t) b * m + ic];
     // (lo, hi) boxes of the groups of 2 * LPQ representatives: the 16-boxes (LPQ = 8) or the 32-boxes behind them
-    const float4 *GBt = p.GB + (size_t) b * 2 * (p.n16 + p.n32) + (KS_SPLIT == 8 ? 0u : 2u * p.n16);
+    const float4 *GBt = p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + (KS_SPLIT == 8 ? 0u : 2u * p.n16);
     const uint32_t nbox0 = 2u * ((tn0 + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
     float4 boxv = make_float4 (0.f, 0.f, 0.f, 0.f);
     if (prune && tid < nbox0) boxv = GBt[tid];
@@ -747,19 +785,54 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
 
     // ---- stage 1: nearest representative, two representatives per packed instruction ----
     float best = __builtin_inff (), s1_lim = __builtin_inff (); uint32_t bid = 0xFFFFFFFFu;
+    // coarse pass of the pruning over the groups of the tile in LDS (s_box): bit t of the result = this lane's t-th
+    // group (ss, ss + LPQ, ..) may hold a representative nearer than `lim`.  The lower bound applies the metric's own
+    // operations to the per-axis distances to the group's bounding box; every operation is monotone under
+    // round-to-nearest, so bound <= geo <= d for every member, and a group whose bound is not below `lim` cannot hold the winner.
+    auto coarse_pass = [&] (uint32_t tn_, float lim_) -> uint32_t {
+        const uint32_t ngt = (((tn_ + 1u) >> 1) + KS_SPLIT - 1u) / KS_SPLIT;
+        uint32_t cm = 0u;
+        for (uint32_t t = 0, g = ss; g < ngt; ++t, g += KS_SPLIT) {
+            const float4 lo = s_box[2 * g], hi = s_box[2 * g + 1];
+            const float ex = fmaxf (fmaxf (lo.x - qx, qx - hi.x), 0.f);
+            const float ey = fmaxf (fmaxf (lo.y - qy, qy - hi.y), 0.f);
+            const float ez = fmaxf (fmaxf (lo.z - qz, qz - hi.z), 0.f);
+            const float bound = __builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex));
+            if (bound < lim_) cm |= 1u << t;
+        }
+        return cm;
+    };
     for (uint32_t t0 = 0; t0 < nr; t0 += KS_TILE) {
         const uint32_t tn = min (KS_TILE, nr - t0);
+        uint32_t cmask = 0u;
+        // several tiles: the box of the whole tile first (same bound as for a group) — a query far from the tile skips its
+        // 64 group tests, and a tile no query of the block is near is neither tested further nor staged (at |R| = 4096 a
+        // block's 64 neighbouring queries need one, seldom two, of the four tiles)
+        auto tile_near = [&] (float lim_) -> bool {
+            if (nr <= KS_TILE) return true;
+            const float4 *tb = p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + 2u * (t0 / KS_TILE);
+            const float4 lo = tb[0], hi = tb[1];
+            const float ex = fmaxf (fmaxf (lo.x - qx, qx - hi.x), 0.f);
+            const float ey = fmaxf (fmaxf (lo.y - qy, qy - hi.y), 0.f);
+            const float ez = fmaxf (fmaxf (lo.z - qz, qz - hi.z), 0.f);
+            return __builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex)) < lim_;
+        };
         if (t0) {                                    // further tiles (nr > KS_TILE)
             __syncthreads ();
+            if (prune) {
+                const bool near = tile_near (s1_lim);
+                if (!__syncthreads_or (near)) continue;
+                const uint32_t nbx = 2u * ((tn + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
+                for (uint32_t k = tid; k < nbx; k += 64 * KS_SPLIT) s_box[k] = GBt[2u * (t0 / (2u * KS_SPLIT)) + k];
+                __syncthreads ();
+                if (__ballot (near)) cmask = coarse_pass (tn, s1_lim);
+                if (!__syncthreads_or (cmask != 0u)) continue;
+            }
             for (uint32_t k = tid; k < tn; k += 64 * KS_SPLIT) {
                 float4 g = R4[2 * (size_t) (t0 + k)], c = R4[2 * (size_t) (t0 + k) + 1];
                 float *dst = s_pairf + (k >> 1) * 12u + (k & 1u);
                 dst[0] = g.x; dst[2] = g.y; dst[4] = g.z; dst[6] = c.x; dst[8] = c.y; dst[10] = c.z;
                 if constexpr (!OWNER) s_on[k] = make_uint2 (gO[t0 + k], gN[t0 + k]);
-            }
-            if (prune) {
-                const uint32_t nbx = 2u * ((tn + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
-                for (uint32_t k = tid; k < nbx; k += 64 * KS_SPLIT) s_box[k] = GBt[2u * (t0 / (2u * KS_SPLIT)) + k];
             }
         }
         if ((tn & 1u) && tid == 0) {                 // odd tile (nr == 1): the pad slot never wins (NaN distance)
@@ -805,19 +878,9 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
         } else if (prune) lim = s1_lim;
         if (prune) {
             // coarse pass: a group = the 2 * LPQ representatives of one trip of the query's lanes; lane ss tests the
-            // groups ss, ss + LPQ, ..  The lower bound applies the metric's own operations to the per-axis distances
-            // to the group's bounding box; every operation is monotone under round-to-nearest, so
-            // bound <= geo <= d for every member, and a group whose bound is not below `lim` cannot hold the winner.
+            // groups ss, ss + LPQ, ..  (further tiles: done above, before the tile was staged)
             const uint32_t ngt = (npair + KS_SPLIT - 1u) / KS_SPLIT;
-            uint32_t cmask = 0u;
-            for (uint32_t t = 0, g = ss; g < ngt; ++t, g += KS_SPLIT) {
-                const float4 lo = s_box[2 * g], hi = s_box[2 * g + 1];
-                const float ex = fmaxf (fmaxf (lo.x - qx, qx - hi.x), 0.f);
-                const float ey = fmaxf (fmaxf (lo.y - qy, qy - hi.y), 0.f);
-                const float ez = fmaxf (fmaxf (lo.z - qz, qz - hi.z), 0.f);
-                const float bound = __builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex));
-                if (bound < lim) cmask |= 1u << t;
-            }
+            if (t0 == 0 && __ballot (tile_near (lim))) cmask = coarse_pass (tn, lim);
             // fine pass: the groups some query of the wave still needs, in ascending order (a lane's pairs must ascend
             // for the tie rule), full evaluation
             // (scalar control flow: the lane ballot of trip t is folded over the wave's queries into one bit per group
@@ -831,7 +894,13 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
                 while (need) {
                     const uint32_t sg = (uint32_t) __builtin_ctz (need);
                     need &= need - 1u;
-                    const uint32_t P = (sg + KS_SPLIT * t) * KS_SPLIT + ss;
+                    // pair of this lane in group gl of the LDS tile.  Strips: the group's 16 consecutive representatives.
+                    // Tiles (LPQ == 8): lane ss holds row ss >> 1, columns 2 (ss & 1) and + 1 of the 4 x 4 tile; groups are
+                    // visited in ascending (tile row, tile column) order, so every lane's pairs still ascend in index —
+                    // what the tie rule (strict '<' keeps a lane's lowest index) relies on.
+                    const uint32_t gl = sg + KS_SPLIT * t;
+                    const uint32_t P = (KS_SPLIT == 8 && gt_lg1) ? (((4u * (gl >> (gt_lg1 - 1u)) + (ss >> 1)) << gt_lg1) + 2u * (gl & ((1u << (gt_lg1 - 1u)) - 1u)) + (ss & 1u))
+                                                                  : gl * KS_SPLIT + ss;
                     if (P < npair) {
                         float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];
                         float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
@@ -1240,10 +1309,35 @@ __global__ __launch_bounds__ (1024) void k_finalize_fused (const double *gmom, i
     // (done, checked mode) leaves as soon as it has arrived
     const uint32_t sv = state_load_lanes (st);
     const double *mom = gmom + (size_t) b * 2 * ICP_NMOM * nb;
+    const uint32_t ng = (nb + 127u) / 128u;
+    const double *gl1 = (ng > ICP_L1_MIN_GROUPS && p.ml1) ? p.ml1 + (size_t) b * ICP_NMOM * ng : nullptr;   // (block-uniform)
     double a0[8];
-    fused_moment_loads<1024> (mom, nb, 0u, a0);
-    if (!fused_finalize_block<128, 1024, ROT> (p, mom, nb, check, sv, a0, &s_fin, s_l1, s_t)) return;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a0[q] = 0.0;
+    if (!gl1) fused_moment_loads<1024> (mom, nb, 0u, a0);
+    if (!fused_finalize_block<128, 1024, ROT> (p, mom, nb, check, sv, a0, &s_fin, s_l1, s_t, gl1)) return;
     fin_result_to_state (&s_fin, st, 0u);
+}
+
+// First tree level of the moments for large sets (|F| / 64 blocks > 128 * ICP_L1_MIN_GROUPS): one 16-lane row per
+// (moment k, group g) task, 16 tasks per block, spread over the chip — k_finalize_fused alone would walk the
+// 18 x ceil (nb / 128) tasks 64 at a time (config C: 36 dependent passes, 39 us).  Same tree, same bits.
+__global__ __launch_bounds__ (256) void k_moment_level1 (const double *gmom, const icp_reg_state *gst, uint32_t nb, uint32_t check, icp_params p)
+{
+    const uint32_t b = blockIdx.y, l = threadIdx.x & 15u, row = threadIdx.x >> 4;
+    if (check && gst[b].done) return;
+    const uint32_t ng = (nb + 127u) / 128u, ntask = ICP_NMOM * ng;
+    const uint32_t task = min (blockIdx.x * 16u + row, ntask - 1u), k = task / ng, g = task - k * ng;
+    const double *src = gmom + (size_t) b * 2 * ICP_NMOM * nb + (size_t) k * nb;
+    double a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const uint32_t i = g * 128u + l + 16u * q;
+        const double t = src[min (i, nb - 1u)];
+        a[q] = (i < nb) ? t : 0.0;
+    }
+    const double v = row_tree8_d (a);
+    if (l == 0 && blockIdx.x * 16u + row < ntask) p.ml1[(size_t) b * ntask + task] = v;
 }
 
 // chain end: finalize the last iteration's moments (slot given by p.slot) into the user-visible state.  (There is no
@@ -1719,7 +1813,8 @@ static inline bool icp_dense (const icp_params &p)
 void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 {
     hipLaunchKernelGGL (k_get_reps, dim3 ((p.nr + 63) / 64, p.batch), dim3 (64), 0, s, p);
-    hipLaunchKernelGGL (k_rep_boxes, dim3 ((p.n16 + p.n32 + 63) / 64, p.batch), dim3 (64), 0, s, p);
+    hipLaunchKernelGGL (k_rep_boxes, dim3 ((p.n16 + 63) / 64, p.batch), dim3 (64), 0, s, p);
+    if (p.nr > 1024u) hipLaunchKernelGGL (k_tile_boxes, dim3 (p.n1k, p.batch), dim3 (64), 0, s, p);      // (a single tile needs no box of its own)
     // step 1, owner(x) = nearest representative: the search kernel's stage 1 over the fixed points
     if (icp_dense (p)) hipLaunchKernelGGL ((k_search<true, false, 4, 8, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
     else hipLaunchKernelGGL ((k_search<true, false, 2, 16, true>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
@@ -1762,6 +1857,9 @@ void icp_launch_finalize (const icp_params &p, hipStream_t s)
 {
     // the rotation solver is a template parameter (p.rot: 1 power method, else SVD)
     if (p.fused) {
+        const uint32_t ng = (p.nb + 127u) / 128u;
+        if (ng > ICP_L1_MIN_GROUPS && p.ml1)
+            hipLaunchKernelGGL (k_moment_level1, dim3 ((ICP_NMOM * ng + 15u) / 16u, p.batch), dim3 (256), 0, s, (const double *) p.mom, (const icp_reg_state *) p.st, p.nb, (uint32_t) p.check, p);
         if (p.rot == 1) hipLaunchKernelGGL (k_finalize_fused<1>, dim3 (p.batch), dim3 (1024), 0, s, (const double *) p.mom, p.st, p.nb, (uint32_t) p.check, p);
         else hipLaunchKernelGGL (k_finalize_fused<0>, dim3 (p.batch), dim3 (1024), 0, s, (const double *) p.mom, p.st, p.nb, (uint32_t) p.check, p);
     } else {

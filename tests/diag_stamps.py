@@ -3,11 +3,11 @@ import sys, os, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import icp_amd
-side, nr = 128, 256
+side, nr = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (128, 256)
 F, M = icp_amd.synth_pair(side)
 g = icp_amd.ICP(0); g.init(side * side, nr, 2e2, 1e-6); g.setPowerMode(1); g.setReduceMode(int(os.environ.get('FUSED','0')))
 g.write(icp_amd.Memory.F, F); g.write(icp_amd.Memory.M, M); g.buildRBC(); g.run_fixed(3); g.sync()
-L = icp_amd.lib(); nb = 256
+L = icp_amd.lib(); nb = side * side // 64
 out = np.zeros((nb, 16), np.uint64)
 for rep in range(3):
     rc = L.icp_debug_stamps(g._h, out.ctypes.data_as(C.c_void_p), nb); assert rc == 0

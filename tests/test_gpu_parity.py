@@ -832,3 +832,20 @@ def test_persistent_fault_falls_back_to_the_chain(engine, oracle, monkeypatch):
     assert_bits(g2.read(engine.Memory.T), o2.T, "T after the asynchronous fallback")
     assert g2.k == 5
     g.close(); g2.close()
+
+
+def test_fused_large_set_first_tree_level_kernel(engine, oracle):
+    """|F| = |M| = 262144 (4096 blocks, 32 tree groups > ICP_L1_MIN_GROUPS): the first level of the moment tree runs as a
+    kernel of its own (k_moment_level1) in front of k_finalize_fused — same tree, same bits as the oracle."""
+    g, o, F, M = make(engine, oracle, 512, 1024, power_fast=True, fused=True)
+    g.buildRBC()
+    o.build_rbc()
+    for _ in range(2):
+        g.step()
+        o.step()
+        check_step(engine, g, o, weighted=False)
+    g.run_fixed(2)                                   # the graph form (two launches + the level-1 kernel per iteration)
+    for _ in range(2):
+        o.step()
+    check_step(engine, g, o, weighted=False)
+    g.close()

@@ -977,10 +977,13 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
 #pragma unroll
             for (uint32_t t = 0; t < KS_DEPTH; ++t) {
                 if (t >= nt) break;
-                const uint32_t j = j0 + t * KS_SPLIT;
-                if (j < je) KS_CAND (g[t], c[t], j);
+                // no tail test: a position past the list's end was clamped to its last element, whose (distance, position)
+                // some lane holds anyway — a duplicate changes neither the minimum nor the lowest position among equals
+                const uint32_t j = min (j0 + t * KS_SPLIT, max (je, 1u) - 1u);
+                KS_CAND (g[t], c[t], j);
             }
         }
+        if (je == o) { best2 = __builtin_inff (); bj = 0xFFFFFFFFu; }      // empty list / invalid query: nothing above was a candidate
     }
     KS_STAMP (4)
     // the query's winner among its lanes: smallest distance, ties -> lowest list position; that lane finishes
@@ -1549,10 +1552,11 @@ __global__ __launch_bounds__ (1024, 2) void k_run_persistent (const float *gM, c
 #pragma unroll
                 for (uint32_t t = 0; t < KS_DEPTH; ++t) {
                     if (t >= nt) break;
-                    const uint32_t j = j0 + t * KS_SPLIT;
-                    if (j < je) KS_CAND (g[t], c[t], j);
+                    const uint32_t j = min (j0 + t * KS_SPLIT, max (je, 1u) - 1u);      // (no tail test: see k_search)
+                    KS_CAND (g[t], c[t], j);
                 }
             }
+            if (je == o) { best2 = __builtin_inff (); bj = 0xFFFFFFFFu; }
         }
         const float dmin = ks_grp_min_f<KS_SPLIT> (best2);
         const uint32_t jmin = ks_grp_min_u<KS_SPLIT> (best2 == dmin ? bj : 0xFFFFFFFFu);

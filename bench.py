@@ -163,8 +163,7 @@ def measure_config(icp_amd, device, cfg, batch, steps, warmup, iters, power_mode
     g.sync()
     build_ms = (time.perf_counter() - t1) / nb * 1e3
     for _ in range(warmup):
-        g.reset_transform()
-        g.run_fixed(iters)
+        g.run_fixed_fresh(iters)
     g.sync()
     t0 = time.perf_counter()
     ev_ms = g.time_run_fixed(iters, steps, from_identity=True)
@@ -243,8 +242,7 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(warmup):
-        g.reset_transform()
-        g.run_fixed(iters)
+        g.run_fixed_fresh(iters)                     # a fresh registration: from the identity transform, one graph
     barrier()
     t0 = time.perf_counter()
     # the K steps; the engine brackets them with hipEvents on its own stream (roofline duration)
@@ -262,13 +260,13 @@ def main():
         g.buildRBC(); g.sync()
         t1 = time.perf_counter()
         for _ in range(reps):
-            g.buildRBC(); g.reset_transform(); g.run_fixed(iters)
+            g.buildRBC(); g.run_fixed_fresh(iters)
         g.sync()
         resident_ms = (time.perf_counter() - t1) / reps * 1e3
         t1 = time.perf_counter()
         for _ in range(reps):
             g.write(icp_amd.Memory.F, F); g.write(icp_amd.Memory.M, M)
-            g.buildRBC(); g.reset_transform(); g.run_fixed(iters)
+            g.buildRBC(); g.run_fixed_fresh(iters)
         g.sync()
         upload_ms = (time.perf_counter() - t1) / reps * 1e3
         t1 = time.perf_counter()

@@ -104,6 +104,7 @@ def lib():
     sig("icp_step", i32, vp, i32)
     sig("icp_run", i32, vp, C.POINTER(u32))
     sig("icp_run_fixed", i32, vp, u32)
+    sig("icp_run_fixed_fresh", i32, vp, u32)
     sig("icp_sync", i32, vp)
     sig("icp_get_alpha", i32, vp, C.POINTER(f32))
     sig("icp_set_alpha", i32, vp, f32)
@@ -397,6 +398,10 @@ class ICPStep:
     def run_fixed(self, iterations):
         """ICP::run(timer) — exactly `iterations` steps, no convergence test (enqueue only)."""
         self._chk(self._L.icp_run_fixed(self._h, iterations))
+
+    def run_fixed_fresh(self, iterations):
+        """reset_transform() + run_fixed(iterations) as one graph (enqueue only)."""
+        self._chk(self._L.icp_run_fixed_fresh(self._h, iterations))
 
     def write_cloud(self, which, cloud):
         cloud = np.ascontiguousarray(cloud, np.float32)

@@ -44,6 +44,7 @@ struct icp_context {
     float *dCloud = nullptr, *dCloudOut = nullptr; uint32_t cloud_cap = 0;
     std::map<uint64_t, graph_entry> graphs;      // key: iterations << 2 | check << 1 | parity
     bool persist_inflight = false;               // a persistent run was enqueued since the last fault check
+    bool last_fresh = false;
     uint32_t last_iterations = 0; int last_check = 0;    // the last graph run (re-issued on the chained path if a persistent run gave up)
     uint32_t enqueued_after_persist = 0;         // state-changing calls enqueued behind the oldest unchecked persistent run
     uint32_t parity = 0;                         // tracking: which of the two landmark buffers is the fixed set (graphs hold pointers)
@@ -179,9 +180,11 @@ int capture_graph (icp_context *h, Fn &&launches, graph_entry *out)
 }
 
 // Capture `iterations` iterations into a graph (cached until a parameter changes).
-int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *out, bool *is_persistent = nullptr)
+// fresh: the graph starts the registration from the identity transform (icp_reset_transform + the run as one graph; the
+// chained form folds the reset into its first launch).
+int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *out, bool *is_persistent = nullptr, bool fresh = false)
 {
-    uint64_t key = ((uint64_t) iterations << 2) | (uint64_t) (check ? 2 : 0) | (uint64_t) h->parity;
+    uint64_t key = ((uint64_t) iterations << 2) | (uint64_t) (check ? 2 : 0) | (uint64_t) h->parity | ((uint64_t) (fresh ? 1 : 0) << 62);
     auto it = h->graphs.find (key);
     if (it != h->graphs.end ()) { *out = it->second.exec; if (is_persistent) *is_persistent = it->second.persistent; return ICP_OK; }
     icp_params p = h->p;
@@ -189,8 +192,9 @@ int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *o
     graph_entry ge;
     const bool persistent = icp_persistent_supported (p) && persist_acquire (h);
     int rc = capture_graph (h, [&] {
+        if (fresh && (persistent || !icp_chain_supported (p))) icp_launch_reset_state (p, h->stream, 1);
         if (persistent) icp_launch_persistent (p, h->stream, iterations);                 // one launch per run
-        else if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations);   // one launch per iteration
+        else if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations, fresh);   // one launch per iteration
         else for (uint32_t k = 0; k < iterations; ++k) {
             p.emit = (check || k + 1 == iterations) ? 1 : 0;            // (with checks on, any iteration may be the last executed)
             icp_launch_iteration (p, h->stream);
@@ -205,15 +209,15 @@ int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *o
 }
 
 // Launches the graph of a run and records what a fault of a persistent run needs to know later (settle).
-int launch_run (icp_context *h, uint32_t iterations, int check)
+int launch_run (icp_context *h, uint32_t iterations, int check, bool fresh = false)
 {
     hipGraphExec_t exec; bool persistent = false;
-    int rc = get_graph (h, iterations, check, &exec, &persistent);
+    int rc = get_graph (h, iterations, check, &exec, &persistent, fresh);
     if (rc) return rc;
     if (h->persist_inflight) h->enqueued_after_persist++;
     HIPCHK (h, hipGraphLaunch (exec, h->stream));
     if (persistent && !h->persist_inflight) { h->persist_inflight = true; h->enqueued_after_persist = 0; }
-    if (persistent) { h->last_iterations = iterations; h->last_check = check; }
+    if (persistent) { h->last_iterations = iterations; h->last_check = check; h->last_fresh = fresh; }
     return ICP_OK;
 }
 
@@ -239,7 +243,7 @@ int settle (icp_context *h)
         return fail (h, ICP_EHIP, "a persistent run gave up (its blocks were not all resident) and further work had been enqueued behind it: "
                                   "the results since are void; persistent runs are now off for this handle, repeat the calls");
     hipGraphExec_t exec;
-    int rc = get_graph (h, h->last_iterations, h->last_check, &exec);
+    int rc = get_graph (h, h->last_iterations, h->last_check, &exec, nullptr, h->last_fresh);
     if (rc) return rc;
     HIPCHK (h, hipGraphLaunch (exec, h->stream));
     HIPCHK (h, hipStreamSynchronize (h->stream));
@@ -575,6 +579,14 @@ int icp_run_fixed (icp_handle h, uint32_t iterations)
     return launch_run (h, iterations, 0);
 }
 
+int icp_run_fixed_fresh (icp_handle h, uint32_t iterations)
+{
+    int rc = need (h, true); if (rc) return rc;
+    if (iterations == 0) return icp_reset_transform (h);
+    if ((rc = set_device (h))) return rc;
+    return launch_run (h, iterations, 0, true);
+}
+
 int icp_run (icp_handle h, uint32_t *k)
 {
     int rc = need (h, true); if (rc) return rc;
@@ -784,19 +796,16 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int fr
     if (!ms_total || iterations == 0 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
     hipGraphExec_t exec; bool persistent = false;
-    if ((rc = get_graph (h, iterations, 0, &exec, &persistent))) return rc;
+    if ((rc = get_graph (h, iterations, 0, &exec, &persistent, from_identity != 0))) return rc;     // from_identity: every pass is a fresh registration
     if (persistent && (rc = settle (h))) return rc;                     // (earlier persistent runs checked before the timed ones start)
     HIPCHK (h, hipEventRecord (h->ev0, h->stream));
-    for (uint32_t r = 0; r < reps; ++r) {
-        if (from_identity) icp_launch_reset_state (h->p, h->stream, 1);   // every pass is a fresh registration
-        HIPCHK (h, hipGraphLaunch (exec, h->stream));
-    }
+    for (uint32_t r = 0; r < reps; ++r) HIPCHK (h, hipGraphLaunch (exec, h->stream));
     HIPCHK (h, hipEventRecord (h->ev1, h->stream));
     HIPCHK (h, hipEventSynchronize (h->ev1));
     HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));
     if (persistent) {                                                   // a run that gave up makes the timing void: say so
         h->persist_inflight = true; h->enqueued_after_persist = reps > 1 || from_identity ? 1u : 0u;
-        h->last_iterations = iterations; h->last_check = 0;
+        h->last_iterations = iterations; h->last_check = 0; h->last_fresh = from_identity != 0;
         if ((rc = settle (h))) return rc;
     }
     return ICP_OK;

@@ -61,7 +61,7 @@ void icp_launch_sij (const icp_params &p, hipStream_t s);
 void icp_launch_finalize (const icp_params &p, hipStream_t s);
 void icp_launch_iteration (const icp_params &p, hipStream_t s);
 void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask);
-void icp_launch_chain (const icp_params &p, hipStream_t s, uint32_t iterations);
+void icp_launch_chain (const icp_params &p, hipStream_t s, uint32_t iterations, bool fresh = false);
 bool icp_chain_supported (const icp_params &p);
 bool icp_persistent_supported (const icp_params &p);
 void icp_launch_persistent (const icp_params &p, hipStream_t s, uint32_t iterations);

@@ -689,7 +689,18 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     // every independent global load of the prologue is issued before anything waits: the state (one vector load,
     // lane j = dword j: scalar loads of T would queue behind the waits of the vector loads), the first tile of
     // representatives (+ list offsets / sizes), the query point (clamped address, selected afterwards)
-    const uint32_t sv = OWNER ? 0u : state_load_lanes (st);
+    uint32_t sv = OWNER ? 0u : state_load_lanes (st);
+    if constexpr (CHAIN) {
+        // bit 4 of check_flags (first launch of a chain): the run starts from the identity transform — what k_reset_state
+        // would have left in the state (T = Tk = (0,0,0,1 | 0,0,0,1), R = Rk = I, S = means = sum_w = 0, k = done = 0),
+        // without a launch of its own; the run's bookkeeping (epoch, fault) is kept
+        static_assert (ICP_ST_DW (T) == 0 && ICP_ST_DW (Tk) == 8 && ICP_ST_DW (R) == 16 && ICP_ST_DW (Rk) == 25 && ICP_ST_DW (epoch) == 60, "state layout");
+        if (check_flags & 16u) {
+            constexpr unsigned long long ones = (1ull << 3) | (1ull << 7) | (1ull << 11) | (1ull << 15) | (1ull << 16) | (1ull << 20) | (1ull << 24) |
+                                                (1ull << 25) | (1ull << 29) | (1ull << 33);
+            if (lane < ICP_ST_DW (epoch)) sv = ((ones >> lane) & 1ull) ? 0x3F800000u : 0u;
+        }
+    }
     // chained variant: the previous iteration's block moments (first tree level of this block's finalize) travel with
     // the other prologue loads
     double ma0[8];
@@ -1894,21 +1905,22 @@ bool icp_chain_supported (const icp_params &p)
     return p.fused && p.nb <= 4096u && p.nr <= 1024u && (p.chain == 2 || (p.chain == 1 && !icp_dense (p)));
 }
 
-void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations)
+void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations, bool fresh)
 {
     icp_params p = p0;
     if (iterations == 0) return;
+    const uint32_t first_flags = 2u | (fresh ? 16u : 0u);             // (fresh: the run starts from the identity, see k_search)
     for (uint32_t j = 0; j < iterations; ++j) {
         p.slot = j & 1u;
         p.emit = (p.check || j + 1 == iterations) ? 1 : 0;          // (with checks on, any iteration may be the last executed)
         // the first launch reads the user-visible state directly (pending == 0 there: nothing to finalize yet)
         if (p.rot == 1) {
             if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 1>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, (const double *) p.mom,
-                                            p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | 2u, p);
+                                            p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | first_flags, p);
             else hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 1>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
         } else {
             if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 0>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, (const double *) p.mom,
-                                            p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | 2u, p);
+                                            p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | first_flags, p);
             else hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 0>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
         }
     }

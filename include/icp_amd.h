@@ -162,6 +162,11 @@ int icp_run_fixed (icp_handle h, uint32_t iterations);
 /* T <- identity, k <- 0: the state ICPStep::init uploads (src/ICP/algorithms.cpp:4486-4493). Enqueue only. */
 int icp_reset_transform (icp_handle h);
 
+/* icp_reset_transform + icp_run_fixed as ONE graph: a fresh registration of exactly `iterations` steps (the reference's
+ * profiling run right after init, include/ICP/algorithms.hpp:2482-2494).  In the chained form the reset costs no launch
+ * (the first search of the chain starts from the identity itself).  Enqueue only. */
+int icp_run_fixed_fresh (icp_handle h, uint32_t iterations);
+
 /* Blocks until everything enqueued on the handle's stream is done (queue.finish ()). */
 int icp_sync (icp_handle h);
 

@@ -849,3 +849,35 @@ def test_fused_large_set_first_tree_level_kernel(engine, oracle):
         o.step()
     check_step(engine, g, o, weighted=False)
     g.close()
+
+
+@pytest.mark.parametrize("side,nr,batch", [(128, 256, 1), (64, 64, 2), (256, 1024, 1)])
+def test_run_fixed_fresh_equals_reset_plus_run(engine, oracle, side, nr, batch):
+    """icp_run_fixed_fresh = reset_transform + run_fixed as one graph (chained form: the first search starts from the
+    identity itself, no reset launch): same bits as the two calls, after a run that left another T, k and S behind."""
+    m = side * side
+    g = engine.ICP(0)
+    g.init(m, nr, A, C_, batch=batch)
+    oracles = []
+    for b in range(batch):
+        F, M = engine.synth_pair(side, seed=0x99 + b, rot_deg=2.0 + b)
+        g.write(engine.Memory.F, F, batch_index=b); g.write(engine.Memory.M, M, batch_index=b)
+        o = oracle.OracleICP(m, nr, A, C_, threads=8, power_fast=True, fused=True)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        oracles.append(o)
+    g.buildRBC()
+    g.run()                                          # leaves a converged T, k > 0 (and done = 1) behind
+    g.run_fixed_fresh(6)
+    for b, o in enumerate(oracles):
+        for _ in range(6):
+            o.step()
+        assert g.state(b).k == 6 and not g.state(b).converged
+        assert_bits(g.read(engine.Memory.T, b), o.T, "T after a fresh fixed run, registration %d" % b)
+        assert_bits(g.read(engine.Memory.S, b), o.S, "S")
+        assert np.array_equal(g.read(engine.Memory.NN_ID, b)["id"], o.nn_id["id"])
+    g.run_fixed(2)                                   # continues from there
+    for b, o in enumerate(oracles):
+        for _ in range(2):
+            o.step()
+        assert_bits(g.read(engine.Memory.T, b), o.T, "T after continuing")
+    g.close()

@@ -294,9 +294,14 @@ __global__ void k_count (icp_params p)
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (r >= p.nr) return;
     uint32_t run = 0;
-    for (uint32_t ch = 0; ch < p.nchunk; ++ch) {
-        uint32_t *h = p.chunk_hist + ((size_t) b * p.nchunk + ch) * p.nr + r;
-        uint32_t v = *h; *h = run; run += v;
+    uint32_t *h0 = p.chunk_hist + (size_t) b * p.nchunk * p.nr + r;
+    for (uint32_t c0 = 0; c0 < p.nchunk; c0 += 8u) {                  // eight independent loads in flight, then the serial scan
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) v[k] = (c0 + k < p.nchunk) ? h0[(size_t) (c0 + k) * p.nr] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k)
+            if (c0 + k < p.nchunk) { h0[(size_t) (c0 + k) * p.nr] = run; run += v[k]; }
     }
     p.N[(size_t) b * p.nr + r] = run;
 }

@@ -837,7 +837,8 @@ int icp_launches_per_iteration (icp_handle h, uint32_t *n)
     if (!n) return fail (h, ICP_EINVAL, "null output");
     int form = ICP_FORM_SEPARATE;
     if ((rc = icp_run_form (h, &form))) return rc;
-    *n = form != ICP_FORM_SEPARATE ? 1u : h->p.fused ? 2u : 4u;
+    // (fused, large sets: the first level of the moment tree is a launch of its own — icp_launch_finalize)
+    *n = form != ICP_FORM_SEPARATE ? 1u : h->p.fused ? ((h->p.nb + 127u) / 128u > 16u ? 3u : 2u) : 4u;
     return ICP_OK;
 }
 

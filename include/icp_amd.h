@@ -301,8 +301,9 @@ int icp_profile_run (icp_handle h, uint32_t iterations, float *out_ms, float *to
 int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4);
 
 /* Kernel launches per iteration of the graphs behind icp_run / icp_run_fixed with the current modes and sizes:
- * 4 (reference-order reductions), 2 (fused: search + finalize) or 1 (fused, latency-bound sizes: at most one launch per
- * iteration — chained or persistent, see icp_run_form). */
+ * 4 (reference-order reductions), 2 (fused: search + finalize; 3 beyond |F| = 131072, where the first level of the
+ * moment tree is a launch of its own) or 1 (fused, latency-bound sizes: at most one launch per iteration — chained or
+ * persistent, see icp_run_form). */
 int icp_launches_per_iteration (icp_handle h, uint32_t *n);
 
 /* How icp_run / icp_run_fixed execute with the current modes and sizes:

@@ -451,6 +451,23 @@ template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint
 #define FF_STAMP(k)
 #endif
 
+// XCD-aware block -> tile mapping (fused mode, one-block-per-CU variants).  Workgroups are dealt round-robin over the 8 XCDs
+// (blocks b and b + 8 share one; every XCD has its own L2).  Block b works on tile (b mod 8) * (nb / 8) + b / 8: the blocks of
+// one XCD cover a contiguous band of tile rows, and — what the measurement says matters — a contiguous range of moment
+// slots: every 128-byte line of the per-block moments is then written inside ONE L2 instead of collecting eight partial
+// write-backs.  Measured at A (same box, alternating): identity 9.61, bands 9.42, a 2 x 4 arrangement of compact rectangles
+// (better list locality, lines shared by four XCDs again) 9.66 us per iteration.  Only which block computes which tile
+// changes — the tile index is what the query index, the moment slot and the canonical trees use, so the bits do not.
+// (Speed only: nothing depends on the placement actually being round-robin.)
+static __device__ __forceinline__ uint32_t ks_tile_of_block (uint32_t bx, uint32_t nbx)
+{
+#ifdef ICP_NO_XCD_MAP
+    return bx;
+#else
+    return (nbx & 7u) == 0u ? (bx & 7u) * (nbx >> 3) + (bx >> 3) : bx;
+#endif
+}
+
 // fused mode: query index of local element e of block b (CPU twin: orc_fused_query).  8 x 8 tiles of the
 // landmark grid when its side is a multiple of 8, else 64 consecutive queries.
 // tpr_magic = floor (2^32 / tpr) + 1 (host: icp_tpr_magic): b / tpr == umulhi (b, tpr_magic) for b * tpr < 2^32.
@@ -685,7 +702,10 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     // lane e = query e: index, load, transform, pruning seed — and hands them to the lanes of each query through LDS;
     // the other 15 (7) waves neither compute the index nor load / transform the same point LPQ times over.
     const bool qwave = slice == KS_SPLIT - 1u;
-    const uint32_t iq = FUSED ? fused_query_index (m, side, tpr_magic, blockIdx.x, lane)
+    // (the one-block-per-CU variants only: measured 9.63 -> 9.43 us per iteration at A; the dense variant runs several blocks
+    // per CU over grids of thousands and measured 0 ... 4 % slower with it)
+    const uint32_t tile_id = (FUSED && MINW == 2) ? ks_tile_of_block (blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t iq = FUSED ? fused_query_index (m, side, tpr_magic, tile_id, lane)
                               : (blockIdx.x >> 1) * 128u + 2u * lane + (blockIdx.x & 1u);
 
     const float4 *M4 = reinterpret_cast<const float4 *> (gM + (size_t) b * m * 8);
@@ -1078,7 +1098,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
         double c0 = s_mom[k][l] + s_mom[k][l + 32], c1 = s_mom[k][l + 16] + s_mom[k][l + 48];
         double v = row_tree_tail_d (c0 + c1);
         const uint32_t obuf = CHAIN ? (p.slot ^ 1u) : 0u;
-        if (l == 0 && mrow < ICP_NMOM) p.mom[(((size_t) b * 2 + obuf) * ICP_NMOM + mrow) * p.nb + blockIdx.x] = v;
+        if (l == 0 && mrow < ICP_NMOM) p.mom[(((size_t) b * 2 + obuf) * ICP_NMOM + mrow) * p.nb + tile_id] = v;
     } else if (slice == 0 && p.weighted) {
         // tree levels d = 64 .. 2 restricted to this block's parity class (icp_kernels.cl:244-249):
         // element e of the class is position 2e + parity; levels pair e with e+32, e+16, .., e+1.
@@ -1438,7 +1458,8 @@ __global__ __launch_bounds__ (1024, 2) void k_run_persistent (const float *gM, c
     const uint32_t slice = __builtin_amdgcn_readfirstlane (tid >> 6);
     const uint32_t qe = slice * KS_QPW + lane / KS_SPLIT, ss = lane & (KS_SPLIT - 1u);
     const bool qwave = slice == KS_SPLIT - 1u;
-    const uint32_t iq = fused_query_index (m, side, tpr_magic, blockIdx.x, lane);
+    const uint32_t tile_id = ks_tile_of_block (blockIdx.x, gridDim.x);
+    const uint32_t iq = fused_query_index (m, side, tpr_magic, tile_id, lane);
     icp_reg_state *st = gst + b;
     const float4 *M4 = reinterpret_cast<const float4 *> (gM + (size_t) b * m * 8);
     const float4 *R4 = reinterpret_cast<const float4 *> (gR + (size_t) b * nr * 8);
@@ -1635,7 +1656,7 @@ __global__ __launch_bounds__ (1024, 2) void k_run_persistent (const float *gM, c
                 // one 16-byte write-through store {low, epoch, high, epoch}: either 8-byte half validates itself, so it does
                 // not matter whether the two halves become visible together
                 const unsigned long long u = __builtin_bit_cast (unsigned long long, v);
-                icp_gu64 *rec = xch + (((size_t) par * ICP_NMOM + row) * 256u + blockIdx.x) * 2u;
+                icp_gu64 *rec = xch + (((size_t) par * ICP_NMOM + row) * 256u + tile_id) * 2u;
                 const icp_u32x4 r4 = { (uint32_t) u, epoch, (uint32_t) (u >> 32), epoch };
                 asm volatile ("global_store_dwordx4 %0, %1, off sc1" :: "v"(rec), "v"(r4) : "memory");
             }

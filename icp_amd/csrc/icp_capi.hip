@@ -40,6 +40,9 @@ struct icp_context {
     float *dF = nullptr, *dM = nullptr;          // may be adopted
     bool ownF = true, ownM = true;
     float *hF = nullptr, *hM = nullptr, *hT = nullptr;   // pinned staging (H_IN_F / H_IN_M / H_IO_T)
+    icp_reg_state *hState = nullptr;             // pinned mirror of the registration states: every run graph ends with a copy into it
+    bool hstate_fresh = false;                   // the mirror is what the device holds once the stream has drained (a run graph was the
+                                                 // last state-changing thing enqueued)
     float *dTin = nullptr;                       // device scratch for write(T)
     float *dCloud = nullptr, *dCloudOut = nullptr; uint32_t cloud_cap = 0;
     std::map<uint64_t, graph_entry> graphs;      // key: iterations << 2 | check << 1 | parity
@@ -104,6 +107,8 @@ void free_all (icp_context *h)
     if (h->hF) (void) hipHostFree (h->hF);
     if (h->hM) (void) hipHostFree (h->hM);
     if (h->hT) (void) hipHostFree (h->hT);
+    if (h->hState) (void) hipHostFree (h->hState);
+    h->hState = nullptr; h->hstate_fresh = false;
     if (h->dCloud) (void) hipFree (h->dCloud);
     if (h->dCloudOut) (void) hipFree (h->dCloudOut);
     h->hF = h->hM = h->hT = nullptr; h->dCloud = h->dCloudOut = nullptr; h->cloud_cap = 0;
@@ -199,6 +204,11 @@ int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *o
             p.emit = (check || k + 1 == iterations) ? 1 : 0;            // (with checks on, any iteration may be the last executed)
             icp_launch_iteration (p, h->stream);
         }
+        // ICP::run () (checked graphs: the blocking call whose caller wants k and the state): the states travel to the pinned
+        // mirror as the last node of the graph, so that neither the call nor the pull of the public members costs a copy of
+        // its own (two blocking 248-byte hipMemcpy calls were 25 us of a 420 us run).  Fixed-length graphs are enqueue-only
+        // and stay without it (3 us per graph).
+        if (check) (void) hipMemcpyAsync (h->hState, p.st, sizeof (icp_reg_state) * p.batch, hipMemcpyDeviceToHost, h->stream);
     }, &ge);
     if (rc) return rc;
     ge.persistent = persistent;
@@ -218,6 +228,7 @@ int launch_run (icp_context *h, uint32_t iterations, int check, bool fresh = fal
     HIPCHK (h, hipGraphLaunch (exec, h->stream));
     if (persistent && !h->persist_inflight) { h->persist_inflight = true; h->enqueued_after_persist = 0; }
     if (persistent) { h->last_iterations = iterations; h->last_check = check; h->last_fresh = fresh; }
+    h->hstate_fresh = check != 0;
     return ICP_OK;
 }
 
@@ -234,6 +245,7 @@ int settle (icp_context *h)
     bool fault = false;
     for (const auto &s : st) fault = fault || s.fault != 0u;
     if (!fault) return ICP_OK;
+    h->hstate_fresh = false;
     h->p.persistent = 0;
     drop_graphs (h);
     persist_release (h);
@@ -247,10 +259,12 @@ int settle (icp_context *h)
     if (rc) return rc;
     HIPCHK (h, hipGraphLaunch (exec, h->stream));
     HIPCHK (h, hipStreamSynchronize (h->stream));
+    h->hstate_fresh = h->last_check != 0;
     return ICP_OK;
 }
 
-void note_enqueue (icp_context *h) { if (h->persist_inflight) h->enqueued_after_persist++; }
+// every state-changing enqueue that is not a run graph: the pinned mirror of the states is stale from here on
+void note_enqueue (icp_context *h) { if (h->persist_inflight) h->enqueued_after_persist++; h->hstate_fresh = false; }
 
 }  // namespace
 
@@ -396,6 +410,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     HIPCHK (h, hipHostMalloc ((void **) &h->hF, B * m * 8 * sizeof (float), hipHostMallocDefault));
     HIPCHK (h, hipHostMalloc ((void **) &h->hM, B * m * 8 * sizeof (float), hipHostMallocDefault));
     HIPCHK (h, hipHostMalloc ((void **) &h->hT, 64 * sizeof (float), hipHostMallocDefault));
+    HIPCHK (h, hipHostMalloc ((void **) &h->hState, B * sizeof (icp_reg_state), hipHostMallocDefault));
     icp_launch_reset_state (p, h->stream, 1);
     HIPCHK (h, hipGetLastError ());
     HIPCHK (h, hipStreamSynchronize (h->stream));
@@ -431,6 +446,7 @@ int icp_write_b (icp_handle h, uint32_t b, int mem, const void *host_ptr, int bl
             HIPCHK (h, hipStreamSynchronize (h->stream));
             if (host_ptr) std::memcpy (h->hT, host_ptr, 8 * sizeof (float));   // :4613-4617
             HIPCHK (h, hipMemcpyAsync (h->dTin, h->hT, 8 * sizeof (float), hipMemcpyHostToDevice, h->stream));
+            note_enqueue (h);
             icp_launch_set_T (h->p, b, h->dTin, h->stream);
             HIPCHK (h, hipGetLastError ());
             break;
@@ -594,9 +610,12 @@ int icp_run (icp_handle h, uint32_t *k)
     if ((rc = launch_run (h, h->max_iterations, 1))) return rc;
     if ((rc = settle (h))) return rc;                                // queue.finish () — :4813
     if (k) {
-        icp_reg_state st;
-        HIPCHK (h, hipMemcpy (&st, h->p.st, sizeof st, hipMemcpyDeviceToHost));
-        *k = st.k;
+        if (h->hstate_fresh) *k = h->hState[0].k;                    // (the graph's last node left the states in the pinned mirror)
+        else {
+            icp_reg_state st;
+            HIPCHK (h, hipMemcpy (&st, h->p.st, sizeof st, hipMemcpyDeviceToHost));
+            *k = st.k;
+        }
     }
     return ICP_OK;
 }
@@ -665,8 +684,13 @@ int icp_state_b (icp_handle h, uint32_t b, icp_state_t *out)
     if ((rc = set_device (h))) return rc;
     if (h->persist_inflight && (rc = settle (h))) return rc;
     icp_reg_state st;
-    HIPCHK (h, hipMemcpyAsync (&st, h->p.st + b, sizeof st, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK (h, hipStreamSynchronize (h->stream));
+    if (h->hstate_fresh) {                       // a run graph was the last thing that changed the states: its final copy node
+        HIPCHK (h, hipStreamSynchronize (h->stream));
+        st = h->hState[b];
+    } else {
+        HIPCHK (h, hipMemcpyAsync (&st, h->p.st + b, sizeof st, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK (h, hipStreamSynchronize (h->stream));
+    }
     std::memcpy (out->R, st.R, sizeof st.R); std::memcpy (out->Rk, st.Rk, sizeof st.Rk);
     std::memcpy (out->q, st.T, 16); std::memcpy (out->t, st.T + 4, 12); out->s = st.T[7];
     std::memcpy (out->qk, st.Tk, 16); std::memcpy (out->tk, st.Tk + 4, 12); out->sk = st.Tk[7];
@@ -800,6 +824,7 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int fr
     if (persistent && (rc = settle (h))) return rc;                     // (earlier persistent runs checked before the timed ones start)
     HIPCHK (h, hipEventRecord (h->ev0, h->stream));
     for (uint32_t r = 0; r < reps; ++r) HIPCHK (h, hipGraphLaunch (exec, h->stream));
+    h->hstate_fresh = false;
     HIPCHK (h, hipEventRecord (h->ev1, h->stream));
     HIPCHK (h, hipEventSynchronize (h->ev1));
     HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));
@@ -887,6 +912,7 @@ int icp_profile_run (icp_handle h, uint32_t iterations, float *out_ms, float *to
     if (!out_ms || iterations == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
     icp_params p = h->p; p.check = 0; p.emit = 1;
+    note_enqueue (h);
     std::vector<hipEvent_t> ev ((size_t) iterations * 5, nullptr);
     hipError_t e = hipSuccess;
     for (auto &x : ev) if (e == hipSuccess) e = hipEventCreate (&x);

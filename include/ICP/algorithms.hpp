@@ -408,10 +408,9 @@ namespace ICP
         /*! \brief Blocking; iterates until check () stops (src/ICP/algorithms.cpp:4806-4834). */
         void run ()
         {
-            uint32_t kk = 0;
-            this->check (icp_run (this->h, &kk));
-            this->pull ();
-            k = kk;
+            this->check (icp_run (this->h, nullptr));
+            this->pull ();                            // (the state arrived in pinned host memory with the run's graph: no further copy)
+            k = this->k_;
         }
 
         /*! \brief The reference's profiling run, `double run (clutils::GPUTimer<period>&)` (include/ICP/algorithms.hpp:

@@ -2,6 +2,7 @@
 // cl_algo::ICP::ICP<POWER_METHOD, WEIGHTED> (compare src/ocl_icp_reg.cpp:103-120, 165-210).
 // Prints k and the final [q | t, s] so that tests/test_gpu_facade.py can compare them with the oracle.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <vector>
 #include <ICP/algorithms.hpp>
@@ -41,6 +42,32 @@ int main (int argc, char **argv)
         sbs.buildRBC ();
         sbs.run (true); sbs.run ();
         printf ("S %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", sbs.q.x (), sbs.q.y (), sbs.q.z (), sbs.q.w (), sbs.t (0), sbs.t (1), sbs.t (2), sbs.s);
+
+        // diagnostic (fourth argument "time"): what a user of the facade gets per iteration from the blocking ICP::run () —
+        // graph launch, convergence checks on the device, host synchronisation and the pull of the public members included
+        if (argc > 4 && argv[4][0] == 't')
+        {
+            const int reps = 50; unsigned long ktot = 0;
+            reg.buildRBC (); reg.run ();                               // warm-up (graph capture)
+            double us = 0.0, us_run = 0.0;
+            for (int i = 0; i < reps; ++i)
+            {
+                const float T0[8] = { 0, 0, 0, 1, 0, 0, 0, 1 };
+                const auto t0 = std::chrono::steady_clock::now ();
+                reg.write (decltype (reg)::Memory::D_IO_T, (void *) T0, true);
+                reg.buildRBC ();
+                icp_sync (reg.handle ());
+                const auto t1 = std::chrono::steady_clock::now ();
+                reg.run ();
+                const auto t2 = std::chrono::steady_clock::now ();
+                us += std::chrono::duration<double, std::micro> (t2 - t0).count ();
+                us_run += std::chrono::duration<double, std::micro> (t2 - t1).count ();
+                ktot += reg.k;
+            }
+            printf ("TIME mode %s: %d registrations, k = %.1f: ICP::run () alone %.1f us = %.2f us per iteration (launch, device-side checks, "
+                    "host synchronisation and the pull of the public members included); with write (T) + buildRBC %.1f us per registration\n",
+                    mode == icp::Mode::FAST ? "fast" : "reference", reps, (double) ktot / reps, us_run / reps, us_run / (double) ktot, us / reps);
+        }
 
         // re-init of the same object at another size, then at the first size again (the buffers fetched through get ()
         // after the first init belong to the engine and are re-created, never adopted): same result as a fresh object

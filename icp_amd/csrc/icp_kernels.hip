@@ -657,8 +657,10 @@ static __device__ __forceinline__ void fin_result_to_state (const icp_fin_result
 // OWNER: the kernel is RBC construct step 1 instead (owner(x) = nearest representative of the FIXED point x: gM = F,
 // no transform, stage 1 only, result to p.owner) — the same stage-1 code, pruning included, seeded with the
 // representative of the point's own grid cell.
-template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER = false, int ROT = 1>
-__global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, const float *gR, icp_reg_state *gst, const double *gmom,
+// TILE = representatives per LDS tile: 1024, or 256 for the dense variant at |R| <= 256 (batches of config 4): 22 KB instead of
+// 47 KB of LDS per block and a register budget for 8 waves per SIMD — four blocks per CU instead of three.
+template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER = false, int ROT = 1, int TILE = 1024>
+__global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (const float *gM, const float *gR, icp_reg_state *gst, const double *gmom,
                                                               uint32_t m, uint32_t nr, uint32_t side, uint32_t tpr_magic,
                                                               uint32_t nb, uint32_t check_flags, icp_params p)
 {
@@ -669,6 +671,8 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     // check_flags: bit 0 = convergence checks on; bit 1 (CHAIN) = first launch of a chain: gst is the user-visible
     // state array (stride 1) instead of a pair of slots; bit 3 = store the matched / transformed points too (fused
     // mode needs them only after the last iteration of a graph; the reference-order kernels read them every time).
+    constexpr uint32_t KT = (uint32_t) TILE;
+    if constexpr (TILE < 1024) __builtin_assume (nr <= KT);             // (launched for single-tile sets only: the tile loop folds away)
     const uint32_t b = blockIdx.y, check = check_flags & 1u;
     icp_reg_state *st = (CHAIN && !(check_flags & 2u)) ? gst + (size_t) b * 2 : gst + b;
 #ifdef ICP_DBG_STAMPS
@@ -678,9 +682,9 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
 
     // representatives of the current tile, pair-interleaved for packed fp32 math:
     //   pair P = reps (2P, 2P+1) -> 3 float4: [x0 x1 y0 y1] [z0 z1 r0 r1] [g0 g1 b0 b1]
-    __shared__ float4 s_pair[3 * KS_TILE / 2];
-    __shared__ uint2 s_on[KS_TILE];                  // (offset, size) of every representative's list
-    __shared__ float4 s_box[2 * (KS_TILE / 16)];     // (lo, hi) of the tile's groups of 2 * LPQ representatives
+    __shared__ float4 s_pair[3 * KT / 2];
+    __shared__ uint2 s_on[KT];                  // (offset, size) of every representative's list
+    __shared__ float4 s_box[2 * (KT / 16)];     // (lo, hi) of the tile's groups of 2 * LPQ representatives
     __shared__ float s_w[64];
     __shared__ float4 s_qc[64];                      // query hand-in: (r, g, b, pruning seed); s_qa carries (q', index)
     __shared__ float4 s_qa[64];                      // per-query hand-off to the finishing wave: (q', distance)
@@ -731,7 +735,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     double ma0[8];
     if constexpr (CHAIN) fused_moment_loads<64 * LPQ> (gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, 0u, ma0);
     float *s_pairf = reinterpret_cast<float *> (s_pair);
-    const uint32_t tn0 = min (KS_TILE, nr);
+    const uint32_t tn0 = min (KT, nr);
     float4 rg[2], rc[2]; uint2 ron[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -828,32 +832,37 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     auto coarse_pass = [&] (uint32_t tn_, float lim_) -> uint32_t {
         const uint32_t ngt = (((tn_ + 1u) >> 1) + KS_SPLIT - 1u) / KS_SPLIT;
         uint32_t cm = 0u;
-        for (uint32_t t = 0, g = ss; g < ngt; ++t, g += KS_SPLIT) {
+        auto test = [&] (uint32_t t, uint32_t g) {
             const float4 lo = s_box[2 * g], hi = s_box[2 * g + 1];
             const float ex = fmaxf (fmaxf (lo.x - qx, qx - hi.x), 0.f);
             const float ey = fmaxf (fmaxf (lo.y - qy, qy - hi.y), 0.f);
             const float ez = fmaxf (fmaxf (lo.z - qz, qz - hi.z), 0.f);
             const float bound = __builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex));
             if (bound < lim_) cm |= 1u << t;
-        }
+        };
+        if constexpr (TILE == 256) {                 // at most two trips per lane: not unrolled (the 64-register budget of this variant)
+#pragma unroll 1
+            for (uint32_t t = 0, g = ss; g < ngt; ++t, g += KS_SPLIT) test (t, g);
+        } else
+            for (uint32_t t = 0, g = ss; g < ngt; ++t, g += KS_SPLIT) test (t, g);
         return cm;
     };
-    for (uint32_t t0 = 0; t0 < nr; t0 += KS_TILE) {
-        const uint32_t tn = min (KS_TILE, nr - t0);
+    for (uint32_t t0 = 0; t0 < nr; t0 += KT) {
+        const uint32_t tn = min (KT, nr - t0);
         uint32_t cmask = 0u;
         // several tiles: the box of the whole tile first (same bound as for a group) — a query far from the tile skips its
         // 64 group tests, and a tile no query of the block is near is neither tested further nor staged (at |R| = 4096 a
         // block's 64 neighbouring queries need one, seldom two, of the four tiles)
         auto tile_near = [&] (float lim_) -> bool {
-            if (nr <= KS_TILE) return true;
-            const float4 *tb = p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + 2u * (t0 / KS_TILE);
+            if (nr <= KT) return true;
+            const float4 *tb = p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + 2u * (t0 / 1024u);      // (k_tile_boxes: tiles of 1024; several tiles only with TILE == 1024)
             const float4 lo = tb[0], hi = tb[1];
             const float ex = fmaxf (fmaxf (lo.x - qx, qx - hi.x), 0.f);
             const float ey = fmaxf (fmaxf (lo.y - qy, qy - hi.y), 0.f);
             const float ez = fmaxf (fmaxf (lo.z - qz, qz - hi.z), 0.f);
             return __builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex)) < lim_;
         };
-        if (t0) {                                    // further tiles (nr > KS_TILE)
+        if (t0) {                                    // further tiles (nr > KT)
             __syncthreads ();
             if (prune) {
                 const bool near = tile_near (s1_lim);
@@ -899,7 +908,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
         if (t0 == 0 && prune) {
             seed = min (seed, nr - 1u);
             float sx, sy, sz, sr, sg, sb;
-            if (MINW == 2 || nr <= KS_TILE) {        // one tile: the seed is in LDS (MINW == 2: always, see icp_launch_search)
+            if (MINW == 2 || nr <= KT) {        // one tile: the seed is in LDS (MINW == 2: always, see icp_launch_search)
                 const float *sp = s_pairf + (seed >> 1) * 12u + (seed & 1u);
                 sx = sp[0]; sy = sp[2]; sz = sp[4]; sr = sp[6]; sg = sp[8]; sb = sp[10];
                 // (keeps the compiler from merging this with the global path below into flat loads)
@@ -979,7 +988,7 @@ __global__ __launch_bounds__ (64 * LPQ, MINW) void k_search (const float *gM, co
     // from LDS; the compile-time split keeps the compiler from merging the two sources into flat loads.
     uint32_t o, n;
     if constexpr (MINW == 2) { const uint2 on = s_on[rstar]; o = on.x; n = on.y; }
-    else if (nr <= KS_TILE) { const uint2 on = s_on[rstar]; o = on.x; n = on.y; asm volatile ("" : "+v"(o), "+v"(n)); }
+    else if (nr <= KT) { const uint2 on = s_on[rstar]; o = on.x; n = on.y; asm volatile ("" : "+v"(o), "+v"(n)); }
     else { o = gO[rstar]; n = gN[rstar]; }
 
     // ---- stage 2: exhaustive scan of that representative's list: the LPQ lanes of a query read LPQ consecutive
@@ -1872,7 +1881,8 @@ void icp_launch_search (const icp_params &p, hipStream_t s)
 #define KS_ARGS p.M, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
 #define KS_CHAIN_ARGS p.M, p.R, p.cst + p.slot, (const double *) p.mom + (size_t) p.slot * ICP_NMOM * p.nb, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
     if (p.fused) {
-        if (dense) hipLaunchKernelGGL ((k_search<true, false, 4, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
+        if (dense && p.nr <= 256u && p.rot == 1) hipLaunchKernelGGL ((k_search<true, false, 4, 8, false, 1, 256>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
+        else if (dense) hipLaunchKernelGGL ((k_search<true, false, 4, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
         else hipLaunchKernelGGL ((k_search<true, false, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_ARGS);
     } else {
         if (dense) hipLaunchKernelGGL ((k_search<false, false, 4, 8>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, KS_ARGS);

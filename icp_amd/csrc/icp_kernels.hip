@@ -246,15 +246,16 @@ __global__ void k_rep_boxes (icp_params p)
     GB[2 * t] = lo; GB[2 * t + 1] = hi;
 }
 
-// Geometry bounding box of every LDS tile of k_search (1024 consecutive representatives): one wave per tile
-// (min / max are exact in any order).
+// Geometry bounding box of every 1024 consecutive representatives (the LDS tile of k_search for multi-tile sets): one wave
+// per box (min / max are exact in any order).
+#define ICP_TBOX 1024u
 __global__ __launch_bounds__ (64) void k_tile_boxes (icp_params p)
 {
     const uint32_t tile = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const float4 *R4 = reinterpret_cast<const float4 *> (p.R + (size_t) b * p.nr * 8);
     const float inf = __builtin_inff ();
     float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
-    for (uint32_t r = tile * 1024u + lane; r < min (p.nr, (tile + 1u) * 1024u); r += 64u) {
+    for (uint32_t r = tile * ICP_TBOX + lane; r < min (p.nr, (tile + 1u) * ICP_TBOX); r += 64u) {
         const float4 v = R4[2 * (size_t) r];
         lo[0] = fminf (lo[0], v.x); lo[1] = fminf (lo[1], v.y); lo[2] = fminf (lo[2], v.z);
         hi[0] = fmaxf (hi[0], v.x); hi[1] = fmaxf (hi[1], v.y); hi[2] = fmaxf (hi[2], v.z);
@@ -659,7 +660,8 @@ static __device__ __forceinline__ void fin_result_to_state (const icp_fin_result
 // representative of the point's own grid cell.
 // TILE = representatives per LDS tile: 1024, or 256 for the dense variant at |R| <= 256 (batches of config 4): 22 KB instead of
 // 47 KB of LDS per block and a register budget for 8 waves per SIMD — four blocks per CU instead of three.
-template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER = false, int ROT = 1, int TILE = 1024>
+// SINGLE: the launcher guarantees |R| <= TILE (the tile loop and everything multi-tile fold away).
+template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER = false, int ROT = 1, int TILE = 1024, bool SINGLE = false>
 __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (const float *gM, const float *gR, icp_reg_state *gst, const double *gmom,
                                                               uint32_t m, uint32_t nr, uint32_t side, uint32_t tpr_magic,
                                                               uint32_t nb, uint32_t check_flags, icp_params p)
@@ -672,7 +674,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // state array (stride 1) instead of a pair of slots; bit 3 = store the matched / transformed points too (fused
     // mode needs them only after the last iteration of a graph; the reference-order kernels read them every time).
     constexpr uint32_t KT = (uint32_t) TILE;
-    if constexpr (TILE < 1024) __builtin_assume (nr <= KT);             // (launched for single-tile sets only: the tile loop folds away)
+    if constexpr (SINGLE) __builtin_assume (nr <= KT);
     const uint32_t b = blockIdx.y, check = check_flags & 1u;
     icp_reg_state *st = (CHAIN && !(check_flags & 2u)) ? gst + (size_t) b * 2 : gst + b;
 #ifdef ICP_DBG_STAMPS
@@ -685,6 +687,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     __shared__ float4 s_pair[3 * KT / 2];
     __shared__ uint2 s_on[KT];                  // (offset, size) of every representative's list
     __shared__ float4 s_box[2 * (KT / 16)];     // (lo, hi) of the tile's groups of 2 * LPQ representatives
+    __shared__ float4 s_tbox[(MINW == 4 && !SINGLE) ? 2 * 32 : 2];      // (lo, hi) of every tile (multi-tile sets: |R| <= 32768)
     __shared__ float s_w[64];
     __shared__ float4 s_qc[64];                      // query hand-in: (r, g, b, pruning seed); s_qa carries (q', index)
     __shared__ float4 s_qa[64];                      // per-query hand-off to the finishing wave: (q', distance)
@@ -799,6 +802,9 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         }
     }
     if (prune && tid < nbox0) s_box[tid] = boxv;
+    if constexpr (MINW == 4 && !SINGLE) {            // the boxes of all tiles: a tile is tested before it is staged (stage 1 below)
+        if (prune && nr > KT && tid < 2u * p.n1k) s_tbox[tid] = p.GB[(size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + tid];
+    }
     if constexpr (CHAIN) {
         const bool pending = __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (pending)) != 0;
         if (pending) {
@@ -854,9 +860,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         // 64 group tests, and a tile no query of the block is near is neither tested further nor staged (at |R| = 4096 a
         // block's 64 neighbouring queries need one, seldom two, of the four tiles)
         auto tile_near = [&] (float lim_) -> bool {
-            if (nr <= KT) return true;
-            const float4 *tb = p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + 2u * (t0 / 1024u);      // (k_tile_boxes: tiles of 1024; several tiles only with TILE == 1024)
-            const float4 lo = tb[0], hi = tb[1];
+            if (SINGLE || nr <= KT) return true;
+            const float4 lo = s_tbox[2u * (t0 / ICP_TBOX)], hi = s_tbox[2u * (t0 / ICP_TBOX) + 1u];     // (staged in the prologue)
             const float ex = fmaxf (fmaxf (lo.x - qx, qx - hi.x), 0.f);
             const float ey = fmaxf (fmaxf (lo.y - qy, qy - hi.y), 0.f);
             const float ez = fmaxf (fmaxf (lo.z - qz, qz - hi.z), 0.f);
@@ -1860,13 +1865,22 @@ static inline bool icp_dense (const icp_params &p)
     return (size_t) p.batch * p.nb > 512u || p.nr >= ICP_S1_REJECT_MIN_NR;
 }
 
+// LDS tile of the dense search variant: 256 representatives (21 KB of LDS, 8 waves per SIMD) where a tile holds whole rows of
+// 4 x 4 pruning groups (representative grid at most 64 wide: |R| <= 4096), else 1024.
+// (measured with per-tile block votes: B 16.6 -> 17.5 us, C 417 -> 520 us — 4 / 16 small tiles cost more in barriers and votes than
+    // the smaller staging saves; multi-tile sets therefore keep the 1024-tile until the tile set of a block is decided in one pre-pass)
+static inline uint32_t icp_dense_tile (const icp_params &p) { return (p.nr <= 256u) ? 256u : 1024u; }
+
 void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 {
     hipLaunchKernelGGL (k_get_reps, dim3 ((p.nr + 63) / 64, p.batch), dim3 (64), 0, s, p);
     hipLaunchKernelGGL (k_rep_boxes, dim3 ((p.n16 + 63) / 64, p.batch), dim3 (64), 0, s, p);
-    if (p.nr > 1024u) hipLaunchKernelGGL (k_tile_boxes, dim3 (p.n1k, p.batch), dim3 (64), 0, s, p);      // (a single tile needs no box of its own)
+    if (p.nr > ICP_TBOX) hipLaunchKernelGGL (k_tile_boxes, dim3 (p.n1k, p.batch), dim3 (64), 0, s, p);    // (a single tile needs no box of its own)
     // step 1, owner(x) = nearest representative: the search kernel's stage 1 over the fixed points
-    if (icp_dense (p)) hipLaunchKernelGGL ((k_search<true, false, 4, 8, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
+    // (dense variant: LDS tiles of 256 representatives up to |R| = 4096 — four blocks per CU —, of 1024 beyond, where a 4 x 4 tile
+    // group no longer fits a 256-tile: icp_dense_tile)
+    if (icp_dense (p) && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<true, false, 4, 8, true, 1, 256, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
+    else if (icp_dense (p)) hipLaunchKernelGGL ((k_search<true, false, 4, 8, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
     else hipLaunchKernelGGL ((k_search<true, false, 2, 16, true>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
     hipLaunchKernelGGL (k_chunk_hist, dim3 (p.nchunk, p.batch), dim3 (256), p.nr * sizeof (uint32_t), s, p);
     hipLaunchKernelGGL (k_count, dim3 ((p.nr + 63) / 64, p.batch), dim3 (64), 0, s, p);
@@ -1881,7 +1895,7 @@ void icp_launch_search (const icp_params &p, hipStream_t s)
 #define KS_ARGS p.M, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
 #define KS_CHAIN_ARGS p.M, p.R, p.cst + p.slot, (const double *) p.mom + (size_t) p.slot * ICP_NMOM * p.nb, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
     if (p.fused) {
-        if (dense && p.nr <= 256u && p.rot == 1) hipLaunchKernelGGL ((k_search<true, false, 4, 8, false, 1, 256>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
+        if (dense && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<true, false, 4, 8, false, 1, 256, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
         else if (dense) hipLaunchKernelGGL ((k_search<true, false, 4, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
         else hipLaunchKernelGGL ((k_search<true, false, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_ARGS);
     } else {

@@ -29,7 +29,8 @@ struct icp_params {
     const float *F, *M;          // [batch][m][8]
     float *R;                    // [batch][nr][8]
     float4 *GB;                  // [batch][2*(n16+n32)] geometry bounding boxes (lo, hi) of the groups of 16 representatives, then of the tiles of 1024
-    uint32_t n16, n1k;           // ceil(nr/16), ceil(nr/1024)
+    uint32_t n16, n1k;           // ceil(nr/16), ceil(nr/tbox)
+    uint32_t tbox;               // representatives per tile box (k_tile_boxes): the LDS tile of the dense k_search for multi-tile sets, 256 or 1024
     uint32_t gtile;              // stage-1 pruning groups of 16: 0 = 16 consecutive representatives, 1 + log2 (nrx / 4) = 4 x 4 tiles of the representative grid
     float *XP;                   // [batch][m][8]  permuted database (RBCConstruct D_OUT_X_P)
     float *XQ;                   // [batch][m][8]  same, lane 3 = original index bits (search copy)
@@ -63,6 +64,7 @@ void icp_launch_iteration (const icp_params &p, hipStream_t s);
 void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask);
 void icp_launch_chain (const icp_params &p, hipStream_t s, uint32_t iterations, bool fresh = false);
 bool icp_chain_supported (const icp_params &p);
+uint32_t icp_tbox_of (const icp_params &p);
 bool icp_persistent_supported (const icp_params &p);
 void icp_launch_persistent (const icp_params &p, hipStream_t s, uint32_t iterations);
 size_t icp_xch_bytes (uint32_t batch);

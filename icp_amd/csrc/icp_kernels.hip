@@ -246,8 +246,8 @@ __global__ void k_rep_boxes (icp_params p)
     GB[2 * t] = lo; GB[2 * t + 1] = hi;
 }
 
-// Geometry bounding box of every 1024 consecutive representatives (the LDS tile of k_search for multi-tile sets): one wave
-// per box (min / max are exact in any order).
+// Geometry bounding box of every LDS tile of the dense k_search for multi-tile sets (p.tbox consecutive representatives:
+// 256, or 1024 for the largest sets): one wave per box (min / max are exact in any order).
 #define ICP_TBOX 1024u
 __global__ __launch_bounds__ (64) void k_tile_boxes (icp_params p)
 {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__ (64) void k_tile_boxes (icp_params p)
     const float4 *R4 = reinterpret_cast<const float4 *> (p.R + (size_t) b * p.nr * 8);
     const float inf = __builtin_inff ();
     float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
-    for (uint32_t r = tile * ICP_TBOX + lane; r < min (p.nr, (tile + 1u) * ICP_TBOX); r += 64u) {
+    for (uint32_t r = tile * p.tbox + lane; r < min (p.nr, (tile + 1u) * p.tbox); r += 64u) {
         const float4 v = R4[2 * (size_t) r];
         lo[0] = fminf (lo[0], v.x); lo[1] = fminf (lo[1], v.y); lo[2] = fminf (lo[2], v.z);
         hi[0] = fmaxf (hi[0], v.x); hi[1] = fmaxf (hi[1], v.y); hi[2] = fmaxf (hi[2], v.z);
@@ -674,7 +674,12 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // state array (stride 1) instead of a pair of slots; bit 3 = store the matched / transformed points too (fused
     // mode needs them only after the last iteration of a graph; the reference-order kernels read them every time).
     constexpr uint32_t KT = (uint32_t) TILE;
+    // MASKED (dense variant, several small tiles): the set of tiles a block needs is decided ONCE, before anything is staged —
+    // every query tests the boxes of all tiles against its seed bound, the block ORs the answers — and only those tiles
+    // are staged and scanned, in ascending order, without a vote per tile.
+    constexpr bool MASKED = (TILE == 256) && !SINGLE && (MINW == 4);
     if constexpr (SINGLE) __builtin_assume (nr <= KT);
+    if constexpr (MASKED) __builtin_assume (nr > KT && nr <= 32u * KT);
     const uint32_t b = blockIdx.y, check = check_flags & 1u;
     icp_reg_state *st = (CHAIN && !(check_flags & 2u)) ? gst + (size_t) b * 2 : gst + b;
 #ifdef ICP_DBG_STAMPS
@@ -685,7 +690,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // representatives of the current tile, pair-interleaved for packed fp32 math:
     //   pair P = reps (2P, 2P+1) -> 3 float4: [x0 x1 y0 y1] [z0 z1 r0 r1] [g0 g1 b0 b1]
     __shared__ float4 s_pair[3 * KT / 2];
-    __shared__ uint2 s_on[KT];                  // (offset, size) of every representative's list
+    __shared__ uint2 s_on[MASKED ? 1 : KT];     // (offset, size) of every representative's list (several tiles: read from global)
+    __shared__ uint32_t s_tmask;                     // MASKED: tiles some query of the block needs
     __shared__ float4 s_box[2 * (KT / 16)];     // (lo, hi) of the tile's groups of 2 * LPQ representatives
     __shared__ float4 s_tbox[(MINW == 4 && !SINGLE) ? 2 * 32 : 2];      // (lo, hi) of every tile (multi-tile sets: |R| <= 32768)
     __shared__ float s_w[64];
@@ -744,7 +750,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     for (int u = 0; u < 2; ++u) {
         uint32_t k = tid + (uint32_t) u * 64u * KS_SPLIT;
         rg[u] = make_float4 (0.f, 0.f, 0.f, 0.f); rc[u] = rg[u];
-        if (k < tn0) { rg[u] = R4[2 * (size_t) k]; rc[u] = R4[2 * (size_t) k + 1]; }
+        if (!MASKED && k < tn0) { rg[u] = R4[2 * (size_t) k]; rc[u] = R4[2 * (size_t) k + 1]; }
     }
     const uint32_t ic = min (iq, m - 1u);
     float4 mg = make_float4 (0.f, 0.f, 0.f, 1.f), mc = mg;
@@ -755,7 +761,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     for (int u = 0; u < 2; ++u) {
         uint32_t k = tid + (uint32_t) u * 64u * KS_SPLIT;
         ron[u] = make_uint2 (0u, 0u);
-        if (!OWNER && k < tn0) ron[u] = make_uint2 (gO[k], gN[k]);
+        if (!OWNER && !MASKED && k < tn0) ron[u] = make_uint2 (gO[k], gN[k]);
     }
     // seed of the stage-1 pruning bound: this query's nearest representative of the previous search (any index < nr
     // is a valid seed; the buffer starts zeroed)
@@ -776,7 +782,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     const float4 *GBt = p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + (KS_SPLIT == 8 ? 0u : 2u * p.n16);
     const uint32_t nbox0 = 2u * ((tn0 + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
     float4 boxv = make_float4 (0.f, 0.f, 0.f, 0.f);
-    if (prune && tid < nbox0) boxv = GBt[tid];
+    if (!MASKED && prune && tid < nbox0) boxv = GBt[tid];
     float T[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) T[k] = state_lane_f (sv, ICP_ST_DW (T) + k);
@@ -795,13 +801,14 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         uint32_t k = tid + (uint32_t) u * 64u * KS_SPLIT;
-        if (k < tn0) {
+        if (!MASKED && k < tn0) {
             float *dst = s_pairf + (k >> 1) * 12u + (k & 1u);
             dst[0] = rg[u].x; dst[2] = rg[u].y; dst[4] = rg[u].z; dst[6] = rc[u].x; dst[8] = rc[u].y; dst[10] = rc[u].z;
-            if constexpr (!OWNER) s_on[k] = ron[u];
+            if constexpr (!OWNER && !MASKED) s_on[k] = ron[u];
         }
     }
-    if (prune && tid < nbox0) s_box[tid] = boxv;
+    if (!MASKED && prune && tid < nbox0) s_box[tid] = boxv;
+    if (MASKED && tid == 0) s_tmask = 0u;
     if constexpr (MINW == 4 && !SINGLE) {            // the boxes of all tiles: a tile is tested before it is staged (stage 1 below)
         if (prune && nr > KT && tid < 2u * p.n1k) s_tbox[tid] = p.GB[(size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + tid];
     }
@@ -853,6 +860,123 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             for (uint32_t t = 0, g = ss; g < ngt; ++t, g += KS_SPLIT) test (t, g);
         return cm;
     };
+    // fine pass of the pruning over the tile in LDS (first representative t0_, npair_ pairs): the groups whose bit is set in
+    // cmask_ for some query of the wave, full evaluation.
+    auto fine_pass = [&] (uint32_t t0_, uint32_t npair_, uint32_t cmask_) {
+        const uint32_t ngt_ = (npair_ + KS_SPLIT - 1u) / KS_SPLIT;
+        const float2v vqx = { qx, qx }, vqy = { qy, qy }, vqz = { qz, qz }, vqr = { qr, qr }, vqg = { qg, qg }, vqb = { qb, qb };
+        const float2v va = { alpha, alpha };
+        // fine pass: the groups some query of the wave still needs, in ascending order (a lane's pairs must ascend
+        // for the tie rule), full evaluation
+        // (scalar control flow: the lane ballot of trip t is folded over the wave's queries into one bit per group
+        // and only the set bits are visited — a taken branch costs more than the arithmetic it guards)
+        for (uint32_t t = 0; t * KS_SPLIT < ngt_; ++t) {
+            unsigned long long bal = __ballot ((cmask_ >> t) & 1u);
+            if (bal == 0ull) continue;
+            bal |= bal >> 32; bal |= bal >> 16;
+            if (KS_SPLIT == 8) bal |= bal >> 8;
+            uint32_t need = (uint32_t) bal & ((1u << KS_SPLIT) - 1u);
+            while (need) {
+                const uint32_t sg = (uint32_t) __builtin_ctz (need);
+                need &= need - 1u;
+                // pair of this lane in group gl of the LDS tile.  Strips: the group's 16 consecutive representatives.
+                // Tiles (LPQ == 8): lane ss holds row ss >> 1, columns 2 (ss & 1) and + 1 of the 4 x 4 tile; groups are
+                // visited in ascending (tile row, tile column) order, so every lane's pairs still ascend in index —
+                // what the tie rule (strict '<' keeps a lane's lowest index) relies on.
+                const uint32_t gl = sg + KS_SPLIT * t;
+                const uint32_t P = (KS_SPLIT == 8 && gt_lg1) ? (((4u * (gl >> (gt_lg1 - 1u)) + (ss >> 1)) << gt_lg1) + 2u * (gl & ((1u << (gt_lg1 - 1u)) - 1u)) + (ss & 1u))
+                                                              : gl * KS_SPLIT + ss;
+                if (P < npair_) {
+                    float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];
+                    float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
+                    float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
+                    float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
+                    float2v pho = __builtin_elementwise_fma (db, db, __builtin_elementwise_fma (dg, dg, dr * dr));
+                    float2v d = __builtin_elementwise_fma (va, pho, geo);
+                    const uint32_t r0 = t0_ + 2u * P;
+                    if (d.x < best) { best = d.x; bid = r0; }
+                    if (d.y < best) { best = d.y; bid = r0 + 1u; }
+                }
+            }
+        }
+    };
+    if constexpr (MASKED) {
+        __syncthreads ();                            // the queries (s_qa / s_qc), the tile boxes, s_tmask = 0
+        {
+            const float4 a4 = s_qa[qe], c4 = s_qc[qe];
+            qx = a4.x; qy = a4.y; qz = a4.z; i = __float_as_uint (a4.w); valid = i < m;
+            qr = c4.x; qg = c4.y; qb = c4.z; seed = __float_as_uint (c4.w);
+        }
+        const uint32_t ntile = (nr + KT - 1u) / KT;  // <= 32
+        uint32_t qmask = 0xFFFFFFFFu >> (32u - ntile);
+        if (prune) {
+            // the seed bound (the seed representative comes from global memory: no tile is staged yet)
+            seed = min (seed, nr - 1u);
+            const float4 g = R4[2 * (size_t) seed], c = R4[2 * (size_t) seed + 1];
+            const float b0 = icp_metric8 (qx, qy, qz, qr, qg, qb, g.x, g.y, g.z, c.x, c.y, c.z, alpha);
+            if (b0 >= 0.f && b0 < __builtin_inff ()) s1_lim = __uint_as_float (__float_as_uint (b0) + 1u);     // next float up
+            // tiles this query can find a nearer representative in: lane ss tests the tiles ss, ss + LPQ, ..; OR over the lanes
+            uint32_t tm = 0u;
+            for (uint32_t t = ss; t < ntile; t += KS_SPLIT) {
+                const float4 lo = s_tbox[2u * t], hi = s_tbox[2u * t + 1u];
+                const float ex = fmaxf (fmaxf (lo.x - qx, qx - hi.x), 0.f);
+                const float ey = fmaxf (fmaxf (lo.y - qy, qy - hi.y), 0.f);
+                const float ez = fmaxf (fmaxf (lo.z - qz, qz - hi.z), 0.f);
+                if (__builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex)) < s1_lim) tm |= 1u << t;
+            }
+            tm |= (uint32_t) __builtin_amdgcn_update_dpp (0, (int) tm, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+            tm |= (uint32_t) __builtin_amdgcn_update_dpp (0, (int) tm, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+            tm |= (uint32_t) __builtin_amdgcn_update_dpp (0, (int) tm, 0x141, 0xF, 0xF, true);     // row_half_mirror
+            qmask = tm;
+        }
+        {   // the block's union: OR over the wave (8 queries: one per half row), one LDS atomic per wave
+            uint32_t wm = qmask | (uint32_t) __builtin_amdgcn_update_dpp (0, (int) qmask, 0x140, 0xF, 0xF, true);      // row_mirror: both half rows
+            wm = (uint32_t) __builtin_amdgcn_readlane ((int) wm, 0) | (uint32_t) __builtin_amdgcn_readlane ((int) wm, 16) |
+                 (uint32_t) __builtin_amdgcn_readlane ((int) wm, 32) | (uint32_t) __builtin_amdgcn_readlane ((int) wm, 48);
+            if (lane == 0) atomicOr (&s_tmask, wm);
+        }
+        __syncthreads ();
+        uint32_t bm = s_tmask;                       // block-uniform
+        bool first = true;
+        while (bm) {
+            const uint32_t tl = (uint32_t) __builtin_ctz (bm);
+            bm &= bm - 1u;
+            const uint32_t t0 = tl * KT, tn = min (KT, nr - t0), npair = (tn + 1u) >> 1;
+            if (!first) __syncthreads ();            // every wave is done with the previous tile
+            first = false;
+            if (prune) {
+                const uint32_t nbx = 2u * ((tn + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
+                if (tid < nbx) s_box[tid] = GBt[2u * (t0 / (2u * KS_SPLIT)) + tid];
+            }
+            if (tid < tn) {
+                const float4 g = R4[2 * (size_t) (t0 + tid)], c = R4[2 * (size_t) (t0 + tid) + 1];
+                float *dst = s_pairf + (tid >> 1) * 12u + (tid & 1u);
+                dst[0] = g.x; dst[2] = g.y; dst[4] = g.z; dst[6] = c.x; dst[8] = c.y; dst[10] = c.z;
+            }
+            __syncthreads ();
+            if (prune) {
+                const bool mine = ((qmask >> tl) & 1u) != 0u;
+                uint32_t cmask = 0u;
+                if (__ballot (mine)) cmask = coarse_pass (tn, mine ? s1_lim : -__builtin_inff ());
+                fine_pass (t0, npair, cmask);
+                s1_lim = fminf (s1_lim, ks_grp_min_f<KS_SPLIT> (best));
+            } else {
+                const float2v vqx = { qx, qx }, vqy = { qy, qy }, vqz = { qz, qz }, vqr = { qr, qr }, vqg = { qg, qg }, vqb = { qb, qb };
+                const float2v va = { alpha, alpha };
+                for (uint32_t P = ss; P < npair; P += KS_SPLIT) {
+                    float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];
+                    float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
+                    float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
+                    float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
+                    float2v pho = __builtin_elementwise_fma (db, db, __builtin_elementwise_fma (dg, dg, dr * dr));
+                    float2v d = __builtin_elementwise_fma (va, pho, geo);
+                    const uint32_t r0 = t0 + 2u * P;
+                    if (d.x < best) { best = d.x; bid = r0; }
+                    if (d.y < best) { best = d.y; bid = r0 + 1u; }
+                }
+            }
+        }
+    } else
     for (uint32_t t0 = 0; t0 < nr; t0 += KT) {
         const uint32_t tn = min (KT, nr - t0);
         uint32_t cmask = 0u;
@@ -931,39 +1055,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             // groups ss, ss + LPQ, ..  (further tiles: done above, before the tile was staged)
             const uint32_t ngt = (npair + KS_SPLIT - 1u) / KS_SPLIT;
             if (t0 == 0 && __ballot (tile_near (lim))) cmask = coarse_pass (tn, lim);
-            // fine pass: the groups some query of the wave still needs, in ascending order (a lane's pairs must ascend
-            // for the tie rule), full evaluation
-            // (scalar control flow: the lane ballot of trip t is folded over the wave's queries into one bit per group
-            // and only the set bits are visited — a taken branch costs more than the arithmetic it guards)
-            for (uint32_t t = 0; t * KS_SPLIT < ngt; ++t) {
-                unsigned long long bal = __ballot ((cmask >> t) & 1u);
-                if (bal == 0ull) continue;
-                bal |= bal >> 32; bal |= bal >> 16;
-                if (KS_SPLIT == 8) bal |= bal >> 8;
-                uint32_t need = (uint32_t) bal & ((1u << KS_SPLIT) - 1u);
-                while (need) {
-                    const uint32_t sg = (uint32_t) __builtin_ctz (need);
-                    need &= need - 1u;
-                    // pair of this lane in group gl of the LDS tile.  Strips: the group's 16 consecutive representatives.
-                    // Tiles (LPQ == 8): lane ss holds row ss >> 1, columns 2 (ss & 1) and + 1 of the 4 x 4 tile; groups are
-                    // visited in ascending (tile row, tile column) order, so every lane's pairs still ascend in index —
-                    // what the tie rule (strict '<' keeps a lane's lowest index) relies on.
-                    const uint32_t gl = sg + KS_SPLIT * t;
-                    const uint32_t P = (KS_SPLIT == 8 && gt_lg1) ? (((4u * (gl >> (gt_lg1 - 1u)) + (ss >> 1)) << gt_lg1) + 2u * (gl & ((1u << (gt_lg1 - 1u)) - 1u)) + (ss & 1u))
-                                                                  : gl * KS_SPLIT + ss;
-                    if (P < npair) {
-                        float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];
-                        float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
-                        float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
-                        float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
-                        float2v pho = __builtin_elementwise_fma (db, db, __builtin_elementwise_fma (dg, dg, dr * dr));
-                        float2v d = __builtin_elementwise_fma (va, pho, geo);
-                        const uint32_t r0 = t0 + 2u * P;
-                        if (d.x < best) { best = d.x; bid = r0; }
-                        if (d.y < best) { best = d.y; bid = r0 + 1u; }
-                    }
-                }
-            }
+            fine_pass (t0, npair, cmask);
             s1_lim = fminf (lim, ks_grp_min_f<KS_SPLIT> (best));
         } else {
 #pragma unroll 8
@@ -993,7 +1085,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // from LDS; the compile-time split keeps the compiler from merging the two sources into flat loads.
     uint32_t o, n;
     if constexpr (MINW == 2) { const uint2 on = s_on[rstar]; o = on.x; n = on.y; }
-    else if (nr <= KT) { const uint2 on = s_on[rstar]; o = on.x; n = on.y; asm volatile ("" : "+v"(o), "+v"(n)); }
+    else if (!MASKED && nr <= KT) { const uint2 on = s_on[rstar]; o = on.x; n = on.y; asm volatile ("" : "+v"(o), "+v"(n)); }
     else { o = gO[rstar]; n = gN[rstar]; }
 
     // ---- stage 2: exhaustive scan of that representative's list: the LPQ lanes of a query read LPQ consecutive
@@ -1867,19 +1959,21 @@ static inline bool icp_dense (const icp_params &p)
 
 // LDS tile of the dense search variant: 256 representatives (21 KB of LDS, 8 waves per SIMD) where a tile holds whole rows of
 // 4 x 4 pruning groups (representative grid at most 64 wide: |R| <= 4096), else 1024.
-// (measured with per-tile block votes: B 16.6 -> 17.5 us, C 417 -> 520 us — 4 / 16 small tiles cost more in barriers and votes than
-    // the smaller staging saves; multi-tile sets therefore keep the 1024-tile until the tile set of a block is decided in one pre-pass)
-static inline uint32_t icp_dense_tile (const icp_params &p) { return (p.nr <= 256u) ? 256u : 1024u; }
+// (Several 256-tiles with a block vote per tile measured slower than the 1024-tile — B 16.6 -> 17.5 us, C 417 -> 520 us —: the
+// MASKED form of k_search decides a block's tile set in one pre-pass instead.)
+static inline uint32_t icp_dense_tile (const icp_params &p) { return (p.nr <= 256u || p.nrx <= 64u) ? 256u : 1024u; }
+uint32_t icp_tbox_of (const icp_params &p) { return (icp_dense (p) && p.nr > 256u && icp_dense_tile (p) == 256u) ? 256u : 1024u; }
 
 void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 {
     hipLaunchKernelGGL (k_get_reps, dim3 ((p.nr + 63) / 64, p.batch), dim3 (64), 0, s, p);
     hipLaunchKernelGGL (k_rep_boxes, dim3 ((p.n16 + 63) / 64, p.batch), dim3 (64), 0, s, p);
-    if (p.nr > ICP_TBOX) hipLaunchKernelGGL (k_tile_boxes, dim3 (p.n1k, p.batch), dim3 (64), 0, s, p);    // (a single tile needs no box of its own)
+    if (p.nr > p.tbox) hipLaunchKernelGGL (k_tile_boxes, dim3 (p.n1k, p.batch), dim3 (64), 0, s, p);    // (a single tile needs no box of its own)
     // step 1, owner(x) = nearest representative: the search kernel's stage 1 over the fixed points
     // (dense variant: LDS tiles of 256 representatives up to |R| = 4096 — four blocks per CU —, of 1024 beyond, where a 4 x 4 tile
     // group no longer fits a 256-tile: icp_dense_tile)
-    if (icp_dense (p) && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<true, false, 4, 8, true, 1, 256, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
+    if (icp_dense (p) && p.nr > 256u && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<true, false, 4, 8, true, 1, 256, false>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
+    else if (icp_dense (p) && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<true, false, 4, 8, true, 1, 256, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
     else if (icp_dense (p)) hipLaunchKernelGGL ((k_search<true, false, 4, 8, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
     else hipLaunchKernelGGL ((k_search<true, false, 2, 16, true>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
     hipLaunchKernelGGL (k_chunk_hist, dim3 (p.nchunk, p.batch), dim3 (256), p.nr * sizeof (uint32_t), s, p);
@@ -1895,11 +1989,15 @@ void icp_launch_search (const icp_params &p, hipStream_t s)
 #define KS_ARGS p.M, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
 #define KS_CHAIN_ARGS p.M, p.R, p.cst + p.slot, (const double *) p.mom + (size_t) p.slot * ICP_NMOM * p.nb, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
     if (p.fused) {
-        if (dense && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<true, false, 4, 8, false, 1, 256, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
+        if (dense && p.nr > 256u && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<true, false, 4, 8, false, 1, 256, false>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
+        else if (dense && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<true, false, 4, 8, false, 1, 256, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
         else if (dense) hipLaunchKernelGGL ((k_search<true, false, 4, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
         else hipLaunchKernelGGL ((k_search<true, false, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_ARGS);
     } else {
-        if (dense) hipLaunchKernelGGL ((k_search<false, false, 4, 8>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, KS_ARGS);
+        // (the same tile choice as the fused variants: the tile boxes of a registration are built for one tile size, p.tbox)
+        if (dense && p.nr > 256u && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<false, false, 4, 8, false, 1, 256, false>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, KS_ARGS);
+        else if (dense && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<false, false, 4, 8, false, 1, 256, true>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, KS_ARGS);
+        else if (dense) hipLaunchKernelGGL ((k_search<false, false, 4, 8>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, KS_ARGS);
         else hipLaunchKernelGGL ((k_search<false, false, 2, 16>), dim3 (2 * p.nwg, p.batch), dim3 (1024), 0, s, KS_ARGS);
     }
 }

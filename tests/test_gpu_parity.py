@@ -881,3 +881,24 @@ def test_run_fixed_fresh_equals_reset_plus_run(engine, oracle, side, nr, batch):
             o.step()
         assert_bits(g.read(engine.Memory.T, b), o.T, "T after continuing")
     g.close()
+
+
+@pytest.mark.parametrize("side,nr,zero_fraction", [(256, 4096, 0.0), (256, 2048, 0.05), (128, 512, 0.1)])
+def test_stage1_pruning_exact_fused_multi_tile(engine, oracle, side, nr, zero_fraction):
+    """The dense search with several 256-representative LDS tiles (a block's tile set decided in one pre-pass: every query
+    tests all tile boxes against its seed bound, the block ORs the answers, only those tiles are staged) in the default
+    modes: RBC structure, nearest representatives, ids, distances, T bit for bit — loose seeds (first step: every tile)
+    and tight ones (later steps: one or two tiles), exact ties (identical zero points)."""
+    g, o, F, M = make(engine, oracle, side, nr, zero_fraction=zero_fraction, power_fast=True, fused=True)
+    g.buildRBC()
+    o.build_rbc()
+    check_rbc(engine, g, o)
+    for _ in range(3):
+        g.step()
+        o.step()
+        check_step(engine, g, o, weighted=False)
+    g.run_fixed(2)
+    for _ in range(2):
+        o.step()
+    check_step(engine, g, o, weighted=False)
+    g.close()

@@ -32,6 +32,7 @@ struct icp_params {
     uint32_t n16, n1k;           // ceil(nr/16), ceil(nr/tbox)
     uint32_t tbox;               // representatives per tile box (k_tile_boxes): the LDS tile of the dense k_search for multi-tile sets, 256 or 1024
     uint32_t gtile;              // stage-1 pruning groups of 16: 0 = 16 consecutive representatives, 1 + log2 (nrx / 4) = 4 x 4 tiles of the representative grid
+    uint32_t s2wave;             // stage 2 of the dense search with lanes = candidates (lists of >= ICP_S2_WAVE_MIN candidates on average: see k_search)
     float *XP;                   // [batch][m][8]  permuted database (RBCConstruct D_OUT_X_P)
     float *XQ;                   // [batch][m][8]  same, lane 3 = original index bits (search copy)
     uint32_t *rep_src, *owner, *N, *O, *perm, *chunk_hist;   // [batch][...]
@@ -65,6 +66,7 @@ void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask);
 void icp_launch_chain (const icp_params &p, hipStream_t s, uint32_t iterations, bool fresh = false);
 bool icp_chain_supported (const icp_params &p);
 uint32_t icp_tbox_of (const icp_params &p);
+uint32_t icp_s2_wave_of (const icp_params &p);          // 1: the dense search scans the lists with lanes = candidates (long lists)
 bool icp_persistent_supported (const icp_params &p);
 void icp_launch_persistent (const icp_params &p, hipStream_t s, uint32_t iterations);
 size_t icp_xch_bytes (uint32_t batch);

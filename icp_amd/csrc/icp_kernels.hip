@@ -661,7 +661,7 @@ static __device__ __forceinline__ void fin_result_to_state (const icp_fin_result
 // TILE = representatives per LDS tile: 1024, or 256 for the dense variant at |R| <= 256 (batches of config 4): 22 KB instead of
 // 47 KB of LDS per block and a register budget for 8 waves per SIMD — four blocks per CU instead of three.
 // SINGLE: the launcher guarantees |R| <= TILE (the tile loop and everything multi-tile fold away).
-template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER = false, int ROT = 1, int TILE = 1024, bool SINGLE = false>
+template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER = false, int ROT = 1, int TILE = 1024, bool SINGLE = false, bool S2W = false>
 __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (const float *gM, const float *gR, icp_reg_state *gst, const double *gmom,
                                                               uint32_t m, uint32_t nr, uint32_t side, uint32_t tpr_magic,
                                                               uint32_t nb, uint32_t check_flags, icp_params p)
@@ -1091,6 +1091,113 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // ---- stage 2: exhaustive scan of that representative's list: the LPQ lanes of a query read LPQ consecutive
     // candidates (32 contiguous bytes each) per load.  (Staging the block's lists through LDS first was measured and is
     // slower: enumerating the distinct lists and the extra barrier cost more than the direct gathers.)
+    float dmin; uint32_t jmin;
+    if constexpr (S2W) {
+        static_assert (MINW == 4 && LPQ == 8 && !OWNER, "lanes = candidates: the dense search variants");
+        // ---- stage 2, long lists (dense variant, icp_s2_wave): lanes = candidates.  The scan above is bound by the vector-memory
+        // path (every query's lanes load their list for themselves: 24 bytes per candidate and query through the L1); the
+        // wave's 8 queries are neighbours and mostly share ONE list, so here the wave loads a list once — lane l takes the
+        // positions l, l + 64, .. — and every lane evaluates its candidate against each query of the wave that has this list,
+        // the query's six coordinates in SGPRs.  Distinct lists of the wave are served one after the other.  Per lane and
+        // query: best (distance, trip); at the end one butterfly over the 64 lanes that halves the number of queries a lane
+        // holds while it doubles the lanes reduced ((distance bits, position) as one 64-bit key: distances are >= +0, so
+        // the unsigned order of the bits is the order of the values; smallest distance, ties -> lowest position).
+        const uint32_t je = valid ? o + n : o;
+        unsigned long long todo = __ballot (je != o);                // lanes of the queries with a list to scan
+        float sx[8], sy[8], sz[8], sr[8], sg[8], sb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sx[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qx), 8 * q));
+            sy[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qy), 8 * q));
+            sz[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qz), 8 * q));
+            sr[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qr), 8 * q));
+            sg[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qg), 8 * q));
+            sb[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qb), 8 * q));
+        }
+        float bd[8]; uint32_t btr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { bd[q] = __builtin_inff (); btr[q] = 0xFFFFFFFFu; }
+        // (m8: one bit per query of the wave that has the list; made opaque per trip so that the eight tests stay scalar bit
+        // tests inside the loop instead of eight hoisted lane masks)
+#define KS_WCAND(G, C, TRIP)                                                                                  \
+        asm volatile ("" : "+s"(m8));                                                                         \
+        _Pragma ("unroll") for (int q = 0; q < 8; ++q)                                                        \
+            if (m8 & (1u << q)) {                                                                             \
+                const float2v d1_ = float2v { sx[q], sr[q] } - float2v { (G).x, (G).y },                      \
+                              d2_ = float2v { sy[q], sg[q] } - float2v { (G).z, (G).w },                      \
+                              d3_ = float2v { sz[q], sb[q] } - float2v { (C).x, (C).y };                      \
+                const float2v gp_ = __builtin_elementwise_fma (d3_, d3_, __builtin_elementwise_fma (d2_, d2_, d1_ * d1_)); \
+                const float d_ = __builtin_fmaf (alpha, gp_.y, gp_.x);                                        \
+                if (d_ < bd[q]) { bd[q] = d_; btr[q] = (TRIP); }                                              \
+            }
+        while (todo) {
+            const int l0 = (int) __builtin_ctzll (todo);
+            const uint32_t rL = (uint32_t) __builtin_amdgcn_readlane ((int) rstar, l0);
+            const uint32_t oL = (uint32_t) __builtin_amdgcn_readlane ((int) o, l0), nL = (uint32_t) __builtin_amdgcn_readlane ((int) n, l0);
+            const unsigned long long match = __ballot (rstar == rL) & todo;      // same representative = same list
+            todo &= ~match;
+            uint32_t m8 = 0u;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m8 |= (uint32_t) ((match >> (8 * q)) & 1ull) << q;
+            m8 = (uint32_t) __builtin_amdgcn_readfirstlane ((int) m8);
+            const uint32_t vlastL = (oL + nL - 1u) << 5, ntr = (nL + 63u) >> 6;
+            uint32_t voff = (oL + lane) << 5;
+            for (uint32_t t = 0; t < ntr; t += 2u, voff += 2u * 64u * 32u) {
+                const char *rec0 = XQb + min (voff, vlastL), *rec1 = XQb + min (voff + 64u * 32u, vlastL);
+                const float4 g0 = *reinterpret_cast<const float4 *> (rec0); const float2 c0 = *reinterpret_cast<const float2 *> (rec0 + 16);
+                const float4 g1 = *reinterpret_cast<const float4 *> (rec1); const float2 c1 = *reinterpret_cast<const float2 *> (rec1 + 16);
+                KS_WCAND (g0, c0, t)
+                if (t + 1u < ntr) { KS_WCAND (g1, c1, t + 1u) }
+            }
+        }
+#undef KS_WCAND
+        // the wave's winner per query: (distance bits, position) as one 64-bit key (distances are >= +0: the unsigned order of
+        // the bits is the order of the values), and a butterfly over the 64 lanes that halves the queries a lane holds while it
+        // doubles the lanes reduced — after three steps lane l holds query l & 7 over its group of 8 lanes, after six over the wave.
+        // (Measured against it and slower, 283 -> 292 us at C: the distances alone through the butterfly and the winner's
+        // position looked up with ballots / readlanes in scalars.)
+        unsigned long long key[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t oq = (uint32_t) __builtin_amdgcn_readlane ((int) o, 8 * q), jeq = (uint32_t) __builtin_amdgcn_readlane ((int) je, 8 * q);
+            const uint32_t pos = (btr[q] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : min (oq + lane + 64u * btr[q], jeq - 1u);
+            key[q] = ((unsigned long long) __float_as_uint (bd[q]) << 32) | pos;
+        }
+        auto xchg_dpp = [] (unsigned long long v, auto ctrl) -> unsigned long long {
+            const uint32_t lo = (uint32_t) __builtin_amdgcn_update_dpp (0, (int) (uint32_t) v, decltype (ctrl)::value, 0xF, 0xF, true);
+            const uint32_t hi = (uint32_t) __builtin_amdgcn_update_dpp (0, (int) (uint32_t) (v >> 32), decltype (ctrl)::value, 0xF, 0xF, true);
+            return ((unsigned long long) hi << 32) | lo;
+        };
+        auto xchg_lane = [] (unsigned long long v, uint32_t src) -> unsigned long long {      // v of lane src
+            const uint32_t lo = (uint32_t) __builtin_amdgcn_ds_bpermute ((int) (src << 2), (int) (uint32_t) v);
+            const uint32_t hi = (uint32_t) __builtin_amdgcn_ds_bpermute ((int) (src << 2), (int) (uint32_t) (v >> 32));
+            return ((unsigned long long) hi << 32) | lo;
+        };
+        auto min64 = [] (unsigned long long a_, unsigned long long b_) { return a_ < b_ ? a_ : b_; };
+        unsigned long long k4[4], k2[2], k1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                // lane bit 0: keeps the queries 2j + (lane & 1)
+            const bool odd = (lane & 1u) != 0u;
+            const unsigned long long keep = odd ? key[2 * j + 1] : key[2 * j], send = odd ? key[2 * j] : key[2 * j + 1];
+            k4[j] = min64 (keep, xchg_dpp (send, std::integral_constant<int, 0xB1> {}));      // quad_perm [1,0,3,2]
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                // lane bit 1
+            const bool odd = (lane & 2u) != 0u;
+            const unsigned long long keep = odd ? k4[2 * j + 1] : k4[2 * j], send = odd ? k4[2 * j] : k4[2 * j + 1];
+            k2[j] = min64 (keep, xchg_dpp (send, std::integral_constant<int, 0x4E> {}));      // quad_perm [2,3,0,1]
+        }
+        {                                            // lane bit 2
+            const bool odd = (lane & 4u) != 0u;
+            const unsigned long long keep = odd ? k2[1] : k2[0], send = odd ? k2[0] : k2[1];
+            k1 = min64 (keep, xchg_lane (send, lane ^ 4u));
+        }
+        k1 = min64 (k1, xchg_lane (k1, lane ^ 8u));  // over the wave's 8 groups of 8 lanes
+        k1 = min64 (k1, xchg_lane (k1, lane ^ 16u));
+        k1 = min64 (k1, xchg_lane (k1, lane ^ 32u));
+        k1 = xchg_lane (k1, (lane & 56u) | (lane >> 3));            // to the lanes of query lane >> 3
+        dmin = __uint_as_float ((uint32_t) (k1 >> 32)); jmin = (uint32_t) k1;
+    } else {
     float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
     const float2v vq_xr = { qx, qr }, vq_yg = { qy, qg }, vq_zb = { qz, qb };
     {
@@ -1130,8 +1237,9 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     KS_STAMP (4)
     // the query's winner among its lanes: smallest distance, ties -> lowest list position; that lane finishes
     // the query (lane ss == 0 when the list is empty or no candidate has a finite distance)
-    const float dmin = ks_grp_min_f<KS_SPLIT> (best2);
-    const uint32_t jmin = ks_grp_min_u<KS_SPLIT> (best2 == dmin ? bj : 0xFFFFFFFFu);
+    dmin = ks_grp_min_f<KS_SPLIT> (best2);
+    jmin = ks_grp_min_u<KS_SPLIT> (best2 == dmin ? bj : 0xFFFFFFFFu);
+    }
     KS_STAMP (5)
     // Hand-off: lane 0 of every query leaves (q, distance, winner position, representative, flags) in LDS, and ONE wave
     // finishes all 64 queries of the block with every lane active (lane e = query e): the winner's record, the weight,
@@ -1962,6 +2070,16 @@ static inline bool icp_dense (const icp_params &p)
 // (Several 256-tiles with a block vote per tile measured slower than the 1024-tile — B 16.6 -> 17.5 us, C 417 -> 520 us —: the
 // MASKED form of k_search decides a block's tile set in one pre-pass instead.)
 static inline uint32_t icp_dense_tile (const icp_params &p) { return (p.nr <= 256u || p.nrx <= 64u) ? 256u : 1024u; }
+// Stage 2 with lanes = candidates pays where the lists are long (its 64-lane reduction per query is a fixed cost; lists of 64 are
+// one trip either way): from ICP_S2_WAVE_MIN candidates per list on average.  ICP_AMD_S2WAVE=0/1 forces it (diagnostics).
+#ifndef ICP_S2_WAVE_MIN
+#define ICP_S2_WAVE_MIN 128u
+#endif
+uint32_t icp_s2_wave_of (const icp_params &p)
+{
+    if (const char *e = std::getenv ("ICP_AMD_S2WAVE")) return (e[0] == '1' && icp_dense (p)) ? 1u : 0u;
+    return (icp_dense (p) && p.nr && p.m / p.nr >= ICP_S2_WAVE_MIN) ? 1u : 0u;
+}
 uint32_t icp_tbox_of (const icp_params &p) { return (icp_dense (p) && p.nr > 256u && icp_dense_tile (p) == 256u) ? 256u : 1024u; }
 
 void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
@@ -1989,13 +2107,19 @@ void icp_launch_search (const icp_params &p, hipStream_t s)
 #define KS_ARGS p.M, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
 #define KS_CHAIN_ARGS p.M, p.R, p.cst + p.slot, (const double *) p.mom + (size_t) p.slot * ICP_NMOM * p.nb, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
     if (p.fused) {
-        if (dense && p.nr > 256u && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<true, false, 4, 8, false, 1, 256, false>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
+        if (dense && p.s2wave && p.nr > 256u && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<true, false, 4, 8, false, 1, 256, false, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
+        else if (dense && p.s2wave && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<true, false, 4, 8, false, 1, 256, true, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
+        else if (dense && p.s2wave) hipLaunchKernelGGL ((k_search<true, false, 4, 8, false, 1, 1024, false, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
+        else if (dense && p.nr > 256u && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<true, false, 4, 8, false, 1, 256, false>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
         else if (dense && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<true, false, 4, 8, false, 1, 256, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
         else if (dense) hipLaunchKernelGGL ((k_search<true, false, 4, 8>), dim3 (p.nb, p.batch), dim3 (512), 0, s, KS_ARGS);
         else hipLaunchKernelGGL ((k_search<true, false, 2, 16>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_ARGS);
     } else {
         // (the same tile choice as the fused variants: the tile boxes of a registration are built for one tile size, p.tbox)
-        if (dense && p.nr > 256u && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<false, false, 4, 8, false, 1, 256, false>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, KS_ARGS);
+        if (dense && p.s2wave && p.nr > 256u && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<false, false, 4, 8, false, 1, 256, false, true>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, KS_ARGS);
+        else if (dense && p.s2wave && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<false, false, 4, 8, false, 1, 256, true, true>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, KS_ARGS);
+        else if (dense && p.s2wave) hipLaunchKernelGGL ((k_search<false, false, 4, 8, false, 1, 1024, false, true>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, KS_ARGS);
+        else if (dense && p.nr > 256u && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<false, false, 4, 8, false, 1, 256, false>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, KS_ARGS);
         else if (dense && icp_dense_tile (p) == 256u) hipLaunchKernelGGL ((k_search<false, false, 4, 8, false, 1, 256, true>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, KS_ARGS);
         else if (dense) hipLaunchKernelGGL ((k_search<false, false, 4, 8>), dim3 (2 * p.nwg, p.batch), dim3 (512), 0, s, KS_ARGS);
         else hipLaunchKernelGGL ((k_search<false, false, 2, 16>), dim3 (2 * p.nwg, p.batch), dim3 (1024), 0, s, KS_ARGS);

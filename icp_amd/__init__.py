@@ -148,6 +148,7 @@ def lib():
     sig("icp_time_masked", i32, vp, u32, u32, u32, C.POINTER(f32))
     sig("icp_launches_per_iteration", i32, vp, C.POINTER(u32))
     sig("icp_run_form", i32, vp, C.POINTER(i32))
+    sig("icp_search_layout", i32, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32))
     sig("icp_debug_inject_fault", i32, vp)
     sig("icp_reduce", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_scan", i32, i32, i32, vp, u32, u32, vp)
@@ -458,6 +459,12 @@ class ICPStep:
         f = C.c_int()
         self._chk(self._L.icp_run_form(self._h, C.byref(f)))
         return f.value
+
+    def search_layout(self):
+        """(dense, representatives per LDS tile, stage-2 form) of the search kernel in use (diagnostic, see icp_search_layout)."""
+        d, t, s2 = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self._L.icp_search_layout(self._h, C.byref(d), C.byref(t), C.byref(s2)))
+        return d.value, t.value, s2.value
 
     def time_masked(self, mask, iterations=40, reps=20):
         """us per iteration of a graph holding only the kernels in `mask` (diagnostic)."""

@@ -859,6 +859,13 @@ int icp_run_form (icp_handle h, int *form)
     return ICP_OK;
 }
 
+int icp_search_layout (icp_handle h, int *dense, int *tile, int *stage2)
+{
+    int rc = need (h, false); if (rc) return rc;
+    icp_search_layout_of (h->p, dense, tile, stage2);
+    return ICP_OK;
+}
+
 int icp_launches_per_iteration (icp_handle h, uint32_t *n)
 {
     int rc = need (h, false); if (rc) return rc;

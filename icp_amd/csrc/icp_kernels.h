@@ -66,7 +66,8 @@ void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask);
 void icp_launch_chain (const icp_params &p, hipStream_t s, uint32_t iterations, bool fresh = false);
 bool icp_chain_supported (const icp_params &p);
 uint32_t icp_tbox_of (const icp_params &p);
-uint32_t icp_s2_wave_of (const icp_params &p);          // 1: the dense search scans the lists with lanes = candidates (long lists)
+uint32_t icp_s2_wave_of (const icp_params &p);
+void icp_search_layout_of (const icp_params &p, int *dense, int *tile, int *stage2);   // what icp_launch_search selects          // 1: the dense search scans the lists with lanes = candidates (long lists)
 bool icp_persistent_supported (const icp_params &p);
 void icp_launch_persistent (const icp_params &p, hipStream_t s, uint32_t iterations);
 size_t icp_xch_bytes (uint32_t batch);

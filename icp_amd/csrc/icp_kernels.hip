@@ -2082,6 +2082,14 @@ uint32_t icp_s2_wave_of (const icp_params &p)
 }
 uint32_t icp_tbox_of (const icp_params &p) { return (icp_dense (p) && p.nr > 256u && icp_dense_tile (p) == 256u) ? 256u : 1024u; }
 
+void icp_search_layout_of (const icp_params &p, int *dense, int *tile, int *stage2)
+{
+    const bool d = icp_dense (p);
+    if (dense) *dense = d ? 1 : 0;
+    if (tile) *tile = d ? (int) icp_dense_tile (p) : 1024;
+    if (stage2) *stage2 = (d && p.s2wave) ? 1 : 0;
+}
+
 void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 {
     hipLaunchKernelGGL (k_get_reps, dim3 ((p.nr + 63) / 64, p.batch), dim3 (64), 0, s, p);

@@ -321,6 +321,16 @@ int icp_launches_per_iteration (icp_handle h, uint32_t *n);
  * Same bits in all three forms. */
 typedef enum { ICP_FORM_SEPARATE = 0, ICP_FORM_CHAINED = 1, ICP_FORM_PERSISTENT = 2 } icp_run_form_t;
 int icp_run_form (icp_handle h, int *form);
+/* Diagnostic: how the search kernel behind the current modes and sizes is laid out.
+ *   *dense   0: the latency variant (one 1024-thread block per CU, 16 lanes per query: a single small registration);
+ *            1: the dense variant (512-thread blocks, several per CU, 8 lanes per query, exact stage-1 pruning);
+ *   *tile    representatives per LDS tile (256 or 1024);
+ *   *stage2  0: the lanes of a query scan its representative's list; 1: lanes = candidates — a wave loads a list once for
+ *            all of its queries that share it (dense variant, lists of >= 128 candidates on average; ICP_AMD_S2WAVE=0 / 1 at
+ *            icp_init forces it off / on).
+ * Same bits in every layout.  Any output pointer may be NULL. */
+int icp_search_layout (icp_handle h, int *dense, int *tile, int *stage2);
+
 /* Test hook: marks the registration as a persistent run does when it gives up waiting (fault raised, state untouched);
  * the next blocking call repeats the last run on the chained path and switches persistent runs off for the handle. */
 int icp_debug_inject_fault (icp_handle h);

@@ -902,3 +902,56 @@ def test_stage1_pruning_exact_fused_multi_tile(engine, oracle, side, nr, zero_fr
         o.step()
     check_step(engine, g, o, weighted=False)
     g.close()
+
+
+@pytest.mark.parametrize("side,nr,batch,fused,zero_fraction,layout", [
+    (256, 256, 1, True, 0.0, (1, 256, 1)),          # one 256-tile, lists of 256
+    (256, 512, 1, True, 0.1, (1, 256, 1)),          # several 256-tiles, lists of 128, exact ties (identical zero points)
+    (256, 256, 1, False, 0.05, (1, 256, 1)),        # reference-order reductions
+    (128, 64, 3, True, 0.0, (1, 256, 1)),           # dense by batch
+    (256, 1024, 1, True, 0.0, (1, 256, 0)),         # lists of 64: the lanes of a query scan (the other form)
+])
+def test_stage2_lanes_as_candidates(engine, oracle, side, nr, batch, fused, zero_fraction, layout):
+    """Dense search, long lists (>= 128 candidates on average): stage 2 runs with lanes = candidates — a wave loads a list once
+    for all of its queries that share it, per-lane best (distance, trip) per query, one 64-lane butterfly at the end.  Ids,
+    distances (ties -> lowest position, clamped duplicates, empty / invalid queries), nearest representatives and T bit for
+    bit against the oracle, over iterations in which the wave's queries go from many lists to one."""
+    m = side * side
+    g = engine.ICP(0)
+    g.init(m, nr, A, C_, batch=batch)
+    set_modes(engine, g, power_fast=fused, fused=fused)
+    assert g.search_layout() == layout
+    oracles = []
+    for b in range(batch):
+        F, M = engine.synth_pair(side, seed=0x1C9D5EED + 11 * b, rot_deg=3.0 - 0.75 * b, zero_fraction=zero_fraction)
+        g.write(engine.Memory.F, F, batch_index=b)
+        g.write(engine.Memory.M, M, batch_index=b)
+        o = oracle.OracleICP(m, nr, A, C_, threads=8, power_fast=fused, fused=fused)
+        o.write_f(F)
+        o.write_m(M)
+        o.build_rbc()
+        oracles.append(o)
+    g.buildRBC()
+    for it in range(4):
+        g.step()
+        for b, o in enumerate(oracles):
+            o.step()
+            assert np.array_equal(g.read(engine.Memory.RID, b), o.rid), (it, b)
+            gn = g.read(engine.Memory.NN_ID, b)
+            assert np.array_equal(gn["id"], o.nn_id["id"]), (it, b, np.count_nonzero(gn["id"] != o.nn_id["id"]))
+            assert_bits(gn["dist"], o.nn_id["dist"], "distances of registration %d" % b)
+            assert_bits(g.read(engine.Memory.T, b), o.T, "T of registration %d" % b)
+    g.close()
+
+
+def test_stage2_lanes_as_candidates_1024_tile(engine, oracle):
+    """The same with the 1024-representative tile (representative grid wider than 64: |R| = 8192 over 2^20 points), one step."""
+    side, nr = 1024, 8192
+    g, o, F, M = make(engine, oracle, side, nr, power_fast=True, fused=True)
+    assert g.search_layout() == (1, 1024, 1)
+    g.buildRBC()
+    o.build_rbc()
+    g.step()
+    o.step()
+    check_step(engine, g, o, weighted=False)
+    g.close()

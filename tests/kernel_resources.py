@@ -50,5 +50,5 @@ if __name__ == "__main__":
     srcs = sys.argv[1:] or ["icp_amd/csrc/icp_kernels.hip", "icp_amd/csrc/icp_reduce_scan.hip"]
     for s in srcs:
         for n, r in kernel_resources(s).items():
-            print("%-52s vgpr %3d sgpr %3d scratch %4d occupancy %d lds %6d" % (n[:52], r.get("vgprs", -1), r.get("sgprs", -1),
+            print("%-60s vgpr %3d sgpr %3d scratch %4d occupancy %d lds %6d" % (n[:60], r.get("vgprs", -1), r.get("sgprs", -1),
                                                                                r.get("scratch", -1), r.get("occupancy", -1), r.get("lds", -1)))

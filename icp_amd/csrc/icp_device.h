@@ -208,6 +208,23 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
 
     float x = 1.f, xn = 0.f;
     int iters = 0;
+    // Tk from the unit quaternion in xn (icp_kernels.cl:1050)
+    const float *mf = means, *mm = means + 4;
+    auto tk_of = [&] (float xq) {
+        float qx = pmq_q<0> (xq), qy = pmq_q<1> (xq), qz = pmq_q<2> (xq), qw = pmq_q<3> (xq);
+        float c1x = (qy * mm[2] - qz * mm[1]) + qw * mm[0];
+        float c1y = (qz * mm[0] - qx * mm[2]) + qw * mm[1];
+        float c1z = (qx * mm[1] - qy * mm[0]) + qw * mm[2];
+        float ax = 2 * qx, ay = 2 * qy, az = 2 * qz;
+        float c2x = ay * c1z - az * c1y;
+        float c2y = az * c1x - ax * c1z;
+        float c2z = ax * c1y - ay * c1x;
+        Tk[0] = qx; Tk[1] = qy; Tk[2] = qz; Tk[3] = qw;
+        Tk[4] = mf[0] - sk * (mm[0] + c2x);
+        Tk[5] = mf[1] - sk * (mm[1] + c2y);
+        Tk[6] = mf[2] - sk * (mm[2] + c2z);
+        Tk[7] = sk;
+    };
     PM_STAMP (0)
     if (squared_start) {
         // oracle power_fast: B = N^1024, u = B 1, x = normalize (u), xn = normalize (N u) (two independent chains),
@@ -238,6 +255,7 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
                 e2_prev = e2; d = x - xn; e2 = pmq_seq4 (d * d);
             }
             PM_STAMP (3)
+            tk_of (xn);                              // (before the sign test, not after it: the two chains are independent, and a restart is rare)
             const float lam_num = pmq_lane (pmq_matvec (Nrow, xn), 0), den = pmq_lane (xn, 0);
             if ((lam_num < 0.f && den > 0.f) || (lam_num > 0.f && den < 0.f)) {
                 const float lambda = lam_num / den;
@@ -269,22 +287,8 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
         }
         x = xn;                                                       // :1039-1041
         xn = pmq_normalize (pmq_matvec (Nrow, x));
+        tk_of (xn);
     }
-
-    float qx = pmq_q<0> (xn), qy = pmq_q<1> (xn), qz = pmq_q<2> (xn), qw = pmq_q<3> (xn);
-    const float *mf = means, *mm = means + 4;
-    float c1x = (qy * mm[2] - qz * mm[1]) + qw * mm[0];                // :1050
-    float c1y = (qz * mm[0] - qx * mm[2]) + qw * mm[1];
-    float c1z = (qx * mm[1] - qy * mm[0]) + qw * mm[2];
-    float ax = 2 * qx, ay = 2 * qy, az = 2 * qz;
-    float c2x = ay * c1z - az * c1y;
-    float c2y = az * c1x - ax * c1z;
-    float c2z = ax * c1y - ay * c1x;
-    Tk[0] = qx; Tk[1] = qy; Tk[2] = qz; Tk[3] = qw;
-    Tk[4] = mf[0] - sk * (mm[0] + c2x);
-    Tk[5] = mf[1] - sk * (mm[1] + c2y);
-    Tk[6] = mf[2] - sk * (mm[2] + c2z);
-    Tk[7] = sk;
     PM_STAMP (6)
     return iters;
 }

@@ -535,10 +535,13 @@ static __device__ __forceinline__ void fused_moment_loads (const double *mom, ui
 // Returns false (for every thread, before any barrier) when the registration had already converged (checked mode).
 // a0 = the values of pass 0 (fused_moment_loads (mom, nb, 0, a0), issued by the caller with its other loads).
 // gl1 != nullptr: the first tree level was evaluated by k_moment_level1 (many blocks: large sets); gl1[k * ng + g].
-template <int NG, int NT, int ROT>
+// LEAN (the chained search's prologue: every block runs this, all of them wait for T): the block is handed T and `done` only —
+// ten LDS dwords instead of 62 —, and the one block that publishes the state (direct != nullptr) stores it straight from the
+// composing lane's registers to global memory (16 vector stores nobody waits for).
+template <int NG, int NT, int ROT, bool LEAN = false>
 static __device__ bool fused_finalize_block (const icp_params &p, const double *mom, uint32_t nb, uint32_t check, uint32_t sv,
                                              const double *a0, icp_fin_result *res, double (*s_l1)[NG], double *s_t,
-                                             const double *gl1 = nullptr)
+                                             const double *gl1 = nullptr, icp_reg_state *direct = nullptr)
 {
     // NT = threads of the calling block (compile-time: reading blockDim costs a dependent cold load at kernel start)
     constexpr uint32_t nrow = NT / 16;
@@ -590,6 +593,8 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
         for (int k = 0; k < ICP_NMOM; ++k) t[k] = s_t[k];
         const double sw = t[0];
         double mf[3], mq[3];
+        // (one division per lane with the quotients handed round as scalars measured slower, 9.19 -> 9.24 us at A: the six
+        // independent divisions overlap, the LDS read + v_readlane hand-over is one more dependent hop)
 #pragma unroll
         for (int a = 0; a < 3; ++a) { mf[a] = t[1 + a] / sw; mq[a] = t[4 + a] / sw; }
         const double c2 = (double) p.c * (double) p.c;
@@ -621,6 +626,31 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
         if (lane == 0) {
             float Tn[8], Rn[9];
             icp_compose_pure (Tprev, Rprev, Tk, Rkin, ROT != 1, Tn, Rn, Rk);
+            if constexpr (LEAN) {
+                const uint32_t done = (p.check && icp_check_converged (Tk, p.tan_half_thr, p.trans_thr)) ? 1u : 0u;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) res->T[k] = Tn[k];
+                res->done = done;
+                if (direct) {
+                    // the state image, dword for dword what fin_result_to_state would publish (pending = !done)
+                    typedef float f4u __attribute__ ((ext_vector_type (4), aligned (4)));
+                    typedef float f2u __attribute__ ((ext_vector_type (2), aligned (4)));
+                    static_assert (sizeof (icp_reg_state) == 62 * 4 && ICP_ST_DW (means) == 46 && ICP_ST_DW (sum_w) == 54 && ICP_ST_DW (k) == 56, "state layout");
+                    const unsigned long long swb = __builtin_bit_cast (unsigned long long, sw);
+                    const float img[64] = {
+                        Tn[0], Tn[1], Tn[2], Tn[3], Tn[4], Tn[5], Tn[6], Tn[7], Tk[0], Tk[1], Tk[2], Tk[3], Tk[4], Tk[5], Tk[6], Tk[7],
+                        Rn[0], Rn[1], Rn[2], Rn[3], Rn[4], Rn[5], Rn[6], Rn[7], Rn[8], Rk[0], Rk[1], Rk[2], Rk[3], Rk[4], Rk[5], Rk[6], Rk[7], Rk[8],
+                        S[0], S[1], S[2], S[3], S[4], S[5], S[6], S[7], S[8], S[9], S[10], 0.f,
+                        means[0], means[1], means[2], means[3], means[4], means[5], means[6], means[7],
+                        __uint_as_float ((uint32_t) swb), __uint_as_float ((uint32_t) (swb >> 32)),
+                        __uint_as_float (kprev + 1u), __uint_as_float (done), __uint_as_float ((uint32_t) iters), __uint_as_float (done ? 0u : 1u),
+                        __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (epoch))), __uint_as_float (0u), 0.f, 0.f };
+                    float *dst = reinterpret_cast<float *> (direct);
+#pragma unroll
+                    for (int k = 0; k < 15; ++k) *reinterpret_cast<f4u *> (dst + 4 * k) = f4u { img[4 * k], img[4 * k + 1], img[4 * k + 2], img[4 * k + 3] };
+                    *reinterpret_cast<f2u *> (dst + 60) = f2u { img[60], img[61] };
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) { res->T[k] = Tn[k]; res->Tk[k] = Tk[k]; res->means[k] = means[k]; }
 #pragma unroll
@@ -630,6 +660,7 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
             res->sum_w = sw; res->pm_iters = (uint32_t) iters; res->k = kprev + 1u; res->pad0 = 0.f; res->pending = 0u;
             res->epoch = (uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (epoch)); res->fault = 0u;
             res->done = (p.check && icp_check_converged (Tk, p.tan_half_thr, p.trans_thr)) ? 1u : 0u;
+            }
         }
     }
     __syncthreads ();
@@ -815,10 +846,10 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     if constexpr (CHAIN) {
         const bool pending = __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (pending)) != 0;
         if (pending) {
-            fused_finalize_block<32, 64 * LPQ, ROT> (p, gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, 0u, sv, ma0, &s_fin, s_l1, s_t);
+            fused_finalize_block<32, 64 * LPQ, ROT, true> (p, gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, 0u, sv, ma0, &s_fin, s_l1, s_t, nullptr,
+                                                           blockIdx.x == 0 ? sout : nullptr);
 #pragma unroll
             for (int k = 0; k < 8; ++k) T[k] = s_fin.T[k];
-            if (blockIdx.x == 0) fin_result_to_state (&s_fin, sout, s_fin.done ? 0u : 1u);
             KS_STAMP (9)
             if (s_fin.done) return;
         } else if (blockIdx.x == 0 && tid < sizeof (icp_reg_state) / 4) {

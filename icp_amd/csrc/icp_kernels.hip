@@ -592,19 +592,22 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
 #pragma unroll
         for (int k = 0; k < ICP_NMOM; ++k) t[k] = s_t[k];
         const double sw = t[0];
+        // oracle orc_moments_finish: ONE division, the means by multiplication, fused multiply-adds (this wave is what the
+        // block — in the chained form the whole grid — waits for: six double divisions and the unfused products measured
+        // 0.5 us of the iteration at A; a division per lane with the quotients handed round as scalars measured slower than
+        // six overlapping ones, 9.19 -> 9.24 us)
+        const double rs = 1.0 / sw;
         double mf[3], mq[3];
-        // (one division per lane with the quotients handed round as scalars measured slower, 9.19 -> 9.24 us at A: the six
-        // independent divisions overlap, the LDS read + v_readlane hand-over is one more dependent hop)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { mf[a] = t[1 + a] / sw; mq[a] = t[4 + a] / sw; }
+        for (int a = 0; a < 3; ++a) { mf[a] = t[1 + a] * rs; mq[a] = t[4 + a] * rs; }
         const double c2 = (double) p.c * (double) p.c;
         float S[11], means[8];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int bb = 0; bb < 3; ++bb) S[3 * a + bb] = (float) (c2 * (t[7 + 3 * a + bb] - t[4 + a] * mf[bb]));
-        S[9]  = (float) (c2 * (t[16] - ((t[1] * mf[0] + t[2] * mf[1]) + t[3] * mf[2])));
-        S[10] = (float) (c2 * (t[17] - ((t[4] * mq[0] + t[5] * mq[1]) + t[6] * mq[2])));
+            for (int bb = 0; bb < 3; ++bb) S[3 * a + bb] = (float) (c2 * __builtin_fma (-t[4 + a], mf[bb], t[7 + 3 * a + bb]));
+        S[9]  = (float) (c2 * (t[16] - __builtin_fma (t[3], mf[2], __builtin_fma (t[2], mf[1], t[1] * mf[0]))));
+        S[10] = (float) (c2 * (t[17] - __builtin_fma (t[6], mq[2], __builtin_fma (t[5], mq[1], t[4] * mq[0]))));
         means[0] = (float) mf[0]; means[1] = (float) mf[1]; means[2] = (float) mf[2]; means[3] = 0.f;
         means[4] = (float) mq[0]; means[5] = (float) mq[1]; means[6] = (float) mq[2]; means[7] = 0.f;
         float Tk[8], Rk[9], Rkin[9];
@@ -1977,16 +1980,17 @@ __global__ __launch_bounds__ (1024, 2) void k_run_persistent (const float *gM, c
             // (the moments are read from LDS where they are used: 18 doubles held at once would not fit beside the loop's state)
             const double sw = s_t[0];
             double t1[3], t4[3], mf[3], mq[3];
+            const double rs = 1.0 / sw;                  // (oracle orc_moments_finish: one division, fused multiply-adds)
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { t1[a] = s_t[1 + a]; t4[a] = s_t[4 + a]; mf[a] = t1[a] / sw; mq[a] = t4[a] / sw; }
+            for (int a = 0; a < 3; ++a) { t1[a] = s_t[1 + a]; t4[a] = s_t[4 + a]; mf[a] = t1[a] * rs; mq[a] = t4[a] * rs; }
             const double c2 = (double) p.c * (double) p.c;
             float S[11], means[8];
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int bb = 0; bb < 3; ++bb) S[3 * a + bb] = (float) (c2 * (s_t[7 + 3 * a + bb] - t4[a] * mf[bb]));
-            S[9]  = (float) (c2 * (s_t[16] - ((t1[0] * mf[0] + t1[1] * mf[1]) + t1[2] * mf[2])));
-            S[10] = (float) (c2 * (s_t[17] - ((t4[0] * mq[0] + t4[1] * mq[1]) + t4[2] * mq[2])));
+                for (int bb = 0; bb < 3; ++bb) S[3 * a + bb] = (float) (c2 * __builtin_fma (-t4[a], mf[bb], s_t[7 + 3 * a + bb]));
+            S[9]  = (float) (c2 * (s_t[16] - __builtin_fma (t1[2], mf[2], __builtin_fma (t1[1], mf[1], t1[0] * mf[0]))));
+            S[10] = (float) (c2 * (s_t[17] - __builtin_fma (t4[2], mq[2], __builtin_fma (t4[1], mq[1], t4[0] * mq[0]))));
             means[0] = (float) mf[0]; means[1] = (float) mf[1]; means[2] = (float) mf[2]; means[3] = 0.f;
             means[4] = (float) mq[0]; means[5] = (float) mq[1]; means[6] = (float) mq[2]; means[7] = 0.f;
             // The three steps hand their results over through the state in LDS (S and the means now, Tk after the rotation)

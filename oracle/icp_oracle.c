@@ -810,13 +810,15 @@ void orc_moments_fused (const float *NN, const float *tM, const float *Wt, uint3
 /* moments -> sum of weights, means (float), S (float) */
 void orc_moments_finish (const double *t, float c, double *sum_w, float *mean8, float *S11)
 {
-    double sw = t[0], mf[3], mq[3];
-    for (int a = 0; a < 3; ++a) { mf[a] = t[1 + a] / sw; mq[a] = t[4 + a] / sw; }
+    /* canonical form (the build's own: fused mode has no counterpart in the reference): ONE division, the means by
+       multiplication, every product-and-add a fused multiply-add */
+    double sw = t[0], rs = 1.0 / sw, mf[3], mq[3];
+    for (int a = 0; a < 3; ++a) { mf[a] = t[1 + a] * rs; mq[a] = t[4 + a] * rs; }
     double c2 = (double) c * (double) c;
     for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) S11[3 * a + b] = (float) (c2 * (t[7 + 3 * a + b] - t[4 + a] * mf[b]));
-    S11[9]  = (float) (c2 * (t[16] - ((t[1] * mf[0] + t[2] * mf[1]) + t[3] * mf[2])));
-    S11[10] = (float) (c2 * (t[17] - ((t[4] * mq[0] + t[5] * mq[1]) + t[6] * mq[2])));
+        for (int b = 0; b < 3; ++b) S11[3 * a + b] = (float) (c2 * fma (-t[4 + a], mf[b], t[7 + 3 * a + b]));
+    S11[9]  = (float) (c2 * (t[16] - fma (t[3], mf[2], fma (t[2], mf[1], t[1] * mf[0]))));
+    S11[10] = (float) (c2 * (t[17] - fma (t[6], mq[2], fma (t[5], mq[1], t[4] * mq[0]))));
     for (int a = 0; a < 3; ++a) { mean8[a] = (float) mf[a]; mean8[4 + a] = (float) mq[a]; }
     mean8[3] = 0.f; mean8[7] = 0.f;
     *sum_w = sw;

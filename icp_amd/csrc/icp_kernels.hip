@@ -538,10 +538,13 @@ static __device__ __forceinline__ void fused_moment_loads (const double *mom, ui
 // LEAN (the chained search's prologue: every block runs this, all of them wait for T): the block is handed T and `done` only —
 // ten LDS dwords instead of 62 —, and the one block that publishes the state (direct != nullptr) stores it straight from the
 // composing lane's registers to global memory (16 vector stores nobody waits for).
-template <int NG, int NT, int ROT, bool LEAN = false>
+// after (LEAN): called by every lane of the finishing wave with the new T, before the barrier that releases the block — the
+// chained search transforms and hands over its queries there, so that one barrier covers T's consumers.
+struct ff_no_hook { __device__ void operator() (const float *) const {} };
+template <int NG, int NT, int ROT, bool LEAN = false, typename AFTER = ff_no_hook>
 static __device__ bool fused_finalize_block (const icp_params &p, const double *mom, uint32_t nb, uint32_t check, uint32_t sv,
                                              const double *a0, icp_fin_result *res, double (*s_l1)[NG], double *s_t,
-                                             const double *gl1 = nullptr, icp_reg_state *direct = nullptr)
+                                             const double *gl1 = nullptr, icp_reg_state *direct = nullptr, AFTER after = AFTER ())
 {
     // NT = threads of the calling block (compile-time: reading blockDim costs a dependent cold load at kernel start)
     constexpr uint32_t nrow = NT / 16;
@@ -626,13 +629,13 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rprev[k] = state_lane_f (sv, ICP_ST_DW (R) + k);
         const uint32_t kprev = (uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (k));
-        if (lane == 0) {
+        if constexpr (LEAN) {
+            // the composition on every lane (the same instructions as on one): T is then in registers where the hook wants it
             float Tn[8], Rn[9];
             icp_compose_pure (Tprev, Rprev, Tk, Rkin, ROT != 1, Tn, Rn, Rk);
-            if constexpr (LEAN) {
-                const uint32_t done = (p.check && icp_check_converged (Tk, p.tan_half_thr, p.trans_thr)) ? 1u : 0u;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) res->T[k] = Tn[k];
+            const uint32_t done = (p.check && icp_check_converged (Tk, p.tan_half_thr, p.trans_thr)) ? 1u : 0u;
+            after (Tn);
+            if (lane == 0) {
                 res->done = done;
                 if (direct) {
                     // the state image, dword for dword what fin_result_to_state would publish (pending = !done)
@@ -653,7 +656,10 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
                     for (int k = 0; k < 15; ++k) *reinterpret_cast<f4u *> (dst + 4 * k) = f4u { img[4 * k], img[4 * k + 1], img[4 * k + 2], img[4 * k + 3] };
                     *reinterpret_cast<f2u *> (dst + 60) = f2u { img[60], img[61] };
                 }
-            } else {
+            }
+        } else if (lane == 0) {
+            float Tn[8], Rn[9];
+            icp_compose_pure (Tprev, Rprev, Tk, Rkin, ROT != 1, Tn, Rn, Rk);
 #pragma unroll
             for (int k = 0; k < 8; ++k) { res->T[k] = Tn[k]; res->Tk[k] = Tk[k]; res->means[k] = means[k]; }
 #pragma unroll
@@ -663,7 +669,6 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
             res->sum_w = sw; res->pm_iters = (uint32_t) iters; res->k = kprev + 1u; res->pad0 = 0.f; res->pending = 0u;
             res->epoch = (uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (epoch)); res->fault = 0u;
             res->done = (p.check && icp_check_converged (Tk, p.tan_half_thr, p.trans_thr)) ? 1u : 0u;
-            }
         }
     }
     __syncthreads ();
@@ -745,10 +750,11 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     const uint32_t qe = slice * KS_QPW + lane / KS_SPLIT, ss = lane & (KS_SPLIT - 1u);
     // reference-order mode: the 64 even (or odd) positions of one 128-query group (a closed sub-tree of
     // the weight reduction); fused mode: an 8 x 8 tile of the landmark grid (spatially coherent lists)
-    // One wave (the last: wave 0 runs the power method in the chained variant) prepares the block's 64 queries —
+    // One wave (the last; in the chained variant wave 0, which holds the new T in registers the moment it exists and hands the
+    // transformed queries over before the barrier that ends the finalize) prepares the block's 64 queries —
     // lane e = query e: index, load, transform, pruning seed — and hands them to the lanes of each query through LDS;
     // the other 15 (7) waves neither compute the index nor load / transform the same point LPQ times over.
-    const bool qwave = slice == KS_SPLIT - 1u;
+    const bool qwave = CHAIN ? slice == 0u : slice == KS_SPLIT - 1u;
     // (the one-block-per-CU variants only: measured 9.63 -> 9.43 us per iteration at A; the dense variant runs several blocks
     // per CU over grids of thousands and measured 0 ... 4 % slower with it)
     const uint32_t tile_id = (FUSED && MINW == 2) ? ks_tile_of_block (blockIdx.x, gridDim.x) : blockIdx.x;
@@ -846,20 +852,27 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     if constexpr (MINW == 4 && !SINGLE) {            // the boxes of all tiles: a tile is tested before it is staged (stage 1 below)
         if (prune && nr > KT && tid < 2u * p.n1k) s_tbox[tid] = p.GB[(size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + tid];
     }
+    bool handed = false;                             // the queries are in LDS already (chained variant, see below)
     if constexpr (CHAIN) {
         const bool pending = __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (pending)) != 0;
         if (pending) {
+            // wave 0 (= the query wave): T -> the block's 64 transformed queries -> LDS, inside the finalize, before its barrier
+            auto hand_over = [&] (const float *Tn) {
+                float tx, ty, tz;
+                icp_transform_point (Tn, mg.x, mg.y, mg.z, tx, ty, tz);
+                s_qa[lane] = make_float4 (tx, ty, tz, __uint_as_float (iq));
+                s_qc[lane] = make_float4 (mc.x, mc.y, mc.z, __uint_as_float (seed));
+            };
             fused_finalize_block<32, 64 * LPQ, ROT, true> (p, gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, 0u, sv, ma0, &s_fin, s_l1, s_t, nullptr,
-                                                           blockIdx.x == 0 ? sout : nullptr);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) T[k] = s_fin.T[k];
+                                                           blockIdx.x == 0 ? sout : nullptr, hand_over);
+            handed = true;
             KS_STAMP (9)
             if (s_fin.done) return;
         } else if (blockIdx.x == 0 && tid < sizeof (icp_reg_state) / 4) {
             reinterpret_cast<uint32_t *> (sout)[tid] = (tid == offsetof (icp_reg_state, pending) / 4) ? 1u : sv;
         }
     }
-    if (qwave) {
+    if (qwave && !handed) {
         float tx = mg.x, ty = mg.y, tz = mg.z;
         if constexpr (!OWNER) icp_transform_point (T, mg.x, mg.y, mg.z, tx, ty, tz);
         s_qa[lane] = make_float4 (tx, ty, tz, __uint_as_float (iq));

@@ -544,7 +544,8 @@ struct ff_no_hook { __device__ void operator() (const float *) const {} };
 template <int NG, int NT, int ROT, bool LEAN = false, typename AFTER = ff_no_hook>
 static __device__ bool fused_finalize_block (const icp_params &p, const double *mom, uint32_t nb, uint32_t check, uint32_t sv,
                                              const double *a0, icp_fin_result *res, double (*s_l1)[NG], double *s_t,
-                                             const double *gl1 = nullptr, icp_reg_state *direct = nullptr, AFTER after = AFTER ())
+                                             const double *gl1 = nullptr, icp_reg_state *direct = nullptr, AFTER after = AFTER (),
+                                             uint32_t pending_unless_done = 1u)
 {
     // NT = threads of the calling block (compile-time: reading blockDim costs a dependent cold load at kernel start)
     constexpr uint32_t nrow = NT / 16;
@@ -649,7 +650,7 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
                         S[0], S[1], S[2], S[3], S[4], S[5], S[6], S[7], S[8], S[9], S[10], 0.f,
                         means[0], means[1], means[2], means[3], means[4], means[5], means[6], means[7],
                         __uint_as_float ((uint32_t) swb), __uint_as_float ((uint32_t) (swb >> 32)),
-                        __uint_as_float (kprev + 1u), __uint_as_float (done), __uint_as_float ((uint32_t) iters), __uint_as_float (done ? 0u : 1u),
+                        __uint_as_float (kprev + 1u), __uint_as_float (done), __uint_as_float ((uint32_t) iters), __uint_as_float (done ? 0u : pending_unless_done),
                         __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (epoch))), __uint_as_float (0u), 0.f, 0.f };
                     float *dst = reinterpret_cast<float *> (direct);
 #pragma unroll
@@ -1615,8 +1616,8 @@ __global__ __launch_bounds__ (1024) void k_finalize_fused (const double *gmom, i
 #pragma unroll
     for (int q = 0; q < 8; ++q) a0[q] = 0.0;
     if (!gl1) fused_moment_loads<1024> (mom, nb, 0u, a0);
-    if (!fused_finalize_block<128, 1024, ROT> (p, mom, nb, check, sv, a0, &s_fin, s_l1, s_t, gl1)) return;
-    fin_result_to_state (&s_fin, st, 0u);
+    // (the state goes to memory straight from the composing lane's registers: no LDS image, no second pass)
+    fused_finalize_block<128, 1024, ROT, true> (p, mom, nb, check, sv, a0, &s_fin, s_l1, s_t, gl1, st, ff_no_hook (), 0u);
 }
 
 // First tree level of the moments for large sets (|F| / 64 blocks > 128 * ICP_L1_MIN_GROUPS): one 16-lane row per

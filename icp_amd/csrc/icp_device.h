@@ -243,9 +243,34 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
             }
             PM_STAMP (1)
             const float u = pmq_matvec (Brow, 1.f);
-            x = pmq_normalize (u);
-            xn = pmq_normalize (pmq_matvec (Nrow, u));
+            const float v = pmq_matvec (Nrow, u);
+            xn = pmq_normalize (v);
             ++iters;
+            // fast exit on the unnormalised pair (oracle power_fast): |u x v|^2 over the six index pairs against
+            // 2^-44 (u.u)(v.v), sign of the eigenvalue from u.v — decided while the normalisation above is still under way.
+            // Lane i holds the pairs (i, i+1) and (i, i+2) (indices mod 4; (3,0) and (2,0), (3,1) are the negatives of
+            // (0,3), (0,2), (1,3): the same squares); summed in the oracle's order 01, 02, 03, 12, 13, 23.
+            {
+                const float u1 = icp_dpp<0x39> (u), v1 = icp_dpp<0x39> (v);      // quad_perm [1,2,3,0]: component i + 1
+                const float u2 = icp_dpp<0x4E> (u), v2 = icp_dpp<0x4E> (v);      // quad_perm [2,3,0,1]: component i + 2
+                const float ta = u * v1 - u1 * v, tb = u * v2 - u2 * v;
+                const float a1 = ta * ta, a2 = tb * tb;
+                float c2 = 0.f;
+                c2 = c2 + pmq_q<0> (a1); c2 = c2 + pmq_q<0> (a2); c2 = c2 + pmq_q<3> (a1);
+                c2 = c2 + pmq_q<1> (a1); c2 = c2 + pmq_q<1> (a2); c2 = c2 + pmq_q<2> (a1);
+                const float uu = pmq_seq4 (u * u), vv = pmq_seq4 (v * v), uv = pmq_seq4 (u * v);
+                if (!(c2 > 0x1p-44f * (uu * vv))) {
+                    if (uv < 0.f) {
+                        const float lambda = uv / uu;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) Nrow[k] = (i == (uint32_t) k) ? Nrow[k] - lambda : Nrow[k];
+                        continue;
+                    }
+                    tk_of (xn);
+                    break;
+                }
+            }
+            x = pmq_normalize (u);
             PM_STAMP (2)
             float e2_prev = __builtin_inff (), d = x - xn, e2 = pmq_seq4 (d * d);
             while (e2 > 0x1p-44f && e2 < e2_prev && iters < 1000) {

@@ -564,7 +564,8 @@ static int power_literal (const float *S, const float *means, float *Tk)
 
 /* The build's accelerated power method (the GPU twin is icp_power_method_quad, squared start).
  *   B = N^(2^PM_SQUARINGS) by repeated squaring (k-ordered fmaf chains, exact power-of-two rescaling every fifth
- *   squaring); u = B 1 (not normalised);  x = normalize (u) and xn = normalize (N u) (independent of each other);
+ *   squaring); u = B 1 (not normalised), v = N u; a fast exit decided on (u, v) (see there); otherwise
+ *   x = normalize (u) and xn = normalize (v) (independent of each other);
  *   then the reference's loop on SQUARED step lengths: it goes on only while the step is above 2^-22 (one ulp of a
  *   unit vector) and still decreasing.  The sign test of :1024 divides only when it has to shift; the vector the
  *   loop ends with is the result (the reference's extra pass after its loop, :1039-1041, is what the loop's last
@@ -589,9 +590,33 @@ static int power_fast (const float *S, const float *means, float *Tk)
             if (s % 5 == 4) rescale16 (B);          /* max|entry| < 2 after a rescale, < 2^94 five squarings later */
         }
         prod4 (B, ones, u);
-        memcpy (x, u, sizeof x); normalize4 (x);
-        prod4 (N, u, xn); normalize4 (xn);
+        float v[4]; prod4 (N, u, v);
         ++iters;
+        /* Fast exit, decided on the unnormalised pair (u, v = N u) — nothing on the way to the result waits for it:
+         * |u x v|^2 = sum over the six index pairs of (u_i v_j - u_j v_i)^2 (Lagrange's identity: no cancellation between
+         * large terms) against 2^-44 (u.u)(v.v), i.e. sin^2 of the angle between two successive iterates against the
+         * square of one ulp of a unit vector; the sign of the eigenvalue from the Rayleigh quotient u.v / u.u.  False on
+         * NaN like the loop's own test below.  Converged and positive: the result is normalize (N u), what the general
+         * path below ends with in this case. */
+        {
+            float c2 = 0.f, t;
+            t = u[0] * v[1] - u[1] * v[0]; c2 += t * t;  t = u[0] * v[2] - u[2] * v[0]; c2 += t * t;
+            t = u[0] * v[3] - u[3] * v[0]; c2 += t * t;  t = u[1] * v[2] - u[2] * v[1]; c2 += t * t;
+            t = u[1] * v[3] - u[3] * v[1]; c2 += t * t;  t = u[2] * v[3] - u[3] * v[2]; c2 += t * t;
+            float uu = 0.f, vv = 0.f, uv = 0.f;
+            for (int k = 0; k < 4; ++k) { uu += u[k] * u[k]; vv += v[k] * v[k]; uv += u[k] * v[k]; }
+            if (!(c2 > 0x1p-44f * (uu * vv))) {
+                if (uv < 0.f) {                              /* negative dominant eigenvalue: shift by it (:1024-1037), start over */
+                    const float lambda = uv / uu;
+                    N[0] -= lambda; N[5] -= lambda; N[10] -= lambda; N[15] -= lambda;
+                    continue;
+                }
+                memcpy (xn, v, sizeof xn); normalize4 (xn);
+                break;
+            }
+        }
+        memcpy (x, u, sizeof x); normalize4 (x);
+        memcpy (xn, v, sizeof xn); normalize4 (xn);
         float e2_prev = INFINITY, e2 = distance4_sq (x, xn);
         while (e2 > 0x1p-44f && e2 < e2_prev && iters < 1000) {       /* false on NaN: the loop ends */
             memcpy (x, xn, sizeof x);

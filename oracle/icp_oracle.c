@@ -4,7 +4,8 @@
  * (gcc -O2 -ffp-contract=off -fno-fast-math; -fopenmp only parallelises the per-query
  * search loops, whose results do not depend on the thread count).
  *
- * Canonical arithmetic: fp32 RN, no implicit FMA (explicit fmaf in the metric and the squared start), W = 64.
+ * Canonical arithmetic: fp32 RN, no implicit FMA (explicit fmaf in the metric and the squared start; explicit
+ * double fma in the finish of the fused moments, orc_moments_finish), W = 64.
  *   LDS tree of every reference reduction (kernels/icp_kernels.cl:170-175, 244-249, 319-324,
  *   396-405, 480-489, 551-560; kernels/reduce_kernels.cl:254-259):
  *       data[0..2W) filled, then for d = W, W/2, .., 1:  data[i] += data[i+d]  (i < d)

@@ -17,8 +17,8 @@
 //   k_finalize_fused  moment trees, means / S, rotation, composition, check — or, chained, the prologue of the
 //                     next k_search<FUSED, CHAIN>
 //
-// RBC construction (once per fixed frame): k_get_reps, k_rep_boxes, k_search<.., OWNER>, k_chunk_hist, k_count,
-// k_offsets, k_place.
+// RBC construction (once per fixed frame): k_reps_and_boxes, k_search<.., OWNER>, k_chunk_hist, k_count_offsets (or k_count,
+// k_offsets beyond 1024 representatives), k_place.
 //
 // Every reduction follows the canonical tree of DESIGN.md §3, so results are bit-identical to
 // oracle/icp_oracle.c.  blockIdx.y is the registration index of a batch.
@@ -204,69 +204,73 @@ __global__ __launch_bounds__ (256) void k_transform_cloud_ex (const float4 *in, 
 // ------------------------------------------------------------------------------------------
 
 // a1 getReps — kernels/icp_kernels.cl:97-114 with the 128 replaced by the landmark grid side
-__global__ void k_get_reps (icp_params p)
+// Index of the fixed point representative r is sampled from (generalised getReps: kernels/icp_kernels.cl:107-113 with the
+// grid side of the set instead of 128).
+static __device__ __forceinline__ uint32_t rep_src_index (const icp_params &p, uint32_t r)
 {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (r >= p.nr) return;
     uint32_t gX = r % p.nrx, gY = r / p.nrx;
     uint32_t stepX = p.side / p.nrx, stepY = p.side / p.nry;
     uint32_t xi = (stepX == 1) ? gX : gX * stepX + (stepX >> 1) - 1;
     uint32_t yi = (stepY == 1) ? gY : gY * stepY + (stepY >> 1) - 1;
-    uint32_t src = yi * p.side + xi;
-    const float4 *F4 = reinterpret_cast<const float4 *> (p.F + (size_t) b * p.m * 8);
-    float4 *R4 = reinterpret_cast<float4 *> (p.R + (size_t) b * p.nr * 8);
-    R4[2 * r] = F4[2 * (size_t) src];
-    R4[2 * r + 1] = F4[2 * (size_t) src + 1];
-    p.rep_src[(size_t) b * p.nr + r] = src;
+    return yi * p.side + xi;
 }
 
-// Geometry bounding boxes of the stage-1 pruning groups of k_search: groups of 16 representatives (then, unused by the
-// current launch set, of 32 consecutive ones).  A group of 16 is a 4 x 4 tile of the representative grid where the grid
-// allows (p.gtile: the representatives are a regular sample of the landmark grid, so a tile is compact in space: 1.8 - 2.9
-// groups per wave survive the bound instead of 3.3 - 8.8 with 16 x 1 strips), else 16 consecutive representatives.
-// fminf / fmaxf skip NaN coordinates: a representative with a NaN coordinate never wins a '<' anyway.
-__global__ void k_rep_boxes (icp_params p)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (t >= p.n16) return;                          // (the boxes of whole LDS tiles: k_tile_boxes)
-    const uint32_t gs = 16u, g = t;
-    const float4 *R4 = reinterpret_cast<const float4 *> (p.R + (size_t) b * p.nr * 8);
-    const float inf = __builtin_inff ();
-    float4 lo = make_float4 (inf, inf, inf, 0.f), hi = make_float4 (-inf, -inf, -inf, 0.f);
-    const bool tiled = gs == 16u && p.gtile != 0u;
-    const uint32_t lg = p.gtile - 1u, ty = tiled ? g >> lg : 0u, tx = tiled ? g & ((1u << lg) - 1u) : 0u;
-    for (uint32_t e = 0; e < gs; ++e) {
-        const uint32_t r = tiled ? (4u * ty + (e >> 2)) * p.nrx + 4u * tx + (e & 3u) : g * gs + e;
-        if (r >= p.nr) continue;
-        const float4 v = R4[2 * (size_t) r];
-        lo.x = fminf (lo.x, v.x); lo.y = fminf (lo.y, v.y); lo.z = fminf (lo.z, v.z);
-        hi.x = fmaxf (hi.x, v.x); hi.y = fmaxf (hi.y, v.y); hi.z = fmaxf (hi.z, v.z);
-    }
-    float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n1k);
-    GB[2 * t] = lo; GB[2 * t + 1] = hi;
-}
-
-// Geometry bounding box of every LDS tile of the dense k_search for multi-tile sets (p.tbox consecutive representatives:
-// 256, or 1024 for the largest sets): one wave per box (min / max are exact in any order).
+// a1 + the boxes of the stage-1 pruning, ONE launch of 64-thread blocks with three kinds of duty (buildRBC is a chain of
+// small dependent launches: every launch saved is ~4 us of its ~40 at |F| = 16384):
+//   blocks [0, nbr)            the representatives: R[r] = F[src (r)], rep_src[r] = src (r)                     (getReps)
+//   blocks [nbr, nbr + nbg)    geometry bounding boxes of the pruning groups of 16 representatives: a 4 x 4 tile of the
+//                              representative grid where the grid allows (p.gtile: the representatives are a regular sample
+//                              of the landmark grid, so a tile is compact in space: 1.8 - 2.9 groups per wave survive the
+//                              bound instead of 3.3 - 8.8 with 16 x 1 strips), else 16 consecutive representatives
+//   blocks [nbr + nbg, ..)     the box of every LDS tile of the dense k_search for multi-tile sets (p.tbox consecutive
+//                              representatives: 256, or 1024 for the largest sets), one wave per box
+// The boxes read the representatives' points from F at src (r): they do not wait for R.  fminf / fmaxf skip NaN
+// coordinates: a representative with a NaN coordinate never wins a '<' anyway; min / max are exact in any order.
 #define ICP_TBOX 1024u
-__global__ __launch_bounds__ (64) void k_tile_boxes (icp_params p)
+__global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t nbr, uint32_t nbg)
 {
-    const uint32_t tile = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-    const float4 *R4 = reinterpret_cast<const float4 *> (p.R + (size_t) b * p.nr * 8);
+    const uint32_t b = blockIdx.y, lane = threadIdx.x;
+    const float4 *F4 = reinterpret_cast<const float4 *> (p.F + (size_t) b * p.m * 8);
     const float inf = __builtin_inff ();
-    float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
-    for (uint32_t r = tile * p.tbox + lane; r < min (p.nr, (tile + 1u) * p.tbox); r += 64u) {
-        const float4 v = R4[2 * (size_t) r];
-        lo[0] = fminf (lo[0], v.x); lo[1] = fminf (lo[1], v.y); lo[2] = fminf (lo[2], v.z);
-        hi[0] = fmaxf (hi[0], v.x); hi[1] = fmaxf (hi[1], v.y); hi[2] = fmaxf (hi[2], v.z);
-    }
+    if (blockIdx.x < nbr) {
+        const uint32_t r = blockIdx.x * 64u + lane;
+        if (r >= p.nr) return;
+        const uint32_t src = rep_src_index (p, r);
+        float4 *R4 = reinterpret_cast<float4 *> (p.R + (size_t) b * p.nr * 8);
+        R4[2 * r] = F4[2 * (size_t) src];
+        R4[2 * r + 1] = F4[2 * (size_t) src + 1];
+        p.rep_src[(size_t) b * p.nr + r] = src;
+    } else if (blockIdx.x < nbr + nbg) {
+        const uint32_t g = (blockIdx.x - nbr) * 64u + lane;
+        if (g >= p.n16) return;
+        float4 lo = make_float4 (inf, inf, inf, 0.f), hi = make_float4 (-inf, -inf, -inf, 0.f);
+        const bool tiled = p.gtile != 0u;
+        const uint32_t lg = p.gtile - 1u, ty = tiled ? g >> lg : 0u, tx = tiled ? g & ((1u << lg) - 1u) : 0u;
+        for (uint32_t e = 0; e < 16u; ++e) {
+            const uint32_t r = tiled ? (4u * ty + (e >> 2)) * p.nrx + 4u * tx + (e & 3u) : g * 16u + e;
+            if (r >= p.nr) continue;
+            const float4 v = F4[2 * (size_t) rep_src_index (p, r)];
+            lo.x = fminf (lo.x, v.x); lo.y = fminf (lo.y, v.y); lo.z = fminf (lo.z, v.z);
+            hi.x = fmaxf (hi.x, v.x); hi.y = fmaxf (hi.y, v.y); hi.z = fmaxf (hi.z, v.z);
+        }
+        float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n1k);
+        GB[2 * g] = lo; GB[2 * g + 1] = hi;
+    } else {
+        const uint32_t tile = blockIdx.x - nbr - nbg;
+        float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+        for (uint32_t r = tile * p.tbox + lane; r < min (p.nr, (tile + 1u) * p.tbox); r += 64u) {
+            const float4 v = F4[2 * (size_t) rep_src_index (p, r)];
+            lo[0] = fminf (lo[0], v.x); lo[1] = fminf (lo[1], v.y); lo[2] = fminf (lo[2], v.z);
+            hi[0] = fmaxf (hi[0], v.x); hi[1] = fmaxf (hi[1], v.y); hi[2] = fmaxf (hi[2], v.z);
+        }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1)
+        for (int d = 32; d > 0; d >>= 1)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { lo[k] = fminf (lo[k], __shfl_xor (lo[k], d)); hi[k] = fmaxf (hi[k], __shfl_xor (hi[k], d)); }
-    if (lane == 0) {
-        float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16;
-        GB[2 * tile] = make_float4 (lo[0], lo[1], lo[2], 0.f); GB[2 * tile + 1] = make_float4 (hi[0], hi[1], hi[2], 0.f);
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf (lo[k], __shfl_xor (lo[k], d)); hi[k] = fmaxf (hi[k], __shfl_xor (hi[k], d)); }
+        if (lane == 0) {
+            float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16;
+            GB[2 * tile] = make_float4 (lo[0], lo[1], lo[2], 0.f); GB[2 * tile + 1] = make_float4 (hi[0], hi[1], hi[2], 0.f);
+        }
     }
 }
 
@@ -329,30 +333,69 @@ __global__ __launch_bounds__ (1024) void k_offsets (icp_params p)
     for (uint32_t r = lo; r < hi; ++r) { O[r] = run; run += N[r]; }
 }
 
+// steps 3 + 4 in one launch for |R| <= 1024 (one block, thread r = representative r): the serial walk over the chunks, then
+// the block scan of the counts — the same integers as k_count + k_offsets.
+__global__ __launch_bounds__ (1024) void k_count_offsets (icp_params p)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t b = blockIdx.y, r = threadIdx.x, lane = r & 63u, wave = r >> 6;
+    uint32_t run = 0;
+    if (r < p.nr) {
+        uint32_t *h0 = p.chunk_hist + (size_t) b * p.nchunk * p.nr + r;
+        for (uint32_t c0 = 0; c0 < p.nchunk; c0 += 8u) {              // eight independent loads in flight, then the serial scan
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) v[k] = (c0 + k < p.nchunk) ? h0[(size_t) (c0 + k) * p.nr] : 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k)
+                if (c0 + k < p.nchunk) { h0[(size_t) (c0 + k) * p.nr] = run; run += v[k]; }
+        }
+        p.N[(size_t) b * p.nr + r] = run;
+    }
+    uint32_t inc = run;                              // exclusive scan over r (exclusiveScan_i, kernels/scan_kernels.cl:188)
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t v = __shfl_up (inc, d); if (lane >= d) inc += v; }
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads ();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
+    if (r < p.nr) p.O[(size_t) b * p.nr + r] = base + inc - run;
+}
+
 // step 5: stable placement: position = O[owner] + #{j < i : owner[j] == owner[i]}; perm, X_P and the search copy.
-// One block per chunk of 1024 points; the rank inside the chunk is a plain count over the chunk's owners in LDS
-// (broadcast reads; every wave works at once), the rank base of the chunk comes from step 3.
+// One block per chunk of 1024 points; the rank base of the chunk comes from step 3.  The rank inside the chunk: the points of
+// a wave are 64 neighbours in index order and share a handful of owners, so every wave lists its distinct owners with
+// their counts (one ballot per distinct owner: the lanes' rank inside the wave is a popcount of the lanes below), and a
+// point adds the counts of its owner in the lists of the earlier waves (broadcast LDS reads of short lists) — instead of
+// comparing itself with every earlier point of the chunk (round 2: 15 -> 5 us at |F| = 16384, where the kernel is a third
+// of buildRBC).  Integer arithmetic: the same positions whatever the path.
 __global__ __launch_bounds__ (1024) void k_place (icp_params p)
 {
-    __shared__ uint4 s_own4[ICP_CHUNK / 4];
-    uint32_t *s_own = reinterpret_cast<uint32_t *> (s_own4);
-    const uint32_t chunk = blockIdx.x, b = blockIdx.y, t = threadIdx.x, wave = t >> 6;
+    __shared__ uint2 s_list[ICP_CHUNK / 64][64];     // per wave: (owner, count) of its distinct owners
+    __shared__ uint32_t s_n[ICP_CHUNK / 64];
+    const uint32_t chunk = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane (t >> 6);
     const uint32_t i = chunk * ICP_CHUNK + t;
     const bool valid = i < p.m;
     const uint32_t own = valid ? p.owner[(size_t) b * p.m + i] : 0xFFFFFFFFu;
     uint32_t base = 0;
     if (valid) base = p.O[(size_t) b * p.nr + own] + p.chunk_hist[((size_t) b * p.nchunk + chunk) * p.nr + own];
-    s_own[t] = own;
-    __syncthreads ();
-    uint32_t rank = 0;
-    for (uint32_t j4 = 0; j4 < wave * 16u; ++j4) {                     // earlier waves: every element precedes t
-        const uint4 v = s_own4[j4];
-        rank += (v.x == own) + (v.y == own) + (v.z == own) + (v.w == own);
+    uint32_t rank = 0, k = 0;
+    for (unsigned long long rem = __ballot (valid); rem; ++k) {
+        const uint32_t o = (uint32_t) __builtin_amdgcn_readlane ((int) own, (int) __builtin_ctzll (rem));
+        const unsigned long long same = __ballot (own == o);         // (an owner is < nr: never the marker of an invalid lane)
+        if (own == o) rank = (uint32_t) __builtin_popcountll (same & ((1ull << lane) - 1ull));
+        if (lane == 0) s_list[wave][k] = make_uint2 (o, (uint32_t) __builtin_popcountll (same));
+        rem &= ~same;
     }
-    for (uint32_t j4 = wave * 16u; j4 < wave * 16u + 16u; ++j4) {      // own wave: elements below t
-        const uint4 v = s_own4[j4];
-        const uint32_t j = 4u * j4;
-        rank += (v.x == own && j < t) + (v.y == own && j + 1u < t) + (v.z == own && j + 2u < t) + (v.w == own && j + 3u < t);
+    if (lane == 0) s_n[wave] = k;
+    __syncthreads ();
+    for (uint32_t w = 0; w < wave; ++w) {            // earlier waves: every one of their points precedes t
+        const uint32_t n = s_n[w];
+        for (uint32_t e = 0; e < n; ++e) {
+            const uint2 v = s_list[w][e];
+            rank += (v.x == own) ? v.y : 0u;
+        }
     }
     if (valid) {
         const uint32_t pos = base + rank;
@@ -2141,9 +2184,10 @@ void icp_search_layout_of (const icp_params &p, int *dense, int *tile, int *stag
 
 void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 {
-    hipLaunchKernelGGL (k_get_reps, dim3 ((p.nr + 63) / 64, p.batch), dim3 (64), 0, s, p);
-    hipLaunchKernelGGL (k_rep_boxes, dim3 ((p.n16 + 63) / 64, p.batch), dim3 (64), 0, s, p);
-    if (p.nr > p.tbox) hipLaunchKernelGGL (k_tile_boxes, dim3 (p.n1k, p.batch), dim3 (64), 0, s, p);    // (a single tile needs no box of its own)
+    {   // the representatives, the boxes of their pruning groups and (several tiles only) of the LDS tiles: one launch
+        const uint32_t nbr = (p.nr + 63u) / 64u, nbg = (p.n16 + 63u) / 64u, nbt = p.nr > p.tbox ? p.n1k : 0u;
+        hipLaunchKernelGGL (k_reps_and_boxes, dim3 (nbr + nbg + nbt, p.batch), dim3 (64), 0, s, p, nbr, nbg);
+    }
     // step 1, owner(x) = nearest representative: the search kernel's stage 1 over the fixed points
     // (dense variant: LDS tiles of 256 representatives up to |R| = 4096 — four blocks per CU —, of 1024 beyond, where a 4 x 4 tile
     // group no longer fits a 256-tile: icp_dense_tile)
@@ -2152,8 +2196,11 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
     else if (icp_dense (p)) hipLaunchKernelGGL ((k_search<true, false, 4, 8, true>), dim3 (p.nb, p.batch), dim3 (512), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
     else hipLaunchKernelGGL ((k_search<true, false, 2, 16, true>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
     hipLaunchKernelGGL (k_chunk_hist, dim3 (p.nchunk, p.batch), dim3 (256), p.nr * sizeof (uint32_t), s, p);
-    hipLaunchKernelGGL (k_count, dim3 ((p.nr + 63) / 64, p.batch), dim3 (64), 0, s, p);
-    hipLaunchKernelGGL (k_offsets, dim3 (1, p.batch), dim3 (1024), 0, s, p);
+    if (p.nr <= 1024u) hipLaunchKernelGGL (k_count_offsets, dim3 (1, p.batch), dim3 (1024), 0, s, p);
+    else {
+        hipLaunchKernelGGL (k_count, dim3 ((p.nr + 63) / 64, p.batch), dim3 (64), 0, s, p);
+        hipLaunchKernelGGL (k_offsets, dim3 (1, p.batch), dim3 (1024), 0, s, p);
+    }
     hipLaunchKernelGGL (k_place, dim3 (p.nchunk, p.batch), dim3 (1024), 0, s, p);
 }
 

@@ -293,22 +293,40 @@ __global__ __launch_bounds__ (256) void k_chunk_hist (icp_params p)
     for (uint32_t r = threadIdx.x; r < p.nr; r += blockDim.x) H[r] = s_hist[r];
 }
 
-// step 3: N[r] = sum over chunks; chunk_hist[chunk][r] becomes the rank base of that chunk in list r
-__global__ void k_count (icp_params p)
+// step 3: N[r] = sum over chunks; chunk_hist[chunk][r] becomes the rank base of that chunk in list r.
+// Block = 64 representatives x 16 groups of consecutive chunks (thread (rr, cg): coalesced over rr): the sum of every group,
+// an exchange through LDS, then the group's chunks again with the running base — two parallel passes instead of one thread
+// walking all chunks of its representative (|F| = 2^20: 1024 chunks, 79 -> 17 us).
+__global__ __launch_bounds__ (1024) void k_count (icp_params p)
 {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (r >= p.nr) return;
-    uint32_t run = 0;
-    uint32_t *h0 = p.chunk_hist + (size_t) b * p.nchunk * p.nr + r;
-    for (uint32_t c0 = 0; c0 < p.nchunk; c0 += 8u) {                  // eight independent loads in flight, then the serial scan
+    __shared__ uint32_t s_sum[16][64];
+    const uint32_t b = blockIdx.y, rr = threadIdx.x & 63u, cg = threadIdx.x >> 6;
+    const uint32_t r = blockIdx.x * 64u + rr;
+    const bool live = r < p.nr;
+    const uint32_t cpg = (p.nchunk + 15u) / 16u, c_lo = min (cg * cpg, p.nchunk), c_hi = min (c_lo + cpg, p.nchunk);
+    uint32_t *h0 = p.chunk_hist + (size_t) b * p.nchunk * p.nr + (live ? r : 0u);
+    uint32_t sum = 0;
+    for (uint32_t c0 = c_lo; c0 < c_hi; c0 += 8u) {                   // eight independent loads in flight
         uint32_t v[8];
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) v[k] = (c0 + k < p.nchunk) ? h0[(size_t) (c0 + k) * p.nr] : 0u;
+        for (uint32_t k = 0; k < 8u; ++k) v[k] = (live && c0 + k < c_hi) ? h0[(size_t) (c0 + k) * p.nr] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) sum += v[k];
+    }
+    s_sum[cg][rr] = sum;
+    __syncthreads ();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < 16u; ++g) { const uint32_t v = s_sum[g][rr]; run += (g < cg) ? v : 0u; total += v; }
+    for (uint32_t c0 = c_lo; c0 < c_hi; c0 += 8u) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) v[k] = (live && c0 + k < c_hi) ? h0[(size_t) (c0 + k) * p.nr] : 0u;
 #pragma unroll
         for (uint32_t k = 0; k < 8u; ++k)
-            if (c0 + k < p.nchunk) { h0[(size_t) (c0 + k) * p.nr] = run; run += v[k]; }
+            if (live && c0 + k < c_hi) { h0[(size_t) (c0 + k) * p.nr] = run; run += v[k]; }
     }
-    p.N[(size_t) b * p.nr + r] = run;
+    if (live && cg == 0u) p.N[(size_t) b * p.nr + r] = total;
 }
 
 // step 4: O = exclusive scan of N (exclusiveScan_i semantics, kernels/scan_kernels.cl:188). One block of 1024 threads:
@@ -2198,7 +2216,7 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
     hipLaunchKernelGGL (k_chunk_hist, dim3 (p.nchunk, p.batch), dim3 (256), p.nr * sizeof (uint32_t), s, p);
     if (p.nr <= 1024u) hipLaunchKernelGGL (k_count_offsets, dim3 (1, p.batch), dim3 (1024), 0, s, p);
     else {
-        hipLaunchKernelGGL (k_count, dim3 ((p.nr + 63) / 64, p.batch), dim3 (64), 0, s, p);
+        hipLaunchKernelGGL (k_count, dim3 ((p.nr + 63) / 64, p.batch), dim3 (1024), 0, s, p);
         hipLaunchKernelGGL (k_offsets, dim3 (1, p.batch), dim3 (1024), 0, s, p);
     }
     hipLaunchKernelGGL (k_place, dim3 (p.nchunk, p.batch), dim3 (1024), 0, s, p);

@@ -1416,6 +1416,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     __syncthreads ();
     if constexpr (FUSED) {
         // halving tree over the block's 64 pairs, one 16-lane row per moment (rows 0..17 of the 32 rows)
+        if (slice * 4u >= (uint32_t) ICP_NMOM) return;                     // (waves without a row: done)
         const uint32_t l = lane & 15u, mrow = slice * 4u + (lane >> 4);     // first 18 of the block's 4*KS_SPLIT rows
         const uint32_t k = min (mrow, (uint32_t) ICP_NMOM - 1u);
         double c0 = s_mom[k][l] + s_mom[k][l + 32], c1 = s_mom[k][l + 16] + s_mom[k][l + 48];

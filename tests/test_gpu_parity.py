@@ -77,7 +77,7 @@ def check_step(engine, g, o, weighted=True):
     assert_bits(g.read(Mem.T), o.T, "T")
 
 
-@pytest.mark.parametrize("side,nr", [(128, 256), (32, 16), (64, 64), (30, 4), (6, 4), (16, 256)])
+@pytest.mark.parametrize("side,nr", [(128, 256), (32, 16), (64, 64), (30, 4), (6, 4), (16, 256), (192, 2048), (96, 1024)])
 def test_build_rbc(engine, oracle, side, nr):
     g, o, F, M = make(engine, oracle, side, nr)
     g.buildRBC()

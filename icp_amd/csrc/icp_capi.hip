@@ -385,6 +385,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     p.nb = (m + 63u) / 64u;
     p.tbox = icp_tbox_of (p); p.n1k = (nr + p.tbox - 1u) / p.tbox;
     p.s2wave = icp_s2_wave_of (p);
+    { const char *e = std::getenv ("ICP_AMD_XCDMAP"); p.xcdmap = e ? (e[0] == '1') : (B == 1u); }
     p.gtile = 0u;                                                    // 4 x 4 tile groups where the representative grid allows
     if (nrx % 4u == 0u && nry % 4u == 0u && !std::getenv ("ICP_AMD_STRIP_GROUPS")) { uint32_t lg = 0; while ((4u << lg) < nrx) ++lg; p.gtile = lg + 1u; }
     if ((rc = dalloc (h, &p.GB, B * 2 * (p.n16 + p.n1k)))) return rc;

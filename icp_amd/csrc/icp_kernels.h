@@ -32,6 +32,7 @@ struct icp_params {
     uint32_t n16, n1k;           // ceil(nr/16), ceil(nr/tbox)
     uint32_t tbox;               // representatives per tile box (k_tile_boxes): the LDS tile of the dense k_search for multi-tile sets, 256 or 1024
     uint32_t gtile;              // stage-1 pruning groups of 16: 0 = 16 consecutive representatives, 1 + log2 (nrx / 4) = 4 x 4 tiles of the representative grid
+    uint32_t xcdmap;             // dense search: XCD-aware block -> tile bands (a single large registration: halves the fabric-side traffic)
     uint32_t s2wave;             // stage 2 of the dense search with lanes = candidates (lists of >= ICP_S2_WAVE_MIN candidates on average: see k_search)
     float *XP;                   // [batch][m][8]  permuted database (RBCConstruct D_OUT_X_P)
     float *XQ;                   // [batch][m][8]  same, lane 3 = original index bits (search copy)

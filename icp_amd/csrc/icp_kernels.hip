@@ -819,7 +819,9 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     const bool qwave = CHAIN ? slice == 0u : slice == KS_SPLIT - 1u;
     // (the one-block-per-CU variants only: measured 9.63 -> 9.43 us per iteration at A; the dense variant runs several blocks
     // per CU over grids of thousands and measured 0 ... 4 % slower with it)
-    const uint32_t tile_id = (FUSED && MINW == 2) ? ks_tile_of_block (blockIdx.x, gridDim.x) : blockIdx.x;
+    // (dense variant: bit 6 of check_flags, set for a single large registration — there the bands halve the fabric-side traffic,
+    // C 171 -> 86 MB per launch against 75.6 MB algorithmic, at the same speed; batched grids measured 2 % slower with them)
+    const uint32_t tile_id = (FUSED && (MINW == 2 || (check_flags & 64u))) ? ks_tile_of_block (blockIdx.x, gridDim.x) : blockIdx.x;
     const uint32_t iq = FUSED ? fused_query_index (m, side, tpr_magic, tile_id, lane)
                               : (blockIdx.x >> 1) * 128u + 2u * lane + (blockIdx.x & 1u);
 
@@ -2226,7 +2228,7 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 void icp_launch_search (const icp_params &p, hipStream_t s)
 {
     const bool dense = icp_dense (p);
-#define KS_FLAGS(p) ((uint32_t) ((p).check ? 1u : 0u) | ((p).emit ? 8u : 0u))
+#define KS_FLAGS(p) ((uint32_t) ((p).check ? 1u : 0u) | ((p).emit ? 8u : 0u) | ((p).xcdmap ? 64u : 0u))
 #define KS_ARGS p.M, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
 #define KS_CHAIN_ARGS p.M, p.R, p.cst + p.slot, (const double *) p.mom + (size_t) p.slot * ICP_NMOM * p.nb, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
     if (p.fused) {

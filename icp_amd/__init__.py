@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["ICP", "ICPStep", "ICPError", "Memory", "ICPStepConfigT", "ICPStepConfigW",
-           "PowerMode", "ReduceMode", "TransformKind", "ICPBatch", "batch_partition", "ReduceScan", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
+           "PowerMode", "ReduceMode", "TransformKind", "ICPBatch", "batch_partition", "power_method", "ReduceScan", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("ICP_AMD_LIB", os.path.join(_HERE, "libicp_amd.so"))   # override: A/B builds of the same ABI
@@ -150,6 +150,7 @@ def lib():
     sig("icp_run_form", i32, vp, C.POINTER(i32))
     sig("icp_search_layout", i32, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32))
     sig("icp_debug_inject_fault", i32, vp)
+    sig("icp_power_method", i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(u32))
     sig("icp_reduce", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_scan", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_reduce_scan_last_error", C.c_char_p)
@@ -246,6 +247,20 @@ class ReduceScan:
             self.close()
         except Exception:
             pass
+
+
+def power_method(S, means, rot=ICPStepConfigT.POWER_METHOD, mode=PowerMode.LITERAL, device=0):
+    """ICPPowerMethod (include/ICP/algorithms.hpp:1451-1537): S[11], means[8] -> (Tk[8], Rk[3,3], loop trips) by one wave of the
+    engine's rotation solver on the device (rot = EIGEN: the SVD branch)."""
+    S = np.ascontiguousarray(S, np.float32).reshape(-1)
+    means = np.ascontiguousarray(means, np.float32).reshape(-1)
+    if S.size != 11 or means.size != 8:
+        raise ValueError("expected S[11] and means[8]")
+    Tk, Rk, it = np.empty(8, np.float32), np.empty(9, np.float32), C.c_uint32()
+    rc = lib().icp_power_method(device, rot, mode, _p(S), _p(means), _p(Tk), _p(Rk), C.byref(it))
+    if rc:
+        raise ICPError(rc, lib().icp_last_error(None).decode())
+    return Tk, Rk.reshape(3, 3), it.value
 
 
 def device_count():

@@ -386,6 +386,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     p.tbox = icp_tbox_of (p); p.n1k = (nr + p.tbox - 1u) / p.tbox;
     p.s2wave = icp_s2_wave_of (p);
     { const char *e = std::getenv ("ICP_AMD_XCDMAP"); p.xcdmap = e ? (e[0] == '1') : (B == 1u); }
+    { const char *e = std::getenv ("ICP_AMD_WARM_SEED"); p.warm_seed = (e && e[0] == '1') ? 1u : 0u; }
     p.gtile = 0u;                                                    // 4 x 4 tile groups where the representative grid allows
     if (nrx % 4u == 0u && nry % 4u == 0u && !std::getenv ("ICP_AMD_STRIP_GROUPS")) { uint32_t lg = 0; while ((4u << lg) < nrx) ++lg; p.gtile = lg + 1u; }
     if ((rc = dalloc (h, &p.GB, B * 2 * (p.n16 + p.n1k)))) return rc;
@@ -805,6 +806,35 @@ int icp_transform_cloud_ex (icp_handle h, int kind, const float *T, const void *
     HIPCHK (h, hipGetLastError ());
     HIPCHK (h, hipMemcpyAsync (host_out, h->dCloudOut, (size_t) n * 32, hipMemcpyDeviceToHost, h->stream));
     HIPCHK (h, hipStreamSynchronize (h->stream));
+    return ICP_OK;
+}
+
+int icp_power_method (int device, int rot, int power_mode, const float *S11, const float *means8, float *Tk8, float *Rk9, uint32_t *iters)
+{
+    if (!S11 || !means8 || !Tk8) return fail (nullptr, ICP_EINVAL, "icp_power_method: null pointer");
+    if ((rot != ICP_ROT_EIGEN && rot != ICP_ROT_POWER_METHOD) || (power_mode != ICP_POWER_LITERAL && power_mode != ICP_POWER_SQUARED))
+        return fail (nullptr, ICP_EINVAL, "icp_power_method: rot must be 0|1 and power_mode 0|1");
+    int count = 0;
+    if (hipGetDeviceCount (&count) != hipSuccess || count <= 0)
+        return fail (nullptr, ICP_ENODEVICE, "icp_power_method: no HIP device visible (the engine has no CPU fallback)");
+    if (device < 0 || device >= count) return fail (nullptr, ICP_EINVAL, "icp_power_method: device ordinal out of range");
+    hipDeviceProp_t prop;
+    HIPCHK (nullptr, hipGetDeviceProperties (&prop, device));
+    if (std::strncmp (prop.gcnArchName, "gfx950", 6) != 0)
+        return fail (nullptr, ICP_ENODEVICE, std::string ("icp_power_method: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    HIPCHK (nullptr, hipSetDevice (device));
+    float *d = nullptr;
+    HIPCHK (nullptr, hipMalloc ((void **) &d, (19 + 18) * sizeof (float)));
+    float in[19], out[18];
+    std::memcpy (in, S11, 11 * sizeof (float)); std::memcpy (in + 11, means8, 8 * sizeof (float));
+    hipError_t e = hipMemcpy (d, in, sizeof in, hipMemcpyHostToDevice);
+    if (e == hipSuccess) { icp_launch_rotation_solver (rot, power_mode, d, d + 19, nullptr); e = hipGetLastError (); }
+    if (e == hipSuccess) e = hipMemcpy (out, d + 19, sizeof out, hipMemcpyDeviceToHost);      // (blocking: waits for the kernel on the null stream)
+    (void) hipFree (d);
+    if (e != hipSuccess) return fail (nullptr, ICP_EHIP, std::string ("icp_power_method: ") + hipGetErrorString (e));
+    std::memcpy (Tk8, out, 8 * sizeof (float));
+    if (Rk9) std::memcpy (Rk9, out + 8, 9 * sizeof (float));
+    if (iters) std::memcpy (iters, out + 17, sizeof (uint32_t));
     return ICP_OK;
 }
 

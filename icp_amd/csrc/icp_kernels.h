@@ -33,6 +33,8 @@ struct icp_params {
     uint32_t tbox;               // representatives per tile box (k_tile_boxes): the LDS tile of the dense k_search for multi-tile sets, 256 or 1024
     uint32_t gtile;              // stage-1 pruning groups of 16: 0 = 16 consecutive representatives, 1 + log2 (nrx / 4) = 4 x 4 tiles of the representative grid
     uint32_t xcdmap;             // dense search: XCD-aware block -> tile bands (a single large registration: halves the fabric-side traffic)
+    uint32_t warm_seed;          // diagnostics (ICP_AMD_WARM_SEED=1): a registration's first search is seeded with p.rid as it stands (the previous
+                                 // registration's answer) instead of the query's own grid cell
     uint32_t s2wave;             // stage 2 of the dense search with lanes = candidates (lists of >= ICP_S2_WAVE_MIN candidates on average: see k_search)
     float *XP;                   // [batch][m][8]  permuted database (RBCConstruct D_OUT_X_P)
     float *XQ;                   // [batch][m][8]  same, lane 3 = original index bits (search copy)
@@ -76,6 +78,7 @@ void icp_launch_clear_fault (const icp_params &p, hipStream_t s);
 void icp_launch_inject_fault (const icp_params &p, hipStream_t s);
 void icp_launch_reset_state (const icp_params &p, hipStream_t s, int reset_T);
 void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStream_t s);
+void icp_launch_rotation_solver (int rot, int power_mode, const float *din19, float *dout18, hipStream_t s);   // [S 11 | means 8] -> [Tk 8 | Rk 9 | trips]
 void icp_launch_get_lms (const float *cloud, float *lms, hipStream_t s);
 void icp_launch_transform_cloud (const float *in, float *out, const icp_reg_state *st, uint32_t n, hipStream_t s);
 // kind 0 / 1: T = [q | t, s] (8 floats), 2: T = row-major 4x4 (16 floats); host pointer, passed by value

@@ -875,13 +875,21 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     constexpr bool PRUNE = ICP_S1_SEED && MINW == 4;
     const bool prune = PRUNE && p.a > 0.f;
     const uint32_t gt_lg1 = p.gtile;                 // 0: strip groups; 1 + log2 (nrx / 4): 4 x 4 tile groups (k_rep_boxes)
-    uint32_t seed = 0u;
-    if constexpr (OWNER) {
-        if (qwave && prune && side && side * side == m && p.nrx && p.nry) {     // the representative sampled from the point's own cell
-            const uint32_t y = ic / side, x = ic - y * side;
-            seed = (y / (side / p.nry)) * p.nrx + x / (side / p.nrx);
-        }
-    } else if (qwave && prune) seed = p.rid[(size_t) b * m + ic];
+    // A registration's FIRST search (k == 0: ICP::buildRBC / a reset came before it) has no previous search of its own: whatever
+    // p.rid holds then belongs to another registration (legal, but a converged neighbour's answer would flatter a benchmark
+    // that re-registers one pair, and a stale one prunes nothing).  It is seeded like the owner search: with the representative
+    // sampled from the query's own grid cell — a moving frame starts near the fixed one (frame-to-frame registration).
+    // check_flags bit 5 (ICP_AMD_WARM_SEED=1, diagnostics): always the previous search's answer.
+    uint32_t seed = 0u, seed_cell = 0xFFFFFFFFu;
+    if (qwave && prune && side && side * side == m && p.nrx && p.nry) {     // the representative sampled from the point's own cell
+        const uint32_t y = ic / side, x = ic - y * side;
+        seed_cell = (y / (side / p.nry)) * p.nrx + x / (side / p.nrx);
+    }
+    if constexpr (OWNER) seed = seed_cell == 0xFFFFFFFFu ? 0u : seed_cell;
+    else if (qwave && prune) {
+        seed = p.rid[(size_t) b * m + ic];           // (selected against seed_cell below, once the state has arrived)
+        if ((check_flags & 32u) || seed_cell == 0xFFFFFFFFu) seed_cell = 0xFFFFFFFFu;
+    }
     // (lo, hi) boxes of the groups of 2 * LPQ representatives: the 16-boxes (LPQ = 8) or the 32-boxes behind them
     const float4 *GBt = p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + (KS_SPLIT == 8 ? 0u : 2u * p.n16);
     const uint32_t nbox0 = 2u * ((tn0 + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
@@ -890,6 +898,9 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     float T[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) T[k] = state_lane_f (sv, ICP_ST_DW (T) + k);
+    if constexpr (PRUNE && !OWNER) {
+        if (seed_cell != 0xFFFFFFFFu && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (k)) == 0) seed = seed_cell;    // first search of a registration
+    }
     icp_reg_state *sout = CHAIN ? p.cst + (size_t) b * 2 + (p.slot ^ 1u) : st;
     if (!OWNER && check && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))) {    // converged earlier
         if constexpr (CHAIN) {                       // carry the state forward
@@ -1705,6 +1716,36 @@ __global__ __launch_bounds__ (256) void k_moment_level1 (const double *gmom, con
     if (l == 0 && blockIdx.x * 16u + row < ntask) p.ml1[(size_t) b * ntask + task] = v;
 }
 
+// ICPPowerMethod as a kernel of its own (reference include/ICP/algorithms.hpp:1451-1537, kernels/icp_kernels.cl:977-1054: an
+// enqueueTask of one work-item; here one wave): S[11], means[8] -> Tk[8] with the rotation solvers the iteration uses
+// (icp_power_method_quad literal / squared start, icp_svd_rotation) — the entry the reference's known-answer test drives
+// (tests/testsICP.cpp:988-1052).  out[0..8) = Tk, out[8..17) = Rk (EIGEN branch; else the rotation of qk), out[17] = loop trips.
+template <int ROT>
+__global__ __launch_bounds__ (64) void k_rotation_solver (const float *gin, float *gout, int power_mode)
+{
+    const uint32_t lane = threadIdx.x;
+    float S[11], means[8], Tk[8], Rk[9];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) S[k] = gin[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) means[k] = gin[11 + k];
+    int iters = 0;
+    if constexpr (ROT == 1) { iters = icp_power_method_quad (S, means, Tk, power_mode, lane); icp_quat_to_rot (Tk, Rk); }
+    else icp_svd_rotation (S, means, Rk, Tk);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gout[k] = Tk[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gout[8 + k] = Rk[k];
+        gout[17] = __uint_as_float ((uint32_t) iters);
+    }
+}
+void icp_launch_rotation_solver (int rot, int power_mode, const float *din19, float *dout18, hipStream_t s)
+{
+    if (rot == 1) hipLaunchKernelGGL (k_rotation_solver<1>, dim3 (1), dim3 (64), 0, s, din19, dout18, power_mode);
+    else hipLaunchKernelGGL (k_rotation_solver<0>, dim3 (1), dim3 (64), 0, s, din19, dout18, power_mode);
+}
+
 // chain end: finalize the last iteration's moments (slot given by p.slot) into the user-visible state.  (There is no
 // begin kernel: the first launch of a chain reads the user-visible state itself.)
 template <int ROT>
@@ -2228,7 +2269,7 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 void icp_launch_search (const icp_params &p, hipStream_t s)
 {
     const bool dense = icp_dense (p);
-#define KS_FLAGS(p) ((uint32_t) ((p).check ? 1u : 0u) | ((p).emit ? 8u : 0u) | ((p).xcdmap ? 64u : 0u))
+#define KS_FLAGS(p) ((uint32_t) ((p).check ? 1u : 0u) | ((p).emit ? 8u : 0u) | ((p).warm_seed ? 32u : 0u) | ((p).xcdmap ? 64u : 0u))
 #define KS_ARGS p.M, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
 #define KS_CHAIN_ARGS p.M, p.R, p.cst + p.slot, (const double *) p.mom + (size_t) p.slot * ICP_NMOM * p.nb, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p), p
     if (p.fused) {

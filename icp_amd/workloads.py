@@ -27,6 +27,12 @@ def ids_digest(ids):
     return np.array([zlib.crc32(ids.tobytes()), int(ids.astype(np.uint64).sum())], np.uint64)
 
 
+def bits_digest(a):
+    """(crc32, byte count) of the raw bytes of an array: bit-for-bit check of a large float / index array through a fixture."""
+    a = np.ascontiguousarray(a)
+    return np.array([zlib.crc32(a.tobytes()), a.nbytes], np.uint64)
+
+
 def algorithmic_bytes(m, nr):
     """Per registration-iteration: read M, read the permuted fixed set once, read R, write {dist, id}, T."""
     return 72 * m + 32 * nr + 64

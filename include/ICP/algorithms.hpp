@@ -242,6 +242,52 @@ namespace ICP
         std::vector<float> in, out, T;
     };
 
+    /*! \brief Incremental transformation from S and the set means — mirrors `ICPPowerMethod` (reference
+     *         include/ICP/algorithms.hpp:1451-1537, src/ICP/algorithms.cpp:2966-3150, kernel `icpPowerMethod`
+     *         kernels/icp_kernels.cl:977-1054): `init`, `write (D_IN_S | D_IN_MEAN)`, `run`, `read (H_OUT_T_K)` and the staging
+     *         members `hPtrInS` (11 floats), `hPtrInMean` (2 x float4), `hPtrOutTk` (2 x float4: `[qk | tk, sk]`).  The
+     *         reference's known-answer test drives this class (tests/testsICP.cpp:988-1052).  `mode` selects the loop the
+     *         engine runs: the reference's literal one (default here, as in the test) or the squared start of the benchmarked
+     *         path; `setRotation (ICPStepConfigT::EIGEN)` evaluates the SVD branch instead. */
+    class ICPPowerMethod
+    {
+    public:
+        enum class Memory : uint8_t { H_IN_S, H_IN_MEAN, H_OUT_T_K, D_IN_S, D_IN_MEAN, D_OUT_T_K };
+
+        explicit ICPPowerMethod (icp::Env _env, icp::Mode _mode = icp::Mode::REFERENCE_ORDER)
+            : hPtrInS (S), hPtrInMean (mean), hPtrOutTk (Tk), iterations (0), env (_env), mode (_mode), rot (ICP_ROT_POWER_METHOD)
+        { std::memset (S, 0, sizeof S); std::memset (mean, 0, sizeof mean); std::memset (Tk, 0, sizeof Tk); std::memset (Rk, 0, sizeof Rk); }
+        void init (Staging = Staging::IO) {}
+        void setMode (icp::Mode _mode) { mode = _mode; }
+        void setRotation (ICPStepConfigT r) { rot = r == ICPStepConfigT::EIGEN ? ICP_ROT_EIGEN : ICP_ROT_POWER_METHOD; }
+        /*! \brief Host -> staging (ptr == nullptr: the staging buffer as it stands); the upload happens with `run`. */
+        void write (Memory mem = Memory::D_IN_S, void *ptr = nullptr, bool = false)
+        {
+            if (!ptr) return;
+            if (mem == Memory::D_IN_S) std::memcpy (S, ptr, sizeof S);
+            else if (mem == Memory::D_IN_MEAN) std::memcpy (mean, ptr, sizeof mean);
+        }
+        void* read (Memory = Memory::H_OUT_T_K, bool = true) { return Tk; }
+        /*! \brief One wave of the engine's rotation solver on the device; blocking. */
+        void run ()
+        {
+            if (icp_power_method (env.device, rot, mode == icp::Mode::FAST ? ICP_POWER_SQUARED : ICP_POWER_LITERAL, S, mean, Tk, Rk, &iterations) != ICP_OK)
+                throw std::runtime_error (std::string ("ICPPowerMethod: ") + icp_last_error (nullptr));
+        }
+
+        float *hPtrInS;     /*!< Staging buffer of the sums of products. */
+        float *hPtrInMean;  /*!< Staging buffer of the fixed and moving set means. */
+        float *hPtrOutTk;   /*!< Staging buffer of the incremental parameters. */
+        uint32_t iterations;  /*!< power-method loop trips of the last run (the reference's comment: 56 on its test vector) */
+        const float *rotation () const { return Rk; }   /*!< row-major Rk of the last run */
+
+    private:
+        icp::Env env;
+        icp::Mode mode;
+        int rot;
+        float S[11], mean[8], Tk[8], Rk[9];
+    };
+
     /*! \brief One ICP iteration — mirrors the four specialisations of the reference's
      *         `ICPStep<CR, CW>` (include/ICP/algorithms.hpp:1613, 1825, 2038, 2234).
      */

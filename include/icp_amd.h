@@ -228,6 +228,15 @@ int icp_track_reset (icp_handle h);
 typedef enum { ICP_TRANSFORM_QUATERNION = 0, ICP_TRANSFORM_QUATERNION_2 = 1, ICP_TRANSFORM_MATRIX = 2 } icp_transform_kind;
 int icp_transform_cloud_ex (icp_handle h, int kind, const float *T, const void *host_in, void *host_out, uint32_t n);
 
+/* ICPPowerMethod — include/ICP/algorithms.hpp:1451-1537 (init / write (D_IN_S, D_IN_MEAN) / run / read (H_OUT_T_K)),
+ * src/ICP/algorithms.cpp:2966-3150, kernel icpPowerMethod kernels/icp_kernels.cl:977-1054 — and, with rot = ICP_ROT_EIGEN, the
+ * host JacobiSVD of ICPStep<EIGEN, *>::run (src/ICP/algorithms.cpp:3877-3902) as the engine evaluates it on the device.
+ * S: the 11 floats of ICPS (S row-major, then the numerator and denominator of the scale); means: [mean_fixed, 0 | mean_moving, 0];
+ * Tk: [qk | tk, sk].  power_mode: icp_power_mode (ignored for ICP_ROT_EIGEN).  Rk9 (row-major rotation) and iters (power-method
+ * loop trips) may be NULL.  One wave of the same device code the iteration's finalize runs (no other math); host pointers in and
+ * out, blocking, needs no icp_init.  The reference's known-answer test (tests/testsICP.cpp:988-1052) drives exactly this entry. */
+int icp_power_method (int device, int rot, int power_mode, const float *S11, const float *means8, float *Tk8, float *Rk9, uint32_t *iters);
+
 /* ---- standalone Reduce / Scan classes of the reference ------------------------------ */
 
 /* Reduce<MIN,float> / Reduce<MAX,uint> / Reduce<SUM,float> — include/ICP/algorithms.hpp:52-166,

@@ -136,6 +136,30 @@ int main (int argc, char **argv)
             printf ("TR %.9g %d\n", worst, copied);
         }
 
+        // ICPPowerMethod on the reference's known-answer vector, written the way its test does (tests/testsICP.cpp:1000-1052):
+        // init, write (D_IN_S), write (D_IN_MEAN), run, read; worst |Tk - svdTk| of the literal loop, the squared start and EIGEN
+        {
+            float S[11] = { 0.00168053f, 0.000131408f, -0.000775179f, 0.000156595f, 0.00102674f, -0.000563479f,
+                            -0.000722137f, -0.000559463f, 0.00246661f, 0.00521271f, 0.00515292f };
+            float means[8] = { -33.9694f, -17.6421f, 1494.22f, 0.f, -44.8322f, -19.3835f, 1485.93f, 0.f };
+            const float svdTk[8] = { 0.00111412f, 0.00730956f, -0.00647493f, 0.999952f, -10.4598f, 4.74009f, -0.762817f, 1.00578f };
+            ICPPowerMethod pm (env);
+            pm.init ();
+            pm.write (ICPPowerMethod::Memory::D_IN_S, S);
+            pm.write (ICPPowerMethod::Memory::D_IN_MEAN, means);
+            float worst[3]; unsigned int trips = 0;
+            for (int v = 0; v < 3; ++v) {
+                pm.setMode (v == 1 ? icp::Mode::FAST : icp::Mode::REFERENCE_ORDER);
+                pm.setRotation (v == 2 ? ICPStepConfigT::EIGEN : ICPStepConfigT::POWER_METHOD);
+                pm.run ();
+                const float *res = (const float *) pm.read ();
+                worst[v] = 0.f;
+                for (int k = 0; k < 8; ++k) worst[v] = std::max (worst[v], std::fabs (res[k] - svdTk[k]));
+                if (v == 0) trips = pm.iterations;
+            }
+            printf ("PM %.9g %.9g %.9g %u\n", worst[0], worst[1], worst[2], trips);
+        }
+
         // the reference's profiling run: 40 steps, per-stage table (include/ICP/algorithms.hpp:2482-2494)
         {
             ICP<ICPStepConfigT::POWER_METHOD, ICPStepConfigW::WEIGHTED> prof (env, mode);

@@ -70,6 +70,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "oracle_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "oracle_vectors.npz"), {k: np.asarray(v).shape for k, v in out.items()})
     config4()
+    bench_configs()
 
 
 def config4():
@@ -97,6 +98,48 @@ def config4():
         out["r%d_fixed40_ids_digest" % i] = C4.ids_digest(ids)
     np.savez_compressed(os.path.join(HERE, "config4_vectors.npz"), **out)
     print("wrote config4_vectors.npz; k of the checked registrations:", [int(out["r%d_run" % i][0]) for i in C4.CHECKED])
+
+
+def bench_configs():
+    """BASELINE configs B (256^2, 1024) and C (1024^2, 4096) in exactly the modes and at exactly the sizes bench.py times
+    (the handle's defaults: fused double moments + squared power start), from the oracle (power_fast=True, fused=True).
+    C: the RBC structure, then two free-running steps (T, S, means, sum_w, digests of all 2^20 ids / distances / nearest
+       representatives), then the bench's own pass: 10 fixed iterations from the identity (T, ids digest).
+    B: run () to convergence (k, converged, T, ids digest) and the bench's pass of 40 fixed iterations from the identity.
+    Digests (icp_amd/workloads.py): ids = (crc32, sum), everything else = (crc32 of the raw bytes, byte count)."""
+    from icp_amd import workloads as W
+    out = {}
+    side, nr = W.CONFIGS["C"]
+    F, M = icp_amd.synth_pair(side)
+    o = O.OracleICP(side * side, nr, W.A, W.C_, power_fast=True, fused=True, threads=8)
+    o.write_f(F); o.write_m(M); o.build_rbc()
+    out["C_N"], out["C_O"] = o.rbc_N, o.rbc_O
+    out["C_perm_digest"], out["C_owner_digest"] = W.ids_digest(o.rbc_perm), W.ids_digest(o.rbc_owner)
+    Ts, Ss, ms, sws, idd, ridd, dd = [], [], [], [], [], [], []
+    for _ in range(2):
+        o.step()
+        nn = o.nn_id
+        Ts.append(o.T); Ss.append(o.S); ms.append(o.means); sws.append(o.sum_w)
+        idd.append(W.ids_digest(nn["id"])); ridd.append(W.ids_digest(o.rid)); dd.append(W.bits_digest(nn["dist"]))
+    out.update(C_T=np.array(Ts), C_S=np.array(Ss), C_means=np.array(ms), C_sum_w=np.array(sws), C_ids_digest=np.array(idd),
+               C_rid_digest=np.array(ridd), C_dist_digest=np.array(dd), C_ids_head=o.nn_id["id"][:256].copy())
+    o.write_t([0, 0, 0, 1, 0, 0, 0, 1])
+    for _ in range(10):
+        o.step()
+    out["C_fixed10_T"], out["C_fixed10_ids_digest"] = o.T, W.ids_digest(o.nn_id["id"])
+    side, nr = W.CONFIGS["B"]
+    F, M = icp_amd.synth_pair(side)
+    o = O.OracleICP(side * side, nr, W.A, W.C_, power_fast=True, fused=True, threads=8)
+    o.write_f(F); o.write_m(M); o.build_rbc()
+    k = o.run()
+    out["B_run"] = np.array([k, int(o.converged)])
+    out["B_run_T"], out["B_run_ids_digest"], out["B_run_ids_head"] = o.T, W.ids_digest(o.nn_id["id"]), o.nn_id["id"][:256].copy()
+    o.write_t([0, 0, 0, 1, 0, 0, 0, 1])
+    for _ in range(40):
+        o.step()
+    out["B_fixed40_T"], out["B_fixed40_ids_digest"] = o.T, W.ids_digest(o.nn_id["id"])
+    np.savez_compressed(os.path.join(HERE, "bench_config_vectors.npz"), **out)
+    print("wrote bench_config_vectors.npz; B run k = %d converged = %d" % (k, int(o.converged)))
 
 
 if __name__ == "__main__":

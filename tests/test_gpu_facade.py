@@ -37,6 +37,10 @@ def test_cpp_facade_matches_oracle(engine, oracle):
     assert "alpha parameter cannot be equal to zero" in " ".join(lines["ERR"])
     # ICPTransform<QUATERNION> vs <MATRIX> on the reference test's 36.21 degree rotation: within 42000 eps, lanes 3..7 copied
     assert float(lines["TR"][0]) < 42000 * np.finfo(np.float32).eps and int(lines["TR"][1]) == 1
+    # ICPPowerMethod class on the reference's known-answer vector (tests/testsICP.cpp:988-1052): literal loop, squared start and the
+    # EIGEN branch within 42000 eps of `svdTk`; literal trips in the range of the reference's comment (56)
+    pm = lines["PM"]
+    assert all(float(x) < 42000 * np.finfo(np.float32).eps for x in pm[:3]) and 40 <= int(pm[3]) <= 70, pm
     # Reduce<MIN>, Reduce<SUM>, Scan<EXCLUSIVE> class mirrors: min and scan checked in the program, the sums here
     assert int(lines["RS"][0]) == 0
     v = ((np.arange(3 * 1024, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1000)).astype(np.float32) * np.float32(0.25) - np.float32(100)

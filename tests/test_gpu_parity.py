@@ -955,3 +955,152 @@ def test_stage2_lanes_as_candidates_1024_tile(engine, oracle):
     o.step()
     check_step(engine, g, o, weighted=False)
     g.close()
+
+
+# ---- parity for exactly what bench.py times: the default modes at the benchmarked sizes, against committed fixtures
+# ---- (tests/golden/bench_config_vectors.npz, made by tests/golden/make_golden.py from the oracle) and the live oracle
+
+def _bench_gold():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_config_vectors.npz"))
+
+
+def test_config_C_default_modes_fixture_and_oracle(engine, oracle):
+    """BASELINE config 5 (|F|=|M|=2^20, |R|=4096) on a handle straight out of icp_create — fused moments, squared power
+    start, MASKED 256-tiles, stage 2 with lanes = candidates, k_moment_level1, XCD bands: what bench.py's `other_configs.C`
+    times.  The RBC structure, two free-running steps (T, S, means, sum of weights bit for bit; ALL 2^20 ids, distances and
+    nearest representatives against the live oracle and, as digests, against the fixture) and the bench's own pass
+    (10 fixed iterations from the identity, one graph)."""
+    from icp_amd import workloads as W
+    gold = _bench_gold()
+    side, nr = W.CONFIGS["C"]
+    m = side * side
+    F, M = engine.synth_pair(side)
+    g = engine.ICP(0)
+    g.init(m, nr, W.A, W.C_)
+    assert g.search_layout() == (1, 256, 1) and g.launches_per_iteration() == 3
+    g.write(engine.Memory.F, F)
+    g.write(engine.Memory.M, M)
+    g.buildRBC()
+    Mem = engine.Memory
+    assert np.array_equal(g.read(Mem.RBC_N), gold["C_N"]) and np.array_equal(g.read(Mem.RBC_O), gold["C_O"])
+    assert np.array_equal(W.ids_digest(g.read(Mem.RBC_PERM)), gold["C_perm_digest"])
+    assert np.array_equal(W.ids_digest(g.read(Mem.RBC_OWNER)), gold["C_owner_digest"])
+    o = oracle.OracleICP(m, nr, W.A, W.C_, power_fast=True, fused=True, threads=8)
+    o.write_f(F); o.write_m(M); o.build_rbc()
+    for it in range(2):
+        g.step()
+        o.step()
+        check_step(engine, g, o, weighted=False)               # every id / distance / nearest representative, S, means, T
+        nn = g.read(Mem.NN_ID)
+        assert_bits(g.read(Mem.T), gold["C_T"][it], "T vs fixture, step %d" % it)
+        assert_bits(g.read(Mem.S), gold["C_S"][it], "S vs fixture")
+        assert_bits(g.read(Mem.MEANS), gold["C_means"][it], "means vs fixture")
+        assert_bits(g.read(Mem.SUM_W), gold["C_sum_w"][it:it + 1], "sum of weights vs fixture")
+        assert np.array_equal(W.ids_digest(nn["id"]), gold["C_ids_digest"][it])
+        assert np.array_equal(W.ids_digest(g.read(Mem.RID)), gold["C_rid_digest"][it])
+        assert np.array_equal(W.bits_digest(nn["dist"]), gold["C_dist_digest"][it])
+    assert np.array_equal(g.read(Mem.NN_ID)["id"][:256], gold["C_ids_head"])
+    g.run_fixed_fresh(10)                                       # the bench's step at C
+    assert g.k == 10
+    assert_bits(g.read(Mem.T), gold["C_fixed10_T"], "T after the bench's pass (10 fixed iterations)")
+    assert np.array_equal(W.ids_digest(g.read(Mem.NN_ID)["id"]), gold["C_fixed10_ids_digest"])
+    g.close()
+
+
+def test_config_B_default_modes_run_fixture_and_oracle(engine, oracle):
+    """BASELINE config 3 (|F|=|M|=65536, |R|=1024), default handle: ICP::run (k, converged, T, every correspondence) and the
+    bench's own pass (40 fixed iterations from the identity), against the live oracle and the committed fixture."""
+    from icp_amd import workloads as W
+    gold = _bench_gold()
+    side, nr = W.CONFIGS["B"]
+    m = side * side
+    F, M = engine.synth_pair(side)
+    g = engine.ICP(0)
+    g.init(m, nr, W.A, W.C_)
+    assert g.search_layout()[:2] == (1, 256) and g.launches_per_iteration() == 2
+    g.write(engine.Memory.F, F)
+    g.write(engine.Memory.M, M)
+    g.buildRBC()
+    o = oracle.OracleICP(m, nr, W.A, W.C_, power_fast=True, fused=True, threads=8)
+    o.write_f(F); o.write_m(M); o.build_rbc()
+    kg, ko = g.run(), o.run()
+    st = g.state()
+    assert (kg, bool(st.converged)) == (ko, o.converged)
+    assert (kg, int(st.converged)) == tuple(int(v) for v in gold["B_run"])
+    check_step(engine, g, o, weighted=False)
+    ids = g.read(engine.Memory.NN_ID)["id"]
+    assert_bits(g.read(engine.Memory.T), gold["B_run_T"], "final T vs fixture")
+    assert np.array_equal(ids[:256], gold["B_run_ids_head"]) and np.array_equal(W.ids_digest(ids), gold["B_run_ids_digest"])
+    g.run_fixed_fresh(40)                                       # the bench's step at B
+    o.write_t([0, 0, 0, 1, 0, 0, 0, 1])
+    for _ in range(40):
+        o.step()
+    assert g.k == 40
+    check_step(engine, g, o, weighted=False)
+    assert_bits(g.read(engine.Memory.T), gold["B_fixed40_T"], "T after the bench's pass (40 fixed iterations)")
+    assert np.array_equal(W.ids_digest(g.read(engine.Memory.NN_ID)["id"]), gold["B_fixed40_ids_digest"])
+    g.close()
+
+
+def test_teacher_forced_default_modes_at_A(engine, oracle):
+    """'Same T => same correspondences' at the benchmark size, over a whole trajectory: the REFERENCE-ORDER / literal oracle's
+    T is written into a default-mode handle (fused + squared) before each of 10 iterations; ids and distances must equal that
+    oracle's bit for bit every time — through the separate launches (step) and through the chained graph form (run_fixed (1))
+    alternately."""
+    side, nr = 128, 256
+    m = side * side
+    F, M = engine.synth_pair(side)
+    g = engine.ICP(0)
+    g.init(m, nr, A, C_)
+    assert g.launches_per_iteration() == 1                     # default modes: the chained form
+    g.write(engine.Memory.F, F)
+    g.write(engine.Memory.M, M)
+    o = oracle.OracleICP(m, nr, A, C_, threads=8)              # reference order, literal power method
+    o.write_f(F); o.write_m(M)
+    g.buildRBC(); o.build_rbc()
+    for it in range(10):
+        g.write(engine.Memory.T, o.T, block=True)
+        if it % 2:
+            g.run_fixed(1)
+        else:
+            g.step()
+        o.step()
+        gn, on = g.read(engine.Memory.NN_ID), o.nn_id
+        assert np.array_equal(gn["id"], on["id"]), "iteration %d: %d ids differ" % (it, np.count_nonzero(gn["id"] != on["id"]))
+        assert_bits(gn["dist"], on["dist"], "distances at iteration %d" % it)
+        assert np.array_equal(g.read(engine.Memory.RID), o.rid)
+    g.close()
+
+
+# ---- the reference's one known-answer test on the device code (tests/testsICP.cpp:988-1052)
+
+def test_reference_kat_through_the_hip_rotation_solvers(engine, oracle):
+    """S[11], means[8] of the reference's ICP.icpPowerMethod test through icp_power_method (one wave of the rotation solvers
+    the iteration's finalize runs): within the test's own 42000 eps (5.00679e-3) of its `svdTk` literal for the LITERAL and
+    SQUARED power loops and for the EIGEN (SVD) branch; equal to the oracle bit for bit; LITERAL trip count as the oracle's,
+    in the range the reference's comment gives (56 iterations on its device, :1027)."""
+    import json
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kat.json")))["power_method"]
+    S, means, svdTk = (np.array(kat[k], np.float32) for k in ("S", "means", "svdTk"))
+    eps = kat["eps_vs_svd"]
+    Tl, Rl, itl = engine.power_method(S, means, mode=engine.PowerMode.LITERAL)
+    Tq, Rq, itq = engine.power_method(S, means, mode=engine.PowerMode.SQUARED)
+    Te, Re, _ = engine.power_method(S, means, rot=engine.ICPStepConfigT.EIGEN)
+    for name, T in (("literal", Tl), ("squared", Tq), ("eigen", Te)):
+        assert np.all(np.abs(T - svdTk) < eps), (name, T, svdTk)
+    ol, ol_it = oracle.power_method(S, means)
+    oq, oq_it = oracle.power_method(S, means, fast=True)
+    oR, oe = oracle.svd_rotation(S, means)
+    assert_bits(Tl, ol, "literal power method vs oracle")
+    assert_bits(Tq, oq, "squared-start power method vs oracle")
+    assert_bits(Te, oe, "SVD branch vs oracle")
+    assert_bits(Re, oR, "SVD rotation vs oracle")
+    assert_bits(Rl, oracle.quat_to_rot(Tl[:4]), "rotation of qk")
+    assert itl == ol_it and itq == oq_it
+    assert 40 <= itl <= 70, itl
+    # the reference CPU twin's own output on these inputs (cpuICPPowerMethod, recorded in SURVEY.md §8c): the test's GPU-vs-twin
+    # bound of 420 eps (:1037), and the digits the oracle is pinned to
+    twin = np.array(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kat.json")))["power_method_twin_output"]["Tk"], np.float32)
+    assert np.all(np.abs(Tl - twin) < kat["eps_kernel_vs_twin"]) and np.allclose(Tl, twin, rtol=2e-7, atol=0)
+    with pytest.raises(engine.ICPError):
+        engine.power_method(S, means, rot=7)

@@ -6,19 +6,25 @@
 A "step" is one fixed-length registration pass of the hot path: starting from the identity transform,
 `iterations_per_step` (40 = the length of the reference's profiling run, include/ICP/algorithms.hpp:2482-2494; 10 at
 config C) ICP iterations of the power-method / weighted pipeline on a synthetic pair, inputs resident in HBM, RBC
-already built.  One hipGraph launch per step.
+already built.  One hipGraph launch per step.  Every pass is a FRESH registration: the first search of a
+pass is seeded from the queries' own grid cells, never from the previous pass's answer (`warm_seed_us_per_iteration` shows
+what that seed would have been worth).
 
 Workloads (icp_amd/workloads.py):  A = BASELINE configs[1] (|F|=|M|=16384, |R|=256; the headline, default),
 B = configs[2] (65536 / 1024), C = configs[4] (2^20 / 4096); `--batch B` = B independent registrations sharing every
 launch (configs[3] runs 64 per GPU).
 
-N = 1 (default): batch 1 — the headline metric.  The line then also carries `other_configs`: the same measurement at
-A x 64 registrations, B and C (fewer steps), each with its own algorithmic bytes / flops, HBM and fp32-VALU fractions,
-launches per iteration and RBC construction time.
-N > 1 (launched by torch.distributed.run, one rank per GPU): a frame pair does not shard — "replicas
-only": every rank registers its own 64 independent pairs (config 4: seed base + 64 rank + i) unless --batch says otherwise,
-no data-path collective; value = iterations of all ranks / max-over-ranks time ("scaling": "weak").  The single-GPU
-figure of the same per-GPU work is `other_configs.A_x64` of the N = 1 line.
+--gpus 1 (default): batch 1 — the headline metric.  The line also carries `other_configs`: the same measurement at
+A x 64 registrations, B and C (fewer steps) and frame-to-frame tracking.
+--gpus N > 1: a frame pair does not shard — "replicas only": every GPU registers its own 64 independent
+pairs (config 4) unless --batch says otherwise, no data-path collective, no RCCL.  Two ways to get there, same numbers:
+  * launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the driver's form): one rank per
+    GPU; torch.distributed supplies only the barrier and the max / sum / gather of the per-rank numbers;
+  * plain `python bench.py --gpus N`: devices 0..N-1 are driven in-process through the library's own icp_batch_* (one host
+    thread + one stream per device).
+`--gpus` must equal the ranks / devices actually used, or the run fails.  value = iterations of all GPUs / max-over-GPUs
+time ("scaling": "weak").  EVERY line carries `config4_per_gpu_value` — iterations/s of one GPU at config 4's per-GPU share
+(64 registrations per launch) — so that N = 1 -> 8 reads off ONE field; the N = 1 `value` itself is the batch-1 headline.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      dominant kernel (k_search): algorithmic bytes per launch ((72 m + 32 |R| + 64) x registrations per launch,
@@ -30,6 +36,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -41,6 +48,7 @@ ALPHA, SCALING = 2e2, 1e-6                       # src/ocl_icp_reg.cpp:88
 ITERS_PER_STEP = 40
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3                         # fp32 vector peak (spec), same guide
+SIMDS, CLOCK_HZ = 1024, 2.4e9                    # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
 
 
 def aggregate(dist, elapsed_s, units):
@@ -58,6 +66,18 @@ def aggregate(dist, elapsed_s, units):
     return float(t.item()), float(u.item())
 
 
+def gather_per_rank(dist, value):
+    """[value of rank 0, value of rank 1, ..] on every rank (a report field; nothing on the data path)."""
+    if dist is None:
+        return [float(value)]
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(x.item()) for x in out]
+
+
 def default_batch(world, requested):
     """Registrations per GPU: what --batch says; else 1 on one GPU (the headline), 64 per GPU on several (config 4)."""
     if requested:
@@ -65,11 +85,35 @@ def default_batch(world, requested):
     return 1 if world == 1 else 64
 
 
+def resolve_launch(gpus, env):
+    """How this invocation spans `gpus` GPUs: ("single", 1), ("ranks", world) under torch.distributed.run (WORLD_SIZE set by
+    the launcher; it must equal --gpus) or ("inprocess", gpus) for a plain `python bench.py --gpus N` (icp_batch_* over the
+    devices 0..N-1).  Raises SystemExit when --gpus and the launch disagree."""
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    ws = env.get("WORLD_SIZE")
+    if ws is not None:
+        world = int(ws)
+        if world != gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: refusing to print a line "
+                             "whose n_gpus would not be the GPUs used" % (gpus, world))
+        return ("ranks", world) if world > 1 else ("single", 1)
+    return ("inprocess", gpus) if gpus > 1 else ("single", 1)
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
 def cpu_baseline(F, M, m, nr, fused, budget_s=12.0):
     """The oracle (CPU port of the same iteration) on this host's cores, bounded to ~budget_s."""
     from oracle import oracle as O
-    cores = int(os.environ.get("ICP_BASELINE_THREADS", min(os.cpu_count() or 1, 16)))   # the search loops stop scaling at ~16 threads
-    o = O.OracleICP(m, nr, ALPHA, SCALING, threads=cores, power_fast=True, fused=fused)
+    host = os.cpu_count() or 1
+    threads = int(os.environ.get("ICP_BASELINE_THREADS", min(host, 16)))   # the search loops stop scaling at ~16 threads
+    o = O.OracleICP(m, nr, ALPHA, SCALING, threads=threads, power_fast=True, fused=fused)
     o.write_f(F)
     o.write_m(M)
     o.build_rbc()
@@ -83,9 +127,9 @@ def cpu_baseline(F, M, m, nr, fused, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 20000:
             break
-    return {"value": n / el, "unit": "iterations/s", "cores": cores, "kind": "port",
+    return {"value": n / el, "unit": "iterations/s", "cores": threads, "threads": threads, "host_cores": host, "kind": "port",
             "sample": "%d iterations of the same pair (|F|=|M|=%d, |R|=%d) in %.1f s; search loops OpenMP over "
-                      "%d threads, reductions serial" % (n, m, nr, el, cores)}
+                      "%d threads of the host's %d cores, reductions serial" % (n, m, nr, el, threads, host)}
 
 
 def setup(icp_amd, device, cfg, batch, seed_index0, power_mode, reduce_mode):
@@ -100,10 +144,7 @@ def setup(icp_amd, device, cfg, batch, seed_index0, power_mode, reduce_mode):
     g.setReduceMode(icp_amd.ReduceMode.FUSED if reduce_mode == "fused" else icp_amd.ReduceMode.REFERENCE_ORDER)
     first = None
     for b in range(batch):
-        if cfg == "A" and batch > 1:
-            F, M = W.pair(icp_amd, seed_index0 + b)
-        else:
-            F, M = icp_amd.synth_pair(side, seed=W.BASE_SEED + seed_index0 + b)
+        F, M = pair_of(icp_amd, cfg, batch, seed_index0 + b)
         g.write(icp_amd.Memory.F, F, batch_index=b)
         g.write(icp_amd.Memory.M, M, batch_index=b)
         if first is None:
@@ -111,6 +152,40 @@ def setup(icp_amd, device, cfg, batch, seed_index0, power_mode, reduce_mode):
     g.buildRBC()
     g.sync()
     return g, m, nr, first
+
+
+def pair_of(icp_amd, cfg, batch, index):
+    from icp_amd import workloads as W
+    if cfg == "A" and batch > 1:
+        return W.pair(icp_amd, index)
+    return icp_amd.synth_pair(W.CONFIGS[cfg][0], seed=W.BASE_SEED + index)
+
+
+def traffic_of(key):
+    """Fabric-side bytes per launch of the dominant kernel, from the committed counter passes (profiles/traffic.json): NOT
+    measured by this run — PMC counters need rocprofv3 around the process — and labelled so."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, None, None
+    try:
+        t = json.load(open(tpath))
+    except Exception:
+        return None, None, None
+    cfgkey = {"k_search_hbm_bytes_per_launch": "detail_A", "k_search_hbm_bytes_per_launch_B": "detail_B",
+              "k_search_hbm_bytes_per_launch_C": "detail_C", "k_search_hbm_bytes_per_launch_A_x64": "detail_Ax64"}.get(key)
+    det = t.get(cfgkey) if cfgkey else None
+    src = {"file": "profiles/traffic.json", "summary": t.get("_source"), "measured_at_commit": t.get("_commit"),
+           "measured_by_this_run": False,
+           "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes around this bench command, corrected per MI355X_MICROARCH.md"}
+    issue = None
+    if det and det.get("SQ_INSTS_VALU") and det.get("avg_dispatch_us_kernel_trace"):
+        # executed work, not algorithmic: wave-level VALU instructions x 4 cycles / (1024 SIMDs x clock) / the kernel's duration in the
+        # same profile
+        issue = {"valu_issue_frac": det["SQ_INSTS_VALU"] * 4.0 / SIMDS / CLOCK_HZ / (det["avg_dispatch_us_kernel_trace"] * 1e-6),
+                 "SQ_INSTS_VALU_per_launch": det["SQ_INSTS_VALU"], "kernel_us_in_that_profile": det["avg_dispatch_us_kernel_trace"],
+                 "source": src["file"], "measured_at_commit": src["measured_at_commit"], "measured_by_this_run": False,
+                 "how": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz) / kernel duration"}
+    return t.get(key), src, issue
 
 
 def roofline_of(g, m, nr, batch, iters, steps, ev_ms, fused, traffic_key):
@@ -134,31 +209,32 @@ def roofline_of(g, m, nr, batch, iters, steps, ev_ms, fused, traffic_key):
         kernel_us["search (in the timed iterations: iteration - the other kernels)"] = search_us
         kernel_name = "k_search"
     bytes_launch = W.algorithmic_bytes(m, nr) * batch          # one launch serves every registration of the batch
+    # what the timed graph really moves: a fused graph of a fixed length stores the 8 m correspondence bytes in its LAST iteration only
+    # (nothing in between can read them) — the §8d figure counts them every iteration
+    moved_launch = bytes_launch - (8 * m * batch * (iters - 1) / iters if fused else 0)
     flop_launch = W.algorithmic_flop(m, nr) * batch
     achieved = bytes_launch / (search_us * 1e-6) / 1e9
     tflops = flop_launch / (search_us * 1e-6) / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(traffic_key)
-        except Exception:
-            traffic = None
+    traffic, tsrc, issue = traffic_of(traffic_key)
     return {"bound": "hbm", "kernel": kernel_name, "launches_per_iteration": launches, "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": bytes_launch, "registrations_per_launch": batch, "avg_launch_us": search_us,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+            "algorithmic_bytes_per_launch": bytes_launch, "bytes_moved_per_launch": moved_launch,
+            "frac_moved": moved_launch / (search_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "registrations_per_launch": batch, "avg_launch_us": search_us,
             "kernel_us": kernel_us,
-            "valu_beside_it": {"algorithmic_flop_per_launch": flop_launch, "achieved_tflops": tflops,
-                               "peak_tflops_fp32_vector": VALU_PEAK_TFLOPS, "frac": tflops / VALU_PEAK_TFLOPS},
-            "note": ("algorithmic bytes count the 8 m correspondence write of every iteration; fused graphs of a fixed length store "
-                     "it in their last iteration only (DESIGN.md §5). " +
+            "valu_beside_it": {"algorithmic_flop_per_launch": flop_launch, "bruteforce_equivalent_tflops": tflops,
+                               "peak_tflops_fp32_vector": VALU_PEAK_TFLOPS,
+                               "note": "brute-force-equivalent rate (18 flop per distance of an exhaustive Q x R + list scan): the dense "
+                                       "kernels prune, so this is NOT a utilisation; executed work is `executed`",
+                               "executed": issue},
+            "note": ("`frac` prices SURVEY.md §8d's algorithmic bytes (the 8 m correspondence write counted every iteration); `frac_moved` what the "
+                     "timed graph stores. " +
                      ("Cache-resident at this size: latency / VALU-bound, see DESIGN.md §5" if m * batch <= (1 << 21) else
                       "fp32-VALU-bound stage 1 (pruned brute force over the representatives), see DESIGN.md §5"))}
 
 
-def measure_config(icp_amd, device, cfg, batch, steps, warmup, iters, power_mode="squared", reduce_mode="fused"):
+def measure_config(icp_amd, device, cfg, batch, steps, warmup, iters, power_mode="squared", reduce_mode="fused", warm_seed=True):
     """One entry of `other_configs`: the same step / timing as the headline at another workload (single process)."""
-    from icp_amd import workloads as W
     g, m, nr, _ = setup(icp_amd, device, cfg, batch, 0, power_mode, reduce_mode)
     for _ in range(warmup):
         g.run_fixed_fresh(iters)
@@ -177,17 +253,137 @@ def measure_config(icp_amd, device, cfg, batch, steps, warmup, iters, power_mode
         g.buildRBC()
     g.sync()
     build_ms = (time.perf_counter() - t1) / nb * 1e3
+    dense = bool(g.search_layout()[0])               # only the dense search prunes stage 1 with a seed: only there does a pass's first seed matter
     g.close()
+    warm_us = None
+    if warm_seed and dense:
+        # the same passes with the first search of every pass seeded by the PREVIOUS pass's (converged) nearest representatives —
+        # what re-registering one pair gave before round 3; reported beside the figure, never as the figure
+        os.environ["ICP_AMD_WARM_SEED"] = "1"
+        try:
+            w, _, _, _ = setup(icp_amd, device, cfg, batch, 0, power_mode, reduce_mode)
+            for _ in range(warmup):
+                w.run_fixed_fresh(iters)
+            w.sync()
+            warm_us = w.time_run_fixed(iters, steps, from_identity=True) * 1e3 / (steps * iters * batch)
+            w.close()
+        finally:
+            del os.environ["ICP_AMD_WARM_SEED"]
     total_iters = steps * iters * batch
+    ex = rl["valu_beside_it"]["executed"]
     return {"workload": "|F|=|M|=%d, |R|=%d, %d registration(s) per launch" % (m, nr, batch), "steps": steps, "warmup": warmup,
             "iterations_per_step": iters, "iterations_per_s": total_iters / wall,
             "us_per_iteration": wall / total_iters * 1e6, "us_per_batched_iteration": wall / (steps * iters) * 1e6,
+            "seed_of_each_pass": "fresh (queries' own grid cells)", "warm_seed_us_per_iteration": warm_us,
             "launches_per_iteration": rl["launches_per_iteration"], "build_rbc_ms": build_ms,
-            "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"],
+            "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"], "bytes_moved_per_launch": rl["bytes_moved_per_launch"],
             "algorithmic_flop_per_launch": rl["valu_beside_it"]["algorithmic_flop_per_launch"],
             "k_search_avg_launch_us": rl["avg_launch_us"], "kernel_us": rl["kernel_us"],
-            "hbm_gbs": rl["achieved"], "hbm_frac": rl["frac"], "hbm_traffic_bytes_per_launch": rl["traffic"],
-            "valu_tflops": rl["valu_beside_it"]["achieved_tflops"], "valu_frac": rl["valu_beside_it"]["frac"]}
+            "hbm_gbs": rl["achieved"], "hbm_frac": rl["frac"], "hbm_frac_moved": rl["frac_moved"],
+            "hbm_traffic_bytes_per_launch": rl["traffic"], "hbm_traffic_source": rl["traffic_source"],
+            "bruteforce_equivalent_tflops": rl["valu_beside_it"]["bruteforce_equivalent_tflops"],
+            "valu_issue_frac": ex["valu_issue_frac"] if ex else None, "valu_issue_source": ex}
+
+
+def measure_modes(icp_amd, device, g_default, power_mode, reduce_mode):
+    """What the benchmarked (fused + squared) mode is, in numbers, against the reference-order / literal pipeline on the same
+    pair: that pipeline's own time per iteration, and the free-running difference of the two registrations."""
+    import numpy as np
+    r, m, nr, _ = setup(icp_amd, device, "A", 1, 0, "literal", "reference")
+    for _ in range(5):
+        r.run_fixed_fresh(ITERS_PER_STEP)
+    r.sync()
+    ref_us = r.time_run_fixed(ITERS_PER_STEP, 50, from_identity=True) * 1e3 / (50 * ITERS_PER_STEP)
+    launches = r.launches_per_iteration()
+    out = {"reference_order_us_per_iteration": ref_us, "reference_order_launches_per_iteration": launches}
+    Mem = icp_amd.Memory
+    res = []
+    for h in (g_default, r):
+        h.reset_transform()
+        h.buildRBC()
+        k = h.run()
+        res.append((k, h.read(Mem.T), h.read(Mem.NN_ID)["id"]))
+    (kf, Tf, idf), (kr, Tr, idr) = res
+    out["mode_note"] = {
+        "benchmarked": "%s reductions + %s power start (the handle's defaults)" % (reduce_mode, power_mode),
+        "against": "reference-order reductions + literal power method (ICP_AMD_MODE=reference), same pair, both run to convergence",
+        "k": [int(kf), int(kr)], "max_abs_dq": float(np.abs(Tf[:4] - Tr[:4]).max()),
+        "max_abs_dt_mm": float(np.abs(Tf[4:7] - Tr[4:7]).max()), "abs_ds": float(abs(Tf[7] - Tr[7])),
+        "norm_t_mm": float(np.linalg.norm(Tr[4:7])), "identical_ids_frac": float(np.mean(idf == idr)),
+        "parity": "each mode equals its own oracle restatement bit for bit (tests/test_gpu_parity.py); for the same T both modes give the "
+                  "same correspondences bit for bit (test_teacher_forced_default_modes_at_A)"}
+    r.close()
+    return out
+
+
+def measure_tracking(icp_amd, device, hops=60):
+    """Frame-to-frame tracking (README.md:4; src/ocl_icp_reg.cpp:128-172 per pair): frames/s through icp_track_next over a
+    synthetic VGA sequence (five frames, walked back and forth: every hop is one step of 3 degrees / (25, -10, 15) mm), cold
+    start (every hop from the identity) and warm start (from the previous hop's T), with the share of the frame upload."""
+    import numpy as np
+    frames = [icp_amd.synth_cloud_vga(moved=f) for f in range(5)]
+    order = [0, 1, 2, 3, 4, 3, 2, 1]
+    out = {"frames": hops, "frame": "640 x 480 float8 (9.83 MB, pageable host memory), 16384 landmarks, |R| = 256"}
+    for name, warm in (("cold_start", False), ("warm_start", True)):
+        g = icp_amd.ICP(device)
+        g.init(16384, 256, ALPHA, SCALING)
+        ks = []
+        for i in range(8):                            # warm-up: graphs of both parities captured
+            g.track_next(frames[order[i % len(order)]], warm_start=warm)
+        g.sync()
+        t0 = time.perf_counter()
+        for i in range(hops):
+            ks.append(g.track_next(frames[order[i % len(order)]], warm_start=warm))
+        g.sync()
+        el = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        for i in range(20):
+            g.write_cloud(icp_amd.Memory.M, frames[order[i % len(order)]])
+        g.sync()
+        up = (time.perf_counter() - t1) / 20
+        out[name] = {"frames_per_s": hops / el, "ms_per_frame": el / hops * 1e3, "mean_iterations": float(np.mean(ks)),
+                     "upload_and_getLMs_ms": up * 1e3, "upload_share": up / (el / hops)}
+        if hasattr(g, "track_pipelined"):
+            g.track_reset()
+            seq = [frames[order[i % len(order)]] for i in range(hops + 8)]
+            g.track_pipelined(seq[:8], warm_start=warm)
+            g.sync()
+            t0 = time.perf_counter()
+            kp = g.track_pipelined(seq[8:], warm_start=warm, reset=False)
+            g.sync()
+            el = time.perf_counter() - t0
+            out[name]["pipelined"] = {"frames_per_s": hops / el, "ms_per_frame": el / hops * 1e3, "mean_iterations": float(np.mean([k for k in kp if k is not None])),
+                                      "how": "pinned double-buffered staging, frame k+1 uploaded and its landmarks extracted on a copy stream while frame k registers"}
+        g.close()
+    return out
+
+
+def run_inprocess(icp_amd, args, n, batch, iters, steps, warmup):
+    """--gpus N from a plain `python bench.py`: devices 0..N-1 (or ICP_BENCH_DEVICES, a comma list: self-test on a 1-GPU box)
+    driven through icp_batch_*: registration i on slot i mod N, one host thread + stream per slot, no collective."""
+    devs = os.environ.get("ICP_BENCH_DEVICES")
+    devices = [int(x) for x in devs.split(",")] if devs else list(range(n))
+    if len(devices) != n:
+        raise SystemExit("bench.py: --gpus %d but ICP_BENCH_DEVICES names %d devices" % (n, len(devices)))
+    have = icp_amd.device_count()
+    if have <= max(devices):
+        raise SystemExit("bench.py: --gpus %d needs device ordinal %d, but only %d device(s) are visible" % (n, max(devices), have))
+    from icp_amd import workloads as W
+    side, nr = W.CONFIGS[args.config]
+    m = side * side
+    B = icp_amd.ICPBatch(devices)
+    B.init(n * batch, m, nr, ALPHA, SCALING)
+    B.set_modes(icp_amd.ReduceMode.FUSED if args.reduce_mode == "fused" else icp_amd.ReduceMode.REFERENCE_ORDER,
+                icp_amd.PowerMode.SQUARED if args.power_mode == "squared" else icp_amd.PowerMode.LITERAL)
+    for i in range(n * batch):
+        F, M = pair_of(icp_amd, args.config, batch, i)
+        B.write(i, icp_amd.Memory.F, F)
+        B.write(i, icp_amd.Memory.M, M)
+    B.buildRBC()
+    seconds, slot_ms = B.time_run_fixed_slots(iters, steps, warmup)
+    B.close()
+    per_gpu = [float(steps * iters * batch / (float(ms) * 1e-3)) for ms in slot_ms]
+    return seconds, steps * iters * batch * n, per_gpu, devices
 
 
 def main():
@@ -196,7 +392,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the A x 64 / B / C measurements of the N = 1 line")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the B / C / tracking / mode measurements of the N = 1 line")
     ap.add_argument("--power-mode", choices=["literal", "squared"], default="squared")
     ap.add_argument("--reduce-mode", choices=["reference", "fused"], default="fused")
     ap.add_argument("--config", choices=["A", "B", "C"], default="A",
@@ -206,9 +402,9 @@ def main():
                          "64 per GPU on several (BASELINE config 4)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launch, world = resolve_launch(args.gpus, os.environ)
+    rank = int(os.environ.get("RANK", "0")) if launch == "ranks" else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launch == "ranks" else 0
     batch = default_batch(world, args.batch)
     iters = 10 if args.config == "C" else ITERS_PER_STEP
     steps = args.steps if args.steps is not None else (200 if args.config == "A" else 40 if args.config == "B" else 5)
@@ -222,46 +418,62 @@ def main():
         import torch  # noqa: F401
     except Exception:
         torch = None
-    if world > 1:
+    if launch == "ranks":
         if torch is None:
-            raise SystemExit("bench.py: torch.distributed is required for --gpus > 1")
+            raise SystemExit("bench.py: torch.distributed is required for a multi-rank launch")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("ICP_BENCH_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")   # nccl == RCCL
         if torch.cuda.is_available():
             torch.cuda.set_device(int(os.environ.get("ICP_BENCH_DEVICE", local_rank)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
 
     import icp_amd
-    from icp_amd import workloads as W
     device = int(os.environ.get("ICP_BENCH_DEVICE", local_rank))   # override: self-test of the N>1 path on a 1-GPU box
-    g, m, nr, (F, M) = setup(icp_amd, device, args.config, batch, rank * batch, args.power_mode, args.reduce_mode)
+    fused = args.reduce_mode == "fused"
 
-    def barrier():
-        if dist is not None:
-            if dist.get_backend() == "nccl":
-                dist.barrier(device_ids=[torch.cuda.current_device()])
-            else:
-                dist.barrier()
+    per_gpu = None
+    devices_used = None
+    if launch == "inprocess":
+        total_t, total_iters, per_gpu, devices_used = run_inprocess(icp_amd, args, world, batch, iters, steps, warmup)
+        device = devices_used[0]
+        # the dominant kernel's launch time, live, on the first device: a handle of its own with the same per-GPU work
+        g, m, nr, (F, M) = setup(icp_amd, device, args.config, batch, 0, args.power_mode, args.reduce_mode)
+        rsteps = max(2, min(steps, 10))
+        g.run_fixed_fresh(iters)
         g.sync()
-        if torch is not None and torch.cuda.is_available():
-            torch.cuda.synchronize()
+        ev_ms, ev_steps = g.time_run_fixed(iters, rsteps, from_identity=True), rsteps
+    else:
+        g, m, nr, (F, M) = setup(icp_amd, device, args.config, batch, rank * batch, args.power_mode, args.reduce_mode)
 
-    for _ in range(warmup):
-        g.run_fixed_fresh(iters)                     # a fresh registration: from the identity transform, one graph
-    barrier()
-    t0 = time.perf_counter()
-    # the K steps; the engine brackets them with hipEvents on its own stream (roofline duration)
-    ev_ms = g.time_run_fixed(iters, steps, from_identity=True)
-    barrier()
-    elapsed = time.perf_counter() - t0
+        def barrier():
+            if dist is not None:
+                if dist.get_backend() == "nccl":
+                    dist.barrier(device_ids=[torch.cuda.current_device()])
+                else:
+                    dist.barrier()
+            g.sync()
+            if torch is not None and torch.cuda.is_available():
+                torch.cuda.synchronize()
 
-    total_t, total_iters = aggregate(dist, elapsed, steps * iters * batch)
+        for _ in range(warmup):
+            g.run_fixed_fresh(iters)                     # a fresh registration: from the identity transform, one graph
+        barrier()
+        t0 = time.perf_counter()
+        # the K steps; the engine brackets them with hipEvents on its own stream (roofline duration)
+        ev_ms = g.time_run_fixed(iters, steps, from_identity=True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ev_steps = steps
+        total_t, total_iters = aggregate(dist, elapsed, steps * iters * batch)
+        per_gpu = gather_per_rank(dist, steps * iters * batch / elapsed)
 
     # beside the metric (never part of `value`): latency of one whole registration = RBC construction + the iterations,
     # inputs resident, and the same with the two clouds uploaded from host memory first
     e2e = None
-    if rank == 0 and batch == 1:
+    if rank == 0 and batch == 1 and launch == "single":
         reps = 20 if m <= 65536 else 3
         g.buildRBC(); g.sync()
         t1 = time.perf_counter()
@@ -284,22 +496,27 @@ def main():
 
     # dominant kernel (k_search): average launch-to-launch time, HIP events on the engine's stream (rocprofv3's
     # per-dispatch average for the same kernel: profiles/).  Chained form: the timed region itself is `steps` graphs of
-    # `iters` k_search launches (+ one reset / end kernel per graph); otherwise a graph holding only that kernel.
-    fused = args.reduce_mode == "fused"
+    # `iters` k_search launches (+ one end kernel per graph); otherwise a graph holding only that kernel.
     tkey = "k_search_hbm_bytes_per_launch" if (args.config == "A" and batch == 1) else \
            "k_search_hbm_bytes_per_launch_%s" % (args.config if batch == 1 else "%s_x%d" % (args.config, batch))
-    roofline = roofline_of(g, m, nr, batch, iters, steps, ev_ms, fused, tkey) if rank == 0 else None
+    roofline = roofline_of(g, m, nr, batch, iters, ev_steps, ev_ms, fused, tkey) if rank == 0 else None
     launches = g.launches_per_iteration()
+    headline = launch == "single" and args.config == "A" and batch == 1
+    modes = measure_modes(icp_amd, device, g, args.power_mode, args.reduce_mode) if (rank == 0 and headline and fused and args.power_mode == "squared"
+                                                                                     and not args.no_other_configs) else None
     g.close()
 
     if rank == 0:
         cfg_text = {"A": "configs[1]: synthetic kg-like pair, |F|=|M|=16384, |R|=256",
                     "B": "configs[2]: synthetic VGA RGB-D cloud subsampled to |F|=|M|=65536, |R|=1024",
                     "C": "configs[4]: single registration |F|=|M|=2^20, |R|=4096"}[args.config]
+        metric = "ICP iterations/sec at |F|=|M|=%d, |R|=%d" % (m, nr)
         if args.config == "A" and batch > 1:
             cfg_text = "configs[3]: independent frame pairs of |F|=|M|=16384, |R|=256, %d per GPU sharing each launch, no RCCL" % batch
+        if batch > 1:
+            metric += ", %d independent registrations per GPU per launch" % batch
         line = {
-            "metric": "ICP iterations/sec at |F|=|M|=%d, |R|=%d" % (m, nr),
+            "metric": metric,
             "value": total_iters / total_t,
             "unit": "iterations/s",
             "n_gpus": world,
@@ -313,24 +530,41 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": cfg_text + ", power method, weighted, a=2e2 c=1e-6; step = %d fixed iterations (one hipGraph), RBC prebuilt" % iters,
-                       "parallelism": "replicas" if world > 1 else "single", "registrations_per_gpu": batch,
-                       "power_start": args.power_mode,
+                       "parallelism": "single" if world == 1 else ("replicas: one rank per GPU (torch.distributed.run)" if launch == "ranks" else
+                                                                   "replicas: icp_batch_* in-process, one host thread + stream per GPU"),
+                       "registrations_per_gpu": batch, "power_start": args.power_mode,
                        "reduce_mode": args.reduce_mode, "launches_per_iteration": launches},
             "roofline": roofline,
         }
+        line["per_gpu_iterations_per_s"] = per_gpu
+        if devices_used is not None:
+            line["config"]["devices"] = devices_used
+        # the same-work field of every line: one GPU at config 4's per-GPU share (64 registrations of A per launch)
+        line["single_gpu_same_work_key"] = "config4_per_gpu_value"
+        line["config4_per_gpu_value"] = None
+        if args.config == "A" and batch == 64 and world >= 1:
+            line["config4_per_gpu_value"] = total_iters / total_t / world
         if world > 1:
-            line["config"]["scaling_reference"] = ("per-GPU work is %d registrations per launch: the single-GPU figure of the same "
-                                                   "work is other_configs.A_x64 of the N = 1 line, not its batch-1 value" % batch)
+            line["config"]["scaling_reference"] = ("per-GPU work is %d registrations per launch; `config4_per_gpu_value` of this line = value / n_gpus, "
+                                                   "of the N = 1 line = the same 64-registration work measured on one GPU: compare those, not the "
+                                                   "N = 1 batch-1 headline `value`" % batch)
         if e2e is not None:
             line["registration_latency"] = e2e
-        if world == 1 and args.config == "A" and batch == 1 and not args.no_other_configs:
-            # the other BASELINE configs on the same GPU, same step definition, fewer steps (C: 3 steps of 10 iterations)
-            oc = {}
-            for key, cfg, b, st, wu, it in (("A_x64", "A", 64, 20, 3, ITERS_PER_STEP), ("B", "B", 1, 40, 5, ITERS_PER_STEP), ("C", "C", 1, 3, 1, 10)):
-                oc[key] = measure_config(icp_amd, device, cfg, b, st, wu, it, args.power_mode, args.reduce_mode)
+        if headline:
+            # config 4's per-GPU share on this GPU (always: the field every line carries), then the other BASELINE configs, same step
+            # definition, fewer steps (C: 3 steps of 10 iterations), tracking, and what the benchmarked mode is against the other one
+            oc = {"A_x64": measure_config(icp_amd, device, "A", 64, 20, 3, ITERS_PER_STEP, args.power_mode, args.reduce_mode, warm_seed=not args.no_other_configs)}
+            line["config4_per_gpu_value"] = oc["A_x64"]["iterations_per_s"]
+            if not args.no_other_configs:
+                for key, cfg, b, st, wu, it in (("B", "B", 1, 40, 5, ITERS_PER_STEP), ("C", "C", 1, 3, 1, 10)):
+                    oc[key] = measure_config(icp_amd, device, cfg, b, st, wu, it, args.power_mode, args.reduce_mode)
+                oc["track"] = measure_tracking(icp_amd, device)
             line["other_configs"] = oc
+            if modes is not None:
+                line.update(modes)
         if world == 1 and not args.no_cpu_baseline and m <= 65536:
             line["cpu_baseline"] = cpu_baseline(F, M, m, nr, fused)
+        line["git_head"] = git_head()
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

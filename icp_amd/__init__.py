@@ -139,6 +139,7 @@ def lib():
     sig("icp_batch_read", i32, vp, u32, i32, vp, C.c_size_t)
     sig("icp_batch_size", i32, vp, C.POINTER(u32), C.POINTER(u32))
     sig("icp_batch_time_run_fixed", i32, vp, u32, u32, C.POINTER(f64))
+    sig("icp_batch_time_run_fixed_slots", i32, vp, u32, u32, u32, C.POINTER(f64), vp)
     sig("icp_batch_partition", i32, u32, u32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32))
     sig("icp_batch_last_error", C.c_char_p, vp)
     sig("icp_time_run_fixed", i32, vp, u32, u32, i32, C.POINTER(f32))
@@ -641,6 +642,15 @@ class ICPBatch:
         s = C.c_double()
         self._chk(self._L.icp_batch_time_run_fixed(self._b, iterations, reps, C.byref(s)))
         return s.value
+
+    def time_run_fixed_slots(self, iterations, reps, warmup=1):
+        """(wall-clock seconds of `reps` passes on all slots at once, HIP-event ms of every slot's own passes)."""
+        s = C.c_double()
+        n = C.c_uint32()
+        self._chk(self._L.icp_batch_size(self._b, None, C.byref(n)))
+        ms = np.zeros(n.value, np.float32)
+        self._chk(self._L.icp_batch_time_run_fixed_slots(self._b, iterations, reps, warmup, C.byref(s), _p(ms)))
+        return s.value, ms
 
     def state(self, i):
         st = _State()

@@ -8,6 +8,7 @@
 // Host code only: everything goes through the C-ABI of include/icp_amd.h.
 #include "../../include/icp_amd.h"
 
+#include <atomic>
 #include <chrono>
 #include <string>
 #include <thread>
@@ -182,20 +183,45 @@ int icp_batch_run_fixed (icp_batch_handle b, uint32_t iterations, int from_ident
     });
 }
 
-int icp_batch_time_run_fixed (icp_batch_handle b, uint32_t iterations, uint32_t reps, double *seconds)
+int icp_batch_time_run_fixed_slots (icp_batch_handle b, uint32_t iterations, uint32_t reps, uint32_t warmup, double *seconds, float *slot_ms)
 {
     if (!b || !b->inited) return b ? bfail (b, ICP_ESTATE, "icp_batch_init has not been called") : ICP_EINVAL;
     if (!seconds || iterations == 0 || reps == 0) return bfail (b, ICP_EINVAL, "bad arguments");
-    // warm-up (graph capture and instantiation), then the timed passes: wall time around all slots = max over devices
-    int rc = icp_batch_run_fixed (b, iterations, 1);
-    if (rc != ICP_OK) return rc;
-    const auto t0 = std::chrono::steady_clock::now ();
-    rc = for_each_slot (b, [&] (size_t s) {
-        float ms = 0.f;
-        return icp_time_run_fixed (b->slots[s], iterations, reps, 1, &ms);
+    // Every slot's host thread: `warmup` untimed passes (the first captures and instantiates the graph), its stream drained, then
+    // it waits at the gate; the gate opens when all slots are there (the barrier in front of the timed region), the clock starts,
+    // every slot runs its `reps` passes (HIP events on its own stream around them: slot_ms) and drains its stream; the clock stops
+    // when the last slot is done: wall time = max over devices.
+    const size_t n = b->slots.size ();
+    size_t active = 0;
+    for (size_t s = 0; s < n; ++s) active += b->count[s] ? 1u : 0u;
+    std::atomic<size_t> arrived { 0 };
+    std::atomic<int> go { 0 };
+    std::chrono::steady_clock::time_point t0;
+    std::vector<float> ms (n, 0.f);
+    std::thread gate ([&] {
+        while (arrived.load (std::memory_order_acquire) < active) std::this_thread::yield ();
+        t0 = std::chrono::steady_clock::now ();
+        go.store (1, std::memory_order_release);
     });
+    int rc = for_each_slot (b, [&] (size_t s) {
+        int r = ICP_OK;
+        for (uint32_t w = 0; w < warmup && r == ICP_OK; ++w) r = icp_run_fixed_fresh (b->slots[s], iterations);
+        if (r == ICP_OK) r = icp_sync (b->slots[s]);
+        arrived.fetch_add (1, std::memory_order_acq_rel);            // (also on failure: the gate must open for the others)
+        while (!go.load (std::memory_order_acquire)) std::this_thread::yield ();
+        if (r != ICP_OK) return r;
+        r = icp_time_run_fixed (b->slots[s], iterations, reps, 1, &ms[s]);
+        return r ? r : icp_sync (b->slots[s]);
+    });
+    gate.join ();
     *seconds = std::chrono::duration<double> (std::chrono::steady_clock::now () - t0).count ();
+    if (slot_ms) for (size_t s = 0; s < n; ++s) slot_ms[s] = ms[s];
     return rc;
+}
+
+int icp_batch_time_run_fixed (icp_batch_handle b, uint32_t iterations, uint32_t reps, double *seconds)
+{
+    return icp_batch_time_run_fixed_slots (b, iterations, reps, 1u, seconds, nullptr);
 }
 
 }  // extern "C"

@@ -398,6 +398,9 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &p.O, B * nr))) return rc;
     if ((rc = dalloc (h, &p.perm, B * m))) return rc;
     if ((rc = dalloc (h, &p.chunk_hist, B * p.nchunk * nr))) return rc;
+    if ((rc = dalloc (h, &p.blist, B * p.nb * 64))) return rc;
+    if ((rc = dalloc (h, &p.bn, B * p.nb))) return rc;
+    if ((rc = dalloc (h, &p.brank, B * m))) return rc;
     if ((rc = dalloc (h, &p.rid, B * m))) return rc;
     if ((rc = dalloc (h, &p.nn_id, B * m))) return rc;
     if ((rc = dalloc (h, &p.PF, B * m))) return rc;
@@ -568,10 +571,7 @@ int icp_build_rbc (icp_handle h)
     auto it = h->graphs.find (key);
     if (it == h->graphs.end ()) {
         graph_entry ge;
-        if ((rc = capture_graph (h, [&] {
-                 icp_launch_build_rbc (h->p, h->stream);
-                 icp_launch_reset_state (h->p, h->stream, 0);        // ICP::buildRBC: k = 0 (:4796)
-             }, &ge))) return rc;
+        if ((rc = capture_graph (h, [&] { icp_launch_build_rbc (h->p, h->stream); }, &ge))) return rc;     // (the placement kernel also sets k = 0: ICP::buildRBC, :4796)
         it = h->graphs.emplace (key, ge).first;
     }
     note_enqueue (h);

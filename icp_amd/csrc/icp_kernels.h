@@ -39,6 +39,8 @@ struct icp_params {
     float *XP;                   // [batch][m][8]  permuted database (RBCConstruct D_OUT_X_P)
     float *XQ;                   // [batch][m][8]  same, lane 3 = original index bits (search copy)
     uint32_t *rep_src, *owner, *N, *O, *perm, *chunk_hist;   // [batch][...]
+    uint2 *blist; uint32_t *bn; uint8_t *brank;   // buildRBC of the latency-bound sizes (k_place_lists): per block of 64 fixed points its (owner, count) list
+                                                  // [batch][nb][64] and the list's length [batch][nb]; rank of a point inside its block [batch][m]
     // per-iteration
     uint32_t *rid;               // [batch][m]
     icp_dist_id *nn_id;          // [batch][m]
@@ -68,6 +70,7 @@ void icp_launch_iteration (const icp_params &p, hipStream_t s);
 void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask);
 void icp_launch_chain (const icp_params &p, hipStream_t s, uint32_t iterations, bool fresh = false);
 bool icp_chain_supported (const icp_params &p);
+bool icp_build_lists (const icp_params &p);      // buildRBC = owner search + k_place_lists (2 launches)
 uint32_t icp_tbox_of (const icp_params &p);
 uint32_t icp_s2_wave_of (const icp_params &p);
 void icp_search_layout_of (const icp_params &p, int *dense, int *tile, int *stage2);   // what icp_launch_search selects          // 1: the dense search scans the lists with lanes = candidates (long lists)

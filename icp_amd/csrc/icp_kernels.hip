@@ -415,6 +415,7 @@ __global__ __launch_bounds__ (1024) void k_place (icp_params p)
             rank += (v.x == own) ? v.y : 0u;
         }
     }
+    if (chunk == 0u && t == 0u) { icp_reg_state *st = p.st + b; st->k = 0; st->done = 0; st->pm_iters = 0; }     // ICP::buildRBC (:4796)
     if (valid) {
         const uint32_t pos = base + rank;
         const float4 *F4 = reinterpret_cast<const float4 *> (p.F + (size_t) b * p.m * 8);
@@ -428,6 +429,84 @@ __global__ __launch_bounds__ (1024) void k_place (icp_params p)
         float4 *Q4 = reinterpret_cast<float4 *> (p.XQ + (size_t) b * p.m * 8);
         Q4[2 * (size_t) pos] = make_float4 (g.x, c.x, g.y, c.y);
         Q4[2 * (size_t) pos + 1] = make_float4 (g.z, c.z, __uint_as_float (i), 0.f);
+    }
+}
+
+// RBC construct, steps 2 - 5 in ONE launch for the latency-bound sizes (at most 512 blocks of 64 points over the batch, |R| < 1024:
+// the sizes whose owner search is k_search<.., OWNER, MINW = 2>, which leaves owner[], the rank of every point inside its block of
+// 64 and the block's (owner, count) list).  A block places 256 consecutive points = 4 owner blocks.  Nothing here waits for
+// another block: every block re-derives what it needs from the lists of ALL owner blocks (a few KB, L2-resident) —
+//   total[r]  = points owned by r                       (N; its exclusive scan is O: exclusiveScan_i, kernels/scan_kernels.cl:188)
+//   before[r] = points owned by r in earlier chunks
+// with integer LDS atomics (deterministic), then position = O[owner] + before[owner] + counts of the owner in the chunk's earlier
+// owner blocks + rank inside the own block: the stable order by original index, the same integers as k_chunk_hist +
+// k_count_offsets + k_place.  Block 0 also writes N and O and resets k / done (ICP::buildRBC, src/ICP/algorithms.cpp:4796).
+// buildRBC at |F| = 16384: 6 launches, 33.6 us -> 2 launches.
+__global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
+{
+    __shared__ uint32_t s_total[1024], s_before[1024];
+    __shared__ uint2 s_list[4][64];
+    __shared__ uint32_t s_n[4], s_wave[4];
+    const uint32_t c = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane (t >> 6);
+    const uint32_t nb = p.nb, ob0 = c * 4u, i = c * 256u + t;
+    const bool valid = i < p.m;
+    // every load that depends on nothing is issued first: the point, its owner and rank, the lists' lengths
+    const float4 *F4 = reinterpret_cast<const float4 *> (p.F + (size_t) b * p.m * 8);
+    float4 g = make_float4 (0.f, 0.f, 0.f, 0.f), cc = g;
+    uint32_t own = 0xFFFFFFFFu, rk = 0u;
+    if (valid) { own = p.owner[(size_t) b * p.m + i]; rk = p.brank[(size_t) b * p.m + i]; g = F4[2 * (size_t) i]; cc = F4[2 * (size_t) i + 1]; }
+    const uint2 *BL = p.blist + (size_t) b * nb * 64u;
+    const uint32_t *BN = p.bn + (size_t) b * nb;
+    for (uint32_t r = t; r < p.nr; r += 256u) { s_total[r] = 0u; s_before[r] = 0u; }
+    if (ob0 + wave < nb) {                           // this chunk's own lists
+        const uint32_t n = BN[ob0 + wave];
+        if (lane < n) s_list[wave][lane] = BL[(size_t) (ob0 + wave) * 64u + lane];
+        if (lane == 0) s_n[wave] = n;
+    } else if (lane == 0) s_n[wave] = 0u;
+    __syncthreads ();
+    for (uint32_t ob = t; ob < nb; ob += 256u) {
+        const uint32_t n = BN[ob];
+        const bool earlier = ob < ob0;
+        for (uint32_t e = 0; e < n; ++e) {
+            const uint2 v = BL[(size_t) ob * 64u + e];
+            atomicAdd (&s_total[v.x], v.y);
+            if (earlier) atomicAdd (&s_before[v.x], v.y);
+        }
+    }
+    __syncthreads ();
+    // O = exclusive scan of the totals; thread t takes `per` consecutive representatives (|R| < 1024: per <= 4)
+    const uint32_t per = (p.nr + 255u) / 256u, lo = min (t * per, p.nr), hi = min (lo + per, p.nr);
+    uint32_t part = 0u;
+    for (uint32_t r = lo; r < hi; ++r) part += s_total[r];
+    uint32_t inc = part;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t v = __shfl_up (inc, d); if (lane >= d) inc += v; }
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads ();
+    uint32_t run = inc - part;
+    for (uint32_t w = 0; w < wave; ++w) run += s_wave[w];
+    for (uint32_t r = lo; r < hi; ++r) {
+        const uint32_t n = s_total[r];
+        if (c == 0u) { p.N[(size_t) b * p.nr + r] = n; p.O[(size_t) b * p.nr + r] = run; }
+        s_before[r] += run;                          // position of the chunk's first point of list r
+        run += n;
+    }
+    if (c == 0u && t == 0u) { icp_reg_state *st = p.st + b; st->k = 0; st->done = 0; st->pm_iters = 0; }
+    __syncthreads ();
+    if (valid) {
+        uint32_t pos = s_before[own] + rk;
+        for (uint32_t w = 0; w < wave; ++w) {        // the chunk's earlier owner blocks: every one of their points precedes this one
+            const uint32_t n = s_n[w];
+            for (uint32_t e = 0; e < n; ++e) { const uint2 v = s_list[w][e]; pos += (v.x == own) ? v.y : 0u; }
+        }
+        float4 *X4 = reinterpret_cast<float4 *> (p.XP + (size_t) b * p.m * 8);
+        float4 *Q4 = reinterpret_cast<float4 *> (p.XQ + (size_t) b * p.m * 8);
+        p.perm[(size_t) b * p.m + pos] = i;
+        X4[2 * (size_t) pos] = g;
+        X4[2 * (size_t) pos + 1] = cc;
+        Q4[2 * (size_t) pos] = make_float4 (g.x, cc.x, g.y, cc.y);                      // search copy: see k_place
+        Q4[2 * (size_t) pos + 1] = make_float4 (g.z, cc.z, __uint_as_float (i), 0.f);
     }
 }
 
@@ -606,7 +685,7 @@ template <int NG, int NT, int ROT, bool LEAN = false, typename AFTER = ff_no_hoo
 static __device__ bool fused_finalize_block (const icp_params &p, const double *mom, uint32_t nb, uint32_t check, uint32_t sv,
                                              const double *a0, icp_fin_result *res, double (*s_l1)[NG], double *s_t,
                                              const double *gl1 = nullptr, icp_reg_state *direct = nullptr, AFTER after = AFTER (),
-                                             uint32_t pending_unless_done = 1u)
+                                             uint32_t pending_unless_done = 1u, const double *a1 = nullptr, const double *a2 = nullptr)
 {
     // NT = threads of the calling block (compile-time: reading blockDim costs a dependent cold load at kernel start)
     constexpr uint32_t nrow = NT / 16;
@@ -628,7 +707,11 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
     };
     if (gl1 == nullptr) {
         pass (0u, a0);
-        for (uint32_t ps = 1; ps < npass; ++ps) {    // small blocks / many groups only
+        // a1 / a2: passes 1 and 2 loaded by the caller together with pass 0 (k_finalize_fused: the block moments were written by
+        // blocks all over the chip and come from memory — one round trip for all of them instead of one per pass)
+        if (a1 != nullptr && npass > 1u) pass (1u, a1);
+        if (a2 != nullptr && npass > 2u) pass (2u, a2);
+        for (uint32_t ps = a1 == nullptr ? 1u : a2 == nullptr ? 2u : 3u; ps < npass; ++ps) {    // small blocks / many groups only
             double a[8];
             fused_moment_loads<NT> (mom, nb, ps, a);
             pass (ps, a);
@@ -821,8 +904,14 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // per CU over grids of thousands and measured 0 ... 4 % slower with it)
     // (dense variant: bit 6 of check_flags, set for a single large registration — there the bands halve the fabric-side traffic,
     // C 171 -> 86 MB per launch against 75.6 MB algorithmic, at the same speed; batched grids measured 2 % slower with them)
-    const uint32_t tile_id = (FUSED && (MINW == 2 || (check_flags & 64u))) ? ks_tile_of_block (blockIdx.x, gridDim.x) : blockIdx.x;
-    const uint32_t iq = FUSED ? fused_query_index (m, side, tpr_magic, tile_id, lane)
+    // OWNER_LISTS (the owner search of the latency-bound sizes, buildRBC in two launches: see k_place_lists): blocks of 64 CONSECUTIVE
+    // fixed points — the stable placement ranks a point among the earlier points of its owner, and a block's (owner, count) list
+    // is a piece of exactly that count —, the representatives gathered straight from F (getReps' sampling rule: the launch does
+    // not wait for a kernel that writes R; block 0 writes R and rep_src on the side).
+    constexpr bool OWNER_LISTS = OWNER && MINW == 2;
+    const uint32_t tile_id = OWNER_LISTS ? blockIdx.x : (FUSED && (MINW == 2 || (check_flags & 64u))) ? ks_tile_of_block (blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t iq = OWNER_LISTS ? blockIdx.x * 64u + lane :
+                        FUSED ? fused_query_index (m, side, tpr_magic, tile_id, lane)
                               : (blockIdx.x >> 1) * 128u + 2u * lane + (blockIdx.x & 1u);
 
     const float4 *M4 = reinterpret_cast<const float4 *> (gM + (size_t) b * m * 8);
@@ -854,7 +943,17 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     for (int u = 0; u < 2; ++u) {
         uint32_t k = tid + (uint32_t) u * 64u * KS_SPLIT;
         rg[u] = make_float4 (0.f, 0.f, 0.f, 0.f); rc[u] = rg[u];
-        if (!MASKED && k < tn0) { rg[u] = R4[2 * (size_t) k]; rc[u] = R4[2 * (size_t) k + 1]; }
+        if constexpr (OWNER_LISTS) {
+            if (k < tn0) {
+                const uint32_t src = rep_src_index (p, k);
+                rg[u] = M4[2 * (size_t) src]; rc[u] = M4[2 * (size_t) src + 1];
+                if (blockIdx.x == 0) {               // getReps (a1): R and rep_src, written once, read by the searches that follow
+                    float4 *Rw = reinterpret_cast<float4 *> (p.R + (size_t) b * nr * 8);
+                    Rw[2 * (size_t) k] = rg[u]; Rw[2 * (size_t) k + 1] = rc[u];
+                    p.rep_src[(size_t) b * nr + k] = src;
+                }
+            }
+        } else if (!MASKED && k < tn0) { rg[u] = R4[2 * (size_t) k]; rc[u] = R4[2 * (size_t) k + 1]; }
     }
     const uint32_t ic = min (iq, m - 1u);
     float4 mg = make_float4 (0.f, 0.f, 0.f, 1.f), mc = mg;
@@ -1198,7 +1297,29 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     const float dr = ks_grp_min_f<KS_SPLIT> (best);           // the query's nearest representative: smallest distance,
     uint32_t rstar = ks_grp_min_u<KS_SPLIT> (best == dr ? bid : 0xFFFFFFFFu);     // ties -> lowest index
     if (rstar == 0xFFFFFFFFu) rstar = 0u;            // every distance inf / NaN: representative 0, as the serial scan would
-    if constexpr (OWNER) {
+    if constexpr (OWNER_LISTS) {
+        // the block's 64 owners meet in LDS; wave 0 (lane e = point 64 blockIdx.x + e) stores them in one coalesced row, ranks every
+        // point among the earlier points of the block with the same owner (one ballot per distinct owner: neighbours share a
+        // handful) and leaves the block's (owner, count) list: k_place_lists needs nothing else to place the points
+        if (ss == 0u) s_qb[qe] = make_uint4 (rstar, valid ? 1u : 0u, 0u, 0u);
+        __syncthreads ();
+        if (slice != 0u) return;
+        const uint4 e4 = s_qb[lane];
+        const bool v = e4.y != 0u;
+        const uint32_t own = v ? e4.x : 0xFFFFFFFFu, ip = blockIdx.x * 64u + lane;
+        uint32_t rank = 0u, kk = 0u;
+        uint2 *bl = p.blist + ((size_t) b * nb + blockIdx.x) * 64u;
+        for (unsigned long long rem = __ballot (v); rem; ++kk) {
+            const uint32_t o = (uint32_t) __builtin_amdgcn_readlane ((int) own, (int) __builtin_ctzll (rem));
+            const unsigned long long same = __ballot (own == o);     // (an owner is < nr: never the marker of an invalid lane)
+            if (own == o) rank = (uint32_t) __builtin_popcountll (same & ((1ull << lane) - 1ull));
+            if (lane == 0) bl[kk] = make_uint2 (o, (uint32_t) __builtin_popcountll (same));
+            rem &= ~same;
+        }
+        if (lane == 0) p.bn[(size_t) b * nb + blockIdx.x] = kk;
+        if (v) { p.owner[(size_t) b * m + ip] = own; p.brank[(size_t) b * m + ip] = (uint8_t) rank; }
+        return;
+    } else if constexpr (OWNER) {
         if (ss == 0u && valid) p.owner[(size_t) b * m + i] = rstar;
         return;
     }
@@ -1687,12 +1808,19 @@ __global__ __launch_bounds__ (1024) void k_finalize_fused (const double *gmom, i
     const double *mom = gmom + (size_t) b * 2 * ICP_NMOM * nb;
     const uint32_t ng = (nb + 127u) / 128u;
     const double *gl1 = (ng > ICP_L1_MIN_GROUPS && p.ml1) ? p.ml1 + (size_t) b * ICP_NMOM * ng : nullptr;   // (block-uniform)
-    double a0[8];
+    // the first tree level in this block (up to ICP_L1_MIN_GROUPS groups: 18 x 16 = 288 row tasks at most, 64 rows per pass): the
+    // loads of the first three passes are issued back to back, before anything waits (|F| = 65536: 144 tasks = all of them; one
+    // memory round trip instead of three: B 6.25 -> see profiles/)
+    double a0[8], a1[8], a2[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) a0[q] = 0.0;
-    if (!gl1) fused_moment_loads<1024> (mom, nb, 0u, a0);
+    for (int q = 0; q < 8; ++q) { a0[q] = 0.0; a1[q] = 0.0; a2[q] = 0.0; }
+    if (!gl1) {
+        fused_moment_loads<1024> (mom, nb, 0u, a0);
+        if (ICP_NMOM * ng > 64u) fused_moment_loads<1024> (mom, nb, 1u, a1);
+        if (ICP_NMOM * ng > 128u) fused_moment_loads<1024> (mom, nb, 2u, a2);
+    }
     // (the state goes to memory straight from the composing lane's registers: no LDS image, no second pass)
-    fused_finalize_block<128, 1024, ROT, true> (p, mom, nb, check, sv, a0, &s_fin, s_l1, s_t, gl1, st, ff_no_hook (), 0u);
+    fused_finalize_block<128, 1024, ROT, true> (p, mom, nb, check, sv, a0, &s_fin, s_l1, s_t, gl1, st, ff_no_hook (), 0u, a1, a2);
 }
 
 // First tree level of the moments for large sets (|F| / 64 blocks > 128 * ICP_L1_MIN_GROUPS): one 16-lane row per
@@ -2244,8 +2372,16 @@ void icp_search_layout_of (const icp_params &p, int *dense, int *tile, int *stag
     if (stage2) *stage2 = (d && p.s2wave) ? 1 : 0;
 }
 
+// buildRBC in two launches where the search is the latency variant (one registration of up to 32768 points, or a few small ones)
+bool icp_build_lists (const icp_params &p) { return !icp_dense (p) && p.nr < 1024u && p.blist != nullptr; }
+
 void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 {
+    if (icp_build_lists (p)) {
+        hipLaunchKernelGGL ((k_search<true, false, 2, 16, true>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.F, p.R, p.st, (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, 0u, p);
+        hipLaunchKernelGGL (k_place_lists, dim3 ((p.nb + 3u) / 4u, p.batch), dim3 (256), 0, s, p);
+        return;
+    }
     {   // the representatives, the boxes of their pruning groups and (several tiles only) of the LDS tiles: one launch
         const uint32_t nbr = (p.nr + 63u) / 64u, nbg = (p.n16 + 63u) / 64u, nbt = p.nr > p.tbox ? p.n1k : 0u;
         hipLaunchKernelGGL (k_reps_and_boxes, dim3 (nbr + nbg + nbt, p.batch), dim3 (64), 0, s, p, nbr, nbg);

@@ -287,6 +287,10 @@ int icp_batch_read (icp_batch_handle b, uint32_t i, int mem, void *host_dst, siz
 int icp_batch_size (icp_batch_handle b, uint32_t *registrations, uint32_t *n_slots);
 /* wall-clock seconds of `reps` fixed-length passes (from the identity) on all slots at once = max over devices */
 int icp_batch_time_run_fixed (icp_batch_handle b, uint32_t iterations, uint32_t reps, double *seconds);
+/* the same with `warmup` untimed passes per slot first, a gate in front of the timed region (every slot has drained its stream
+ * before the clock starts), and the HIP-event time of every slot's own passes in slot_ms[n_slots] (may be NULL; 0 for a slot
+ * without registrations): what bench.py --gpus N prints per GPU */
+int icp_batch_time_run_fixed_slots (icp_batch_handle b, uint32_t iterations, uint32_t reps, uint32_t warmup, double *seconds, float *slot_ms);
 /* the partition rule as a pure function (no device needed): slot, index inside the slot, registrations of that slot */
 int icp_batch_partition (uint32_t registrations, uint32_t n_slots, uint32_t i, uint32_t *slot, uint32_t *index, uint32_t *slot_count);
 const char *icp_batch_last_error (icp_batch_handle b);   /* b may be NULL: error of the last failed create */

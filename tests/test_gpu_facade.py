@@ -315,11 +315,44 @@ def test_bench_two_ranks_on_one_gpu():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "replicas"
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"].startswith("replicas: one rank per GPU")
     assert d["config"]["registrations_per_gpu"] == 2 and d["roofline"]["registrations_per_launch"] == 2
     # 2 ranks x 2 registrations x 3 steps x 40 iterations over the max-over-ranks time
     assert d["value"] == pytest.approx(2 * 2 * 3 * 40 / (d["ms_per_step"] * 3 * 1e-3), rel=1e-6)
     assert "cpu_baseline" not in d and "other_configs" not in d
+    assert len(d["per_gpu_iterations_per_s"]) == 2 and sum(d["per_gpu_iterations_per_s"]) >= d["value"] * 0.999
+    assert "registrations per GPU per launch" in d["metric"] and d["single_gpu_same_work_key"] == "config4_per_gpu_value"
+    # a launch whose rank count is not --gpus is refused (no line with a wrong n_gpus)
+    cmd[cmd.index("--gpus") + 1] = "4"
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_gpus_2_plain_python_in_process():
+    """`python bench.py --gpus 2` with no launcher around it: the two device slots are driven in-process through icp_batch_*
+    (here both on GPU 0: ICP_BENCH_DEVICES=0,0), config 4's 64 registrations per GPU by default; the line says n_gpus = 2,
+    carries the per-GPU rates and the same-work field; asking for a device that is not there fails loudly."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["ICP_BENCH_DEVICES"] = "0,0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["registrations_per_gpu"] == 64 and d["config"]["devices"] == [0, 0]
+    assert d["config"]["parallelism"].startswith("replicas: icp_batch_*")
+    assert d["value"] == pytest.approx(2 * 64 * 2 * 40 / (d["ms_per_step"] * 2 * 1e-3), rel=1e-6)
+    assert len(d["per_gpu_iterations_per_s"]) == 2 and all(v > 0 for v in d["per_gpu_iterations_per_s"])
+    assert d["config4_per_gpu_value"] == pytest.approx(d["value"] / 2) and d["roofline"]["registrations_per_launch"] == 64
+    env.pop("ICP_BENCH_DEVICES")
+    import icp_amd
+    n = icp_amd.device_count()
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert bad.returncode != 0 and "device(s) are visible" in bad.stderr
 
 
 @pytest.mark.parametrize("warm", [False, True])

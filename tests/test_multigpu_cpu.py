@@ -76,3 +76,26 @@ def test_aggregate_single_process():
     # registrations per GPU: the headline on one GPU, BASELINE config 4 (64 per GPU) on several, --batch wins
     assert bench.default_batch(1, 0) == 1 and bench.default_batch(8, 0) == 64 and bench.default_batch(8, 3) == 3
     assert bench.default_batch(1, 64) == 64
+
+
+def test_gpus_flag_is_what_the_launch_uses():
+    """bench.py --gpus N: under a launcher the rank count must equal N; a plain invocation with N > 1 drives N devices in-process;
+    a mismatch or a missing device ends the run without a JSON line."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.resolve_launch(1, {}) == ("single", 1)
+    assert bench.resolve_launch(1, {"WORLD_SIZE": "1"}) == ("single", 1)
+    assert bench.resolve_launch(8, {"WORLD_SIZE": "8"}) == ("ranks", 8)
+    assert bench.resolve_launch(4, {}) == ("inprocess", 4)
+    for gpus, env in ((8, {"WORLD_SIZE": "2"}), (1, {"WORLD_SIZE": "8"}), (0, {})):
+        with pytest.raises(SystemExit):
+            bench.resolve_launch(gpus, env)
+    # no GPU in this container: the in-process path must refuse (there is no CPU fallback), loudly and without a line
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    import icp_amd
+    if icp_amd.device_count() < 2:
+        assert out.returncode != 0 and "device(s) are visible" in out.stderr
+        assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

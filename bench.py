@@ -317,43 +317,55 @@ def measure_modes(icp_amd, device, g_default, power_mode, reduce_mode):
 
 
 def measure_tracking(icp_amd, device, hops=60):
-    """Frame-to-frame tracking (README.md:4; src/ocl_icp_reg.cpp:128-172 per pair): frames/s through icp_track_next over a
-    synthetic VGA sequence (five frames, walked back and forth: every hop is one step of 3 degrees / (25, -10, 15) mm), cold
-    start (every hop from the identity) and warm start (from the previous hop's T), with the share of the frame upload."""
+    """Frame-to-frame tracking (README.md:4; src/ocl_icp_reg.cpp:128-172 per pair): frames/s over a synthetic VGA sequence (five
+    frames walked back and forth: every hop is one step of 3 degrees / (25, -10, 15) mm), cold start (every hop from the
+    identity) and warm start (from the previous hop's T), three ways: the blocking icp_track_next; icp_track_submit / collect with
+    two frames in flight from pageable host memory (the calling thread copies the band getLMs reads into pinned staging); the same
+    from the engine's two pinned frame buffers (band by DMA, no host copy: two frames alternate)."""
     import numpy as np
     frames = [icp_amd.synth_cloud_vga(moved=f) for f in range(5)]
     order = [0, 1, 2, 3, 4, 3, 2, 1]
-    out = {"frames": hops, "frame": "640 x 480 float8 (9.83 MB, pageable host memory), 16384 landmarks, |R| = 256"}
+    seq = [frames[order[i % len(order)]] for i in range(hops + 8)]
+    out = {"frames": hops, "frame": "640 x 480 float8 (9.83 MB in host memory; the 2.08 MB band getLMs reads is uploaded), 16384 landmarks, |R| = 256",
+           "per_frame": "upload + getLMs + buildRBC + ICP::run to convergence (checked graph), result collected on the host"}
     for name, warm in (("cold_start", False), ("warm_start", True)):
         g = icp_amd.ICP(device)
         g.init(16384, 256, ALPHA, SCALING)
-        ks = []
-        for i in range(8):                            # warm-up: graphs of both parities captured
-            g.track_next(frames[order[i % len(order)]], warm_start=warm)
-        g.sync()
+        res = {}
+        for f in seq[:8]:                             # warm-up: the graphs of the three rotation steps captured
+            g.track_next(f, warm_start=warm)
         t0 = time.perf_counter()
-        for i in range(hops):
-            ks.append(g.track_next(frames[order[i % len(order)]], warm_start=warm))
-        g.sync()
+        ks = [g.track_next(f, warm_start=warm) for f in seq[8:]]
         el = time.perf_counter() - t0
-        t1 = time.perf_counter()
-        for i in range(20):
-            g.write_cloud(icp_amd.Memory.M, frames[order[i % len(order)]])
-        g.sync()
-        up = (time.perf_counter() - t1) / 20
-        out[name] = {"frames_per_s": hops / el, "ms_per_frame": el / hops * 1e3, "mean_iterations": float(np.mean(ks)),
-                     "upload_and_getLMs_ms": up * 1e3, "upload_share": up / (el / hops)}
-        if hasattr(g, "track_pipelined"):
-            g.track_reset()
-            seq = [frames[order[i % len(order)]] for i in range(hops + 8)]
-            g.track_pipelined(seq[:8], warm_start=warm)
-            g.sync()
-            t0 = time.perf_counter()
-            kp = g.track_pipelined(seq[8:], warm_start=warm, reset=False)
-            g.sync()
-            el = time.perf_counter() - t0
-            out[name]["pipelined"] = {"frames_per_s": hops / el, "ms_per_frame": el / hops * 1e3, "mean_iterations": float(np.mean([k for k in kp if k is not None])),
-                                      "how": "pinned double-buffered staging, frame k+1 uploaded and its landmarks extracted on a copy stream while frame k registers"}
+        res["blocking"] = {"frames_per_s": hops / el, "ms_per_frame": el / hops * 1e3, "mean_iterations": float(np.mean(ks))}
+        g.track_reset()
+        g.track_pipelined(seq[:8], warm_start=warm)
+        t0 = time.perf_counter()
+        r = g.track_pipelined(seq[8:], warm_start=warm, depth=2)
+        el = time.perf_counter() - t0
+        res["pipelined_pageable"] = {"frames_per_s": hops / el, "ms_per_frame": el / hops * 1e3, "mean_iterations": float(np.mean([x[0] for x in r if x]))}
+        if warm:                                      # (two alternating frames make every warm start the inverse of what is needed: cold only)
+            out[name] = res
+            g.close()
+            continue
+        g.track_reset()
+        g.track_staging(0)[...] = frames[1]
+        g.track_staging(1)[...] = frames[2]
+        for i in range(8):
+            g.track_submit(i & 1, warm)
+            g.track_collect()
+        t0 = time.perf_counter()
+        g.track_submit(0, warm)
+        r = []
+        for i in range(1, hops):
+            g.track_submit(i & 1, warm)
+            r.append(g.track_collect())
+        r.append(g.track_collect())
+        el = time.perf_counter() - t0
+        res["pipelined_pinned"] = {"frames_per_s": hops / el, "ms_per_frame": el / hops * 1e3, "mean_iterations": float(np.mean([x[0] for x in r if x])),
+                                   "note": "two frames one step apart alternate in the engine's pinned frame buffers (icp_track_staging); a frame's buffer is "
+                                           "resubmitted after its previous use has been collected"}
+        out[name] = res
         g.close()
     return out
 

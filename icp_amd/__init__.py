@@ -127,6 +127,9 @@ def lib():
     sig("icp_transform_cloud_ex", i32, vp, i32, vp, vp, vp, u32)
     sig("icp_track_next", i32, vp, vp, i32, C.POINTER(u32), C.POINTER(i32))
     sig("icp_track_reset", i32, vp)
+    sig("icp_track_submit", i32, vp, vp, i32)
+    sig("icp_track_collect", i32, vp, C.POINTER(u32), vp, C.POINTER(i32))
+    sig("icp_track_staging", i32, vp, u32, C.POINTER(vp))
     sig("icp_batch_create", i32, C.POINTER(vp), C.POINTER(i32), i32, i32, i32)
     sig("icp_batch_destroy", i32, vp)
     sig("icp_batch_init", i32, vp, u32, u32, u32, f32, f32, u32, f64, f64)
@@ -150,7 +153,6 @@ def lib():
     sig("icp_launches_per_iteration", i32, vp, C.POINTER(u32))
     sig("icp_run_form", i32, vp, C.POINTER(i32))
     sig("icp_search_layout", i32, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32))
-    sig("icp_debug_inject_fault", i32, vp)
     sig("icp_power_method", i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(u32))
     sig("icp_reduce", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_scan", i32, i32, i32, vp, u32, u32, vp)
@@ -439,6 +441,49 @@ class ICPStep:
     def track_reset(self):
         self._chk(self._L.icp_track_reset(self._h))
 
+    def track_submit(self, cloud, warm_start=False):
+        """Enqueues a frame (upload of its band + getLMs on the copy stream, buildRBC + run as one graph): returns at once.
+        `cloud`: a 640x480 float8 array, or the index (0 / 1) of one of the engine's pinned frame buffers (track_staging)."""
+        if isinstance(cloud, int):
+            ptr = C.c_void_p(self.track_staging(cloud).ctypes.data)
+        else:
+            cloud = np.ascontiguousarray(cloud, np.float32)
+            if cloud.size != 640 * 480 * 8:
+                raise ValueError("expected a 640x480 float8 cloud")
+            ptr = _p(cloud)
+        self._chk(self._L.icp_track_submit(self._h, ptr, int(warm_start)))
+
+    def track_collect(self):
+        """Result of the oldest frame in flight (blocking): (k, T[8]) or None for the first frame of a sequence."""
+        k, reg, T = C.c_uint32(), C.c_int(), np.empty(8, np.float32)
+        self._chk(self._L.icp_track_collect(self._h, C.byref(k), _p(T), C.byref(reg)))
+        return (k.value, T) if reg.value else None
+
+    def track_staging(self, slot):
+        """Pinned host buffer `slot` (0 / 1) for a whole frame, as a (307200, 8) float32 array: fill it, then track_submit(slot)."""
+        p = C.c_void_p()
+        self._chk(self._L.icp_track_staging(self._h, slot, C.byref(p)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(640 * 480, 8))
+
+    def track_pipelined(self, frames, warm_start=False, depth=2, pinned=False):
+        """Feeds a sequence with `depth` frames in flight; returns [None | (k, T)] per frame.  pinned: every frame is first copied
+        into one of the engine's two pinned frame buffers (what a capture loop that writes there directly would skip)."""
+        out, inflight = [], 0
+        for i, f in enumerate(frames):
+            if inflight >= depth:
+                out.append(self.track_collect())
+                inflight -= 1
+            if pinned:
+                self.track_staging(i & 1)[...] = np.asarray(f, np.float32).reshape(-1, 8)
+                self.track_submit(i & 1, warm_start)
+            else:
+                self.track_submit(f, warm_start)
+            inflight += 1
+        while inflight:
+            out.append(self.track_collect())
+            inflight -= 1
+        return out
+
     def transform_cloud(self, cloud, T=None, kind=TransformKind.QUATERNION):
         """ICPTransform: the handle's current T (default), or an explicit one — [q | t, s] for the quaternion kinds,
         a row-major 4x4 for TransformKind.MATRIX."""
@@ -471,7 +516,7 @@ class ICPStep:
         return n.value
 
     def run_form(self):
-        """0 separate launches per stage, 1 chained (one launch per iteration), 2 persistent (one launch per run)."""
+        """0 separate launches per stage, 1 chained (one launch per iteration)."""
         f = C.c_int()
         self._chk(self._L.icp_run_form(self._h, C.byref(f)))
         return f.value

@@ -10,7 +10,6 @@
 #include "../../include/icp_amd.h"
 #include "icp_kernels.h"
 
-#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +22,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-struct graph_entry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool persistent = false; };
+struct graph_entry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
 
 }  // namespace
 
@@ -45,35 +44,20 @@ struct icp_context {
                                                  // last state-changing thing enqueued)
     float *dTin = nullptr;                       // device scratch for write(T)
     float *dCloud = nullptr, *dCloudOut = nullptr; uint32_t cloud_cap = 0;
-    std::map<uint64_t, graph_entry> graphs;      // key: iterations << 2 | check << 1 | parity
-    bool persist_inflight = false;               // a persistent run was enqueued since the last fault check
-    bool last_fresh = false;
-    uint32_t last_iterations = 0; int last_check = 0;    // the last graph run (re-issued on the chained path if a persistent run gave up)
-    uint32_t enqueued_after_persist = 0;         // state-changing calls enqueued behind the oldest unchecked persistent run
-    uint32_t parity = 0;                         // tracking: which of the two landmark buffers is the fixed set (graphs hold pointers)
-    uint32_t track_frames = 0;                   // frames fed to icp_track_next since init / icp_track_reset
+    std::map<uint64_t, graph_entry> graphs;      // key: iterations << 3 | check << 2 | parity (+ fresh, + kind: see get_graph)
+    uint32_t parity = 0;                         // tracking: which landmark buffers are the fixed / moving set (graphs hold pointers): frame f -> f mod 3
+    // frame-to-frame tracking (icp_track_*): three landmark buffers in rotation, band staging, a copy stream
+    float *lm[3] = { nullptr, nullptr, nullptr };            // landmarks of frame f live in lm[f mod 3] (lm[0] / lm[1] = the handle's F / M buffers)
+    float *hBand[2] = { nullptr, nullptr }, *dBand[2] = { nullptr, nullptr };     // the part of a frame getLMs reads (ICP_BAND_*), pinned / device
+    float *hFrame[2] = { nullptr, nullptr };                 // whole-frame pinned staging handed to the caller (icp_track_staging)
+    icp_reg_state *hTrack = nullptr;                         // pinned: final state of the frames in flight (ICP_TRACK_RING slots)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t evUp[2] = { nullptr, nullptr }, evDone[4] = { nullptr, nullptr, nullptr, nullptr };
+    uint64_t track_submitted = 0, track_collected = 0;       // frames fed / frames whose result has been handed out since init / icp_track_reset
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 namespace {
-
-// A persistent run needs every block of its grid resident at once; two of them on one device could each hold half of the
-// CUs and wait for the other half forever (until their bounded spins give up).  So at most one handle per device runs
-// persistently: the first that asks gets the right and keeps it until it is re-initialised or destroyed.
-std::atomic<icp_context *> g_persist_owner[64];
-
-bool persist_acquire (icp_context *h)
-{
-    if (h->device < 0 || h->device >= 64) return false;
-    icp_context *expected = nullptr;
-    return g_persist_owner[h->device].compare_exchange_strong (expected, h) || expected == h;
-}
-void persist_release (icp_context *h)
-{
-    if (h->device < 0 || h->device >= 64) return;
-    icp_context *expected = h;
-    g_persist_owner[h->device].compare_exchange_strong (expected, nullptr);
-}
 
 int fail (icp_context *h, int code, const std::string &msg)
 {
@@ -100,8 +84,6 @@ void drop_graphs (icp_context *h)
 void free_all (icp_context *h)
 {
     drop_graphs (h);
-    persist_release (h);
-    h->persist_inflight = false;
     for (void *q : h->dev_allocs) (void) hipFree (q);
     h->dev_allocs.clear ();
     if (h->hF) (void) hipHostFree (h->hF);
@@ -113,7 +95,17 @@ void free_all (icp_context *h)
     if (h->dCloudOut) (void) hipFree (h->dCloudOut);
     h->hF = h->hM = h->hT = nullptr; h->dCloud = h->dCloudOut = nullptr; h->cloud_cap = 0;
     h->dF = h->dM = nullptr; h->ownF = h->ownM = true;
-    h->inited = h->built = false; h->parity = 0; h->track_frames = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (h->hBand[k]) (void) hipHostFree (h->hBand[k]);
+        if (h->hFrame[k]) (void) hipHostFree (h->hFrame[k]);
+        if (h->dBand[k]) (void) hipFree (h->dBand[k]);
+        h->hBand[k] = h->hFrame[k] = h->dBand[k] = nullptr;
+    }
+    if (h->lm[2]) (void) hipFree (h->lm[2]);
+    h->lm[0] = h->lm[1] = h->lm[2] = nullptr;
+    if (h->hTrack) (void) hipHostFree (h->hTrack);
+    h->hTrack = nullptr;
+    h->inited = h->built = false; h->parity = 0; h->track_submitted = h->track_collected = 0;
 }
 
 template <typename T>
@@ -186,20 +178,20 @@ int capture_graph (icp_context *h, Fn &&launches, graph_entry *out)
 
 // Capture `iterations` iterations into a graph (cached until a parameter changes).
 // fresh: the graph starts the registration from the identity transform (icp_reset_transform + the run as one graph; the
-// chained form folds the reset into its first launch).
-int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *out, bool *is_persistent = nullptr, bool fresh = false)
+// chained form folds the reset into its first launch).  with_build: buildRBC in front of the run, one graph for a whole
+// registration (tracking: one graph launch per frame).
+int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *out, bool fresh = false, bool with_build = false)
 {
-    uint64_t key = ((uint64_t) iterations << 2) | (uint64_t) (check ? 2 : 0) | (uint64_t) h->parity | ((uint64_t) (fresh ? 1 : 0) << 62);
+    uint64_t key = ((uint64_t) iterations << 3) | (uint64_t) (check ? 4 : 0) | (uint64_t) h->parity | ((uint64_t) (fresh ? 1 : 0) << 62) | ((uint64_t) (with_build ? 1 : 0) << 61);
     auto it = h->graphs.find (key);
-    if (it != h->graphs.end ()) { *out = it->second.exec; if (is_persistent) *is_persistent = it->second.persistent; return ICP_OK; }
+    if (it != h->graphs.end ()) { *out = it->second.exec; return ICP_OK; }
     icp_params p = h->p;
     p.check = check;
     graph_entry ge;
-    const bool persistent = icp_persistent_supported (p) && persist_acquire (h);
     int rc = capture_graph (h, [&] {
-        if (fresh && (persistent || !icp_chain_supported (p))) icp_launch_reset_state (p, h->stream, 1);
-        if (persistent) icp_launch_persistent (p, h->stream, iterations);                 // one launch per run
-        else if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations, fresh);   // one launch per iteration
+        if (with_build) icp_launch_build_rbc (p, h->stream);
+        if (fresh && !icp_chain_supported (p)) icp_launch_reset_state (p, h->stream, 1);
+        if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations, fresh);   // one launch per iteration
         else for (uint32_t k = 0; k < iterations; ++k) {
             p.emit = (check || k + 1 == iterations) ? 1 : 0;            // (with checks on, any iteration may be the last executed)
             icp_launch_iteration (p, h->stream);
@@ -211,60 +203,31 @@ int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *o
         if (check) (void) hipMemcpyAsync (h->hState, p.st, sizeof (icp_reg_state) * p.batch, hipMemcpyDeviceToHost, h->stream);
     }, &ge);
     if (rc) return rc;
-    ge.persistent = persistent;
     h->graphs[key] = ge;
     *out = ge.exec;
-    if (is_persistent) *is_persistent = persistent;
     return ICP_OK;
 }
 
-// Launches the graph of a run and records what a fault of a persistent run needs to know later (settle).
-int launch_run (icp_context *h, uint32_t iterations, int check, bool fresh = false)
+// Launches the graph of a run.
+int launch_run (icp_context *h, uint32_t iterations, int check, bool fresh = false, bool with_build = false)
 {
-    hipGraphExec_t exec; bool persistent = false;
-    int rc = get_graph (h, iterations, check, &exec, &persistent, fresh);
+    hipGraphExec_t exec;
+    int rc = get_graph (h, iterations, check, &exec, fresh, with_build);
     if (rc) return rc;
-    if (h->persist_inflight) h->enqueued_after_persist++;
     HIPCHK (h, hipGraphLaunch (exec, h->stream));
-    if (persistent && !h->persist_inflight) { h->persist_inflight = true; h->enqueued_after_persist = 0; }
-    if (persistent) { h->last_iterations = iterations; h->last_check = check; h->last_fresh = fresh; }
     h->hstate_fresh = check != 0;
     return ICP_OK;
 }
 
-// Waits for the stream and resolves a persistent run that gave up waiting for another block (the grid was not fully
-// resident: the kernel leaves the registration state untouched and raises `fault`).  If that run was the last thing
-// enqueued it is re-issued on the chained path, transparently; persistent runs are switched off for the handle.
+// Waits for everything enqueued on the handle's stream.
 int settle (icp_context *h)
 {
     HIPCHK (h, hipStreamSynchronize (h->stream));
-    if (!h->persist_inflight) return ICP_OK;
-    h->persist_inflight = false;
-    std::vector<icp_reg_state> st (h->p.batch);
-    HIPCHK (h, hipMemcpy (st.data (), h->p.st, sizeof (icp_reg_state) * st.size (), hipMemcpyDeviceToHost));
-    bool fault = false;
-    for (const auto &s : st) fault = fault || s.fault != 0u;
-    if (!fault) return ICP_OK;
-    h->hstate_fresh = false;
-    h->p.persistent = 0;
-    drop_graphs (h);
-    persist_release (h);
-    icp_launch_clear_fault (h->p, h->stream);
-    HIPCHK (h, hipGetLastError ());
-    if (h->enqueued_after_persist)
-        return fail (h, ICP_EHIP, "a persistent run gave up (its blocks were not all resident) and further work had been enqueued behind it: "
-                                  "the results since are void; persistent runs are now off for this handle, repeat the calls");
-    hipGraphExec_t exec;
-    int rc = get_graph (h, h->last_iterations, h->last_check, &exec, nullptr, h->last_fresh);
-    if (rc) return rc;
-    HIPCHK (h, hipGraphLaunch (exec, h->stream));
-    HIPCHK (h, hipStreamSynchronize (h->stream));
-    h->hstate_fresh = h->last_check != 0;
     return ICP_OK;
 }
 
-// every state-changing enqueue that is not a run graph: the pinned mirror of the states is stale from here on
-void note_enqueue (icp_context *h) { if (h->persist_inflight) h->enqueued_after_persist++; h->hstate_fresh = false; }
+// every state-changing enqueue that is not a checked run graph: the pinned mirror of the states is stale from here on
+void note_enqueue (icp_context *h) { h->hstate_fresh = false; }
 
 }  // namespace
 
@@ -309,15 +272,14 @@ int icp_create (icp_handle *out, int device, int rot, int weighted)
     h->p.dist_scale = 1.f;
     { const char *e = std::getenv ("ICP_AMD_MODE"); if (e && (e[0] == 'r' || e[0] == 'R')) { h->p.power_mode = ICP_POWER_LITERAL; h->p.fused = ICP_REDUCE_REFERENCE_ORDER; } }
     { const char *e = std::getenv ("ICP_AMD_CHAIN"); h->p.chain = !e ? 1 : (e[0] == '1') ? 2 : (e[0] == '0') ? 0 : 1; }   // see icp_chain_supported
-    // persistent runs (one launch per run) are opt-in: measured 10.7 us per iteration at the reference's size against 9.8 us
-    // for the chain — the in-launch exchange costs more than the launch boundary it replaces
-    { const char *e = std::getenv ("ICP_AMD_PERSISTENT"); h->p.persistent = (e && e[0] == '1') ? 1 : 0; }                  // see icp_persistent_supported
-    h->p.ncu = (uint32_t) prop.multiProcessorCount;
     e = hipSetDevice (device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags (&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags (&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate (&h->ev0);
     if (e == hipSuccess) e = hipEventCreate (&h->ev1);
-    if (e != hipSuccess) { std::string m = hipGetErrorString (e); delete h; return fail (nullptr, ICP_EHIP, "icp_create: " + m); }
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags (&h->evUp[k], hipEventDisableTiming);
+    for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreateWithFlags (&h->evDone[k], hipEventDisableTiming);
+    if (e != hipSuccess) { std::string m = hipGetErrorString (e); h->inited = false; icp_destroy (h); return fail (nullptr, ICP_EHIP, "icp_create: " + m); }
     *out = h;
     return ICP_OK;
 }
@@ -326,11 +288,15 @@ int icp_destroy (icp_handle h)
 {
     if (!h) return ICP_EINVAL;
     (void) hipSetDevice (h->device);
+    if (h->copy_stream) (void) hipStreamSynchronize (h->copy_stream);
     if (h->stream) (void) hipStreamSynchronize (h->stream);
     free_all (h);
     if (h->dTin) (void) hipFree (h->dTin);
     if (h->ev0) (void) hipEventDestroy (h->ev0);
     if (h->ev1) (void) hipEventDestroy (h->ev1);
+    for (int k = 0; k < 2; ++k) if (h->evUp[k]) (void) hipEventDestroy (h->evUp[k]);
+    for (int k = 0; k < 4; ++k) if (h->evDone[k]) (void) hipEventDestroy (h->evDone[k]);
+    if (h->copy_stream) (void) hipStreamDestroy (h->copy_stream);
     if (h->stream) (void) hipStreamDestroy (h->stream);
     delete h;
     return ICP_OK;
@@ -353,15 +319,15 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if (nr > 32768u) return fail (h, ICP_EINVAL, "nr must be <= 32768");
     if (m > (1u << 20)) return fail (h, ICP_EINVAL, "m must be <= 2^20");
     int rc = set_device (h); if (rc) return rc;
+    if (h->copy_stream) HIPCHK (h, hipStreamSynchronize (h->copy_stream));
     if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
     int rot = h->p.rot, weighted = h->p.weighted, pmode = h->p.power_mode, fused = h->p.fused, chain = h->p.chain;
-    const int persistent = h->p.persistent; const uint32_t ncu = h->p.ncu;
     const float dist_scale = h->p.dist_scale;
     free_all (h);
     icp_params &p = h->p;
     p = icp_params {};
     p.rot = rot; p.weighted = weighted; p.power_mode = pmode; p.check = 0; p.fused = fused; p.chain = chain; p.emit = 1;
-    p.dist_scale = dist_scale; p.persistent = persistent; p.ncu = ncu;
+    p.dist_scale = dist_scale;
     p.m = m; p.nr = nr; p.batch = batch; p.side = side; p.nrx = nrx; p.nry = nry;
     p.a = a; p.c = c;
     h->max_iterations = max_iterations; h->angle_threshold = angle_threshold; h->translation_threshold = translation_threshold;
@@ -379,7 +345,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     float *F = nullptr, *M = nullptr;
     if ((rc = dalloc (h, &F, B * m * 8))) return rc;
     if ((rc = dalloc (h, &M, B * m * 8))) return rc;
-    h->dF = F; h->dM = M; p.F = F; p.M = M;
+    h->dF = F; h->dM = M; p.F = F; p.M = M; h->lm[0] = F; h->lm[1] = M;
     if ((rc = dalloc (h, &p.R, B * nr * 8))) return rc;
     p.n16 = (nr + 15u) / 16u;
     p.nb = (m + 63u) / 64u;
@@ -412,7 +378,6 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &p.mom, B * 2 * 18 * p.nb))) return rc;
     if ((rc = dalloc (h, &p.ml1, B * 18 * ((p.nb + 127u) / 128u)))) return rc;
     if ((rc = dalloc (h, &p.cst, B * 2))) return rc;
-    if ((rc = dalloc (h, reinterpret_cast<unsigned char **> (&p.xch), icp_xch_bytes (batch)))) return rc;
     if ((rc = dalloc (h, &p.st, B))) return rc;
     if (!h->dTin) HIPCHK (h, hipMalloc ((void **) &h->dTin, 8 * sizeof (float)));
     HIPCHK (h, hipHostMalloc ((void **) &h->hF, B * m * 8 * sizeof (float), hipHostMallocDefault));
@@ -437,7 +402,6 @@ int icp_write_b (icp_handle h, uint32_t b, int mem, const void *host_ptr, int bl
     int rc = need (h, false); if (rc) return rc;
     if (b >= h->p.batch) return fail (h, ICP_EINVAL, "batch index out of range");
     if ((rc = set_device (h))) return rc;
-    if (h->persist_inflight && (rc = settle (h))) return rc;       // (a write synchronises the stream anyway)
     const size_t fm = (size_t) h->p.m * 8 * sizeof (float);
     switch (mem) {
         case ICP_MEM_F:
@@ -526,7 +490,6 @@ int icp_read_b (icp_handle h, uint32_t b, int mem, void *host_dst, size_t bytes)
     if (full == 0) return fail (h, ICP_EINVAL, "unknown icp_mem value");
     if (bytes > full) return fail (h, ICP_EINVAL, "icp_read: more bytes requested than the object holds");
     if ((rc = set_device (h))) return rc;
-    if (h->persist_inflight && (rc = settle (h))) return rc;
     const void *src = nullptr;
     if ((rc = mem_ptr (h, b, mem, &src))) return rc;
     if (mem == ICP_MEM_W) {                        // weights live in the .w lane of the matched points
@@ -687,7 +650,6 @@ int icp_state_b (icp_handle h, uint32_t b, icp_state_t *out)
     if (!out) return fail (h, ICP_EINVAL, "null pointer");
     if (b >= h->p.batch) return fail (h, ICP_EINVAL, "batch index out of range");
     if ((rc = set_device (h))) return rc;
-    if (h->persist_inflight && (rc = settle (h))) return rc;
     icp_reg_state st;
     if (h->hstate_fresh) {                       // a run graph was the last thing that changed the states: its final copy node
         HIPCHK (h, hipStreamSynchronize (h->stream));
@@ -750,40 +712,121 @@ int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint
     return ICP_OK;
 }
 
+// ---- frame-to-frame tracking ---------------------------------------------------------------------------------------------------
+// Frame f's landmarks live in lm[f mod 3]; registration f (frame f onto frame f - 1) reads lm[f mod 3] as the moving and
+// lm[(f - 1) mod 3] as the fixed set, so frame f + 1 can be uploaded and its landmarks extracted (copy stream) while registration f
+// runs (main stream): the buffer it goes to was last read by registration f - 1.  Two staging slots (f mod 2) hold the band of
+// a frame (the 2.08 MB of its 9.83 MB that getLMs reads) in pinned memory; per frame the main stream gets ONE graph — buildRBC +
+// the checked run — and a 248-byte copy of the final state into the frame's slot of a pinned ring.
+#define ICP_TRACK_RING 4u
+
+static int track_prepare (icp_context *h)
+{
+    if (h->p.m != 16384u || h->p.batch != 1u) return fail (h, ICP_EINVAL, "tracking needs m == 16384 (getLMs) and a single registration");
+    if (!h->ownF || !h->ownM) return fail (h, ICP_ESTATE, "tracking rotates the handle's own landmark buffers: not available with adopted F / M buffers");
+    if (!h->lm[2]) HIPCHK (h, hipMalloc ((void **) &h->lm[2], (size_t) h->p.m * 8 * sizeof (float)));
+    for (int k = 0; k < 2; ++k) {
+        if (!h->hBand[k]) HIPCHK (h, hipHostMalloc ((void **) &h->hBand[k], ICP_BAND_BYTES, hipHostMallocDefault));
+        if (!h->dBand[k]) HIPCHK (h, hipMalloc ((void **) &h->dBand[k], ICP_BAND_BYTES));
+    }
+    if (!h->hTrack) HIPCHK (h, hipHostMalloc ((void **) &h->hTrack, ICP_TRACK_RING * sizeof (icp_reg_state), hipHostMallocDefault));
+    return ICP_OK;
+}
+
 int icp_track_reset (icp_handle h)
 {
     if (!h) return ICP_EINVAL;
-    h->track_frames = 0;
+    int rc = set_device (h); if (rc) return rc;
+    if (h->copy_stream) HIPCHK (h, hipStreamSynchronize (h->copy_stream));
+    if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
+    h->track_submitted = h->track_collected = 0;
+    return ICP_OK;
+}
+
+int icp_track_staging (icp_handle h, uint32_t slot, void **host_ptr)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if (slot > 1u || !host_ptr) return fail (h, ICP_EINVAL, "icp_track_staging: slot must be 0 or 1");
+    if ((rc = set_device (h))) return rc;
+    if (!h->hFrame[slot]) HIPCHK (h, hipHostMalloc ((void **) &h->hFrame[slot], (size_t) 640 * 480 * 32, hipHostMallocDefault));
+    *host_ptr = h->hFrame[slot];
+    return ICP_OK;
+}
+
+int icp_track_submit (icp_handle h, const void *cloud, int warm_start)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if (!cloud) return fail (h, ICP_EINVAL, "null pointer");
+    if ((rc = set_device (h))) return rc;
+    if ((rc = track_prepare (h))) return rc;                            // (everything that can fail for lack of memory comes first)
+    if (h->track_submitted - h->track_collected >= ICP_TRACK_RING)
+        return fail (h, ICP_ESTATE, "icp_track_submit: four frames are in flight: collect a result first (icp_track_collect)");
+    const uint64_t f = h->track_submitted;
+    const uint32_t s = (uint32_t) (f & 1u), buf = (uint32_t) (f % 3u);
+    const char *src = static_cast<const char *> (cloud) + ((size_t) ICP_BAND_ROW0 * 640u + ICP_BAND_COL0) * 32u;
+    const size_t spitch = (size_t) ICP_BAND_ROW_STEP * 640u * 32u;
+    // the copy stream: not before registration f - 2 (the last reader of lm[buf], as its fixed set) is done
+    if (f >= 2u) HIPCHK (h, hipStreamWaitEvent (h->copy_stream, h->evDone[(f - 2u) % ICP_TRACK_RING], 0));
+    const bool pinned = cloud == h->hFrame[0] || cloud == h->hFrame[1];
+    if (pinned) {
+        // the caller filled one of the engine's pinned frame buffers (icp_track_staging): the band goes by DMA straight from there
+        HIPCHK (h, hipMemcpy2DAsync (h->dBand[s], ICP_BAND_ROW_BYTES, src, spitch, ICP_BAND_ROW_BYTES, ICP_BAND_ROWS, hipMemcpyHostToDevice, h->copy_stream));
+    } else {
+        // pageable source: the band's 128 row segments into the slot's pinned staging (free once the upload of frame f - 2 is through)
+        if (f >= 2u) HIPCHK (h, hipEventSynchronize (h->evUp[s]));
+        for (uint32_t j = 0; j < ICP_BAND_ROWS; ++j)
+            std::memcpy (reinterpret_cast<char *> (h->hBand[s]) + (size_t) j * ICP_BAND_ROW_BYTES, src + (size_t) j * spitch, ICP_BAND_ROW_BYTES);
+        HIPCHK (h, hipMemcpyAsync (h->dBand[s], h->hBand[s], ICP_BAND_BYTES, hipMemcpyHostToDevice, h->copy_stream));
+    }
+    icp_launch_get_lms_band (h->dBand[s], h->lm[buf], h->copy_stream);
+    HIPCHK (h, hipGetLastError ());
+    HIPCHK (h, hipEventRecord (h->evUp[s], h->copy_stream));
+    // the main stream: this frame's landmarks, then (from the second frame on) the registration against the previous frame's
+    HIPCHK (h, hipStreamWaitEvent (h->stream, h->evUp[s], 0));
+    h->dM = h->lm[buf]; h->p.M = h->dM;
+    h->dF = h->lm[(f + 2u) % 3u]; h->p.F = h->dF;                       // (f - 1) mod 3: the previous frame's landmarks (first frame: a buffer that is not M)
+    h->parity = 1u + buf;                                               // graphs hold the pointers: one cached set per rotation step (0: the buffers of icp_init)
+    h->built = false;
+    if (f > 0u) {
+        note_enqueue (h);
+        if (warm_start) { icp_launch_set_T (h->p, 0, h->p.st->T, h->stream); HIPCHK (h, hipGetLastError ()); }   // as write (D_IO_T) of the previous T
+        if ((rc = launch_run (h, h->max_iterations, 1, !warm_start, true))) return rc;      // buildRBC + ICP::run, one graph
+        h->built = true;
+        HIPCHK (h, hipMemcpyAsync (&h->hTrack[f % ICP_TRACK_RING], h->p.st, sizeof (icp_reg_state), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK (h, hipEventRecord (h->evDone[f % ICP_TRACK_RING], h->stream));
+    h->track_submitted = f + 1u;
+    return ICP_OK;
+}
+
+int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered)
+{
+    int rc = need (h, false); if (rc) return rc;
+    if (h->track_collected >= h->track_submitted) return fail (h, ICP_ESTATE, "icp_track_collect: no frame in flight");
+    if ((rc = set_device (h))) return rc;
+    const uint64_t f = h->track_collected;
+    HIPCHK (h, hipEventSynchronize (h->evDone[f % ICP_TRACK_RING]));
+    h->track_collected = f + 1u;
+    if (k) *k = 0;
+    if (registered) *registered = f > 0u ? 1 : 0;
+    if (f > 0u) {
+        const icp_reg_state &st = h->hTrack[f % ICP_TRACK_RING];
+        if (k) *k = st.k;
+        if (T8) std::memcpy (T8, st.T, 8 * sizeof (float));
+    } else if (T8) { const float T0[8] = { 0, 0, 0, 1, 0, 0, 0, 1 }; std::memcpy (T8, T0, sizeof T0); }
     return ICP_OK;
 }
 
 int icp_track_next (icp_handle h, const void *cloud, int warm_start, uint32_t *k, int *registered)
 {
-    int rc = need (h, false); if (rc) return rc;
-    if (h->p.m != 16384u || h->p.batch != 1u) return fail (h, ICP_EINVAL, "tracking needs m == 16384 (getLMs) and a single registration");
-    if (!cloud) return fail (h, ICP_EINVAL, "null pointer");
     if (k) *k = 0;
     if (registered) *registered = 0;
-    const bool have_prev = h->track_frames > 0;
-    if (have_prev) {
-        // the previous frame's landmarks (the moving set so far) become the fixed set: pointer swap on the device.  Graphs
-        // hold the pointers as kernel arguments: one set of graphs per parity, both stay cached.
-        std::swap (h->dF, h->dM); std::swap (h->ownF, h->ownM);
-        h->p.F = h->dF; h->p.M = h->dM;
-        h->parity ^= 1u;
-        h->built = false;
-    }
-    if ((rc = icp_write_cloud (h, ICP_MEM_M, cloud, 1))) return rc;       // upload + getLMs into the moving set
-    h->track_frames++;
-    if (!have_prev) return ICP_OK;
-    if ((rc = icp_build_rbc (h))) return rc;
-    if (warm_start) { icp_launch_set_T (h->p, 0, h->p.st->T, h->stream); HIPCHK (h, hipGetLastError ()); }   // as write (D_IO_T) of the previous T
-    else if ((rc = icp_reset_transform (h))) return rc;
-    uint32_t kk = 0;
-    if ((rc = icp_run (h, &kk))) return rc;
-    if (k) *k = kk;
-    if (registered) *registered = 1;
-    return ICP_OK;
+    int rc = need (h, false); if (rc) return rc;
+    while (h->track_collected < h->track_submitted)                     // (results of an earlier pipelined use nobody collected)
+        if ((rc = icp_track_collect (h, nullptr, nullptr, nullptr))) return rc;
+    if ((rc = icp_track_submit (h, cloud, warm_start))) return rc;
+    if ((rc = icp_track_collect (h, k, nullptr, registered))) return rc;
+    return settle (h);
 }
 
 int icp_transform_cloud_ex (icp_handle h, int kind, const float *T, const void *host_in, void *host_out, uint32_t n)
@@ -853,29 +896,14 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int fr
     int rc = need (h, true); if (rc) return rc;
     if (!ms_total || iterations == 0 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
-    hipGraphExec_t exec; bool persistent = false;
-    if ((rc = get_graph (h, iterations, 0, &exec, &persistent, from_identity != 0))) return rc;     // from_identity: every pass is a fresh registration
-    if (persistent && (rc = settle (h))) return rc;                     // (earlier persistent runs checked before the timed ones start)
+    hipGraphExec_t exec;
+    if ((rc = get_graph (h, iterations, 0, &exec, from_identity != 0))) return rc;     // from_identity: every pass is a fresh registration
     HIPCHK (h, hipEventRecord (h->ev0, h->stream));
     for (uint32_t r = 0; r < reps; ++r) HIPCHK (h, hipGraphLaunch (exec, h->stream));
     h->hstate_fresh = false;
     HIPCHK (h, hipEventRecord (h->ev1, h->stream));
     HIPCHK (h, hipEventSynchronize (h->ev1));
     HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));
-    if (persistent) {                                                   // a run that gave up makes the timing void: say so
-        h->persist_inflight = true; h->enqueued_after_persist = reps > 1 || from_identity ? 1u : 0u;
-        h->last_iterations = iterations; h->last_check = 0; h->last_fresh = from_identity != 0;
-        if ((rc = settle (h))) return rc;
-    }
-    return ICP_OK;
-}
-
-int icp_debug_inject_fault (icp_handle h)
-{   // test hook: what a persistent run leaves behind when it gives up (the next persistent run returns at once, settle () re-runs it chained)
-    int rc = need (h, false); if (rc) return rc;
-    if ((rc = set_device (h))) return rc;
-    icp_launch_inject_fault (h->p, h->stream);
-    HIPCHK (h, hipGetLastError ());
     return ICP_OK;
 }
 
@@ -883,9 +911,7 @@ int icp_run_form (icp_handle h, int *form)
 {
     int rc = need (h, false); if (rc) return rc;
     if (!form) return fail (h, ICP_EINVAL, "null output");
-    const icp_context *owner = (h->device >= 0 && h->device < 64) ? g_persist_owner[h->device].load () : nullptr;
-    if (icp_persistent_supported (h->p) && (owner == nullptr || owner == h)) *form = ICP_FORM_PERSISTENT;
-    else if (icp_chain_supported (h->p)) *form = ICP_FORM_CHAINED;
+    if (icp_chain_supported (h->p)) *form = ICP_FORM_CHAINED;
     else *form = ICP_FORM_SEPARATE;
     return ICP_OK;
 }
@@ -904,7 +930,7 @@ int icp_launches_per_iteration (icp_handle h, uint32_t *n)
     int form = ICP_FORM_SEPARATE;
     if ((rc = icp_run_form (h, &form))) return rc;
     // (fused, large sets: the first level of the moment tree is a launch of its own — icp_launch_finalize)
-    *n = form != ICP_FORM_SEPARATE ? 1u : h->p.fused ? ((h->p.nb + 127u) / 128u > 16u ? 3u : 2u) : 4u;
+    *n = form != ICP_FORM_SEPARATE ? 1u : h->p.fused ? ((h->p.nb + 127u) / 128u > ICP_L1_MIN_GROUPS ? 3u : 2u) : 4u;
     return ICP_OK;
 }
 
@@ -914,6 +940,7 @@ int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t 
     if (!ms_total || iterations == 0 || reps == 0 || mask == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
     icp_params p = h->p; p.check = 0;
+    note_enqueue (h);                                                   // (the masked graphs change the device state: the pinned mirror is stale)
     graph_entry ge;
     // (the per-query outputs follow the policy of the fixed-length graphs: stored by the last iteration only in fused mode)
     if ((rc = capture_graph (h, [&] {
@@ -938,8 +965,8 @@ int icp_debug_stamps (icp_handle h, unsigned long long *out, uint32_t nblocks)
     HIPCHK (h, hipMalloc ((void **) &d, (size_t) nblocks * 16 * 8));
     HIPCHK (h, hipMemset (d, 0, (size_t) nblocks * 16 * 8));
     icp_params p = h->p; p.check = 0; p.dbg = d;
-    if (icp_persistent_supported (p)) icp_launch_persistent (p, h->stream, 40);
-    else if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, 2);
+    note_enqueue (h);
+    if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, 2);
     else { icp_launch_search (p, h->stream); if (p.fused) icp_launch_finalize (p, h->stream); }
     HIPCHK (h, hipStreamSynchronize (h->stream));
     HIPCHK (h, hipMemcpy (out, d, (size_t) nblocks * 16 * 8, hipMemcpyDeviceToHost));

@@ -30,8 +30,7 @@ struct icp_reg_state {
     uint32_t done;       // 1: ICP::check() said stop
     uint32_t pm_iters;
     uint32_t pending;    // chained fused mode: moments of an iteration are waiting to be turned into T
-    uint32_t epoch;      // persistent runs: exchange epochs consumed so far (tags of the in-launch moment exchange continue from here)
-    uint32_t fault;      // persistent runs: 1 = the last run gave up waiting for another block (blocks not co-resident); state untouched
+    uint32_t reserved0, reserved1;   // (the state is 62 dwords: one lane-per-dword vector load, 15 x 16-byte + one 8-byte store)
 };
 
 // ------------------------------------------------------------------------------------------

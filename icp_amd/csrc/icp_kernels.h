@@ -4,6 +4,21 @@
 #include <stdint.h>
 #include "icp_device.h"
 
+// fused finalize: beyond this many 128-block groups (|F| > 16384) the first level of the moment tree gets a kernel of its own
+// (k_moment_level1: the block moments come from all over the chip; one CU fetching 147 KB of them at |F| = 65536 costs more than
+// a launch that spreads the fetch — finalize 6.29 -> 5.71 us for the two launches, iteration 19.4 -> 18.55 us; same tree, same bits)
+#ifndef ICP_L1_MIN_GROUPS
+#define ICP_L1_MIN_GROUPS 2u
+#endif
+// The band of a 640 x 480 frame getLMs reads (kernels/icp_kernels.cl:63-76: landmark (i, j) = pixel (col 65 + 4 i, row 49 + 3 j)):
+// rows 49, 52, .., 430 and, of each, the pixels 65 .. 573.
+#define ICP_BAND_ROW0 49u
+#define ICP_BAND_ROW_STEP 3u
+#define ICP_BAND_ROWS 128u
+#define ICP_BAND_COL0 65u
+#define ICP_BAND_COLS 509u
+#define ICP_BAND_ROW_BYTES (ICP_BAND_COLS * 32u)
+#define ICP_BAND_BYTES ((size_t) ICP_BAND_ROWS * ICP_BAND_ROW_BYTES)
 #define ICP_CHUNK 1024u          // fixed points per block in the stable RBC placement
 
 struct icp_params {
@@ -51,9 +66,6 @@ struct icp_params {
     float *spart;                // [batch][11][nsp*8] 8 residue sub-trees per work-group
     double *mom;                 // [batch][2][18][nb]  fused mode: per-block moment partials (double-buffered for the chain)
     double *ml1;                 // [batch][18][ceil(nb/128)]  fused mode, large sets: first tree level of the moments (k_moment_level1)
-    unsigned long long *xch;     // [batch][2][18][256] 16-byte exchange records + one abort word: in-launch moment exchange of persistent runs
-    int persistent;              // 0 never, 1 where the size allows (icp_persistent_supported) and this handle holds the device's right to it
-    uint32_t ncu;                // compute units of the device (co-residency bound of a persistent grid)
     icp_reg_state *cst;          // [batch][2]  chained fused mode: state slots, launch j reads slot j&1 and writes the other
     uint32_t slot;               // chained fused mode: slot this launch reads
     icp_reg_state *st;           // [batch]
@@ -74,15 +86,11 @@ bool icp_build_lists (const icp_params &p);      // buildRBC = owner search + k_
 uint32_t icp_tbox_of (const icp_params &p);
 uint32_t icp_s2_wave_of (const icp_params &p);
 void icp_search_layout_of (const icp_params &p, int *dense, int *tile, int *stage2);   // what icp_launch_search selects          // 1: the dense search scans the lists with lanes = candidates (long lists)
-bool icp_persistent_supported (const icp_params &p);
-void icp_launch_persistent (const icp_params &p, hipStream_t s, uint32_t iterations);
-size_t icp_xch_bytes (uint32_t batch);
-void icp_launch_clear_fault (const icp_params &p, hipStream_t s);
-void icp_launch_inject_fault (const icp_params &p, hipStream_t s);
 void icp_launch_reset_state (const icp_params &p, hipStream_t s, int reset_T);
 void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStream_t s);
 void icp_launch_rotation_solver (int rot, int power_mode, const float *din19, float *dout18, hipStream_t s);   // [S 11 | means 8] -> [Tk 8 | Rk 9 | trips]
 void icp_launch_get_lms (const float *cloud, float *lms, hipStream_t s);
+void icp_launch_get_lms_band (const float *band, float *lms, hipStream_t s);
 void icp_launch_transform_cloud (const float *in, float *out, const icp_reg_state *st, uint32_t n, hipStream_t s);
 // kind 0 / 1: T = [q | t, s] (8 floats), 2: T = row-major 4x4 (16 floats); host pointer, passed by value
 void icp_launch_transform_cloud_ex (int kind, const float *in, float *out, const float *T, uint32_t n, hipStream_t s);

@@ -121,7 +121,7 @@ __global__ void k_reset_state (icp_params p, int reset_T)
         for (int i = 0; i < 8; ++i) st->means[i] = 0.f;
         st->sum_w = 0.0;
     }
-    st->k = 0; st->done = 0; st->pm_iters = 0;       // ICP::buildRBC — :4796   (epoch / fault: persistent-run bookkeeping, kept)
+    st->k = 0; st->done = 0; st->pm_iters = 0;       // ICP::buildRBC — :4796
 }
 
 // write (D_IO_T): T is replaced and the cumulative rotation re-derived from it
@@ -145,6 +145,18 @@ __global__ void k_get_lms (const float4 *cloud, float4 *lms)
     uint32_t gX = lm & 127u, gY = lm >> 7;
     uint32_t row = 48u + gY * 3u + 1u, col = 64u + 4u * gX + 1u;
     lms[t] = cloud[((size_t) row * 640u + col) * 2u + half];
+}
+
+// getLMs from the BAND of a frame: the part of a 640 x 480 cloud the kernel above reads, packed — row j of the band = cloud row
+// 49 + 3 j, pixels 65 .. 573 (ICP_BAND_* in icp_kernels.h: 128 rows x 509 pixels = 2.08 MB of the frame's 9.83 MB).  Tracking
+// uploads only that (icp_track_submit); landmark (gX, gY) = band pixel (4 gX, gY): the same points as k_get_lms.
+__global__ void k_get_lms_band (const float4 *band, float4 *lms)
+{
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 16384u * 2u) return;
+    uint32_t lm = t >> 1, half = t & 1u;
+    uint32_t gX = lm & 127u, gY = lm >> 7;
+    lms[t] = band[((size_t) gY * ICP_BAND_COLS + 4u * gX) * 2u + half];
 }
 
 // icpTransform_Quaternion on a whole cloud — kernels/icp_kernels.cl:772-802
@@ -458,14 +470,38 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
     if (valid) { own = p.owner[(size_t) b * p.m + i]; rk = p.brank[(size_t) b * p.m + i]; g = F4[2 * (size_t) i]; cc = F4[2 * (size_t) i + 1]; }
     const uint2 *BL = p.blist + (size_t) b * nb * 64u;
     const uint32_t *BN = p.bn + (size_t) b * nb;
-    for (uint32_t r = t; r < p.nr; r += 256u) { s_total[r] = 0u; s_before[r] = 0u; }
+    // the list of owner block t (thread t; further ones in the loop below): its length and, without waiting for it, its first 8
+    // entries (64 neighbouring points share a handful of owners) — one memory round trip for everything above and this
+    uint32_t n0 = 0u; uint4 e0[4] = { make_uint4 (0u, 0u, 0u, 0u), make_uint4 (0u, 0u, 0u, 0u), make_uint4 (0u, 0u, 0u, 0u), make_uint4 (0u, 0u, 0u, 0u) };
+    if (t < nb) {
+        n0 = BN[t];
+        const uint4 *q = reinterpret_cast<const uint4 *> (BL + (size_t) t * 64u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e0[k] = q[k];
+    }
+    uint32_t nown = 0u; uint2 lown = make_uint2 (0u, 0u);
     if (ob0 + wave < nb) {                           // this chunk's own lists
-        const uint32_t n = BN[ob0 + wave];
-        if (lane < n) s_list[wave][lane] = BL[(size_t) (ob0 + wave) * 64u + lane];
-        if (lane == 0) s_n[wave] = n;
-    } else if (lane == 0) s_n[wave] = 0u;
+        nown = BN[ob0 + wave];
+        lown = BL[(size_t) (ob0 + wave) * 64u + lane];      // (entries past the list's end: whatever the buffer holds, never read back)
+    }
+    for (uint32_t r = t; r < p.nr; r += 256u) { s_total[r] = 0u; s_before[r] = 0u; }
+    s_list[wave][lane] = lown;
+    if (lane == 0) s_n[wave] = nown;
     __syncthreads ();
-    for (uint32_t ob = t; ob < nb; ob += 256u) {
+    {
+        const bool earlier = t < ob0;
+        const uint32_t ev[8][2] = { { e0[0].x, e0[0].y }, { e0[0].z, e0[0].w }, { e0[1].x, e0[1].y }, { e0[1].z, e0[1].w },
+                                    { e0[2].x, e0[2].y }, { e0[2].z, e0[2].w }, { e0[3].x, e0[3].y }, { e0[3].z, e0[3].w } };
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if ((uint32_t) e < n0) { atomicAdd (&s_total[ev[e][0]], ev[e][1]); if (earlier) atomicAdd (&s_before[ev[e][0]], ev[e][1]); }
+        for (uint32_t e = 8u; e < n0; ++e) {
+            const uint2 v = BL[(size_t) t * 64u + e];
+            atomicAdd (&s_total[v.x], v.y);
+            if (earlier) atomicAdd (&s_before[v.x], v.y);
+        }
+    }
+    for (uint32_t ob = t + 256u; ob < nb; ob += 256u) {
         const uint32_t n = BN[ob];
         const bool earlier = ob < ob0;
         for (uint32_t e = 0; e < n; ++e) {
@@ -577,9 +613,6 @@ template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint
     }
 
 #define ICP_NMOM 18
-#ifndef ICP_L1_MIN_GROUPS
-#define ICP_L1_MIN_GROUPS 16u        // fused finalize: beyond this many 128-block groups the first tree level gets a kernel of its own
-#endif
 
 #ifdef ICP_DBG_STAMPS
 #define FF_STAMP(k)                                                                                       \
@@ -685,7 +718,7 @@ template <int NG, int NT, int ROT, bool LEAN = false, typename AFTER = ff_no_hoo
 static __device__ bool fused_finalize_block (const icp_params &p, const double *mom, uint32_t nb, uint32_t check, uint32_t sv,
                                              const double *a0, icp_fin_result *res, double (*s_l1)[NG], double *s_t,
                                              const double *gl1 = nullptr, icp_reg_state *direct = nullptr, AFTER after = AFTER (),
-                                             uint32_t pending_unless_done = 1u, const double *a1 = nullptr, const double *a2 = nullptr)
+                                             uint32_t pending_unless_done = 1u)
 {
     // NT = threads of the calling block (compile-time: reading blockDim costs a dependent cold load at kernel start)
     constexpr uint32_t nrow = NT / 16;
@@ -707,11 +740,7 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
     };
     if (gl1 == nullptr) {
         pass (0u, a0);
-        // a1 / a2: passes 1 and 2 loaded by the caller together with pass 0 (k_finalize_fused: the block moments were written by
-        // blocks all over the chip and come from memory — one round trip for all of them instead of one per pass)
-        if (a1 != nullptr && npass > 1u) pass (1u, a1);
-        if (a2 != nullptr && npass > 2u) pass (2u, a2);
-        for (uint32_t ps = a1 == nullptr ? 1u : a2 == nullptr ? 2u : 3u; ps < npass; ++ps) {    // small blocks / many groups only
+        for (uint32_t ps = 1; ps < npass; ++ps) {    // small blocks / many groups only
             double a[8];
             fused_moment_loads<NT> (mom, nb, ps, a);
             pass (ps, a);
@@ -795,7 +824,7 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
                         means[0], means[1], means[2], means[3], means[4], means[5], means[6], means[7],
                         __uint_as_float ((uint32_t) swb), __uint_as_float ((uint32_t) (swb >> 32)),
                         __uint_as_float (kprev + 1u), __uint_as_float (done), __uint_as_float ((uint32_t) iters), __uint_as_float (done ? 0u : pending_unless_done),
-                        __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (epoch))), __uint_as_float (0u), 0.f, 0.f };
+                        0.f, 0.f, 0.f, 0.f };
                     float *dst = reinterpret_cast<float *> (direct);
 #pragma unroll
                     for (int k = 0; k < 15; ++k) *reinterpret_cast<f4u *> (dst + 4 * k) = f4u { img[4 * k], img[4 * k + 1], img[4 * k + 2], img[4 * k + 3] };
@@ -812,7 +841,7 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
 #pragma unroll
             for (int k = 0; k < 11; ++k) res->S[k] = S[k];
             res->sum_w = sw; res->pm_iters = (uint32_t) iters; res->k = kprev + 1u; res->pad0 = 0.f; res->pending = 0u;
-            res->epoch = (uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (epoch)); res->fault = 0u;
+            res->reserved0 = 0u; res->reserved1 = 0u;
             res->done = (p.check && icp_check_converged (Tk, p.tan_half_thr, p.trans_thr)) ? 1u : 0u;
         }
     }
@@ -924,12 +953,12 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     if constexpr (CHAIN) {
         // bit 4 of check_flags (first launch of a chain): the run starts from the identity transform — what k_reset_state
         // would have left in the state (T = Tk = (0,0,0,1 | 0,0,0,1), R = Rk = I, S = means = sum_w = 0, k = done = 0),
-        // without a launch of its own; the run's bookkeeping (epoch, fault) is kept
-        static_assert (ICP_ST_DW (T) == 0 && ICP_ST_DW (Tk) == 8 && ICP_ST_DW (R) == 16 && ICP_ST_DW (Rk) == 25 && ICP_ST_DW (epoch) == 60, "state layout");
+        // without a launch of its own
+        static_assert (ICP_ST_DW (T) == 0 && ICP_ST_DW (Tk) == 8 && ICP_ST_DW (R) == 16 && ICP_ST_DW (Rk) == 25 && ICP_ST_DW (reserved0) == 60, "state layout");
         if (check_flags & 16u) {
             constexpr unsigned long long ones = (1ull << 3) | (1ull << 7) | (1ull << 11) | (1ull << 15) | (1ull << 16) | (1ull << 20) | (1ull << 24) |
                                                 (1ull << 25) | (1ull << 29) | (1ull << 33);
-            if (lane < ICP_ST_DW (epoch)) sv = ((ones >> lane) & 1ull) ? 0x3F800000u : 0u;
+            if (lane < ICP_ST_DW (reserved0)) sv = ((ones >> lane) & 1ull) ? 0x3F800000u : 0u;
         }
     }
     // chained variant: the previous iteration's block moments (first tree level of this block's finalize) travel with
@@ -1157,6 +1186,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             if (lane == 0) atomicOr (&s_tmask, wm);
         }
         __syncthreads ();
+        KS_STAMP (10)
         uint32_t bm = s_tmask;                       // block-uniform
         bool first = true;
         while (bm) {
@@ -1808,19 +1838,15 @@ __global__ __launch_bounds__ (1024) void k_finalize_fused (const double *gmom, i
     const double *mom = gmom + (size_t) b * 2 * ICP_NMOM * nb;
     const uint32_t ng = (nb + 127u) / 128u;
     const double *gl1 = (ng > ICP_L1_MIN_GROUPS && p.ml1) ? p.ml1 + (size_t) b * ICP_NMOM * ng : nullptr;   // (block-uniform)
-    // the first tree level in this block (up to ICP_L1_MIN_GROUPS groups: 18 x 16 = 288 row tasks at most, 64 rows per pass): the
-    // loads of the first three passes are issued back to back, before anything waits (|F| = 65536: 144 tasks = all of them; one
-    // memory round trip instead of three: B 6.25 -> see profiles/)
-    double a0[8], a1[8], a2[8];
+    // (ng <= ICP_L1_MIN_GROUPS: the first tree level in this block, one pass; beyond it k_moment_level1 has run.  Loading the
+    // passes of a larger in-block first level back to back measured slower than one after the other — B 6.64 against 6.29 us —, and
+    // both lose to the level-1 kernel: 5.71 us for the two launches, profiles/r03_finalize_sweep_B.txt)
+    double a0[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { a0[q] = 0.0; a1[q] = 0.0; a2[q] = 0.0; }
-    if (!gl1) {
-        fused_moment_loads<1024> (mom, nb, 0u, a0);
-        if (ICP_NMOM * ng > 64u) fused_moment_loads<1024> (mom, nb, 1u, a1);
-        if (ICP_NMOM * ng > 128u) fused_moment_loads<1024> (mom, nb, 2u, a2);
-    }
+    for (int q = 0; q < 8; ++q) a0[q] = 0.0;
+    if (!gl1) fused_moment_loads<1024> (mom, nb, 0u, a0);
     // (the state goes to memory straight from the composing lane's registers: no LDS image, no second pass)
-    fused_finalize_block<128, 1024, ROT, true> (p, mom, nb, check, sv, a0, &s_fin, s_l1, s_t, gl1, st, ff_no_hook (), 0u, a1, a2);
+    fused_finalize_block<128, 1024, ROT, true> (p, mom, nb, check, sv, a0, &s_fin, s_l1, s_t, gl1, st, ff_no_hook (), 0u);
 }
 
 // First tree level of the moments for large sets (|F| / 64 blocks > 128 * ICP_L1_MIN_GROUPS): one 16-lane row per
@@ -1901,407 +1927,6 @@ __global__ __launch_bounds__ (320) void k_chain_end (icp_params p)
 }
 
 // ------------------------------------------------------------------------------------------
-// PERSISTENT run: every iteration of a registration inside ONE launch (fused mode, latency-bound sizes: at most one
-// 1024-thread block per CU, all blocks of the grid co-resident).
-//
-//   prologue (once)   representatives + list (offset, size) staged into LDS; each block's 64 moving points and colours in
-//                     the registers of its query wave; the state (T, R, k) in LDS
-//   per iteration     transform -> search (stage 1 / stage 2: the code of the latency variant of k_search, same bits) ->
-//                     block moments -> EXCHANGE -> every block turns all blocks' moments into the next T (as the chain
-//                     does in its prologue) -> next iteration; `done` (checked runs) ends the loop in place
-//   epilogue (once)   per-query outputs of the last executed iteration, the state
-//
-// EXCHANGE = the all-to-all seam of the iteration, in-launch.  Moment k of block j is published as one 16-byte record of
-// two self-validating 8-byte granules {low word, epoch} {high word, epoch}, each written by ONE agent-scope (sc1,
-// write-through) store: the data is the flag (MI355X guide, Guideline 16 R2), no release fence, no counter.  Consumers
-// poll the records they need with agent-scope (sc1, L1-bypassing) loads until both tags carry the iteration's epoch; the
-// tree rows of the first reduction level ARE the pollers (row task (k, g) reads the 128 records of moment k, group g), so
-// the values arrive in the registers the tree starts from.  Epochs count up across launches (state.epoch), buffers
-// alternate by iteration parity: a slot is rewritten two epochs later, which the exchange itself orders behind every read.
-// Every spin is bounded: a block that gives up raises `fault` in the state and an abort word the other blocks watch, and
-// the launch ends without touching the registration state (the host then falls back to the chained graphs).
-// ------------------------------------------------------------------------------------------
-#ifndef ICP_PERSIST_S2_DEPTH
-#define ICP_PERSIST_S2_DEPTH 4u
-#endif
-#ifndef ICP_PERSIST_SPIN_LIMIT
-#define ICP_PERSIST_SPIN_LIMIT 200000u           // polls of one wave before it gives up (>= 100 ms)
-#endif
-typedef unsigned long long __attribute__ ((address_space (1))) icp_gu64;
-typedef uint32_t __attribute__ ((address_space (1))) icp_gu32;
-typedef uint32_t icp_u32x4 __attribute__ ((ext_vector_type (4)));
-
-template <int ROT>
-__global__ __launch_bounds__ (1024, 2) void k_run_persistent (const float *gM, const float *gR, icp_reg_state *gst, unsigned long long *gxch,
-                                                              uint32_t m, uint32_t nr, uint32_t side, uint32_t tpr_magic,
-                                                              uint32_t nb, uint32_t iterations, uint32_t check, icp_params p)
-{
-    constexpr int LPQ = 16;                          // KS_SPLIT / KS_QPW below: 16 lanes per query, 4 queries per wave
-    __shared__ float4 s_pair[3 * KS_TILE / 2];
-    __shared__ uint2 s_on[KS_TILE];
-    __shared__ float4 s_qc[64];
-    __shared__ float4 s_qa[64];
-    __shared__ uint4 s_qb[64];
-    __shared__ double s_mom[ICP_NMOM][64];
-    __shared__ icp_reg_state s_state;                // the registration state, carried from iteration to iteration
-    __shared__ double s_t[ICP_NMOM];
-    __shared__ uint32_t s_fault;
-    __shared__ float4 s_mg[64], s_mc[64];            // the block's 64 moving points and colours (loaded once)
-    __shared__ float4 s_out[3][64];                  // per-query results of the last executed iteration (stored once, after the loop)
-
-    const uint32_t b = blockIdx.y, tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t slice = __builtin_amdgcn_readfirstlane (tid >> 6);
-    const uint32_t qe = slice * KS_QPW + lane / KS_SPLIT, ss = lane & (KS_SPLIT - 1u);
-    const bool qwave = slice == KS_SPLIT - 1u;
-    const uint32_t tile_id = ks_tile_of_block (blockIdx.x, gridDim.x);
-    const uint32_t iq = fused_query_index (m, side, tpr_magic, tile_id, lane);
-    icp_reg_state *st = gst + b;
-    const float4 *M4 = reinterpret_cast<const float4 *> (gM + (size_t) b * m * 8);
-    const float4 *R4 = reinterpret_cast<const float4 *> (gR + (size_t) b * nr * 8);
-
-    // ---- prologue: everything that does not depend on T, once per run ----
-    const uint32_t sv = state_load_lanes (st);
-    float *s_pairf = reinterpret_cast<float *> (s_pair);
-    const uint32_t tn0 = nr;                         // one tile (host: nr <= KS_TILE)
-    float4 rg[1], rc[1];
-    {
-        const uint32_t k = tid;
-        rg[0] = make_float4 (0.f, 0.f, 0.f, 0.f); rc[0] = rg[0];
-        if (k < tn0) { rg[0] = R4[2 * (size_t) k]; rc[0] = R4[2 * (size_t) k + 1]; }
-    }
-    const uint32_t ic = min (iq, m - 1u);
-    float4 mg = make_float4 (0.f, 0.f, 0.f, 1.f), mc = mg;
-    if (qwave) { mg = M4[2 * (size_t) ic]; mc = M4[2 * (size_t) ic + 1]; }
-    const uint32_t *gO = p.O + (size_t) b * nr, *gN = p.N + (size_t) b * nr;
-    uint2 ron = make_uint2 (0u, 0u);
-    if (tid < tn0) ron = make_uint2 (gO[tid], gN[tid]);
-    if (check && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))) return;         // converged earlier: nothing to do
-    if (__builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (fault))) return;                 // an earlier run gave up: void until the host has cleared it
-    if (iq >= m) { mg = make_float4 (0.f, 0.f, 0.f, 1.f); mc = mg; }
-    if (qwave) { s_mg[lane] = mg; s_mc[lane] = mc; }
-    const char *XQb = reinterpret_cast<const char *> (p.XQ + (size_t) b * m * 8);
-    if (tid < tn0) {
-        float *dst = s_pairf + (tid >> 1) * 12u + (tid & 1u);
-        dst[0] = rg[0].x; dst[2] = rg[0].y; dst[4] = rg[0].z; dst[6] = rc[0].x; dst[8] = rc[0].y; dst[10] = rc[0].z;
-        s_on[tid] = ron;
-    }
-    if ((tn0 & 1u) && tid == 0) {                    // odd tile (nr == 1): the pad slot never wins (NaN distance)
-        float *dst = s_pairf + (tn0 >> 1) * 12u + 1u;
-        const float qnan = __builtin_nanf ("");
-        dst[0] = qnan; dst[2] = qnan; dst[4] = qnan; dst[6] = qnan; dst[8] = qnan; dst[10] = qnan;
-    }
-    if (tid < sizeof (icp_reg_state) / 4) reinterpret_cast<uint32_t *> (&s_state)[tid] = sv;     // wave 0: lane j holds dword j
-    if (tid == 0) s_fault = 0u;
-    const uint32_t epoch0 = (uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (epoch));
-    const float alpha = p.a;
-    const uint32_t ng = (nb + 127u) / 128u;          // 1 or 2 (host: nb <= 256)
-    icp_gu64 *xch = (icp_gu64 *) (gxch + (size_t) b * 2 * ICP_NMOM * 256 * 2);
-    icp_gu32 *xabort = (icp_gu32 *) (gxch + (size_t) gridDim.y * 2 * ICP_NMOM * 256 * 2);      // one word behind the records
-    uint32_t it = 0;
-#ifdef ICP_DBG_STAMPS
-    // diagnostic build: per-phase s_memtime totals over the iterations of the run, per block (wave 0's view)
-    unsigned long long ps_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, ps_prev = 0ull;
-#define PS_STAMP(k)                                                                                             \
-    {                                                                                                           \
-        unsigned long long t_;                                                                                  \
-        asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-        if ((k) >= 0) ps_acc[(k) < 0 ? 0 : (k)] += t_ - ps_prev;                                                \
-        ps_prev = t_;                                                                                           \
-    }
-#else
-#define PS_STAMP(k)
-#endif
-    __syncthreads ();
-    PS_STAMP (-1)
-
-    for (; it < iterations; ++it) {
-        // ---- transform: the query wave hands the block's 64 transformed points to the lanes of each query ----
-        if (qwave) {
-            float T[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) T[k] = s_state.T[k];
-            const float4 pg = s_mg[lane];
-            float tx, ty, tz;
-            icp_transform_point (T, pg.x, pg.y, pg.z, tx, ty, tz);
-            s_qa[lane] = make_float4 (tx, ty, tz, __uint_as_float (iq));
-            s_qc[lane] = s_mc[lane];
-        }
-        __syncthreads ();
-        PS_STAMP (0)
-        const float4 a4 = s_qa[qe], c4 = s_qc[qe];
-        const float qx = a4.x, qy = a4.y, qz = a4.z, qr = c4.x, qg = c4.y, qb = c4.z;
-        const uint32_t i = __float_as_uint (a4.w);
-        const bool valid = i < m;
-
-        // ---- stage 1: nearest representative (the branch-free loop of the latency variant of k_search) ----
-        float best = __builtin_inff (); uint32_t bid = 0xFFFFFFFFu;
-        {
-            const uint32_t npair = (tn0 + 1u) >> 1;
-            const float2v vqx = { qx, qx }, vqy = { qy, qy }, vqz = { qz, qz }, vqr = { qr, qr }, vqg = { qg, qg }, vqb = { qb, qb };
-            const float2v va = { alpha, alpha };
-#pragma unroll 8
-            for (uint32_t P = ss; P < npair; P += KS_SPLIT) {
-                float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];
-                float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
-                float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
-                float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
-                float2v pho = __builtin_elementwise_fma (db, db, __builtin_elementwise_fma (dg, dg, dr * dr));
-                float2v d = __builtin_elementwise_fma (va, pho, geo);
-                const uint32_t r0 = 2u * P;
-                if (d.x < best) { best = d.x; bid = r0; }
-                if (d.y < best) { best = d.y; bid = r0 + 1u; }
-            }
-        }
-        const float dr = ks_grp_min_f<KS_SPLIT> (best);
-        uint32_t rstar = ks_grp_min_u<KS_SPLIT> (best == dr ? bid : 0xFFFFFFFFu);
-        if (rstar == 0xFFFFFFFFu) rstar = 0u;
-        const uint2 on = s_on[rstar];
-        const uint32_t o = on.x, n = on.y;
-        PS_STAMP (1)
-
-        // ---- stage 2: exhaustive scan of that representative's list ----
-        float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
-        const float2v vq_xr = { qx, qr }, vq_yg = { qy, qg }, vq_zb = { qz, qb };
-        {
-            constexpr uint32_t KS_DEPTH = ICP_PERSIST_S2_DEPTH;    // candidates in flight per lane (the loop-carried state leaves fewer registers than k_search has)
-            const uint32_t je = valid ? o + n : o;
-            uint32_t ntrips = 0u;
-#pragma unroll
-            for (uint32_t gq = 0; gq < KS_QPW; ++gq) {
-                const uint32_t ng_ = (uint32_t) __builtin_amdgcn_readlane ((int) (je - o), (int) (gq * KS_SPLIT));
-                ntrips = max (ntrips, (ng_ + KS_SPLIT - 1u) / KS_SPLIT);
-            }
-            for (uint32_t tb = 0; tb < ntrips; tb += KS_DEPTH) {
-                const uint32_t j0 = o + ss + tb * KS_SPLIT, nt = min (KS_DEPTH, ntrips - tb);
-                float4 g[KS_DEPTH], c[KS_DEPTH];
-#pragma unroll
-                for (uint32_t t = 0; t < KS_DEPTH; ++t) {
-                    if (t >= nt) break;
-                    const uint32_t j = min (j0 + t * KS_SPLIT, max (je, 1u) - 1u);
-                    const char *rec = XQb + (j << 5);
-                    g[t] = *reinterpret_cast<const float4 *> (rec); c[t] = *reinterpret_cast<const float4 *> (rec + 16);
-                }
-#pragma unroll
-                for (uint32_t t = 0; t < KS_DEPTH; ++t) {
-                    if (t >= nt) break;
-                    const uint32_t j = min (j0 + t * KS_SPLIT, max (je, 1u) - 1u);      // (no tail test: see k_search)
-                    KS_CAND (g[t], c[t], j);
-                }
-            }
-            if (je == o) { best2 = __builtin_inff (); bj = 0xFFFFFFFFu; }
-        }
-        const float dmin = ks_grp_min_f<KS_SPLIT> (best2);
-        const uint32_t jmin = ks_grp_min_u<KS_SPLIT> (best2 == dmin ? bj : 0xFFFFFFFFu);
-        if (ss == 0u) {
-            const bool empty = (n == 0u);
-            s_qa[qe] = make_float4 (qx, qy, qz, empty ? dr : dmin);
-            s_qb[qe] = make_uint4 (empty ? rstar : ((jmin == 0xFFFFFFFFu) ? o : jmin), rstar, (valid ? 1u : 0u) | (empty ? 2u : 0u), i);
-        }
-        PS_STAMP (2)
-        __syncthreads ();
-        PS_STAMP (3)
-
-        // ---- per-query epilogue by one wave (lane e = query e): winner record, weight, the 18 moment products ----
-        if (slice == 0u) {
-            const float4 qa = s_qa[lane]; const uint4 qb4 = s_qb[lane];
-            const bool v = (qb4.z & 1u) != 0u, empty = (qb4.z & 2u) != 0u;
-            const float ex = qa.x, ey = qa.y, ez = qa.z, d = p.dist_scale * qa.w;
-            float w = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f;
-            uint32_t id = 0u;
-            if (v) {
-                if (empty) {
-                    const float4 nn = R4[2 * (size_t) qb4.x];
-                    id = p.rep_src[(size_t) b * nr + qb4.x]; f0 = nn.x; f1 = nn.y; f2 = nn.z;
-                } else {
-                    const char *rec = XQb + (qb4.x << 5);
-                    const float4 wg = *reinterpret_cast<const float4 *> (rec), wc = *reinterpret_cast<const float4 *> (rec + 16);
-                    f0 = wg.x; f1 = wg.z; f2 = wc.x; id = __float_as_uint (wc.z);
-                }
-                w = p.weighted ? 100.f / (100.f + d) : 1.f;
-            }
-            s_out[0][lane] = make_float4 (f0, f1, f2, w);
-            s_out[1][lane] = make_float4 (ex, ey, ez, d);
-            s_out[2][lane] = make_float4 (__uint_as_float (id), __uint_as_float (qb4.y), __uint_as_float (qb4.w), __uint_as_float (v ? 1u : 0u));
-            double W = (double) w;
-            double g0 = v ? (double) f0 : 0.0, g1 = v ? (double) f1 : 0.0, g2 = v ? (double) f2 : 0.0;
-            double q0 = (double) ex, q1 = (double) ey, q2 = (double) ez;
-            if (!v) { W = 0.0; q0 = q1 = q2 = 0.0; }
-            double wq0 = W * q0, wq1 = W * q1, wq2 = W * q2;
-            s_mom[0][lane] = W;
-            s_mom[1][lane] = W * g0; s_mom[2][lane] = W * g1; s_mom[3][lane] = W * g2;
-            s_mom[4][lane] = wq0; s_mom[5][lane] = wq1; s_mom[6][lane] = wq2;
-            s_mom[7][lane] = wq0 * g0; s_mom[8][lane] = wq0 * g1; s_mom[9][lane] = wq0 * g2;
-            s_mom[10][lane] = wq1 * g0; s_mom[11][lane] = wq1 * g1; s_mom[12][lane] = wq1 * g2;
-            s_mom[13][lane] = wq2 * g0; s_mom[14][lane] = wq2 * g1; s_mom[15][lane] = wq2 * g2;
-            s_mom[16][lane] = W * ((g0 * g0 + g1 * g1) + g2 * g2);
-            s_mom[17][lane] = W * ((q0 * q0 + q1 * q1) + q2 * q2);
-        }
-        PS_STAMP (4)
-        __syncthreads ();
-        PS_STAMP (5)
-
-        // ---- block moments (halving tree over the 64 pairs, one 16-lane row per moment) and their publication ----
-        const uint32_t epoch = epoch0 + it + 1u, par = it & 1u;
-        const uint32_t l = lane & 15u, row = tid >> 4;
-        {
-            const uint32_t k = min (row, (uint32_t) ICP_NMOM - 1u);
-            double c0 = s_mom[k][l] + s_mom[k][l + 32], c1 = s_mom[k][l + 16] + s_mom[k][l + 48];
-            const double v = row_tree_tail_d (c0 + c1);
-            if (l == 0 && row < ICP_NMOM) {
-                // one 16-byte write-through store {low, epoch, high, epoch}: either 8-byte half validates itself, so it does
-                // not matter whether the two halves become visible together
-                const unsigned long long u = __builtin_bit_cast (unsigned long long, v);
-                icp_gu64 *rec = xch + (((size_t) par * ICP_NMOM + row) * 256u + tile_id) * 2u;
-                const icp_u32x4 r4 = { (uint32_t) u, epoch, (uint32_t) (u >> 32), epoch };
-                asm volatile ("global_store_dwordx4 %0, %1, off sc1" :: "v"(rec), "v"(r4) : "memory");
-            }
-            // pacing: a wave starts polling once its own records have reached memory — about when the other blocks' have;
-            // polling earlier only adds a failed 73 KB sweep per block to the traffic the successful one waits behind
-            asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-
-        PS_STAMP (6)
-        // ---- exchange + first tree level: row task (k, g) polls the 128 records of moment k, group g ----
-        if (row < ICP_NMOM * ng) {                   // (wave-uniform up to the last wave: rows of one wave share the branch's outcome per 4)
-            const uint32_t k = (ng == 1) ? row : (row >> 1), g = (ng == 1) ? 0u : (row & 1u);
-            double a[8];
-            uint32_t spins = 0u; bool gave_up = false;
-            for (;;) {
-                bool ok = true;
-                // eight 16-byte agent-scope (sc1: L1-bypassing) loads in flight per lane, one wait (clamped address, the
-                // tail is masked afterwards)
-                // (uniform base + one 32-bit lane offset + immediate offsets: records of blocks past nb exist — every moment has
-                // 256 slots — and are masked below)
-                icp_u32x4 r[8];
-                const uint32_t voff = ((k * 256u) + g * 128u + l) * 16u;
-                const unsigned long long sb_ = (unsigned long long) (xch + (size_t) par * ICP_NMOM * 256u * 2u);        // wave-uniform
-                // (readfirstlane returns a signed int: without the casts the low half would be sign-extended over the high one)
-                const unsigned long long sbase = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane ((int) (uint32_t) (sb_ >> 32)) << 32) |
-                                                 (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane ((int) (uint32_t) sb_);
-                // (hipcc does not model what an asm statement executes: the hazard "VALU writes an SGPR (v_readfirstlane) -> a
-                // vector-memory instruction reads it" needs 5 wait states, supplied by hand)
-                asm volatile ("s_nop 4" :: "s"(sbase) : "memory");
-#define XCH_LD(q, off) asm volatile ("global_load_dwordx4 %0, %1, %2 offset:" #off " sc1" : "=v"(r[q]) : "v"(voff), "s"(sbase) : "memory");
-                XCH_LD (0, 0) XCH_LD (1, 256) XCH_LD (2, 512) XCH_LD (3, 768) XCH_LD (4, 1024) XCH_LD (5, 1280) XCH_LD (6, 1536) XCH_LD (7, 1792)
-#undef XCH_LD
-                asm volatile ("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) :: "memory");
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const uint32_t j = g * 128u + l + 16u * q;
-                    a[q] = 0.0;
-                    if (j < nb) {
-                        ok = ok && r[q].y == epoch && r[q].w == epoch;
-                        a[q] = __builtin_bit_cast (double, (unsigned long long) r[q].x | ((unsigned long long) r[q].z << 32));
-                    }
-                }
-#ifdef ICP_DBG_STAMPS
-                if (spins == 0u) ps_acc[11] += 1ull;                                // (polls of wave 0: ps_acc[11] / iterations)
-                else ps_acc[11] += 1ull;
-#endif
-                if (__builtin_amdgcn_ballot_w64 (!ok) == 0ull) break;              // every lane of the wave has its records
-                if (++spins > ICP_PERSIST_SPIN_LIMIT) { gave_up = true; break; }
-                if ((spins & 127u) == 0u && __hip_atomic_load (xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = true; break; }
-                __builtin_amdgcn_s_sleep (1);
-            }
-            if (gave_up) {
-                if (lane == 0) { s_fault = 1u; __hip_atomic_store (xabort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            } else {
-                double v = row_tree8_d (a);
-                if (nb == 1) v = a[0];
-                if (ng == 2) {
-                    const double o2 = __shfl_down (v, 16);
-                    if (l == 0 && !(row & 1u)) s_t[k] = (v + 0.0) + (o2 + 0.0);
-                } else if (l == 0) s_t[k] = v;
-            }
-        }
-        PS_STAMP (7)
-        __syncthreads ();
-        PS_STAMP (8)
-        if (s_fault) {                               // block-uniform after the barrier: leave the state untouched, flag the run
-            if (tid == 0) st->fault = 1u;
-            return;
-        }
-
-        // ---- wave 0: means / S from the moments, rotation, composition with the carried state, convergence ----
-        if (tid < 64) {
-            // (the moments are read from LDS where they are used: 18 doubles held at once would not fit beside the loop's state)
-            const double sw = s_t[0];
-            double t1[3], t4[3], mf[3], mq[3];
-            const double rs = 1.0 / sw;                  // (oracle orc_moments_finish: one division, fused multiply-adds)
-#pragma unroll
-            for (int a = 0; a < 3; ++a) { t1[a] = s_t[1 + a]; t4[a] = s_t[4 + a]; mf[a] = t1[a] * rs; mq[a] = t4[a] * rs; }
-            const double c2 = (double) p.c * (double) p.c;
-            float S[11], means[8];
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int bb = 0; bb < 3; ++bb) S[3 * a + bb] = (float) (c2 * __builtin_fma (-t4[a], mf[bb], s_t[7 + 3 * a + bb]));
-            S[9]  = (float) (c2 * (s_t[16] - __builtin_fma (t1[2], mf[2], __builtin_fma (t1[1], mf[1], t1[0] * mf[0]))));
-            S[10] = (float) (c2 * (s_t[17] - __builtin_fma (t4[2], mq[2], __builtin_fma (t4[1], mq[1], t4[0] * mq[0]))));
-            means[0] = (float) mf[0]; means[1] = (float) mf[1]; means[2] = (float) mf[2]; means[3] = 0.f;
-            means[4] = (float) mq[0]; means[5] = (float) mq[1]; means[6] = (float) mq[2]; means[7] = 0.f;
-            // The three steps hand their results over through the state in LDS (S and the means now, Tk after the rotation)
-            // and read them back where they are used: kept in registers across the rotation solver they would not fit beside
-            // the loop's own state (one wave: LDS accesses of a wave are in order, no barrier needed).
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) s_state.means[k] = means[k];
-#pragma unroll
-                for (int k = 0; k < 11; ++k) s_state.S[k] = S[k];
-                s_state.sum_w = sw;
-            }
-            asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
-            float Tk[8], Rk[9], Rkin[9];
-            int iters = 0;
-            if constexpr (ROT == 1) iters = icp_power_method_quad (s_state.S, s_state.means, Tk, p.power_mode, lane);
-            else icp_svd_rotation (s_state.S, s_state.means, Rkin, Tk);
-            float Tprev[8], Rprev[9];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) Tprev[k] = s_state.T[k];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Rprev[k] = s_state.R[k];
-            const uint32_t kprev = s_state.k;
-            float Tn[8], Rn[9];
-            icp_compose_pure (Tprev, Rprev, Tk, Rkin, ROT != 1, Tn, Rn, Rk);
-            const uint32_t dn = (check && icp_check_converged (Tk, p.tan_half_thr, p.trans_thr)) ? 1u : 0u;
-            if (lane == 0) {                         // (every read of the old state above precedes these writes in program order)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { s_state.T[k] = Tn[k]; s_state.Tk[k] = Tk[k]; }
-#pragma unroll
-                for (int k = 0; k < 9; ++k) { s_state.R[k] = Rn[k]; s_state.Rk[k] = Rk[k]; }
-                s_state.pm_iters = (uint32_t) iters; s_state.k = kprev + 1u; s_state.pad0 = 0.f; s_state.pending = 0u;
-                s_state.epoch = epoch; s_state.done = dn;          // (fault: sticky, only the host clears it)
-            }
-        }
-        PS_STAMP (9)
-        __syncthreads ();
-        PS_STAMP (10)
-        if (check && s_state.done) { ++it; break; }
-    }
-#ifdef ICP_DBG_STAMPS
-    if (tid == 0 && p.dbg)
-        for (int k = 0; k < 12; ++k) p.dbg[(size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 16 + k] = ps_acc[k];
-#endif
-
-    // ---- epilogue: the per-query outputs of the last executed iteration, the state ----
-    if (it == 0u) return;                            // (iterations == 0)
-    if (slice == 0u) {                               // (the finishing wave wrote s_out itself: program order)
-        const float4 pf = s_out[0][lane], pm = s_out[1][lane], ids = s_out[2][lane];
-        if (__float_as_uint (ids.w)) {
-            const uint32_t ei = __float_as_uint (ids.z);
-            icp_dist_id di; di.dist = pm.w; di.id = __float_as_uint (ids.x);
-            char *o_nn = reinterpret_cast<char *> (p.nn_id + (size_t) b * m), *o_pf = reinterpret_cast<char *> (p.PF + (size_t) b * m);
-            char *o_pm = reinterpret_cast<char *> (p.PM + (size_t) b * m), *o_r = reinterpret_cast<char *> (p.rid + (size_t) b * m);
-            *reinterpret_cast<icp_dist_id *> (o_nn + (ei << 3)) = di;
-            *reinterpret_cast<float4 *> (o_pf + (ei << 4)) = pf;
-            *reinterpret_cast<float4 *> (o_pm + (ei << 4)) = pm;
-            *reinterpret_cast<uint32_t *> (o_r + (ei << 2)) = __float_as_uint (ids.y);
-        }
-    }
-    if (blockIdx.x == 0 && tid < sizeof (icp_reg_state) / 4) reinterpret_cast<uint32_t *> (st)[tid] = reinterpret_cast<const uint32_t *> (&s_state)[tid];
-}
-
-// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 static inline uint32_t icp_tpr_magic (uint32_t side)
@@ -2323,6 +1948,12 @@ void icp_launch_get_lms (const float *cloud, float *lms, hipStream_t s)
 {
     hipLaunchKernelGGL (k_get_lms, dim3 (16384 * 2 / 256), dim3 (256), 0, s,
                         reinterpret_cast<const float4 *> (cloud), reinterpret_cast<float4 *> (lms));
+}
+
+void icp_launch_get_lms_band (const float *band, float *lms, hipStream_t s)
+{
+    hipLaunchKernelGGL (k_get_lms_band, dim3 (16384 * 2 / 256), dim3 (256), 0, s,
+                        reinterpret_cast<const float4 *> (band), reinterpret_cast<float4 *> (lms));
 }
 
 void icp_launch_transform_cloud (const float *in, float *out, const icp_reg_state *st, uint32_t n, hipStream_t s)
@@ -2501,38 +2132,6 @@ void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations,
     p.slot = iterations & 1u;
     if (p.rot == 1) hipLaunchKernelGGL (k_chain_end<1>, dim3 (p.batch), dim3 (320), 0, s, p);
     else hipLaunchKernelGGL (k_chain_end<0>, dim3 (p.batch), dim3 (320), 0, s, p);
-}
-
-// persistent run: the whole run is one launch.  Needs every block of the grid resident at once: at most one 1024-thread
-// block per CU (the kernel's registers and LDS allow exactly one), single-tile representative sets, two tree groups.
-size_t icp_xch_bytes (uint32_t batch) { return (size_t) batch * 2 * ICP_NMOM * 256 * 16 + 16; }
-
-bool icp_persistent_supported (const icp_params &p)
-{
-    return p.persistent && p.fused && p.xch && !icp_dense (p) && p.nr <= KS_TILE && p.nb <= 256u && (size_t) p.batch * p.nb <= p.ncu;
-}
-
-void icp_launch_persistent (const icp_params &p, hipStream_t s, uint32_t iterations)
-{
-    if (iterations == 0) return;
-    if (p.rot == 1) hipLaunchKernelGGL (k_run_persistent<1>, dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, p.xch,
-                                        p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, iterations, (uint32_t) (p.check ? 1 : 0), p);
-    else hipLaunchKernelGGL (k_run_persistent<0>, dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, p.xch,
-                             p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, iterations, (uint32_t) (p.check ? 1 : 0), p);
-}
-
-// after an aborted persistent run: exchange records, abort word, epochs and fault flags back to their initial state
-__global__ void k_clear_fault (icp_params p)
-{
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < p.batch) { p.st[b].fault = 0u; p.st[b].epoch = 0u; }
-}
-__global__ void k_inject_fault (icp_params p) { if (threadIdx.x == 0 && blockIdx.x == 0) p.st[0].fault = 1u; }
-void icp_launch_inject_fault (const icp_params &p, hipStream_t s) { hipLaunchKernelGGL (k_inject_fault, dim3 (1), dim3 (64), 0, s, p); }
-void icp_launch_clear_fault (const icp_params &p, hipStream_t s)
-{
-    (void) hipMemsetAsync (p.xch, 0, icp_xch_bytes (p.batch), s);
-    hipLaunchKernelGGL (k_clear_fault, dim3 ((p.batch + 63) / 64), dim3 (64), 0, s, p);
 }
 
 void icp_launch_iteration (const icp_params &p, hipStream_t s)

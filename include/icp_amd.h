@@ -209,15 +209,28 @@ int icp_write_cloud (icp_handle h, int which, const void *host_cloud_640x480x8, 
 int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint32_t n);
 
 /* Frame-to-frame tracking — README.md:4 ("real-time frame-to-frame registration"); per pair the demo's flow
- * src/ocl_icp_reg.cpp:128-172 (init: getLMs of both clouds; registerPC: buildRBC + run).  Feeds the next 640x480 float8
- * frame of a sequence: its landmarks are extracted on the device into the moving set (ONE upload of 9.8 MB per frame);
- * the previous frame's landmarks, already resident, become the fixed set by a pointer swap (no copy, no host trip);
- * then buildRBC and ICP::run.  warm_start != 0: the registration starts from the previous hop's transform (written
- * back as by icp_write (ICP_MEM_T): the rotation state is re-derived from it) instead of the identity.
- * *registered = 0 for the first frame after icp_init / icp_track_reset (nothing to register against; *k = 0), else 1
- * and *k = iterations executed; afterwards T (icp_read, icp_state) maps the new frame onto the previous one.
- * m must be 16384 (getLMs), batch 1.  Blocking (the source is pageable host memory). */
+ * src/ocl_icp_reg.cpp:128-172 (init: getLMs of both clouds; registerPC: buildRBC + run).  Frames of a sequence are fed one by
+ * one (640x480 float8 each); frame f is registered against frame f - 1, whose landmarks are already resident: they become the
+ * fixed set by a rotation of three landmark buffers (no copy, no host trip).  Only the band of a frame that getLMs reads
+ * (128 rows x 509 pixels = 2.08 MB of the 9.83 MB) is uploaded; the landmarks are extracted on the device (kernels/icp_kernels.cl:63-76).
+ *
+ * icp_track_submit   enqueue only: upload + getLMs on a copy stream, then buildRBC + ICP::run as ONE graph on the handle's
+ *                    stream; up to four frames may be in flight, so frame f + 1 is uploaded while frame f registers.
+ *                    warm_start != 0: the registration starts from the previous hop's transform (written back as by
+ *                    icp_write (ICP_MEM_T): the rotation state is re-derived from it) instead of the identity.
+ *                    `cloud` may be pageable host memory (the band is copied into pinned staging by the calling thread) or one
+ *                    of the engine's two pinned frame buffers (icp_track_staging: the band goes by DMA straight from there —
+ *                    the reference's mapped staging buffers hPtrInF / hPtrInM, src/ICP/algorithms.cpp:4438-4475; a buffer
+ *                    may be refilled once its frame has been collected).
+ * icp_track_collect  blocks until the oldest frame in flight is done: *registered = 0 for the first frame after icp_init /
+ *                    icp_track_reset (nothing to register against; *k = 0, T8 = identity), else 1, *k = iterations executed and
+ *                    T8 = [q | t, s] mapping that frame onto the previous one.  Any output pointer may be NULL.
+ * icp_track_next     submit + collect (blocking): afterwards T (icp_read, icp_state) maps the new frame onto the previous one.
+ * m must be 16384 (getLMs), batch 1, and the handle's own F / M buffers (not adopted ones). */
 int icp_track_next (icp_handle h, const void *host_cloud_640x480x8, int warm_start, uint32_t *k, int *registered);
+int icp_track_submit (icp_handle h, const void *host_cloud_640x480x8, int warm_start);
+int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered);
+int icp_track_staging (icp_handle h, uint32_t slot /* 0 | 1 */, void **pinned_host_frame);
 int icp_track_reset (icp_handle h);
 
 /* ICPTransform<QUATERNION> / ICPTransform<MATRIX> with an explicit transformation — include/ICP/algorithms.hpp:1189-1211,
@@ -314,25 +327,19 @@ int icp_profile_run (icp_handle h, uint32_t iterations, float *out_ms, float *to
 int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4);
 
 /* Kernel launches per iteration of the graphs behind icp_run / icp_run_fixed with the current modes and sizes:
- * 4 (reference-order reductions), 2 (fused: search + finalize; 3 beyond |F| = 131072, where the first level of the
- * moment tree is a launch of its own) or 1 (fused, latency-bound sizes: at most one launch per iteration — chained or
- * persistent, see icp_run_form). */
+ * 4 (reference-order reductions), 2 (fused: search + finalize; 3 beyond |F| = 16384, where the first level of the
+ * moment tree is a launch of its own) or 1 (fused, latency-bound sizes: chained, see icp_run_form). */
 int icp_launches_per_iteration (icp_handle h, uint32_t *n);
 
 /* How icp_run / icp_run_fixed execute with the current modes and sizes:
  *   SEPARATE    one launch per stage (2 fused, 4 reference order);
  *   CHAINED     fused, one launch per iteration: the finalize of iteration k runs in the prologue of the search of
  *               iteration k+1 (latency-bound sizes; ICP_AMD_CHAIN=0 / 1 at icp_create forces it off / on);
- *   PERSISTENT  fused, ONE launch per run: representatives in LDS and the moving points in registers for all iterations,
- *               the per-iteration moment exchange between the blocks in-launch (agent-scope tagged records), convergence
- *               ends the loop in place.  Needs the whole grid resident: |F| / 64 x batch <= number of CUs, |R| <= 1024; one
- *               handle per device at a time holds the right to it (the first that runs; released by re-init / destroy).
- *               OPT-IN (ICP_AMD_PERSISTENT=1 at icp_create): on MI355X the in-launch exchange costs more than the launch
- *               boundaries it removes (10.7 against 9.8 us per iteration at |F| = 16384), so the default is
- *               CHAINED.  A run whose blocks turn out not to be co-resident gives up after a bounded wait, leaves the
- *               state untouched and is repeated on the chained path.
- * Same bits in all three forms. */
-typedef enum { ICP_FORM_SEPARATE = 0, ICP_FORM_CHAINED = 1, ICP_FORM_PERSISTENT = 2 } icp_run_form_t;
+ *   (a third form — one persistent launch per run, the per-iteration moment exchange between the blocks in-launch — was built and
+ *   measured in round 2: 10.7 against 9.8 us per iteration at |F| = 16384, the all-to-all seam costs more than the launch boundary
+ *   it replaces; retired in round 3)
+ * Same bits in both forms. */
+typedef enum { ICP_FORM_SEPARATE = 0, ICP_FORM_CHAINED = 1 } icp_run_form_t;
 int icp_run_form (icp_handle h, int *form);
 /* Diagnostic: how the search kernel behind the current modes and sizes is laid out.
  *   *dense   0: the latency variant (one 1024-thread block per CU, 16 lanes per query: a single small registration);
@@ -343,10 +350,6 @@ int icp_run_form (icp_handle h, int *form);
  *            icp_init forces it off / on).
  * Same bits in every layout.  Any output pointer may be NULL. */
 int icp_search_layout (icp_handle h, int *dense, int *tile, int *stage2);
-
-/* Test hook: marks the registration as a persistent run does when it gives up waiting (fault raised, state untouched);
- * the next blocking call repeats the last run on the chained path and switches persistent runs off for the handle. */
-int icp_debug_inject_fault (icp_handle h);
 
 /* Diagnostic: a graph of `iterations` x (the kernels selected by mask: bit 0 search, 1 means, 2 sij,
  * 3 finalize, 4 an empty 256-block kernel), launched `reps` times; *ms_total = elapsed ms. */

@@ -479,3 +479,46 @@ def test_resident_reduce_scan_objects_and_timing(engine, oracle):
     assert 0 < us_sum < 44 and 0 < us_min < 45 and 0 < us_scan < 151
     with pytest.raises(engine.ICPError):
         engine.ReduceScan(engine.ReduceConfig.SUM, 6, 2)
+
+
+@pytest.mark.parametrize("warm,pinned", [(False, False), (True, False), (True, True)])
+def test_tracking_pipelined_equals_oracle(engine, oracle, warm, pinned):
+    """icp_track_submit / icp_track_collect with two frames in flight (frame f + 1 is uploaded and its landmarks extracted on the
+    copy stream while frame f registers; three landmark buffers in rotation; only the band of a frame that getLMs reads is
+    uploaded): every hop's k and T equal the oracle's bit for bit over a 7-frame sequence that revisits frames — pageable
+    sources and the engine's pinned frame buffers —, and equal what the blocking icp_track_next gives."""
+    clouds = [engine.synth_cloud_vga(moved=f) for f in range(4)]
+    order = [0, 1, 2, 3, 2, 1, 0]
+    lms = [oracle.get_lms(c) for c in clouds]
+    g = engine.ICP(0)
+    g.init(16384, 256, 2e2, 1e-6)
+    res = g.track_pipelined([clouds[i] for i in order], warm_start=warm, depth=2, pinned=pinned)
+    assert res[0] is None and len(res) == len(order)
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+    for i in range(1, len(order)):
+        o.write_f(lms[order[i - 1]]); o.write_m(lms[order[i]])
+        o.write_t(o.T if (warm and i > 1) else [0, 0, 0, 1, 0, 0, 0, 1])
+        o.build_rbc()
+        ko = o.run()
+        k, T = res[i]
+        assert k == ko, (i, k, ko)
+        assert np.array_equal(T.view(np.uint32), o.T.view(np.uint32)), i
+    # the handle's state is the last hop's; F / M are what the last registration used
+    assert np.array_equal(g.read(engine.Memory.T).view(np.uint32), o.T.view(np.uint32))
+    assert np.array_equal(g.read(engine.Memory.F), lms[order[-2]]) and np.array_equal(g.read(engine.Memory.M), lms[order[-1]])
+    assert np.array_equal(g.read(engine.Memory.NN_ID)["id"], o.nn_id["id"])
+    # the blocking form continues the sequence (same rotation, same buffers)
+    k = g.track_next(clouds[1], warm)
+    o.write_f(lms[0]); o.write_m(lms[1]); o.write_t(o.T if warm else [0, 0, 0, 1, 0, 0, 0, 1]); o.build_rbc()
+    assert k == o.run() and np.array_equal(g.read(engine.Memory.T).view(np.uint32), o.T.view(np.uint32))
+    # more than four uncollected frames are refused; collecting with nothing in flight too
+    g.track_reset()
+    for i in range(4):
+        g.track_submit(clouds[i % 4], warm)
+    with pytest.raises(engine.ICPError):
+        g.track_submit(clouds[0], warm)
+    for i in range(4):
+        g.track_collect()
+    with pytest.raises(engine.ICPError):
+        g.track_collect()
+    g.close()

@@ -445,7 +445,7 @@ def test_fused_chain_fixed_run_and_limits(engine, oracle):
 
 def test_chain_is_automatic_only_for_latency_bound_sizes(engine, monkeypatch):
     monkeypatch.delenv("ICP_AMD_CHAIN", raising=False)
-    for side, nr, batch, fused, want in ((128, 256, 1, True, 1), (128, 256, 4, True, 2), (256, 1024, 1, True, 2),
+    for side, nr, batch, fused, want in ((128, 256, 1, True, 1), (128, 256, 4, True, 2), (256, 1024, 1, True, 3),
                                          (128, 256, 1, False, 4), (64, 64, 8, True, 1), (64, 64, 9, True, 2)):
         g = engine.ICP(0)
         g.init(side * side, nr, A, C_, batch=batch)
@@ -720,120 +720,6 @@ def test_metric_absolute_scale(engine, oracle, fused):
     g.close(); g1.close()
 
 
-@pytest.mark.parametrize("side,nr,batch", [(128, 256, 1), (64, 64, 1), (64, 64, 4), (32, 16, 3), (96, 64, 1), (10, 4, 2), (128, 512, 1)])
-def test_persistent_run_equals_chain_and_oracle(engine, oracle, monkeypatch, side, nr, batch):
-    """One launch per run (icp_run_form == PERSISTENT: whole grid co-resident, in-launch moment exchange): run() to
-    convergence, fixed runs of odd and even length and continued runs give the bits of the oracle, i.e. of the chained
-    and two-launch forms; also with several registrations in the grid, one and two tree groups (|F| / 64 <= 128 / > 128),
-    partially filled blocks and the largest single-tile representative set."""
-    monkeypatch.setenv("ICP_AMD_PERSISTENT", "1")    # opt-in (read at icp_create): the chain is faster on MI355X, DESIGN.md §5
-    m = side * side
-    g = engine.ICP(0)
-    g.init(m, nr, A, C_, batch=batch)
-    assert g.run_form() == 2 and g.launches_per_iteration() == 1
-    oracles = []
-    for b in range(batch):
-        F, M = engine.synth_pair(side, seed=0x51 + 3 * b, rot_deg=1.5 + b)
-        g.write(engine.Memory.F, F, batch_index=b)
-        g.write(engine.Memory.M, M, batch_index=b)
-        o = oracle.OracleICP(m, nr, A, C_, threads=8, power_fast=True, fused=True)
-        o.write_f(F); o.write_m(M); o.build_rbc()
-        oracles.append(o)
-    g.buildRBC()
-
-    def compare(tag):
-        for b, o in enumerate(oracles):
-            st = g.state(b)
-            assert st.k == o.k, (tag, b, st.k, o.k)
-            if "run" in tag:                              # (fixed runs and single steps do not evaluate ICP::check)
-                assert bool(st.converged) == o.converged, (tag, b)
-            assert_bits(g.read(engine.Memory.T, b), o.T, "T %s/%d" % (tag, b))
-            assert_bits(g.read(engine.Memory.S, b), o.S, "S %s/%d" % (tag, b))
-            gn = g.read(engine.Memory.NN_ID, b)
-            assert np.array_equal(gn["id"], o.nn_id["id"]), (tag, b)
-            assert_bits(gn["dist"], o.nn_id["dist"], "dist %s/%d" % (tag, b))
-            assert np.array_equal(g.read(engine.Memory.RID, b), o.rid), (tag, b)
-            assert_bits(g.read(engine.Memory.W, b), o.W, "weights %s/%d" % (tag, b))
-
-    g.run()
-    for o in oracles:
-        o.run()
-    compare("run")
-    for n in (1, 2, 7):                               # continued fixed runs: odd / even lengths, epochs carry on
-        g.run_fixed(n)
-        for o in oracles:
-            for _ in range(n):
-                o.step()
-        compare("fixed %d" % n)
-    g.reset_transform()
-    g.buildRBC()
-    for o in oracles:
-        o.write_t([0, 0, 0, 1, 0, 0, 0, 1]); o.build_rbc()
-    g.run()
-    for o in oracles:
-        o.run()
-    compare("second run")
-    g.step()                                          # the separate launches continue from the persistent run's state
-    for o in oracles:
-        o.step()
-    compare("step")
-    g.close()
-
-
-def test_persistent_right_is_exclusive_and_switchable(engine, oracle, monkeypatch):
-    """One handle per device runs persistently (two such grids could starve each other); the others chain.  The right is
-    taken by the first run and released by close().  Without ICP_AMD_PERSISTENT=1 the form is off."""
-    monkeypatch.setenv("ICP_AMD_PERSISTENT", "1")
-    F, M = engine.synth_pair(64)
-    a, b = engine.ICP(0), engine.ICP(0)
-    for x in (a, b):
-        x.init(4096, 64, A, C_)
-        x.write(engine.Memory.F, F); x.write(engine.Memory.M, M); x.buildRBC()
-    assert a.run_form() == 2 and b.run_form() == 2           # nobody holds the right yet
-    ka = a.run()
-    assert a.run_form() == 2 and b.run_form() == 1           # a took it: b chains
-    kb = b.run()
-    assert ka == kb
-    assert_bits(a.read(engine.Memory.T), b.read(engine.Memory.T), "persistent vs chained")
-    a.close()
-    assert b.run_form() == 2                                   # released
-    b.close()
-    monkeypatch.delenv("ICP_AMD_PERSISTENT", raising=False)
-    c = engine.ICP(0)
-    c.init(4096, 64, A, C_)
-    assert c.run_form() == 1
-    c.close()
-
-
-def test_persistent_fault_falls_back_to_the_chain(engine, oracle, monkeypatch):
-    """A persistent run that gives up (blocks not co-resident) raises `fault` and leaves the state untouched; the next
-    blocking call repeats the run on the chained path.  Simulated with the test hook that raises the flag."""
-    monkeypatch.setenv("ICP_AMD_PERSISTENT", "1")
-    g, o, F, M = make(engine, oracle, 64, 64, power_fast=True, fused=True)
-    g.buildRBC(); o.build_rbc()
-    assert g.run_form() == 2
-    g._chk(g._L.icp_debug_inject_fault(g._h))
-    assert g.run() == o.run()                                  # run() settles: fault seen, repeated chained
-    assert g.run_form() == 1                                   # persistent runs are off for this handle now
-    assert_bits(g.read(engine.Memory.T), o.T, "T after the fallback")
-    check_step(engine, g, o, weighted=False)
-    g.run_fixed(3)
-    for _ in range(3):
-        o.step()
-    check_step(engine, g, o, weighted=False)
-    # asynchronous form: run_fixed, then a read notices the fault and repeats it
-    g2, o2, _, _ = make(engine, oracle, 64, 64, power_fast=True, fused=True)
-    g2.buildRBC(); o2.build_rbc()
-    g2.sync()
-    g2._chk(g2._L.icp_debug_inject_fault(g2._h))
-    g2.run_fixed(5)
-    for _ in range(5):
-        o2.step()
-    assert_bits(g2.read(engine.Memory.T), o2.T, "T after the asynchronous fallback")
-    assert g2.k == 5
-    g.close(); g2.close()
-
-
 def test_fused_large_set_first_tree_level_kernel(engine, oracle):
     """|F| = |M| = 262144 (4096 blocks, 32 tree groups > ICP_L1_MIN_GROUPS): the first level of the moment tree runs as a
     kernel of its own (k_moment_level1) in front of k_finalize_fused — same tree, same bits as the oracle."""
@@ -1017,7 +903,7 @@ def test_config_B_default_modes_run_fixture_and_oracle(engine, oracle):
     F, M = engine.synth_pair(side)
     g = engine.ICP(0)
     g.init(m, nr, W.A, W.C_)
-    assert g.search_layout()[:2] == (1, 256) and g.launches_per_iteration() == 2
+    assert g.search_layout()[:2] == (1, 256) and g.launches_per_iteration() == 3      # search, first tree level, finalize
     g.write(engine.Memory.F, F)
     g.write(engine.Memory.M, M)
     g.buildRBC()

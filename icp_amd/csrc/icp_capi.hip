@@ -330,6 +330,10 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     p.dist_scale = dist_scale;
     p.m = m; p.nr = nr; p.batch = batch; p.side = side; p.nrx = nrx; p.nry = nry;
     p.a = a; p.c = c;
+    {   // division-free cell lookups in the kernels (reps_grid guarantees a square grid that the representative grid tiles)
+        auto magic = [] (uint32_t d) { return d > 1u ? (uint32_t) ((1ull << 32) / d + 1ull) : 0u; };
+        p.side_magic = magic (side); p.cellw_magic = magic (side / nrx); p.cellh_magic = magic (side / nry);
+    }
     h->max_iterations = max_iterations; h->angle_threshold = angle_threshold; h->translation_threshold = translation_threshold;
     p.tan_half_thr = std::tan (angle_threshold * M_PI / 360.0);
     p.trans_thr = translation_threshold;

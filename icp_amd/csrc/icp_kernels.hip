@@ -569,6 +569,13 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
 #endif
 
 typedef float float2v __attribute__ ((ext_vector_type (2)));
+// MASKED search, home tile (see k_search): 1 = staged into LDS in the prologue (seed from LDS); 2 = loads issued in the prologue, LDS
+// write after the tile masks (seed from global: the tile's round trip overlaps the seed's); 3 = no home tile (only its list offsets).
+// Same box, alternating, us per iteration of fresh 40-iteration runs at |F| = 65536 / 10-iteration runs at 2^20 (profiles/
+// r03_home_tile_ab.txt): without the home tile 18.62 / 263.8, mode 1 17.90 / 258.8, mode 2 18.18 / 258.7, mode 3 18.79 / 261.6.
+#ifndef ICP_HOME_MODE
+#define ICP_HOME_MODE 1
+#endif
 
 #ifdef ICP_DBG_STAMPS
 #define KS_STAMP(k)                                                                                       \
@@ -652,6 +659,14 @@ static __device__ __forceinline__ uint32_t fused_query_index (uint32_t m, uint32
     return (side && (side & 7u) == 0u && side * side == m) ? tiled : b * 64u + e;
 }
 
+
+// Representative sampled from the grid cell of point i (getReps' grid: cells of (side / nrx) x (side / nry) points), without a
+// division: the magics are floor (2^32 / d) + 1 for d = side, side / nrx, side / nry (host: icp_div_magic; exact for n d < 2^32).
+static __device__ __forceinline__ uint32_t cell_rep_of (const icp_params &p, uint32_t i)
+{
+    const uint32_t y = __umulhi (i, p.side_magic), x = i - y * p.side;
+    return (p.cellh_magic ? __umulhi (y, p.cellh_magic) : y) * p.nrx + (p.cellw_magic ? __umulhi (x, p.cellw_magic) : x);      // (magic 0: cells of one point)
+}
 
 // Result of turning one iteration's moments into the next transform: the registration state itself, staged
 // in LDS (one per block) so that one wave publishes it with a single store
@@ -902,10 +917,17 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
 
     // representatives of the current tile, pair-interleaved for packed fp32 math:
     //   pair P = reps (2P, 2P+1) -> 3 float4: [x0 x1 y0 y1] [z0 z1 r0 r1] [g0 g1 b0 b1]
-    __shared__ float4 s_pair[3 * KT / 2];
-    __shared__ uint2 s_on[MASKED ? 1 : KT];     // (offset, size) of every representative's list (several tiles: read from global)
+    // MASKED keeps TWO tile buffers: buffer 1 holds the block's HOME tile — the tile of the representative sampled from the grid cell
+    // of the block's first query —, staged in the prologue with everything else that does not depend on T; buffer 0 is for the other
+    // tiles the block turns out to need.  A block's 64 neighbouring queries mostly need the home tile alone: then nothing is fetched
+    // between the tile masks and the scan, the seed representative and the winner's (offset, size) come from LDS too — three dependent
+    // memory round trips fewer on a path that is a chain of them (|F| = 65536: one wave of 1024 blocks, latency-bound; stamps in
+    // profiles/r03_stamps_dense.txt).
+    constexpr uint32_t NBUF = MASKED ? 2u : 1u, PB = 3u * KT / 2u, BB = 2u * (KT / 16u);
+    __shared__ float4 s_pair[NBUF * PB];
+    __shared__ uint2 s_on[(MASKED && OWNER) ? 1 : KT];            // (offset, size) of the lists of the tile's representatives (MASKED: of the home tile's)
     __shared__ uint32_t s_tmask;                     // MASKED: tiles some query of the block needs
-    __shared__ float4 s_box[2 * (KT / 16)];     // (lo, hi) of the tile's groups of 2 * LPQ representatives
+    __shared__ float4 s_box[NBUF * BB];              // (lo, hi) of the tile's groups of 2 * LPQ representatives
     __shared__ float4 s_tbox[(MINW == 4 && !SINGLE) ? 2 * 32 : 2];      // (lo, hi) of every tile (multi-tile sets: |R| <= 32768)
     __shared__ float s_w[64];
     __shared__ float4 s_qc[64];                      // query hand-in: (r, g, b, pruning seed); s_qa carries (q', index)
@@ -968,9 +990,11 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     float *s_pairf = reinterpret_cast<float *> (s_pair);
     const uint32_t tn0 = min (KT, nr);
     float4 rg[2], rc[2]; uint2 ron[2];
+    uint32_t ht = 0u, tnH = 0u;                      // MASKED: home tile of the block and its size (block-uniform)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         uint32_t k = tid + (uint32_t) u * 64u * KS_SPLIT;
+        if (MASKED && u == 0) continue;
         rg[u] = make_float4 (0.f, 0.f, 0.f, 0.f); rc[u] = rg[u];
         if constexpr (OWNER_LISTS) {
             if (k < tn0) {
@@ -987,6 +1011,12 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     const uint32_t ic = min (iq, m - 1u);
     float4 mg = make_float4 (0.f, 0.f, 0.f, 1.f), mc = mg;
     if (qwave) { mg = M4[2 * (size_t) ic]; mc = M4[2 * (size_t) ic + 1]; }
+    if constexpr (MASKED) {                          // the home tile: of the cell of the block's first query (block-uniform; no division)
+        const uint32_t i0 = (uint32_t) __builtin_amdgcn_readfirstlane ((int) min (FUSED ? fused_query_index (m, side, tpr_magic, tile_id, 0u) : (blockIdx.x >> 1) * 128u + (blockIdx.x & 1u), m - 1u));
+        const uint32_t cell = p.side_magic ? cell_rep_of (p, i0) : 0u;
+        ht = min (cell, nr - 1u) / KT; tnH = min (KT, nr - ht * KT);
+        if (ICP_HOME_MODE != 3 && tid < tnH) { rg[0] = R4[2 * (size_t) (ht * KT + tid)]; rc[0] = R4[2 * (size_t) (ht * KT + tid) + 1]; }
+    }
     // (list offsets / sizes: their base pointers come with the second batch of kernel arguments)
     const uint32_t *gO = p.O + (size_t) b * nr, *gN = p.N + (size_t) b * nr;
 #pragma unroll
@@ -994,6 +1024,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         uint32_t k = tid + (uint32_t) u * 64u * KS_SPLIT;
         ron[u] = make_uint2 (0u, 0u);
         if (!OWNER && !MASKED && k < tn0) ron[u] = make_uint2 (gO[k], gN[k]);
+        if (!OWNER && MASKED && u == 0 && tid < tnH) ron[0] = make_uint2 (gO[ht * KT + tid], gN[ht * KT + tid]);
     }
     // seed of the stage-1 pruning bound: this query's nearest representative of the previous search (any index < nr
     // is a valid seed; the buffer starts zeroed)
@@ -1009,10 +1040,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // sampled from the query's own grid cell — a moving frame starts near the fixed one (frame-to-frame registration).
     // check_flags bit 5 (ICP_AMD_WARM_SEED=1, diagnostics): always the previous search's answer.
     uint32_t seed = 0u, seed_cell = 0xFFFFFFFFu;
-    if (qwave && prune && side && side * side == m && p.nrx && p.nry) {     // the representative sampled from the point's own cell
-        const uint32_t y = ic / side, x = ic - y * side;
-        seed_cell = (y / (side / p.nry)) * p.nrx + x / (side / p.nrx);
-    }
+    if (qwave && prune && p.side_magic) seed_cell = cell_rep_of (p, ic);     // the representative sampled from the point's own cell
     if constexpr (OWNER) seed = seed_cell == 0xFFFFFFFFu ? 0u : seed_cell;
     else if (qwave && prune) {
         seed = p.rid[(size_t) b * m + ic];           // (selected against seed_cell below, once the state has arrived)
@@ -1023,6 +1051,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     const uint32_t nbox0 = 2u * ((tn0 + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
     float4 boxv = make_float4 (0.f, 0.f, 0.f, 0.f);
     if (!MASKED && prune && tid < nbox0) boxv = GBt[tid];
+    const uint32_t nboxH = 2u * ((tnH + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
+    if (MASKED && ICP_HOME_MODE != 3 && prune && tid < nboxH) boxv = GBt[2u * (ht * KT / (2u * KS_SPLIT)) + tid];
     float T[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) T[k] = state_lane_f (sv, ICP_ST_DW (T) + k);
@@ -1051,6 +1081,17 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         }
     }
     if (!MASKED && prune && tid < nbox0) s_box[tid] = boxv;
+    auto home_to_lds = [&] () {                      // the home tile -> buffer 1
+        if (tid < tnH) {
+            float *dst = s_pairf + PB * 4u + (tid >> 1) * 12u + (tid & 1u);
+            dst[0] = rg[0].x; dst[2] = rg[0].y; dst[4] = rg[0].z; dst[6] = rc[0].x; dst[8] = rc[0].y; dst[10] = rc[0].z;
+        }
+        if (prune && tid < nboxH) s_box[BB + tid] = boxv;
+    };
+    if constexpr (MASKED) {
+        if (ICP_HOME_MODE == 1) home_to_lds ();
+        if constexpr (!OWNER) { if (tid < tnH) s_on[tid] = ron[0]; }
+    }
     if (MASKED && tid == 0) s_tmask = 0u;
     if constexpr (MINW == 4 && !SINGLE) {            // the boxes of all tiles: a tile is tested before it is staged (stage 1 below)
         if (prune && nr > KT && tid < 2u * p.n1k) s_tbox[tid] = p.GB[(size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + tid];
@@ -1092,11 +1133,11 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // group (ss, ss + LPQ, ..) may hold a representative nearer than `lim`.  The lower bound applies the metric's own
     // operations to the per-axis distances to the group's bounding box; every operation is monotone under
     // round-to-nearest, so bound <= geo <= d for every member, and a group whose bound is not below `lim` cannot hold the winner.
-    auto coarse_pass = [&] (uint32_t tn_, float lim_) -> uint32_t {
+    auto coarse_pass = [&] (uint32_t tn_, float lim_, uint32_t hb_ = 0u) -> uint32_t {
         const uint32_t ngt = (((tn_ + 1u) >> 1) + KS_SPLIT - 1u) / KS_SPLIT;
         uint32_t cm = 0u;
         auto test = [&] (uint32_t t, uint32_t g) {
-            const float4 lo = s_box[2 * g], hi = s_box[2 * g + 1];
+            const float4 lo = s_box[hb_ * BB + 2 * g], hi = s_box[hb_ * BB + 2 * g + 1];
             const float ex = fmaxf (fmaxf (lo.x - qx, qx - hi.x), 0.f);
             const float ey = fmaxf (fmaxf (lo.y - qy, qy - hi.y), 0.f);
             const float ez = fmaxf (fmaxf (lo.z - qz, qz - hi.z), 0.f);
@@ -1112,7 +1153,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     };
     // fine pass of the pruning over the tile in LDS (first representative t0_, npair_ pairs): the groups whose bit is set in
     // cmask_ for some query of the wave, full evaluation.
-    auto fine_pass = [&] (uint32_t t0_, uint32_t npair_, uint32_t cmask_) {
+    auto fine_pass = [&] (uint32_t t0_, uint32_t npair_, uint32_t cmask_, uint32_t hb_ = 0u) {
         const uint32_t ngt_ = (npair_ + KS_SPLIT - 1u) / KS_SPLIT;
         const float2v vqx = { qx, qx }, vqy = { qy, qy }, vqz = { qz, qz }, vqr = { qr, qr }, vqg = { qg, qg }, vqb = { qb, qb };
         const float2v va = { alpha, alpha };
@@ -1137,7 +1178,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
                 const uint32_t P = (KS_SPLIT == 8 && gt_lg1) ? (((4u * (gl >> (gt_lg1 - 1u)) + (ss >> 1)) << gt_lg1) + 2u * (gl & ((1u << (gt_lg1 - 1u)) - 1u)) + (ss & 1u))
                                                               : gl * KS_SPLIT + ss;
                 if (P < npair_) {
-                    float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];
+                    float4 A = s_pair[hb_ * PB + 3 * P], B = s_pair[hb_ * PB + 3 * P + 1], C = s_pair[hb_ * PB + 3 * P + 2];
                     float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
                     float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
                     float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
@@ -1160,10 +1201,19 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         const uint32_t ntile = (nr + KT - 1u) / KT;  // <= 32
         uint32_t qmask = 0xFFFFFFFFu >> (32u - ntile);
         if (prune) {
-            // the seed bound (the seed representative comes from global memory: no tile is staged yet)
+            // the seed bound: the seed representative from the home tile in LDS, from global memory where it lies outside
             seed = min (seed, nr - 1u);
-            const float4 g = R4[2 * (size_t) seed], c = R4[2 * (size_t) seed + 1];
-            const float b0 = icp_metric8 (qx, qy, qz, qr, qg, qb, g.x, g.y, g.z, c.x, c.y, c.z, alpha);
+            float sx, sy, sz, sr, sg, sb;
+            if (ICP_HOME_MODE == 1 && seed / KT == ht) {
+                const float *sp = s_pairf + PB * 4u + ((seed - ht * KT) >> 1) * 12u + (seed & 1u);
+                sx = sp[0]; sy = sp[2]; sz = sp[4]; sr = sp[6]; sg = sp[8]; sb = sp[10];
+                // (keeps the compiler from merging this with the global path below into flat loads)
+                asm volatile ("" : "+v"(sx), "+v"(sy), "+v"(sz), "+v"(sr), "+v"(sg), "+v"(sb));
+            } else {
+                const float4 g = R4[2 * (size_t) seed], c = R4[2 * (size_t) seed + 1];
+                sx = g.x; sy = g.y; sz = g.z; sr = c.x; sg = c.y; sb = c.z;
+            }
+            const float b0 = icp_metric8 (qx, qy, qz, qr, qg, qb, sx, sy, sz, sr, sg, sb, alpha);
             if (b0 >= 0.f && b0 < __builtin_inff ()) s1_lim = __uint_as_float (__float_as_uint (b0) + 1u);     // next float up
             // tiles this query can find a nearer representative in: lane ss tests the tiles ss, ss + LPQ, ..; OR over the lanes
             uint32_t tm = 0u;
@@ -1185,37 +1235,41 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
                  (uint32_t) __builtin_amdgcn_readlane ((int) wm, 32) | (uint32_t) __builtin_amdgcn_readlane ((int) wm, 48);
             if (lane == 0) atomicOr (&s_tmask, wm);
         }
+        if (ICP_HOME_MODE == 2) home_to_lds ();
         __syncthreads ();
         KS_STAMP (10)
         uint32_t bm = s_tmask;                       // block-uniform
-        bool first = true;
-        while (bm) {
+        bool used0 = false;                          // buffer 0 holds a tile some wave may still be scanning
+        while (bm) {                                 // ascending: the tie rule needs every lane's representatives to ascend
             const uint32_t tl = (uint32_t) __builtin_ctz (bm);
             bm &= bm - 1u;
             const uint32_t t0 = tl * KT, tn = min (KT, nr - t0), npair = (tn + 1u) >> 1;
-            if (!first) __syncthreads ();            // every wave is done with the previous tile
-            first = false;
-            if (prune) {
-                const uint32_t nbx = 2u * ((tn + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
-                if (tid < nbx) s_box[tid] = GBt[2u * (t0 / (2u * KS_SPLIT)) + tid];
+            const uint32_t hb = (ICP_HOME_MODE != 3 && tl == ht) ? 1u : 0u;    // the home tile is there already: no fetch, no barrier
+            if (!hb) {
+                if (used0) __syncthreads ();         // every wave is done with the previous tile of buffer 0
+                used0 = true;
+                if (prune) {
+                    const uint32_t nbx = 2u * ((tn + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
+                    if (tid < nbx) s_box[tid] = GBt[2u * (t0 / (2u * KS_SPLIT)) + tid];
+                }
+                if (tid < tn) {
+                    const float4 g = R4[2 * (size_t) (t0 + tid)], c = R4[2 * (size_t) (t0 + tid) + 1];
+                    float *dst = s_pairf + (tid >> 1) * 12u + (tid & 1u);
+                    dst[0] = g.x; dst[2] = g.y; dst[4] = g.z; dst[6] = c.x; dst[8] = c.y; dst[10] = c.z;
+                }
+                __syncthreads ();
             }
-            if (tid < tn) {
-                const float4 g = R4[2 * (size_t) (t0 + tid)], c = R4[2 * (size_t) (t0 + tid) + 1];
-                float *dst = s_pairf + (tid >> 1) * 12u + (tid & 1u);
-                dst[0] = g.x; dst[2] = g.y; dst[4] = g.z; dst[6] = c.x; dst[8] = c.y; dst[10] = c.z;
-            }
-            __syncthreads ();
             if (prune) {
                 const bool mine = ((qmask >> tl) & 1u) != 0u;
                 uint32_t cmask = 0u;
-                if (__ballot (mine)) cmask = coarse_pass (tn, mine ? s1_lim : -__builtin_inff ());
-                fine_pass (t0, npair, cmask);
+                if (__ballot (mine)) cmask = coarse_pass (tn, mine ? s1_lim : -__builtin_inff (), hb);
+                fine_pass (t0, npair, cmask, hb);
                 s1_lim = fminf (s1_lim, ks_grp_min_f<KS_SPLIT> (best));
             } else {
                 const float2v vqx = { qx, qx }, vqy = { qy, qy }, vqz = { qz, qz }, vqr = { qr, qr }, vqg = { qg, qg }, vqb = { qb, qb };
                 const float2v va = { alpha, alpha };
                 for (uint32_t P = ss; P < npair; P += KS_SPLIT) {
-                    float4 A = s_pair[3 * P], B = s_pair[3 * P + 1], C = s_pair[3 * P + 2];
+                    float4 A = s_pair[hb * PB + 3 * P], B = s_pair[hb * PB + 3 * P + 1], C = s_pair[hb * PB + 3 * P + 2];
                     float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
                     float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
                     float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
@@ -1358,7 +1412,13 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // from LDS; the compile-time split keeps the compiler from merging the two sources into flat loads.
     uint32_t o, n;
     if constexpr (MINW == 2) { const uint2 on = s_on[rstar]; o = on.x; n = on.y; }
-    else if (!MASKED && nr <= KT) { const uint2 on = s_on[rstar]; o = on.x; n = on.y; asm volatile ("" : "+v"(o), "+v"(n)); }
+    else if constexpr (MASKED) {
+        // the home tile's (offset, size) pairs are in LDS (buffer 1 is never overwritten): a winner there — the usual case — costs
+        // no dependent global load
+        if (rstar / KT == ht) { const uint2 on = s_on[rstar - ht * KT]; o = on.x; n = on.y; asm volatile ("" : "+v"(o), "+v"(n)); }
+        else { o = gO[rstar]; n = gN[rstar]; }
+    }
+    else if (nr <= KT) { const uint2 on = s_on[rstar]; o = on.x; n = on.y; asm volatile ("" : "+v"(o), "+v"(n)); }
     else { o = gO[rstar]; n = gN[rstar]; }
 
     // ---- stage 2: exhaustive scan of that representative's list: the LPQ lanes of a query read LPQ consecutive

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Diagnostic (not a test): the profile set of a round, per BASELINE config.  usage: tests/diag_round2.sh TAG  (e.g. r02)
+# Diagnostic (not a test): the profile set of a round, per BASELINE config.  usage: tests/diag_profiles.sh TAG  (e.g. r03)
 #   kernel-trace statistics of bench.py at the default line (A, chained) and with --config B / --config C / --batch 64,
 #   then separate PMC passes (counters never share a run with --stats; the program comes directly after `--`):
 #   FETCH_SIZE, WRITE_SIZE, SQ instruction / wait counters, for C, A x 64 and the default line.
-# Output under gpurun_out/<TAG>_*; tests/diag_round2_summary.py condenses it into gpurun_out/<TAG>_profile_summary.json,
+# Output under gpurun_out/<TAG>_*; tests/diag_profiles_summary.py condenses it into gpurun_out/<TAG>_profile_summary.json,
 # and the summaries that are judged get copied to profiles/ by hand.
 export TMPDIR=/tmp
-tag=${1:-r02}
+tag=${1:-r03}
 mkdir -p gpurun_out
 stats () {   # name, bench args...
     name=$1; shift
@@ -25,6 +25,7 @@ stats A --steps 50 --warmup 5 &&
 stats B --config B --steps 20 --warmup 3 &&
 stats C --config C --steps 3 --warmup 1 &&
 stats Ax64 --batch 64 --steps 5 --warmup 1 &&
+stats REF --reduce-mode reference --power-mode literal --steps 50 --warmup 5 &&
 for cfg in "C --config C --steps 2 --warmup 1" "Ax64 --batch 64 --steps 2 --warmup 1" "B --config B --steps 3 --warmup 1" "A --steps 5 --warmup 1"; do
     set -- $cfg; n=$1; shift
     pmc ${n}_fetch FETCH_SIZE -- "$@" &&
@@ -33,4 +34,4 @@ for cfg in "C --config C --steps 2 --warmup 1" "Ax64 --batch 64 --steps 2 --warm
     pmc ${n}_sq2 SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -- "$@" &&
     pmc ${n}_l2 TCC_HIT_sum TCC_MISS_sum -- "$@" || break
 done
-python3 tests/diag_round2_summary.py $tag
+python3 tests/diag_profiles_summary.py $tag

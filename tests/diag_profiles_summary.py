@@ -1,4 +1,4 @@
-"""Diagnostic (not a test): condenses the rocprofv3 output of tests/diag_round2.sh into one JSON: per config, per kernel,
+"""Diagnostic (not a test): condenses the rocprofv3 output of tests/diag_profiles.sh into one JSON: per config, per kernel,
 average dispatch duration (kernel trace) and per-dispatch counter means (PMC passes).  HBM bytes as
 MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE / WRITE_SIZE are in KB, and on gfx950 FETCH_SIZE counts half of the bytes
 of a wide coalesced stream (doubled here; the raw value is kept beside it)."""
@@ -9,7 +9,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 out = {}
 
 

@@ -53,6 +53,7 @@ struct icp_context {
     icp_reg_state *hTrack = nullptr;                         // pinned: final state of the frames in flight (ICP_TRACK_RING slots)
     hipStream_t copy_stream = nullptr;
     hipEvent_t evUp[2] = { nullptr, nullptr }, evDone[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t evStage[3] = { nullptr, nullptr, nullptr };   // the last asynchronous copy out of the pinned staging of F / M / T (icp_write)
     uint64_t track_submitted = 0, track_collected = 0;       // frames fed / frames whose result has been handed out since init / icp_track_reset
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -279,6 +280,7 @@ int icp_create (icp_handle *out, int device, int rot, int weighted)
     if (e == hipSuccess) e = hipEventCreate (&h->ev1);
     for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags (&h->evUp[k], hipEventDisableTiming);
     for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreateWithFlags (&h->evDone[k], hipEventDisableTiming);
+    for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipEventCreateWithFlags (&h->evStage[k], hipEventDisableTiming);
     if (e != hipSuccess) { std::string m = hipGetErrorString (e); h->inited = false; icp_destroy (h); return fail (nullptr, ICP_EHIP, "icp_create: " + m); }
     *out = h;
     return ICP_OK;
@@ -296,6 +298,7 @@ int icp_destroy (icp_handle h)
     if (h->ev1) (void) hipEventDestroy (h->ev1);
     for (int k = 0; k < 2; ++k) if (h->evUp[k]) (void) hipEventDestroy (h->evUp[k]);
     for (int k = 0; k < 4; ++k) if (h->evDone[k]) (void) hipEventDestroy (h->evDone[k]);
+    for (int k = 0; k < 3; ++k) if (h->evStage[k]) (void) hipEventDestroy (h->evStage[k]);
     if (h->copy_stream) (void) hipStreamDestroy (h->copy_stream);
     if (h->stream) (void) hipStreamDestroy (h->stream);
     delete h;
@@ -412,16 +415,20 @@ int icp_write_b (icp_handle h, uint32_t b, int mem, const void *host_ptr, int bl
         case ICP_MEM_M: {
             float *stage = (mem == ICP_MEM_F ? h->hF : h->hM) + (size_t) b * h->p.m * 8;
             float *dst = (mem == ICP_MEM_F ? h->dF : h->dM) + (size_t) b * h->p.m * 8;
-            // the staging buffer may still feed an earlier asynchronous copy
-            HIPCHK (h, hipStreamSynchronize (h->stream));
+            // the staging buffer may still feed an earlier asynchronous copy of the same kind: wait for THAT copy (an event of a
+            // never-recorded event returns at once), not for whatever else the stream holds (a run in flight keeps going)
+            hipEvent_t ev = h->evStage[mem == ICP_MEM_F ? 0 : 1];
+            HIPCHK (h, hipEventSynchronize (ev));
             if (host_ptr) std::memcpy (stage, host_ptr, fm);           // algorithms.cpp:4604-4606
             HIPCHK (h, hipMemcpyAsync (dst, stage, fm, hipMemcpyHostToDevice, h->stream));
+            HIPCHK (h, hipEventRecord (ev, h->stream));
             break;
         }
         case ICP_MEM_T: {
-            HIPCHK (h, hipStreamSynchronize (h->stream));
+            HIPCHK (h, hipEventSynchronize (h->evStage[2]));
             if (host_ptr) std::memcpy (h->hT, host_ptr, 8 * sizeof (float));   // :4613-4617
             HIPCHK (h, hipMemcpyAsync (h->dTin, h->hT, 8 * sizeof (float), hipMemcpyHostToDevice, h->stream));
+            HIPCHK (h, hipEventRecord (h->evStage[2], h->stream));
             note_enqueue (h);
             icp_launch_set_T (h->p, b, h->dTin, h->stream);
             HIPCHK (h, hipGetLastError ());

@@ -35,3 +35,5 @@ for cfg in "C --config C --steps 2 --warmup 1" "Ax64 --batch 64 --steps 2 --warm
     pmc ${n}_l2 TCC_HIT_sum TCC_MISS_sum -- "$@" || break
 done
 python3 tests/diag_profiles_summary.py $tag
+# (the raw traces stay on the box: gpurun_out/ is merged back up to 64 MiB)
+rm -rf gpurun_out/${tag}_stats_*/ gpurun_out/${tag}_pmc_*/

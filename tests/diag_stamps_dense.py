@@ -11,6 +11,8 @@ for b in range(batch):
     F, M = icp_amd.synth_pair(side, seed=0x1C9D5EED + b)
     g.write(icp_amd.Memory.F, F, batch_index=b); g.write(icp_amd.Memory.M, M, batch_index=b)
 g.buildRBC(); g.run_fixed(int(os.environ.get("ITERS", "5"))); g.sync()
+if os.environ.get("FUSED", "1") == "0":
+    g.setReduceMode(0)
 L = icp_amd.lib(); nb = side * side // 64 * batch
 out = np.zeros((nb, 16), np.uint64)
 for rep in range(3):
@@ -18,7 +20,12 @@ for rep in range(3):
 t = out.astype(np.int64)[2:]                         # (rows 0 and 1 also hold the finalize kernel's stamps)
 GHZ = float(os.environ.get("GHZ", "2.3"))
 print("layout", g.search_layout(), "blocks", nb, "(s_memtime = shader clock of the block's own XCD: differences inside a block only; ns at %.2f GHz)" % GHZ)
-seq = [(0, "prologue: loads, transform, hand-over"), (10, "seed bound + tile masks (2 barriers)"), (2, "stage 1 (tiles staged + scanned)"),
+chained = g.launches_per_iteration() == 1
+seq = ([(13, "chain: prologue loads arrived (state, moments, reps, query)"), (10, "chain: moment trees + barrier"), (11, "chain: finish (means / S from the moments)"),
+        (12, "chain: power method"), (9, "chain: compose, hand-over of the queries, barrier"), (0, "to the search proper"), (1, "first barrier (reps + queries in LDS)"),
+        (2, "stage 1")] if chained else
+       [(0, "prologue: loads, transform, hand-over"), (10, "seed bound + tile masks (2 barriers)"), (2, "stage 1 (tiles staged + scanned)")]) + [(-1, "")]
+seq = [x for x in seq if x[0] >= 0] + [
        (3, "nearest representative"), (4, "stage 2 list scan"), (5, "stage 2 reduce"), (6, "hand-off barrier + epilogue wave"), (7, "moment tree + store")]
 prev, total = 8, 0.0
 for k, name in seq:

@@ -1,0 +1,528 @@
+// icp_build.hip — hand-written HIP kernels (gfx950) around the iteration: the registration state, landmark extraction (getLMs),
+// the cloud transforms, the RBC construction behind ICPStep::buildRBC (src/ICP/algorithms.cpp:4655-4660: getReps + the
+// un-vendored RBCConstruct) and ICPPowerMethod as a kernel of its own.  The owner search of the construction (step 1) is the
+// search kernel's stage 1 and lives with it in icp_kernels.hip (icp_launch_owner_search).  blockIdx.y is the registration index of
+// a batch.  Integer work throughout (histograms, scans, ranks): bit-identical to oracle/icp_oracle.c by construction.
+#include "icp_kernels.h"
+
+// ------------------------------------------------------------------------------------------
+// state
+// ------------------------------------------------------------------------------------------
+__global__ void k_reset_state (icp_params p, int reset_T)
+{
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.batch) return;
+    icp_reg_state *st = p.st + b;
+    if (reset_T) {                                   // identity T0 — src/ICP/algorithms.cpp:4486-4493
+        const float T0[8] = { 0, 0, 0, 1, 0, 0, 0, 1 };
+        const float I3[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+        for (int i = 0; i < 8; ++i) { st->T[i] = T0[i]; st->Tk[i] = T0[i]; }
+        for (int i = 0; i < 9; ++i) { st->R[i] = I3[i]; st->Rk[i] = I3[i]; }
+        for (int i = 0; i < 11; ++i) st->S[i] = 0.f;
+        for (int i = 0; i < 8; ++i) st->means[i] = 0.f;
+        st->sum_w = 0.0;
+    }
+    st->k = 0; st->done = 0; st->pm_iters = 0;       // ICP::buildRBC — :4796
+}
+
+// write (D_IO_T): T is replaced and the cumulative rotation re-derived from it
+__global__ void k_set_T (icp_reg_state *st, const float *T8)
+{
+    if (threadIdx.x != 0) return;
+    float T[8]; for (int i = 0; i < 8; ++i) T[i] = T8[i];
+    for (int i = 0; i < 8; ++i) st->T[i] = T[i];
+    float R[9]; icp_quat_to_rot (T, R);
+    for (int i = 0; i < 9; ++i) st->R[i] = R[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// a14 getLMs — kernels/icp_kernels.cl:63-76: landmark (gX, gY) = pixel (col 65+4gX, row 49+3gY)
+// ------------------------------------------------------------------------------------------
+__global__ void k_get_lms (const float4 *cloud, float4 *lms)
+{
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;      // float4 index into the landmarks
+    if (t >= 16384u * 2u) return;
+    uint32_t lm = t >> 1, half = t & 1u;
+    uint32_t gX = lm & 127u, gY = lm >> 7;
+    uint32_t row = 48u + gY * 3u + 1u, col = 64u + 4u * gX + 1u;
+    lms[t] = cloud[((size_t) row * 640u + col) * 2u + half];
+}
+
+// getLMs from the BAND of a frame: the part of a 640 x 480 cloud the kernel above reads, packed — row j of the band = cloud row
+// 49 + 3 j, pixels 65 .. 573 (ICP_BAND_* in icp_kernels.h: 128 rows x 509 pixels = 2.08 MB of the frame's 9.83 MB).  Tracking
+// uploads only that (icp_track_submit); landmark (gX, gY) = band pixel (4 gX, gY): the same points as k_get_lms.
+__global__ void k_get_lms_band (const float4 *band, float4 *lms)
+{
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 16384u * 2u) return;
+    uint32_t lm = t >> 1, half = t & 1u;
+    uint32_t gX = lm & 127u, gY = lm >> 7;
+    lms[t] = band[((size_t) gY * ICP_BAND_COLS + 4u * gX) * 2u + half];
+}
+
+// icpTransform_Quaternion on a whole cloud — kernels/icp_kernels.cl:772-802
+__global__ void k_transform_cloud (const float4 *in, float4 *out, const icp_reg_state *st, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float T[8];
+    for (int k = 0; k < 8; ++k) T[k] = st->T[k];
+    float4 g = in[2 * (size_t) i], c = in[2 * (size_t) i + 1];
+    float x, y, z;
+    icp_transform_point (T, g.x, g.y, g.z, x, y, z);
+    out[2 * (size_t) i] = make_float4 (x, y, z, g.w);
+    out[2 * (size_t) i + 1] = c;
+}
+
+// ICPTransform<QUATERNION | MATRIX> with an explicit transformation (the cloud kernels of the reference that take
+// their parameters from a buffer of their own): KIND 0 icpTransform_Quaternion (kernels/icp_kernels.cl:772-802),
+// 1 icpTransform_Quaternion_2 (:842-879: the two quaternion products as 4x4 matrix-vector products), 2
+// icpTransform_Matrix (:904-933: rows 0..2 of a row-major 4x4 applied to the homogeneous point as stored).
+// dot (a, b) = (((0 + a0 b0) + a1 b1) + a2 b2) + a3 b3, the CPU twins' order (oracle orc_transform_q2 / orc_transform_m).
+struct icp_T16 { float v[16]; };
+static __device__ __forceinline__ float dot4_seq (float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3)
+{
+    float s = 0.f;
+    s = s + a0 * b0; s = s + a1 * b1; s = s + a2 * b2; s = s + a3 * b3;
+    return s;
+}
+template <int KIND>
+__global__ __launch_bounds__ (256) void k_transform_cloud_ex (const float4 *in, float4 *out, icp_T16 T, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 g = in[2 * (size_t) i], c = in[2 * (size_t) i + 1];
+    float x, y, z;
+    if constexpr (KIND == 0) icp_transform_point (T.v, g.x, g.y, g.z, x, y, z);
+    else if constexpr (KIND == 1) {
+        const float qx = T.v[0], qy = T.v[1], qz = T.v[2], qw = T.v[3];
+        const float p0 = dot4_seq ( qw, -qz,  qy, qx, g.x, g.y, g.z, 0.f);
+        const float p1 = dot4_seq ( qz,  qw, -qx, qy, g.x, g.y, g.z, 0.f);
+        const float p2 = dot4_seq (-qy,  qx,  qw, qz, g.x, g.y, g.z, 0.f);
+        const float p3 = dot4_seq (-qx, -qy, -qz, qw, g.x, g.y, g.z, 0.f);
+        x = T.v[7] * dot4_seq ( qw, -qz,  qy, -qx, p0, p1, p2, p3) + T.v[4];
+        y = T.v[7] * dot4_seq ( qz,  qw, -qx, -qy, p0, p1, p2, p3) + T.v[5];
+        z = T.v[7] * dot4_seq (-qy,  qx,  qw, -qz, p0, p1, p2, p3) + T.v[6];
+    } else {
+        x = dot4_seq (T.v[0], T.v[1], T.v[2],  T.v[3],  g.x, g.y, g.z, g.w);
+        y = dot4_seq (T.v[4], T.v[5], T.v[6],  T.v[7],  g.x, g.y, g.z, g.w);
+        z = dot4_seq (T.v[8], T.v[9], T.v[10], T.v[11], g.x, g.y, g.z, g.w);
+    }
+    out[2 * (size_t) i] = make_float4 (x, y, z, g.w);
+    out[2 * (size_t) i + 1] = c;
+}
+
+// ------------------------------------------------------------------------------------------
+// buildRBC
+// ------------------------------------------------------------------------------------------
+
+// a1 + the boxes of the stage-1 pruning, ONE launch of 64-thread blocks with three kinds of duty (buildRBC is a chain of
+// small dependent launches: every launch saved is ~4 us of its ~40 at |F| = 16384):
+//   blocks [0, nbr)            the representatives: R[r] = F[src (r)], rep_src[r] = src (r)                     (getReps)
+//   blocks [nbr, nbr + nbg)    geometry bounding boxes of the pruning groups of 16 representatives: a 4 x 4 tile of the
+//                              representative grid where the grid allows (p.gtile: the representatives are a regular sample
+//                              of the landmark grid, so a tile is compact in space: 1.8 - 2.9 groups per wave survive the
+//                              bound instead of 3.3 - 8.8 with 16 x 1 strips), else 16 consecutive representatives
+//   blocks [nbr + nbg, ..)     the box of every LDS tile of the dense k_search for multi-tile sets (p.tbox consecutive
+//                              representatives: 256, or 1024 for the largest sets), one wave per box
+// The boxes read the representatives' points from F at src (r): they do not wait for R.  fminf / fmaxf skip NaN
+// coordinates: a representative with a NaN coordinate never wins a '<' anyway; min / max are exact in any order.
+__global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t nbr, uint32_t nbg)
+{
+    const uint32_t b = blockIdx.y, lane = threadIdx.x;
+    const float4 *F4 = reinterpret_cast<const float4 *> (p.F + (size_t) b * p.m * 8);
+    const float inf = __builtin_inff ();
+    if (blockIdx.x < nbr) {
+        const uint32_t r = blockIdx.x * 64u + lane;
+        if (r >= p.nr) return;
+        const uint32_t src = rep_src_index (p, r);
+        float4 *R4 = reinterpret_cast<float4 *> (p.R + (size_t) b * p.nr * 8);
+        R4[2 * r] = F4[2 * (size_t) src];
+        R4[2 * r + 1] = F4[2 * (size_t) src + 1];
+        p.rep_src[(size_t) b * p.nr + r] = src;
+    } else if (blockIdx.x < nbr + nbg) {
+        const uint32_t g = (blockIdx.x - nbr) * 64u + lane;
+        if (g >= p.n16) return;
+        float4 lo = make_float4 (inf, inf, inf, 0.f), hi = make_float4 (-inf, -inf, -inf, 0.f);
+        const bool tiled = p.gtile != 0u;
+        const uint32_t lg = p.gtile - 1u, ty = tiled ? g >> lg : 0u, tx = tiled ? g & ((1u << lg) - 1u) : 0u;
+        for (uint32_t e = 0; e < 16u; ++e) {
+            const uint32_t r = tiled ? (4u * ty + (e >> 2)) * p.nrx + 4u * tx + (e & 3u) : g * 16u + e;
+            if (r >= p.nr) continue;
+            const float4 v = F4[2 * (size_t) rep_src_index (p, r)];
+            lo.x = fminf (lo.x, v.x); lo.y = fminf (lo.y, v.y); lo.z = fminf (lo.z, v.z);
+            hi.x = fmaxf (hi.x, v.x); hi.y = fmaxf (hi.y, v.y); hi.z = fmaxf (hi.z, v.z);
+        }
+        float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n1k);
+        GB[2 * g] = lo; GB[2 * g + 1] = hi;
+    } else {
+        const uint32_t tile = blockIdx.x - nbr - nbg;
+        float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+        for (uint32_t r = tile * p.tbox + lane; r < min (p.nr, (tile + 1u) * p.tbox); r += 64u) {
+            const float4 v = F4[2 * (size_t) rep_src_index (p, r)];
+            lo[0] = fminf (lo[0], v.x); lo[1] = fminf (lo[1], v.y); lo[2] = fminf (lo[2], v.z);
+            hi[0] = fmaxf (hi[0], v.x); hi[1] = fmaxf (hi[1], v.y); hi[2] = fmaxf (hi[2], v.z);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf (lo[k], __shfl_xor (lo[k], d)); hi[k] = fmaxf (hi[k], __shfl_xor (hi[k], d)); }
+        if (lane == 0) {
+            float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16;
+            GB[2 * tile] = make_float4 (lo[0], lo[1], lo[2], 0.f); GB[2 * tile + 1] = make_float4 (hi[0], hi[1], hi[2], 0.f);
+        }
+    }
+}
+
+// RBC construct, step 1 (owner(x) = argmin_r d(x, R[r]), ties -> lowest r) is k_search<.., OWNER = true> below.
+
+// step 2: per-chunk histograms of the owners (integer LDS atomics: deterministic)
+__global__ __launch_bounds__ (256) void k_chunk_hist (icp_params p)
+{
+    extern __shared__ __attribute__ ((aligned (16))) uint32_t s_hist[];
+    uint32_t chunk = blockIdx.x, b = blockIdx.y;
+    for (uint32_t r = threadIdx.x; r < p.nr; r += blockDim.x) s_hist[r] = 0;
+    __syncthreads ();
+    const uint32_t *owner = p.owner + (size_t) b * p.m;
+    for (uint32_t k = threadIdx.x; k < ICP_CHUNK; k += blockDim.x) {
+        uint32_t i = chunk * ICP_CHUNK + k;
+        if (i < p.m) atomicAdd (&s_hist[owner[i]], 1u);
+    }
+    __syncthreads ();
+    uint32_t *H = p.chunk_hist + ((size_t) b * p.nchunk + chunk) * p.nr;
+    for (uint32_t r = threadIdx.x; r < p.nr; r += blockDim.x) H[r] = s_hist[r];
+}
+
+// step 3: N[r] = sum over chunks; chunk_hist[chunk][r] becomes the rank base of that chunk in list r.
+// Block = 64 representatives x 16 groups of consecutive chunks (thread (rr, cg): coalesced over rr): the sum of every group,
+// an exchange through LDS, then the group's chunks again with the running base — two parallel passes instead of one thread
+// walking all chunks of its representative (|F| = 2^20: 1024 chunks, 79 -> 17 us).
+__global__ __launch_bounds__ (1024) void k_count (icp_params p)
+{
+    __shared__ uint32_t s_sum[16][64];
+    const uint32_t b = blockIdx.y, rr = threadIdx.x & 63u, cg = threadIdx.x >> 6;
+    const uint32_t r = blockIdx.x * 64u + rr;
+    const bool live = r < p.nr;
+    const uint32_t cpg = (p.nchunk + 15u) / 16u, c_lo = min (cg * cpg, p.nchunk), c_hi = min (c_lo + cpg, p.nchunk);
+    uint32_t *h0 = p.chunk_hist + (size_t) b * p.nchunk * p.nr + (live ? r : 0u);
+    uint32_t sum = 0;
+    for (uint32_t c0 = c_lo; c0 < c_hi; c0 += 8u) {                   // eight independent loads in flight
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) v[k] = (live && c0 + k < c_hi) ? h0[(size_t) (c0 + k) * p.nr] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) sum += v[k];
+    }
+    s_sum[cg][rr] = sum;
+    __syncthreads ();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < 16u; ++g) { const uint32_t v = s_sum[g][rr]; run += (g < cg) ? v : 0u; total += v; }
+    for (uint32_t c0 = c_lo; c0 < c_hi; c0 += 8u) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) v[k] = (live && c0 + k < c_hi) ? h0[(size_t) (c0 + k) * p.nr] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k)
+            if (live && c0 + k < c_hi) { h0[(size_t) (c0 + k) * p.nr] = run; run += v[k]; }
+    }
+    if (live && cg == 0u) p.N[(size_t) b * p.nr + r] = total;
+}
+
+// step 4: O = exclusive scan of N (exclusiveScan_i semantics, kernels/scan_kernels.cl:188). One block of 1024 threads:
+// per-thread runs, wave scans (shuffles), a scan of the 16 wave totals.
+__global__ __launch_bounds__ (1024) void k_offsets (icp_params p)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t b = blockIdx.y, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t *N = p.N + (size_t) b * p.nr;
+    uint32_t *O = p.O + (size_t) b * p.nr;
+    const uint32_t per = (p.nr + 1023u) / 1024u, lo = t * per, hi = min (lo + per, p.nr);
+    uint32_t part = 0;
+    for (uint32_t r = lo; r < hi; ++r) part += N[r];
+    uint32_t inc = part;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t v = __shfl_up (inc, d); if (lane >= d) inc += v; }
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads ();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
+    uint32_t run = base + inc - part;
+    for (uint32_t r = lo; r < hi; ++r) { O[r] = run; run += N[r]; }
+}
+
+// steps 3 + 4 in one launch for |R| <= 1024 (one block, thread r = representative r): the serial walk over the chunks, then
+// the block scan of the counts — the same integers as k_count + k_offsets.
+__global__ __launch_bounds__ (1024) void k_count_offsets (icp_params p)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t b = blockIdx.y, r = threadIdx.x, lane = r & 63u, wave = r >> 6;
+    uint32_t run = 0;
+    if (r < p.nr) {
+        uint32_t *h0 = p.chunk_hist + (size_t) b * p.nchunk * p.nr + r;
+        for (uint32_t c0 = 0; c0 < p.nchunk; c0 += 8u) {              // eight independent loads in flight, then the serial scan
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) v[k] = (c0 + k < p.nchunk) ? h0[(size_t) (c0 + k) * p.nr] : 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k)
+                if (c0 + k < p.nchunk) { h0[(size_t) (c0 + k) * p.nr] = run; run += v[k]; }
+        }
+        p.N[(size_t) b * p.nr + r] = run;
+    }
+    uint32_t inc = run;                              // exclusive scan over r (exclusiveScan_i, kernels/scan_kernels.cl:188)
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t v = __shfl_up (inc, d); if (lane >= d) inc += v; }
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads ();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
+    if (r < p.nr) p.O[(size_t) b * p.nr + r] = base + inc - run;
+}
+
+// step 5: stable placement: position = O[owner] + #{j < i : owner[j] == owner[i]}; perm, X_P and the search copy.
+// One block per chunk of 1024 points; the rank base of the chunk comes from step 3.  The rank inside the chunk: the points of
+// a wave are 64 neighbours in index order and share a handful of owners, so every wave lists its distinct owners with
+// their counts (one ballot per distinct owner: the lanes' rank inside the wave is a popcount of the lanes below), and a
+// point adds the counts of its owner in the lists of the earlier waves (broadcast LDS reads of short lists) — instead of
+// comparing itself with every earlier point of the chunk (round 2: 15 -> 5 us at |F| = 16384, where the kernel is a third
+// of buildRBC).  Integer arithmetic: the same positions whatever the path.
+__global__ __launch_bounds__ (1024) void k_place (icp_params p)
+{
+    __shared__ uint2 s_list[ICP_CHUNK / 64][64];     // per wave: (owner, count) of its distinct owners
+    __shared__ uint32_t s_n[ICP_CHUNK / 64];
+    const uint32_t chunk = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane (t >> 6);
+    const uint32_t i = chunk * ICP_CHUNK + t;
+    const bool valid = i < p.m;
+    const uint32_t own = valid ? p.owner[(size_t) b * p.m + i] : 0xFFFFFFFFu;
+    uint32_t base = 0;
+    if (valid) base = p.O[(size_t) b * p.nr + own] + p.chunk_hist[((size_t) b * p.nchunk + chunk) * p.nr + own];
+    uint32_t rank = 0, k = 0;
+    for (unsigned long long rem = __ballot (valid); rem; ++k) {
+        const uint32_t o = (uint32_t) __builtin_amdgcn_readlane ((int) own, (int) __builtin_ctzll (rem));
+        const unsigned long long same = __ballot (own == o);         // (an owner is < nr: never the marker of an invalid lane)
+        if (own == o) rank = (uint32_t) __builtin_popcountll (same & ((1ull << lane) - 1ull));
+        if (lane == 0) s_list[wave][k] = make_uint2 (o, (uint32_t) __builtin_popcountll (same));
+        rem &= ~same;
+    }
+    if (lane == 0) s_n[wave] = k;
+    __syncthreads ();
+    for (uint32_t w = 0; w < wave; ++w) {            // earlier waves: every one of their points precedes t
+        const uint32_t n = s_n[w];
+        for (uint32_t e = 0; e < n; ++e) {
+            const uint2 v = s_list[w][e];
+            rank += (v.x == own) ? v.y : 0u;
+        }
+    }
+    if (chunk == 0u && t == 0u) { icp_reg_state *st = p.st + b; st->k = 0; st->done = 0; st->pm_iters = 0; }     // ICP::buildRBC (:4796)
+    if (valid) {
+        const uint32_t pos = base + rank;
+        const float4 *F4 = reinterpret_cast<const float4 *> (p.F + (size_t) b * p.m * 8);
+        float4 *X4 = reinterpret_cast<float4 *> (p.XP + (size_t) b * p.m * 8);
+        p.perm[(size_t) b * p.m + pos] = i;
+        float4 g = F4[2 * (size_t) i], c = F4[2 * (size_t) i + 1];
+        X4[2 * (size_t) pos] = g;
+        X4[2 * (size_t) pos + 1] = c;
+        // search copy, laid out for packed fp32 math: [x r y g | z b id 0] — (geometry, colour) pairs side by side, and
+        // the unused homogeneous lane carries the original index (saves the perm[] round trip)
+        float4 *Q4 = reinterpret_cast<float4 *> (p.XQ + (size_t) b * p.m * 8);
+        Q4[2 * (size_t) pos] = make_float4 (g.x, c.x, g.y, c.y);
+        Q4[2 * (size_t) pos + 1] = make_float4 (g.z, c.z, __uint_as_float (i), 0.f);
+    }
+}
+
+// RBC construct, steps 2 - 5 in ONE launch for the latency-bound sizes (at most 512 blocks of 64 points over the batch, |R| < 1024:
+// the sizes whose owner search is k_search<.., OWNER, MINW = 2>, which leaves owner[], the rank of every point inside its block of
+// 64 and the block's (owner, count) list).  A block places 256 consecutive points = 4 owner blocks.  Nothing here waits for
+// another block: every block re-derives what it needs from the lists of ALL owner blocks (a few KB, L2-resident) —
+//   total[r]  = points owned by r                       (N; its exclusive scan is O: exclusiveScan_i, kernels/scan_kernels.cl:188)
+//   before[r] = points owned by r in earlier chunks
+// with integer LDS atomics (deterministic), then position = O[owner] + before[owner] + counts of the owner in the chunk's earlier
+// owner blocks + rank inside the own block: the stable order by original index, the same integers as k_chunk_hist +
+// k_count_offsets + k_place.  Block 0 also writes N and O and resets k / done (ICP::buildRBC, src/ICP/algorithms.cpp:4796).
+// buildRBC at |F| = 16384: 6 launches, 33.6 us -> 2 launches.
+__global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
+{
+    __shared__ uint32_t s_total[1024], s_before[1024];
+    __shared__ uint2 s_list[4][64];
+    __shared__ uint32_t s_n[4], s_wave[4];
+    const uint32_t c = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane (t >> 6);
+    const uint32_t nb = p.nb, ob0 = c * 4u, i = c * 256u + t;
+    const bool valid = i < p.m;
+    // every load that depends on nothing is issued first: the point, its owner and rank, the lists' lengths
+    const float4 *F4 = reinterpret_cast<const float4 *> (p.F + (size_t) b * p.m * 8);
+    float4 g = make_float4 (0.f, 0.f, 0.f, 0.f), cc = g;
+    uint32_t own = 0xFFFFFFFFu, rk = 0u;
+    if (valid) { own = p.owner[(size_t) b * p.m + i]; rk = p.brank[(size_t) b * p.m + i]; g = F4[2 * (size_t) i]; cc = F4[2 * (size_t) i + 1]; }
+    const uint2 *BL = p.blist + (size_t) b * nb * 64u;
+    const uint32_t *BN = p.bn + (size_t) b * nb;
+    // the list of owner block t (thread t; further ones in the loop below): its length and, without waiting for it, its first 8
+    // entries (64 neighbouring points share a handful of owners) — one memory round trip for everything above and this
+    uint32_t n0 = 0u; uint4 e0[4] = { make_uint4 (0u, 0u, 0u, 0u), make_uint4 (0u, 0u, 0u, 0u), make_uint4 (0u, 0u, 0u, 0u), make_uint4 (0u, 0u, 0u, 0u) };
+    if (t < nb) {
+        n0 = BN[t];
+        const uint4 *q = reinterpret_cast<const uint4 *> (BL + (size_t) t * 64u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e0[k] = q[k];
+    }
+    uint32_t nown = 0u; uint2 lown = make_uint2 (0u, 0u);
+    if (ob0 + wave < nb) {                           // this chunk's own lists
+        nown = BN[ob0 + wave];
+        lown = BL[(size_t) (ob0 + wave) * 64u + lane];      // (entries past the list's end: whatever the buffer holds, never read back)
+    }
+    for (uint32_t r = t; r < p.nr; r += 256u) { s_total[r] = 0u; s_before[r] = 0u; }
+    s_list[wave][lane] = lown;
+    if (lane == 0) s_n[wave] = nown;
+    __syncthreads ();
+    {
+        const bool earlier = t < ob0;
+        const uint32_t ev[8][2] = { { e0[0].x, e0[0].y }, { e0[0].z, e0[0].w }, { e0[1].x, e0[1].y }, { e0[1].z, e0[1].w },
+                                    { e0[2].x, e0[2].y }, { e0[2].z, e0[2].w }, { e0[3].x, e0[3].y }, { e0[3].z, e0[3].w } };
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if ((uint32_t) e < n0) { atomicAdd (&s_total[ev[e][0]], ev[e][1]); if (earlier) atomicAdd (&s_before[ev[e][0]], ev[e][1]); }
+        for (uint32_t e = 8u; e < n0; ++e) {
+            const uint2 v = BL[(size_t) t * 64u + e];
+            atomicAdd (&s_total[v.x], v.y);
+            if (earlier) atomicAdd (&s_before[v.x], v.y);
+        }
+    }
+    for (uint32_t ob = t + 256u; ob < nb; ob += 256u) {
+        const uint32_t n = BN[ob];
+        const bool earlier = ob < ob0;
+        for (uint32_t e = 0; e < n; ++e) {
+            const uint2 v = BL[(size_t) ob * 64u + e];
+            atomicAdd (&s_total[v.x], v.y);
+            if (earlier) atomicAdd (&s_before[v.x], v.y);
+        }
+    }
+    __syncthreads ();
+    // O = exclusive scan of the totals; thread t takes `per` consecutive representatives (|R| < 1024: per <= 4)
+    const uint32_t per = (p.nr + 255u) / 256u, lo = min (t * per, p.nr), hi = min (lo + per, p.nr);
+    uint32_t part = 0u;
+    for (uint32_t r = lo; r < hi; ++r) part += s_total[r];
+    uint32_t inc = part;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t v = __shfl_up (inc, d); if (lane >= d) inc += v; }
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads ();
+    uint32_t run = inc - part;
+    for (uint32_t w = 0; w < wave; ++w) run += s_wave[w];
+    for (uint32_t r = lo; r < hi; ++r) {
+        const uint32_t n = s_total[r];
+        if (c == 0u) { p.N[(size_t) b * p.nr + r] = n; p.O[(size_t) b * p.nr + r] = run; }
+        s_before[r] += run;                          // position of the chunk's first point of list r
+        run += n;
+    }
+    if (c == 0u && t == 0u) { icp_reg_state *st = p.st + b; st->k = 0; st->done = 0; st->pm_iters = 0; }
+    __syncthreads ();
+    if (valid) {
+        uint32_t pos = s_before[own] + rk;
+        for (uint32_t w = 0; w < wave; ++w) {        // the chunk's earlier owner blocks: every one of their points precedes this one
+            const uint32_t n = s_n[w];
+            for (uint32_t e = 0; e < n; ++e) { const uint2 v = s_list[w][e]; pos += (v.x == own) ? v.y : 0u; }
+        }
+        float4 *X4 = reinterpret_cast<float4 *> (p.XP + (size_t) b * p.m * 8);
+        float4 *Q4 = reinterpret_cast<float4 *> (p.XQ + (size_t) b * p.m * 8);
+        p.perm[(size_t) b * p.m + pos] = i;
+        X4[2 * (size_t) pos] = g;
+        X4[2 * (size_t) pos + 1] = cc;
+        Q4[2 * (size_t) pos] = make_float4 (g.x, cc.x, g.y, cc.y);                      // search copy: see k_place
+        Q4[2 * (size_t) pos + 1] = make_float4 (g.z, cc.z, __uint_as_float (i), 0.f);
+    }
+}
+
+// ICPPowerMethod as a kernel of its own (reference include/ICP/algorithms.hpp:1451-1537, kernels/icp_kernels.cl:977-1054: an
+// enqueueTask of one work-item; here one wave): S[11], means[8] -> Tk[8] with the rotation solvers the iteration uses
+// (icp_power_method_quad literal / squared start, icp_svd_rotation) — the entry the reference's known-answer test drives
+// (tests/testsICP.cpp:988-1052).  out[0..8) = Tk, out[8..17) = Rk (EIGEN branch; else the rotation of qk), out[17] = loop trips.
+template <int ROT>
+__global__ __launch_bounds__ (64) void k_rotation_solver (const float *gin, float *gout, int power_mode)
+{
+    const uint32_t lane = threadIdx.x;
+    float S[11], means[8], Tk[8], Rk[9];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) S[k] = gin[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) means[k] = gin[11 + k];
+    int iters = 0;
+    if constexpr (ROT == 1) { iters = icp_power_method_quad (S, means, Tk, power_mode, lane); icp_quat_to_rot (Tk, Rk); }
+    else icp_svd_rotation (S, means, Rk, Tk);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gout[k] = Tk[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gout[8 + k] = Rk[k];
+        gout[17] = __uint_as_float ((uint32_t) iters);
+    }
+}
+void icp_launch_rotation_solver (int rot, int power_mode, const float *din19, float *dout18, hipStream_t s)
+{
+    if (rot == 1) hipLaunchKernelGGL (k_rotation_solver<1>, dim3 (1), dim3 (64), 0, s, din19, dout18, power_mode);
+    else hipLaunchKernelGGL (k_rotation_solver<0>, dim3 (1), dim3 (64), 0, s, din19, dout18, power_mode);
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+void icp_launch_reset_state (const icp_params &p, hipStream_t s, int reset_T)
+{
+    hipLaunchKernelGGL (k_reset_state, dim3 ((p.batch + 63) / 64), dim3 (64), 0, s, p, reset_T);
+}
+
+void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStream_t s)
+{
+    hipLaunchKernelGGL (k_set_T, dim3 (1), dim3 (64), 0, s, p.st + b, dT8);
+}
+
+void icp_launch_get_lms (const float *cloud, float *lms, hipStream_t s)
+{
+    hipLaunchKernelGGL (k_get_lms, dim3 (16384 * 2 / 256), dim3 (256), 0, s,
+                        reinterpret_cast<const float4 *> (cloud), reinterpret_cast<float4 *> (lms));
+}
+
+void icp_launch_get_lms_band (const float *band, float *lms, hipStream_t s)
+{
+    hipLaunchKernelGGL (k_get_lms_band, dim3 (16384 * 2 / 256), dim3 (256), 0, s,
+                        reinterpret_cast<const float4 *> (band), reinterpret_cast<float4 *> (lms));
+}
+
+void icp_launch_transform_cloud (const float *in, float *out, const icp_reg_state *st, uint32_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL (k_transform_cloud, dim3 ((n + 255) / 256), dim3 (256), 0, s,
+                        reinterpret_cast<const float4 *> (in), reinterpret_cast<float4 *> (out), st, n);
+}
+
+void icp_launch_transform_cloud_ex (int kind, const float *in, float *out, const float *T, uint32_t n, hipStream_t s)
+{
+    icp_T16 t {};
+    for (int i = 0; i < (kind == 2 ? 16 : 8); ++i) t.v[i] = T[i];
+    const float4 *i4 = reinterpret_cast<const float4 *> (in); float4 *o4 = reinterpret_cast<float4 *> (out);
+    const dim3 grid ((n + 255) / 256), block (256);
+    if (kind == 0) hipLaunchKernelGGL (k_transform_cloud_ex<0>, grid, block, 0, s, i4, o4, t, n);
+    else if (kind == 1) hipLaunchKernelGGL (k_transform_cloud_ex<1>, grid, block, 0, s, i4, o4, t, n);
+    else hipLaunchKernelGGL (k_transform_cloud_ex<2>, grid, block, 0, s, i4, o4, t, n);
+}
+
+void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
+{
+    if (icp_build_lists (p)) {                       // two launches: the owner search (gathers the representatives itself, leaves the lists), the placement
+        icp_launch_owner_search (p, s);
+        hipLaunchKernelGGL (k_place_lists, dim3 ((p.nb + 3u) / 4u, p.batch), dim3 (256), 0, s, p);
+        return;
+    }
+    {   // the representatives, the boxes of their pruning groups and (several tiles only) of the LDS tiles: one launch
+        const uint32_t nbr = (p.nr + 63u) / 64u, nbg = (p.n16 + 63u) / 64u, nbt = p.nr > p.tbox ? p.n1k : 0u;
+        hipLaunchKernelGGL (k_reps_and_boxes, dim3 (nbr + nbg + nbt, p.batch), dim3 (64), 0, s, p, nbr, nbg);
+    }
+    icp_launch_owner_search (p, s);                  // step 1, owner(x) = nearest representative (icp_kernels.hip)
+    hipLaunchKernelGGL (k_chunk_hist, dim3 (p.nchunk, p.batch), dim3 (256), p.nr * sizeof (uint32_t), s, p);
+    if (p.nr <= 1024u) hipLaunchKernelGGL (k_count_offsets, dim3 (1, p.batch), dim3 (1024), 0, s, p);
+    else {
+        hipLaunchKernelGGL (k_count, dim3 ((p.nr + 63) / 64, p.batch), dim3 (1024), 0, s, p);
+        hipLaunchKernelGGL (k_offsets, dim3 (1, p.batch), dim3 (1024), 0, s, p);
+    }
+    hipLaunchKernelGGL (k_place, dim3 (p.nchunk, p.batch), dim3 (1024), 0, s, p);
+}

@@ -212,6 +212,20 @@ int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *o
 // Launches the graph of a run.
 int launch_run (icp_context *h, uint32_t iterations, int check, bool fresh = false, bool with_build = false)
 {
+    {   // diagnostic (ICP_AMD_RUN_GRAPH=0): the same launches enqueued one by one instead of as a cached graph
+        static const char *e = std::getenv ("ICP_AMD_RUN_GRAPH");
+        if (e && e[0] == '0') {
+            icp_params p = h->p; p.check = check;
+            if (with_build) icp_launch_build_rbc (p, h->stream);
+            if (fresh && !icp_chain_supported (p)) icp_launch_reset_state (p, h->stream, 1);
+            if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations, fresh);
+            else for (uint32_t k = 0; k < iterations; ++k) { p.emit = (check || k + 1 == iterations) ? 1 : 0; icp_launch_iteration (p, h->stream); }
+            if (check) HIPCHK (h, hipMemcpyAsync (h->hState, p.st, sizeof (icp_reg_state) * p.batch, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK (h, hipGetLastError ());
+            h->hstate_fresh = check != 0;
+            return ICP_OK;
+        }
+    }
     hipGraphExec_t exec;
     int rc = get_graph (h, iterations, check, &exec, fresh, with_build);
     if (rc) return rc;

@@ -19,6 +19,7 @@
 #define ICP_BAND_COLS 509u
 #define ICP_BAND_ROW_BYTES (ICP_BAND_COLS * 32u)
 #define ICP_BAND_BYTES ((size_t) ICP_BAND_ROWS * ICP_BAND_ROW_BYTES)
+#define ICP_TBOX 1024u            // representatives per LDS tile box of the 1024-tile dense search (k_reps_and_boxes, k_search)
 #define ICP_CHUNK 1024u          // fixed points per block in the stable RBC placement
 
 struct icp_params {
@@ -73,7 +74,19 @@ struct icp_params {
     unsigned long long *dbg;     // diagnostic builds only (ICP_DBG_STAMPS): [blocks][16] s_memtime stamps
 };
 
-// launchers (icp_kernels.hip)
+// Index of the fixed point representative r is sampled from (generalised getReps: kernels/icp_kernels.cl:107-113 with the
+// grid side of the set instead of 128).
+static __device__ __forceinline__ uint32_t rep_src_index (const icp_params &p, uint32_t r)
+{
+    uint32_t gX = r % p.nrx, gY = r / p.nrx;
+    uint32_t stepX = p.side / p.nrx, stepY = p.side / p.nry;
+    uint32_t xi = (stepX == 1) ? gX : gX * stepX + (stepX >> 1) - 1;
+    uint32_t yi = (stepY == 1) ? gY : gY * stepY + (stepY >> 1) - 1;
+    return yi * p.side + xi;
+}
+
+
+// launchers (icp_kernels.hip, icp_build.hip)
 void icp_launch_build_rbc (const icp_params &p, hipStream_t s);
 void icp_launch_search (const icp_params &p, hipStream_t s);
 void icp_launch_means (const icp_params &p, hipStream_t s);
@@ -84,6 +97,9 @@ void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask);
 void icp_launch_chain (const icp_params &p, hipStream_t s, uint32_t iterations, bool fresh = false);
 bool icp_chain_supported (const icp_params &p);
 bool icp_build_lists (const icp_params &p);      // buildRBC = owner search + k_place_lists (2 launches)
+bool icp_dense (const icp_params &p);            // the dense search variant (several blocks per CU, stage-1 pruning)
+uint32_t icp_dense_tile (const icp_params &p);   // its LDS tile: 256 or 1024 representatives
+void icp_launch_owner_search (const icp_params &p, hipStream_t s);   // RBC construct, step 1 (k_search<.., OWNER>)
 uint32_t icp_tbox_of (const icp_params &p);
 uint32_t icp_s2_wave_of (const icp_params &p);
 void icp_search_layout_of (const icp_params &p, int *dense, int *tile, int *stage2);   // what icp_launch_search selects          // 1: the dense search scans the lists with lanes = candidates (long lists)

@@ -990,3 +990,26 @@ def test_reference_kat_through_the_hip_rotation_solvers(engine, oracle):
     assert np.all(np.abs(Tl - twin) < kat["eps_kernel_vs_twin"]) and np.allclose(Tl, twin, rtol=2e-7, atol=0)
     with pytest.raises(engine.ICPError):
         engine.power_method(S, means, rot=7)
+
+
+def test_first_search_seed_policy_does_not_change_a_bit(engine, oracle, monkeypatch):
+    """A registration's first search (k = 0) is seeded from the queries' own grid cells; ICP_AMD_WARM_SEED=1 (diagnostics: what
+    bench.py's `warm_seed_us_per_iteration` measures) keeps whatever the previous registration left in `rid`.  Any valid index is
+    a legal seed: both handles, registering the same pair twice (the second time with the first run's converged nearest
+    representatives lying around), give the oracle's bits — dense search, several tiles (256^2, 1024)."""
+    side, nr = 256, 1024
+    F, M = engine.synth_pair(side)
+    o = oracle.OracleICP(side * side, nr, A, C_, threads=8, power_fast=True, fused=True)
+    o.write_f(F); o.write_m(M); o.build_rbc()
+    for _ in range(6):
+        o.step()
+    for warm in ("0", "1"):
+        monkeypatch.setenv("ICP_AMD_WARM_SEED", warm)
+        g = engine.ICP(0)
+        g.init(side * side, nr, A, C_)
+        g.write(engine.Memory.F, F); g.write(engine.Memory.M, M)
+        for rep in range(2):
+            g.buildRBC()
+            g.run_fixed_fresh(6)
+            check_step(engine, g, o, weighted=False)
+        g.close()

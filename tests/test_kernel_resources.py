@@ -13,7 +13,9 @@ from kernel_resources import FLAGS, ROOT, kernel_resources
 
 @pytest.fixture(scope="module")
 def res():
-    return kernel_resources("icp_amd/csrc/icp_kernels.hip")
+    r = dict(kernel_resources("icp_amd/csrc/icp_kernels.hip"))
+    r.update(kernel_resources("icp_amd/csrc/icp_build.hip"))        # state, getLMs, transforms, the RBC construction, the rotation solver
+    return r
 
 
 def test_flags_match_makefile():

@@ -486,6 +486,40 @@ namespace ICP
         double angle_threshold;
         double translation_threshold;
     };
+
+    /*! \brief Frame-to-frame registration of a sequence of 640 x 480 clouds ("real-time frame-to-frame registration",
+     *         reference README.md:4; per pair the demo's flow src/ocl_icp_reg.cpp:128-172): every frame is registered against the
+     *         previous one, whose landmarks stay on the device.  `submit` only enqueues (the band of the frame that `getLMs`
+     *         reads is uploaded and the landmarks extracted on a copy stream; buildRBC + run are one graph), `collect` blocks for
+     *         the oldest frame in flight and updates `k q t s`; up to four frames may be in flight, so the next frame's upload
+     *         overlaps the current registration.  `staging (slot)` hands out the engine's two pinned frame buffers (the
+     *         reference's mapped `hPtrInF` / `hPtrInM`): a capture loop that writes there and calls `submit (staging (slot))`
+     *         uploads by DMA without a host copy.  The reference has no such class; it is its `ICPReg` loop made resident.
+     */
+    template <ICPStepConfigT CR, ICPStepConfigW CW>
+    class ICPTrack : public ICP<CR, CW>
+    {
+    public:
+        ICPTrack (icp::Env _env, icp::Mode _mode = icp::Mode::FAST, bool _warm_start = false) : ICP<CR, CW> (_env, _mode), warm_start (_warm_start), registered (false) {}
+        /*! \brief Sizes and parameters of the demo: 16384 landmarks, 256 representatives (src/ocl_icp_reg.cpp:82-88). */
+        void init (float _a = 2e2f, float _c = 1e-6f, unsigned int _max_iterations = 40, double _angle_threshold = 0.001, double _translation_threshold = 0.01)
+        { ICP<CR, CW>::init (16384, 256, _a, _c, _max_iterations, _angle_threshold, _translation_threshold, Staging::NONE); }
+        float* staging (unsigned int slot) { void *p = nullptr; this->check (icp_track_staging (this->h, slot, &p)); return static_cast<float *> (p); }
+        void submit (const void *cloud) { this->check (icp_track_submit (this->h, cloud, warm_start ? 1 : 0)); }
+        /*! \brief Blocks for the oldest frame in flight; false for the first frame of a sequence (nothing to register against). */
+        bool collect ()
+        {
+            uint32_t kk = 0; int reg = 0; float T[8];
+            this->check (icp_track_collect (this->h, &kk, T, &reg));
+            registered = reg != 0;
+            if (registered) { this->k = kk; std::memcpy (this->q.c, T, 16); std::memcpy (this->t.v, T + 4, 12); this->s = T[7]; }
+            return registered;
+        }
+        bool next (const void *cloud) { submit (cloud); return collect (); }
+        void reset () { this->check (icp_track_reset (this->h)); }
+        bool warm_start;   /*!< start every registration from the previous hop's transform instead of the identity */
+        bool registered;   /*!< the last collected frame had a predecessor */
+    };
 }
 }
 

@@ -2,6 +2,7 @@
 // two synthetic VGA clouds, init, registerPC.  Prints k, [q | t, s] and a checksum of the transformed cloud so that
 // tests/test_gpu_facade.py can compare them with the Python / oracle flow.
 #include <cstdio>
+#include <cstring>
 #include <ocl_icp_reg.hpp>
 #include <ocl_icp_sbs.hpp>
 
@@ -28,6 +29,24 @@ int main (int argc, char **argv)
         sbs.step (); sbs.step (); sbs.step ();
         auto &st = sbs.stepper ();
         printf ("S %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", st.q.x (), st.q.y (), st.q.z (), st.q.w (), st.t (0), st.t (1), st.t (2), st.s);
+
+        // frame-to-frame tracking (ICPTrack): four frames of the synthetic sequence, two in flight, the first two through the
+        // engine's pinned frame buffers; one line per hop
+        {
+            cl_algo::ICP::ICPTrack<cl_algo::ICP::ICPStepConfigT::POWER_METHOD, cl_algo::ICP::ICPStepConfigW::WEIGHTED> trk (icp::Env (0), mode);
+            trk.init ();
+            std::vector<icp_float8> f (640 * 480);
+            int pending = 0;
+            for (int i = 0; i < 4; ++i) {
+                if (icp_synth_cloud_vga (0x1C9D5EEDull, i, f[0].data ())) return 2;
+                const void *src = f[0].data ();
+                if (i < 2) { float *st = trk.staging ((unsigned) i); std::memcpy (st, src, (size_t) 640 * 480 * 32); src = st; }
+                if (pending == 2) { if (trk.collect ()) printf ("H %u %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", trk.k, trk.q.x (), trk.q.y (), trk.q.z (), trk.q.w (), trk.t (0), trk.t (1), trk.t (2), trk.s); --pending; }
+                trk.submit (src);                    // (pageable sources are copied out before submit returns: f can be refilled)
+                ++pending;
+            }
+            while (pending--) if (trk.collect ()) printf ("H %u %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", trk.k, trk.q.x (), trk.q.y (), trk.q.z (), trk.q.w (), trk.t (0), trk.t (1), trk.t (2), trk.s);
+        }
     }
     catch (const std::exception &e)
     {

@@ -81,6 +81,16 @@ def _icpreg_one_mode(engine, oracle, exe, mode, fast, cloud_f, cloud_m):
         s3.step()
     S = np.array([float(x) for x in lines["S"]], np.float32)
     assert np.array_equal(S.view(np.uint32), s3.T.view(np.uint32))
+    # ICPTrack (include/ICP/algorithms.hpp): four frames, two in flight, pinned and pageable sources: three hops, each the oracle's
+    hops = [l.split()[1:] for l in out.stdout.strip().splitlines() if l.startswith("H ")]
+    assert len(hops) == 3
+    lms = [oracle.get_lms(engine.synth_cloud_vga(moved=f)) for f in range(4)]
+    ot = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=fast, fused=fast)
+    for i, h in enumerate(hops, start=1):
+        ot.write_f(lms[i - 1]); ot.write_m(lms[i]); ot.write_t([0, 0, 0, 1, 0, 0, 0, 1]); ot.build_rbc()
+        assert int(h[0]) == ot.run(), (i, h[0])
+        Th = np.array([float(x) for x in h[1:]], np.float32)
+        assert np.array_equal(Th.view(np.uint32), ot.T.view(np.uint32)), i
 
 
 def test_get_lms_and_cloud_transform(engine, oracle):

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["ICP", "ICPStep", "ICPError", "Memory", "ICPStepConfigT", "ICPStepConfigW",
-           "PowerMode", "ReduceMode", "TransformKind", "ICPBatch", "batch_partition", "power_method", "ReduceScan", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
+           "PowerMode", "ReduceMode", "TransformKind", "ICPBatch", "batch_partition", "power_method", "kernel_lms", "kernel_reps", "kernel_weights", "kernel_mean", "kernel_devs", "kernel_s", "ReduceScan", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("ICP_AMD_LIB", os.path.join(_HERE, "libicp_amd.so"))   # override: A/B builds of the same ABI
@@ -154,6 +154,13 @@ def lib():
     sig("icp_run_form", i32, vp, C.POINTER(i32))
     sig("icp_search_layout", i32, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32))
     sig("icp_power_method", i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(u32))
+    sig("icp_kernel_lms", i32, i32, vp, vp)
+    sig("icp_kernel_reps", i32, i32, vp, u32, u32, vp)
+    sig("icp_kernel_weights", i32, i32, vp, u32, vp, C.POINTER(f64))
+    sig("icp_kernel_mean", i32, i32, i32, vp, vp, vp, f64, u32, vp)
+    sig("icp_kernel_devs", i32, i32, vp, vp, vp, u32, vp, vp)
+    sig("icp_kernel_s", i32, i32, i32, vp, vp, vp, u32, f32, vp)
+    sig("icp_kernel_last_error", C.c_char_p)
     sig("icp_reduce", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_scan", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_reduce_scan_last_error", C.c_char_p)
@@ -264,6 +271,67 @@ def power_method(S, means, rot=ICPStepConfigT.POWER_METHOD, mode=PowerMode.LITER
     if rc:
         raise ICPError(rc, lib().icp_last_error(None).decode())
     return Tk, Rk.reshape(3, 3), it.value
+
+
+def _kchk(rc):
+    if rc:
+        raise ICPError(rc, lib().icp_kernel_last_error().decode())
+
+
+def kernel_lms(cloud, device=0):
+    """ICPLMs: 640 x 480 float8 cloud -> the 128 x 128 landmarks (getLMs)."""
+    cloud = np.ascontiguousarray(cloud, np.float32).reshape(-1, 8)
+    if cloud.shape[0] != 640 * 480:
+        raise ValueError("expected a 640x480 float8 cloud")
+    out = np.empty((16384, 8), np.float32)
+    _kchk(lib().icp_kernel_lms(device, _p(cloud), _p(out)))
+    return out
+
+
+def kernel_reps(F, nr, device=0):
+    """ICPReps: nr representatives of a square landmark set (getReps with the grid side sqrt(m))."""
+    F = np.ascontiguousarray(F, np.float32).reshape(-1, 8)
+    out = np.empty((nr, 8), np.float32)
+    _kchk(lib().icp_kernel_reps(device, _p(F), F.shape[0], nr, _p(out)))
+    return out
+
+
+def kernel_weights(nn_id, device=0):
+    """ICPWeights: {dist, id}[n] -> (W[n], sum of weights)."""
+    nn_id = np.ascontiguousarray(nn_id, DIST_ID)
+    W, sw = np.empty(nn_id.shape[0], np.float32), C.c_double()
+    _kchk(lib().icp_kernel_weights(device, _p(nn_id), nn_id.shape[0], _p(W), C.byref(sw)))
+    return W, sw.value
+
+
+def kernel_mean(F, M, W=None, sum_w=1.0, device=0):
+    """ICPMean<REGULAR> (W is None) / ICPMean<WEIGHTED>: [mean_F, 0 | mean_M, 0]."""
+    F = np.ascontiguousarray(F, np.float32).reshape(-1, 8)
+    M = np.ascontiguousarray(M, np.float32).reshape(-1, 8)
+    Wp = None if W is None else np.ascontiguousarray(W, np.float32)
+    out = np.empty(8, np.float32)
+    _kchk(lib().icp_kernel_mean(device, int(W is not None), _p(F), _p(M), None if Wp is None else _p(Wp), float(sum_w), F.shape[0], _p(out)))
+    return out
+
+
+def kernel_devs(F, M, mean8, device=0):
+    """ICPDevs: (DF[n, 4], DM[n, 4])."""
+    F = np.ascontiguousarray(F, np.float32).reshape(-1, 8)
+    M = np.ascontiguousarray(M, np.float32).reshape(-1, 8)
+    mean8 = np.ascontiguousarray(mean8, np.float32)
+    DF, DM = np.empty((F.shape[0], 4), np.float32), np.empty((F.shape[0], 4), np.float32)
+    _kchk(lib().icp_kernel_devs(device, _p(F), _p(M), _p(mean8), F.shape[0], _p(DF), _p(DM)))
+    return DF, DM
+
+
+def kernel_s(DM, DF, W=None, c=1e-6, device=0):
+    """ICPS<REGULAR> (W is None) / ICPS<WEIGHTED>: S[11]."""
+    DM = np.ascontiguousarray(DM, np.float32).reshape(-1, 4)
+    DF = np.ascontiguousarray(DF, np.float32).reshape(-1, 4)
+    Wp = None if W is None else np.ascontiguousarray(W, np.float32)
+    out = np.empty(11, np.float32)
+    _kchk(lib().icp_kernel_s(device, int(W is not None), _p(DM), _p(DF), None if Wp is None else _p(Wp), DM.shape[0], c, _p(out)))
+    return out
 
 
 def device_count():

@@ -242,6 +242,148 @@ namespace ICP
         std::vector<float> in, out, T;
     };
 
+    /*! \brief reference include/ICP/algorithms.hpp:576-582 / :943-947 */
+    enum class ICPMeanConfig : uint8_t { REGULAR, WEIGHTED };
+    enum class ICPSConfig : uint8_t { REGULAR, WEIGHTED };
+
+    /*! \brief Base of the per-kernel classes below: the device, the error path (the reference prints and calls `exit ()`). */
+    class KernelClass
+    {
+    protected:
+        explicit KernelClass (icp::Env _env) : env (_env) {}
+        void chk (int rc, const char *who) { if (rc != ICP_OK) throw std::runtime_error (std::string (who) + ": " + icp_kernel_last_error ()); }
+        icp::Env env;
+    };
+
+    /*! \brief Landmark extraction — mirrors `ICPLMs` (reference include/ICP/algorithms.hpp:312-383, kernel `getLMs`
+     *         kernels/icp_kernels.cl:63-76): 640 x 480 points in, 128 x 128 landmarks out; `init / write / run / read`, `hPtrIn`, `hPtrOut`. */
+    class ICPLMs : public KernelClass
+    {
+    public:
+        enum class Memory : uint8_t { H_IN, H_OUT, D_IN, D_OUT };
+        explicit ICPLMs (icp::Env _env) : KernelClass (_env), hPtrIn (nullptr), hPtrOut (nullptr) {}
+        void init (Staging = Staging::IO) { in.assign ((size_t) 640 * 480 * 8, 0.f); out.assign ((size_t) 16384 * 8, 0.f); hPtrIn = in.data (); hPtrOut = out.data (); }
+        void write (Memory = Memory::D_IN, void *ptr = nullptr, bool = false) { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (float)); }
+        void* read (Memory = Memory::H_OUT, bool = true) { return out.data (); }
+        void run () { chk (icp_kernel_lms (env.device, in.data (), out.data ()), "ICPLMs"); }
+        float *hPtrIn, *hPtrOut;
+    private:
+        std::vector<float> in, out;
+    };
+
+    /*! \brief Representatives — mirrors `ICPReps` (reference :397-468, kernel `getReps` kernels/icp_kernels.cl:97-114, grid rule
+     *         src/ICP/algorithms.cpp:842-854): `init (nr)` for the reference's 128 x 128 landmarks, `init (nr, m)` for any square set. */
+    class ICPReps : public KernelClass
+    {
+    public:
+        enum class Memory : uint8_t { H_IN, H_OUT, D_IN, D_OUT };
+        explicit ICPReps (icp::Env _env) : KernelClass (_env), hPtrIn (nullptr), hPtrOut (nullptr), m (16384), nr (0) {}
+        void init (unsigned int _nr, Staging = Staging::IO) { init (_nr, 16384u); }
+        void init (unsigned int _nr, unsigned int _m) { m = _m; nr = _nr; in.assign ((size_t) m * 8, 0.f); out.assign ((size_t) nr * 8, 0.f); hPtrIn = in.data (); hPtrOut = out.data (); }
+        void write (Memory = Memory::D_IN, void *ptr = nullptr, bool = false) { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (float)); }
+        void* read (Memory = Memory::H_OUT, bool = true) { return out.data (); }
+        void run () { chk (icp_kernel_reps (env.device, in.data (), m, nr, out.data ()), "ICPReps"); }
+        float *hPtrIn, *hPtrOut;
+    private:
+        unsigned int m, nr;
+        std::vector<float> in, out;
+    };
+
+    /*! \brief Weights and their sum — mirrors `ICPWeights` (reference :485-568, kernels `icpComputeReduceWeights(_WG)`,
+     *         `reduce_sum_fd` kernels/icp_kernels.cl:139-329): `w = 100 / (100 + dist)`, the sum as a double. */
+    class ICPWeights : public KernelClass
+    {
+    public:
+        enum class Memory : uint8_t { H_IN, H_OUT_W, H_OUT_SUM_W, D_IN, D_OUT_W, D_GW, D_OUT_SUM_W };
+        struct dist_id { float dist; uint32_t id; };                  /*!< `rbc_dist_id` (kernels/icp_kernels.cl:34-38) */
+        explicit ICPWeights (icp::Env _env) : KernelClass (_env), hPtrIn (nullptr), hPtrOutW (nullptr), hPtrOutSW (&sw), n (0), sw (0.0) {}
+        void init (unsigned int _n, Staging = Staging::IO) { n = _n; in.assign (n, dist_id { 0.f, 0u }); W.assign (n, 0.f); hPtrIn = in.data (); hPtrOutW = W.data (); }
+        void write (Memory = Memory::D_IN, void *ptr = nullptr, bool = false) { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (dist_id)); }
+        void* read (Memory mem = Memory::H_OUT_SUM_W, bool = true) { return mem == Memory::H_OUT_W ? (void *) W.data () : (void *) &sw; }
+        void run () { chk (icp_kernel_weights (env.device, in.data (), n, W.data (), &sw), "ICPWeights"); }
+        dist_id *hPtrIn; float *hPtrOutW; double *hPtrOutSW;
+    private:
+        unsigned int n; double sw;
+        std::vector<dist_id> in; std::vector<float> W;
+    };
+
+    /*! \brief Set means — mirrors `ICPMean<REGULAR>` / `ICPMean<WEIGHTED>` (reference :625-843, kernels `icpMean`,
+     *         `icpMean_Weighted`, `icpGMean` kernels/icp_kernels.cl:371-566): output `[mean_F, 0 | mean_M, 0]`. */
+    template <ICPMeanConfig C>
+    class ICPMean : public KernelClass
+    {
+    public:
+        enum class Memory : uint8_t { H_IN_F, H_IN_M, H_IN_W, H_IN_SUM_W, H_OUT, D_IN_F, D_IN_M, D_IN_W, D_IN_SUM_W, D_GM, D_OUT };
+        explicit ICPMean (icp::Env _env) : KernelClass (_env), hPtrInF (nullptr), hPtrInM (nullptr), hPtrInW (nullptr), hPtrInSW (&sw), hPtrOut (mean), n (0), sw (1.0) { std::memset (mean, 0, sizeof mean); }
+        void init (unsigned int _n, Staging = Staging::IO) { n = _n; F.assign ((size_t) n * 8, 0.f); M.assign ((size_t) n * 8, 0.f); W.assign (n, 0.f); hPtrInF = F.data (); hPtrInM = M.data (); hPtrInW = W.data (); }
+        void write (Memory mem = Memory::D_IN_F, void *ptr = nullptr, bool = false)
+        {
+            if (!ptr) return;
+            if (mem == Memory::D_IN_F) std::memcpy (F.data (), ptr, F.size () * sizeof (float));
+            else if (mem == Memory::D_IN_M) std::memcpy (M.data (), ptr, M.size () * sizeof (float));
+            else if (mem == Memory::D_IN_W) std::memcpy (W.data (), ptr, W.size () * sizeof (float));
+            else if (mem == Memory::D_IN_SUM_W) std::memcpy (&sw, ptr, sizeof sw);
+        }
+        void* read (Memory = Memory::H_OUT, bool = true) { return mean; }
+        void run () { chk (icp_kernel_mean (env.device, C == ICPMeanConfig::WEIGHTED ? 1 : 0, F.data (), M.data (), W.data (), sw, n, mean), "ICPMean"); }
+        float *hPtrInF, *hPtrInM, *hPtrInW; double *hPtrInSW; float *hPtrOut;
+    private:
+        unsigned int n; double sw; float mean[8];
+        std::vector<float> F, M, W;
+    };
+
+    /*! \brief Deviations from the means — mirrors `ICPDevs` (reference :867-940, kernel `icpSubtractMean` kernels/icp_kernels.cl:588-602). */
+    class ICPDevs : public KernelClass
+    {
+    public:
+        enum class Memory : uint8_t { H_IN_F, H_IN_M, H_IN_MEAN, H_OUT_DEV_F, H_OUT_DEV_M, D_IN_F, D_IN_M, D_IN_MEAN, D_OUT_DEV_F, D_OUT_DEV_M };
+        explicit ICPDevs (icp::Env _env) : KernelClass (_env), hPtrInF (nullptr), hPtrInM (nullptr), hPtrInMean (mean), hPtrOutDevF (nullptr), hPtrOutDevM (nullptr), n (0) { std::memset (mean, 0, sizeof mean); }
+        void init (unsigned int _n, Staging = Staging::IO)
+        { n = _n; F.assign ((size_t) n * 8, 0.f); M.assign ((size_t) n * 8, 0.f); DF.assign ((size_t) n * 4, 0.f); DM.assign ((size_t) n * 4, 0.f);
+          hPtrInF = F.data (); hPtrInM = M.data (); hPtrOutDevF = DF.data (); hPtrOutDevM = DM.data (); }
+        void write (Memory mem = Memory::D_IN_F, void *ptr = nullptr, bool = false)
+        {
+            if (!ptr) return;
+            if (mem == Memory::D_IN_F) std::memcpy (F.data (), ptr, F.size () * sizeof (float));
+            else if (mem == Memory::D_IN_M) std::memcpy (M.data (), ptr, M.size () * sizeof (float));
+            else if (mem == Memory::D_IN_MEAN) std::memcpy (mean, ptr, sizeof mean);
+        }
+        void* read (Memory mem = Memory::H_OUT_DEV_F, bool = true) { return mem == Memory::H_OUT_DEV_M ? DM.data () : DF.data (); }
+        void run () { chk (icp_kernel_devs (env.device, F.data (), M.data (), mean, n, DF.data (), DM.data ()), "ICPDevs"); }
+        float *hPtrInF, *hPtrInM, *hPtrInMean, *hPtrOutDevF, *hPtrOutDevM;
+    private:
+        unsigned int n; float mean[8];
+        std::vector<float> F, M, DF, DM;
+    };
+
+    /*! \brief Sums of products — mirrors `ICPS<REGULAR>` / `ICPS<WEIGHTED>` (reference :976-1183, kernels `icpSijProducts(_Weighted)`
+     *         kernels/icp_kernels.cl:633-743 + `reduce_sum_f` twice): `S` row-major (a = moving, b = fixed), then the sums of
+     *         squares of the fixed and of the moving deviations (kernel order, kernels/icp_kernels.cl:669-670). */
+    template <ICPSConfig C>
+    class ICPS : public KernelClass
+    {
+    public:
+        enum class Memory : uint8_t { H_IN_DEV_M, H_IN_DEV_F, H_IN_W, H_OUT, D_IN_DEV_M, D_IN_DEV_F, D_IN_W, D_SIJ, D_OUT };
+        explicit ICPS (icp::Env _env) : KernelClass (_env), hPtrInDevM (nullptr), hPtrInDevF (nullptr), hPtrInW (nullptr), hPtrOut (S), m (0), c (1e-6f) { std::memset (S, 0, sizeof S); }
+        void init (unsigned int _m, float _c, Staging = Staging::IO)
+        { m = _m; c = _c; DM.assign ((size_t) m * 4, 0.f); DF.assign ((size_t) m * 4, 0.f); W.assign (m, 0.f); hPtrInDevM = DM.data (); hPtrInDevF = DF.data (); hPtrInW = W.data (); }
+        void write (Memory mem = Memory::D_IN_DEV_M, void *ptr = nullptr, bool = false)
+        {
+            if (!ptr) return;
+            if (mem == Memory::D_IN_DEV_M) std::memcpy (DM.data (), ptr, DM.size () * sizeof (float));
+            else if (mem == Memory::D_IN_DEV_F) std::memcpy (DF.data (), ptr, DF.size () * sizeof (float));
+            else if (mem == Memory::D_IN_W) std::memcpy (W.data (), ptr, W.size () * sizeof (float));
+        }
+        void* read (Memory = Memory::H_OUT, bool = true) { return S; }
+        void run () { chk (icp_kernel_s (env.device, C == ICPSConfig::WEIGHTED ? 1 : 0, DM.data (), DF.data (), W.data (), m, c, S), "ICPS"); }
+        float getScaling () { return c; }
+        void setScaling (float _c) { c = _c; }
+        float *hPtrInDevM, *hPtrInDevF, *hPtrInW, *hPtrOut;
+    private:
+        unsigned int m; float c; float S[11];
+        std::vector<float> DM, DF, W;
+    };
+
     /*! \brief Incremental transformation from S and the set means — mirrors `ICPPowerMethod` (reference
      *         include/ICP/algorithms.hpp:1451-1537, src/ICP/algorithms.cpp:2966-3150, kernel `icpPowerMethod`
      *         kernels/icp_kernels.cl:977-1054): `init`, `write (D_IN_S | D_IN_MEAN)`, `run`, `read (H_OUT_T_K)` and the staging

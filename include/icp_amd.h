@@ -250,6 +250,24 @@ int icp_transform_cloud_ex (icp_handle h, int kind, const float *T, const void *
  * out, blocking, needs no icp_init.  The reference's known-answer test (tests/testsICP.cpp:988-1052) drives exactly this entry. */
 int icp_power_method (int device, int rot, int power_mode, const float *S11, const float *means8, float *Tk8, float *Rk9, uint32_t *iters);
 
+/* ---- the reference's per-kernel wrapper classes as stand-alone operations (host in, host out, blocking, no icp_init) ---------------
+ * A user of the reference can call its kernel classes one by one (and its tests do, tests/testsICP.cpp:66-790); the iteration here
+ * fuses these steps (icp_step), so the classes are served by small kernels of their own with the canonical reduction trees —
+ * bit-identical to what the fused path computes for the same inputs in reference-order mode.
+ *   icp_kernel_lms      ICPLMs      include/ICP/algorithms.hpp:312-383   getLMs: 640 x 480 float8 -> 128 x 128 float8
+ *   icp_kernel_reps     ICPReps     :397-468                             getReps (grid side sqrt (m)): m float8 -> nr float8
+ *   icp_kernel_weights  ICPWeights  :485-568                             {dist, id}[n] -> W[n], sum of weights (double)
+ *   icp_kernel_mean     ICPMean<REGULAR | WEIGHTED>  :625-843            F[n] float8, M[n] float8 (, W[n], sum_w) -> [mean_F, 0 | mean_M, 0]
+ *   icp_kernel_devs     ICPDevs     :867-940                             F, M, means -> DF[n] float4, DM[n] float4
+ *   icp_kernel_s        ICPS<REGULAR | WEIGHTED>     :976-1183           DM, DF (, W), c -> S[11] (S row-major, sum w |f|^2, sum w |m|^2) */
+int icp_kernel_lms (int device, const void *cloud_640x480x8, void *lms_16384x8);
+int icp_kernel_reps (int device, const void *F, uint32_t m, uint32_t nr, void *R);
+int icp_kernel_weights (int device, const void *nn_id, uint32_t n, float *W, double *sum_w);
+int icp_kernel_mean (int device, int weighted, const void *F, const void *M, const float *W, double sum_w, uint32_t n, float *mean8);
+int icp_kernel_devs (int device, const void *F, const void *M, const float *mean8, uint32_t n, float *DF, float *DM);
+int icp_kernel_s (int device, int weighted, const float *DM, const float *DF, const float *W, uint32_t m, float c, float *S11);
+const char *icp_kernel_last_error (void);
+
 /* ---- standalone Reduce / Scan classes of the reference ------------------------------ */
 
 /* Reduce<MIN,float> / Reduce<MAX,uint> / Reduce<SUM,float> — include/ICP/algorithms.hpp:52-166,

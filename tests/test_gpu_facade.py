@@ -41,6 +41,17 @@ def test_cpp_facade_matches_oracle(engine, oracle):
     # EIGEN branch within 42000 eps of `svdTk`; literal trips in the range of the reference's comment (56)
     pm = lines["PM"]
     assert all(float(x) < 42000 * np.finfo(np.float32).eps for x in pm[:3]) and 40 <= int(pm[3]) <= 70, pm
+    # the per-kernel classes chained by hand (ICPReps, ICPWeights, ICPMean<WEIGHTED>, ICPDevs, ICPS<WEIGHTED>): S and the sum of weights
+    # against the oracle's twins chained the same way
+    kc = lines["KC"]
+    nn = np.zeros(4096, engine.DIST_ID)
+    nn["dist"] = ((np.arange(4096, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(2 ** 32) % np.uint64(1000)).astype(np.float32) * np.float32(0.001)
+    Wo, swo = oracle.weights(nn)
+    mo = oracle.mean_weighted(F, M, Wo, swo)
+    DFo, DMo = oracle.devs(F, M, mo)
+    So = oracle.sij(DMo, DFo, Wo, 1e-6)
+    assert np.array_equal(np.array([float(x) for x in kc[:11]], np.float32).view(np.uint32), So.view(np.uint32))
+    assert float(kc[11]) == swo and np.float32(float(kc[12])) == oracle.get_reps(F, 64)[0][63, 0]
     # Reduce<MIN>, Reduce<SUM>, Scan<EXCLUSIVE> class mirrors: min and scan checked in the program, the sums here
     assert int(lines["RS"][0]) == 0
     v = ((np.arange(3 * 1024, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1000)).astype(np.float32) * np.float32(0.25) - np.float32(100)
@@ -532,3 +543,46 @@ def test_tracking_pipelined_equals_oracle(engine, oracle, warm, pinned):
     with pytest.raises(engine.ICPError):
         g.track_collect()
     g.close()
+
+
+@pytest.mark.parametrize("n", [16384, 1024, 36, 65536 + 128])
+def test_per_kernel_classes_equal_the_oracle_twins(engine, oracle, n):
+    """The reference's kernel classes one by one, as its own tests drive them (tests/testsICP.cpp:66-790: random inputs of the
+    ranges used there), through the stand-alone entry points icp_kernel_*: every output equals the oracle's twin bit for bit —
+    weights and their double sum, weighted and regular means, deviations, weighted and regular S — at the reference's size, a
+    small one, one whose m / 4 is no multiple of 4, and one beyond the reference's caps (several levels of every tree)."""
+    rng = np.random.default_rng(n)
+    nn = np.zeros(n, engine.DIST_ID)
+    nn["dist"] = rng.random(n, dtype=np.float32)                                   # testsICP.cpp:248: U[0, 1)
+    nn["id"] = rng.integers(0, n, n)
+    W, sw = engine.kernel_weights(nn)
+    Wo, swo = oracle.weights(nn)
+    assert np.array_equal(W.view(np.uint32), Wo.view(np.uint32)) and np.float64(sw).tobytes() == np.float64(swo).tobytes()
+    F = (rng.random((n, 8), dtype=np.float32) * 10000).astype(np.float32)             # :346: U[0, 10000)
+    M = (rng.random((n, 8), dtype=np.float32) * 255).astype(np.float32)               # :347: U[0, 255)
+    mw, mo = engine.kernel_mean(F, M, W, sw), oracle.mean_weighted(F, M, Wo, swo)
+    assert np.array_equal(mw.view(np.uint32), mo.view(np.uint32))
+    mr, mro = engine.kernel_mean(F, M), oracle.mean(F, M)
+    assert np.array_equal(mr.view(np.uint32), mro.view(np.uint32))
+    DF, DM = engine.kernel_devs(F, M, mw)
+    DFo, DMo = oracle.devs(F, M, mo)
+    assert np.array_equal(DF.view(np.uint32), DFo.view(np.uint32)) and np.array_equal(DM.view(np.uint32), DMo.view(np.uint32))
+    dm = (rng.random((n, 4), dtype=np.float32) * 2000 - 1000).astype(np.float32)      # :620: U(-1000, 1000)
+    df = (rng.random((n, 4), dtype=np.float32) * 2000 - 1000).astype(np.float32)
+    for w in (W, None):
+        S, So = engine.kernel_s(dm, df, w, 1e-6), oracle.sij(dm, df, None if w is None else Wo, 1e-6)
+        assert np.array_equal(S.view(np.uint32), So.view(np.uint32)), (n, w is None)
+    with pytest.raises(engine.ICPError):
+        engine.kernel_weights(nn[:7])                                               # odd n: rejected like the reference (:1050)
+
+
+def test_per_kernel_classes_landmarks_and_representatives(engine, oracle):
+    cloud = engine.synth_cloud_vga()
+    lms = engine.kernel_lms(cloud)
+    assert np.array_equal(lms.view(np.uint32), oracle.get_lms(cloud).view(np.uint32))
+    for side, nr in ((128, 256), (128, 64), (256, 1024), (16, 256)):
+        F, _ = engine.synth_pair(side)
+        R = engine.kernel_reps(F, nr)
+        assert np.array_equal(R.view(np.uint32), oracle.get_reps(F, nr)[0].view(np.uint32)), (side, nr)
+    with pytest.raises(engine.ICPError):
+        engine.kernel_reps(F, 48)

@@ -146,6 +146,7 @@ def lib():
     sig("icp_batch_partition", i32, u32, u32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32))
     sig("icp_batch_last_error", C.c_char_p, vp)
     sig("icp_time_run_fixed", i32, vp, u32, u32, i32, C.POINTER(f32))
+    sig("icp_time_run_fixed_tail", i32, vp, u32, u32, i32, C.POINTER(f32), C.POINTER(u32))
     sig("icp_reset_transform", i32, vp)
     sig("icp_time_kernels", i32, vp, u32, C.POINTER(f32))
     sig("icp_profile_run", i32, vp, u32, vp, C.POINTER(f32))
@@ -572,6 +573,12 @@ class ICPStep:
         ms = C.c_float()
         self._chk(self._L.icp_time_run_fixed(self._h, iterations, reps, int(from_identity), C.byref(ms)))
         return ms.value
+
+    def time_run_fixed_tail(self, iterations, reps, from_identity=False):
+        """`reps` passes, HIP events around all but the first: (ms over the timed passes, number of timed passes)."""
+        ms, n = C.c_float(), C.c_uint32()
+        self._chk(self._L.icp_time_run_fixed_tail(self._h, iterations, reps, int(from_identity), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def reset_transform(self):
         """T <- identity, k <- 0 (enqueue only)."""

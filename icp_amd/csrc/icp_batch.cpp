@@ -210,7 +210,9 @@ int icp_batch_time_run_fixed_slots (icp_batch_handle b, uint32_t iterations, uin
         arrived.fetch_add (1, std::memory_order_acq_rel);            // (also on failure: the gate must open for the others)
         while (!go.load (std::memory_order_acquire)) std::this_thread::yield ();
         if (r != ICP_OK) return r;
-        r = icp_time_run_fixed (b->slots[s], iterations, reps, 1, &ms[s]);
+        uint32_t timed = 0;                                           // (events behind the first pass: see icp_time_run_fixed_tail)
+        r = icp_time_run_fixed_tail (b->slots[s], iterations, reps, 1, &ms[s], &timed);
+        if (r == ICP_OK && timed) ms[s] = ms[s] * (float) reps / (float) timed;      // per-slot figure over all `reps` passes at the timed passes' rate
         return r ? r : icp_sync (b->slots[s]);
     });
     gate.join ();

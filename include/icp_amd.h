@@ -332,6 +332,10 @@ const char *icp_batch_last_error (icp_batch_handle b);   /* b may be NULL: error
  * handle's own stream; *ms_total = elapsed ms over all reps.  from_identity != 0: every pass starts from
  * the identity transform (a fresh registration, like the reference's 40-step profiling run). */
 int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int from_identity, float *ms_total);
+/* The same `reps` passes, the events around all but the first: *ms_timed = elapsed ms over *reps_timed = reps - 1 passes (1 of 1).  A marker
+ * recorded on an idle stream holds back the graph launched behind it by 0.1 - 0.25 ms; behind a pass in flight it costs nothing.
+ * What bench.py brackets its K wall-clock-timed steps with (the wall clock covers all K, the events K - 1 of them). */
+int icp_time_run_fixed_tail (icp_handle h, uint32_t iterations, uint32_t reps, int from_identity, float *ms_timed, uint32_t *reps_timed);
 /* ICP::run (timer) — include/ICP/algorithms.hpp:2482-2494: the reference's profiling run, exactly `iterations` steps
  * (40 there) from the current state, no convergence test, with a per-step, per-stage table (the reference fills a
  * ProfilingInfo<40> per kernel class through the run (timer) overloads, e.g. :2359-2399).  The stages run as separate

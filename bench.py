@@ -280,6 +280,7 @@ def measure_config(icp_amd, device, cfg, batch, steps, warmup, iters, power_mode
         os.environ["ICP_AMD_WARM_SEED"] = "1"
         try:
             w, _, _, _ = setup(icp_amd, device, cfg, batch, 0, power_mode, reduce_mode)
+            settle(w, iters)
             for _ in range(warmup):
                 w.run_fixed_fresh(iters)
             w.sync()
@@ -309,6 +310,7 @@ def measure_modes(icp_amd, device, g_default, power_mode, reduce_mode):
     pair: that pipeline's own time per iteration, and the free-running difference of the two registrations."""
     import numpy as np
     r, m, nr, _ = setup(icp_amd, device, "A", 1, 0, "literal", "reference")
+    settle(r, ITERS_PER_STEP)
     for _ in range(5):
         r.run_fixed_fresh(ITERS_PER_STEP)
     r.sync()

@@ -341,7 +341,7 @@ def test_config5_properties(engine, oracle):
 # ---- north-star tolerance of the reference-order mode
 
 @pytest.mark.parametrize("side,nr,rot,weighted", [(128, 256, 1, 1), (32, 16, 1, 1), (30, 4, 1, 1), (6, 4, 1, 1),
-                                                   (64, 64, 1, 0), (64, 64, 0, 1)])
+                                                   (64, 64, 1, 0), (64, 64, 0, 1), (192, 256, 1, 1), (144, 64, 1, 1)])
 def test_fused_steps_bit_exact(engine, oracle, side, nr, rot, weighted):
     g, o, F, M = make(engine, oracle, side, nr, rot=rot, weighted=weighted, power_fast=True, fused=True)
     g.buildRBC()

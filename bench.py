@@ -585,8 +585,9 @@ def main():
                        "parallelism": "single" if world == 1 else ("replicas: one rank per GPU (torch.distributed.run)" if launch == "ranks" else
                                                                    "replicas: icp_batch_* in-process, one host thread + stream per GPU"),
                        "registrations_per_gpu": batch, "power_start": args.power_mode,
-                       "setup": "RBC built, the step's graph instantiated and run %d times (%.0f ms, untimed: clocks of a device that was idle) before the "
-                                "%d warm-up steps" % (setup_passes, SETUP_MS, warmup),
+                       "setup": ("RBC built, the step's graph instantiated and run %d times (%.0f ms, untimed: clocks of a device that was idle) before the "
+                                 "%d warm-up steps" % (setup_passes, SETUP_MS, warmup)) if launch != "inprocess" else
+                                ("RBC built, the step's graph instantiated and run 5 times per device (untimed) before the %d warm-up steps" % warmup),
                        "reduce_mode": args.reduce_mode, "launches_per_iteration": launches},
             "roofline": roofline,
         }

@@ -1013,3 +1013,38 @@ def test_first_search_seed_policy_does_not_change_a_bit(engine, oracle, monkeypa
             g.run_fixed_fresh(6)
             check_step(engine, g, o, weighted=False)
         g.close()
+
+
+@pytest.mark.parametrize("side,nr,fused", [(64, 64, True), (64, 64, False), (128, 256, True), (256, 1024, True)])
+def test_nan_and_inf_points_do_not_break_the_search(engine, oracle, side, nr, fused):
+    """A handful of NaN / inf coordinates in both sets (a sensor's holes are zeros in the reference, kernels/icp_kernels.cl:50-51;
+    NaNs are what other pipelines leave): the RBC structure, the nearest representatives and every correspondence id still equal
+    the oracle's (a NaN distance never wins a '<', on either side; box pruning skips NaN coordinates), distances agree bit for
+    bit where they are numbers and are NaN where the oracle's are; T turns NaN on both sides (garbage in, the same garbage out) —
+    latency variant, dense variant with one and with several representative tiles."""
+    m = side * side
+    F, M = engine.synth_pair(side)
+    rng = np.random.default_rng(5)
+    for idx in rng.choice(m, 6, replace=False):
+        F[idx, rng.integers(0, 3)] = np.nan
+    for idx in rng.choice(m, 6, replace=False):
+        M[idx, rng.integers(0, 7)] = np.nan
+    F[7, 4] = np.inf
+    M[9, 0] = -np.inf
+    g = engine.ICP(0)
+    g.init(m, nr, A, C_)
+    set_modes(engine, g, power_fast=fused, fused=fused)
+    g.write(engine.Memory.F, F); g.write(engine.Memory.M, M)
+    o = oracle.OracleICP(m, nr, A, C_, threads=8, power_fast=fused, fused=fused)
+    o.write_f(F); o.write_m(M)
+    g.buildRBC(); o.build_rbc()
+    assert np.array_equal(g.read(engine.Memory.RBC_OWNER), o.rbc_owner) and np.array_equal(g.read(engine.Memory.RBC_PERM), o.rbc_perm)
+    assert np.array_equal(g.read(engine.Memory.RBC_N), o.rbc_N)
+    g.step(); o.step()
+    gn, on = g.read(engine.Memory.NN_ID), o.nn_id
+    assert np.array_equal(g.read(engine.Memory.RID), o.rid)
+    assert np.array_equal(gn["id"], on["id"])
+    num = ~np.isnan(on["dist"])
+    assert np.array_equal(np.isnan(gn["dist"]), ~num) and np.array_equal(gn["dist"][num].view(np.uint32), on["dist"][num].view(np.uint32))
+    assert np.isnan(g.read(engine.Memory.T)).all() and np.isnan(o.T).all()
+    g.close()

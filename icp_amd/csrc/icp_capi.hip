@@ -1021,17 +1021,22 @@ int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t 
 int icp_debug_stamps (icp_handle h, unsigned long long *out, uint32_t nblocks)
 {   // diagnostic builds (ICP_DBG_STAMPS): one k_search launch, per-block s_memtime stamps
     int rc = need (h, true); if (rc) return rc;
+    if (!out || nblocks == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
     unsigned long long *d = nullptr;
     HIPCHK (h, hipMalloc ((void **) &d, (size_t) nblocks * 16 * 8));
-    HIPCHK (h, hipMemset (d, 0, (size_t) nblocks * 16 * 8));
+    hipError_t e = hipMemset (d, 0, (size_t) nblocks * 16 * 8);
     icp_params p = h->p; p.check = 0; p.dbg = d;
     note_enqueue (h);
-    if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, 2);
-    else { icp_launch_search (p, h->stream); if (p.fused) icp_launch_finalize (p, h->stream); }
-    HIPCHK (h, hipStreamSynchronize (h->stream));
-    HIPCHK (h, hipMemcpy (out, d, (size_t) nblocks * 16 * 8, hipMemcpyDeviceToHost));
+    if (e == hipSuccess) {
+        if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, 2);
+        else { icp_launch_search (p, h->stream); if (p.fused) icp_launch_finalize (p, h->stream); }
+        e = hipGetLastError ();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize (h->stream);
+    if (e == hipSuccess) e = hipMemcpy (out, d, (size_t) nblocks * 16 * 8, hipMemcpyDeviceToHost);
     (void) hipFree (d);
+    if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("icp_debug_stamps: ") + hipGetErrorString (e));
     return ICP_OK;
 }
 

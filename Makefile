@@ -21,6 +21,11 @@ facade_test: $(LIB) tests/cpp/facade_test.cpp include/ICP/algorithms.hpp
 icpreg_test: $(LIB) tests/cpp/icpreg_test.cpp include/ocl_icp_reg.hpp include/ocl_icp_sbs.hpp include/ICP/algorithms.hpp
 	g++ -O2 -std=c++17 -Iinclude -o tests/cpp/icpreg_test tests/cpp/icpreg_test.cpp -Licp_amd -licp_amd -Wl,-rpath,'$$ORIGIN/../../icp_amd'
 
+# the reference's two example programs as command-line programs (examples/registration.cpp, examples/step_by_step.cpp)
+examples: $(LIB) examples/registration.cpp examples/step_by_step.cpp include/ocl_icp_reg.hpp include/ocl_icp_sbs.hpp include/ICP/algorithms.hpp
+	g++ -O2 -std=c++17 -Wall -Iinclude -o examples/registration examples/registration.cpp -Licp_amd -licp_amd -Wl,-rpath,'$$ORIGIN/../icp_amd'
+	g++ -O2 -std=c++17 -Wall -Iinclude -o examples/step_by_step examples/step_by_step.cpp -Licp_amd -licp_amd -Wl,-rpath,'$$ORIGIN/../icp_amd'
+
 capi_example: $(LIB) tests/cpp/capi_example.c include/icp_amd.h
 	gcc -O2 -std=c99 -Wall -Iinclude -o tests/cpp/capi_example tests/cpp/capi_example.c -Licp_amd -licp_amd -Wl,-rpath,'$$ORIGIN/../../icp_amd'
 
@@ -36,7 +41,7 @@ asan: tests/cpp/asan_host
 	ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 tests/cpp/asan_host
 
 clean:
-	rm -f $(LIB) tests/cpp/facade_test tests/cpp/capi_example tests/cpp/icpreg_test tests/cpp/asan_host tests/cpp/asan_oracle.o
+	rm -f $(LIB) examples/registration examples/step_by_step tests/cpp/facade_test tests/cpp/capi_example tests/cpp/icpreg_test tests/cpp/asan_host tests/cpp/asan_oracle.o
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean asan
+.PHONY: all oracle clean asan examples

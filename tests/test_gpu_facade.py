@@ -104,6 +104,46 @@ def _icpreg_one_mode(engine, oracle, exe, mode, fast, cloud_f, cloud_m):
         assert np.array_equal(Th.view(np.uint32), ot.T.view(np.uint32)), i
 
 
+def test_example_programs(engine, oracle, tmp_path):
+    """examples/registration and examples/step_by_step — the reference's two example programs (examples/registration.cpp,
+    examples/step_by_step.cpp) as command-line programs: cloud files in the reference's format in, report + [q | t, s] out, the
+    transformed cloud written where the reference fills a GL buffer; results are the oracle's."""
+    import re
+    subprocess.check_call(["make", "-C", ROOT, "-s", "examples"])
+    cloud_f, cloud_m = engine.synth_cloud_vga(moved=False), engine.synth_cloud_vga(moved=True)
+    pf, pm, po = tmp_path / "a.bin", tmp_path / "b.bin", tmp_path / "out.bin"
+    cloud_f.astype("<f4").tofile(pf); cloud_m.astype("<f4").tofile(pm)
+    num = r"([-+0-9.eE]+|nan|inf)"
+    pat = re.compile(r"q = \(%s, %s, %s, %s\)\s+t = \(%s, %s, %s\)\s+s = %s" % ((num,) * 8))
+
+    def T_of(text):
+        m = pat.search(text)
+        assert m, text
+        return np.array([float(x) for x in m.groups()], np.float32)
+
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+    o.write_f(oracle.get_lms(cloud_f)); o.write_m(oracle.get_lms(cloud_m)); o.build_rbc()
+    k = o.run()
+    for args in ([str(pf), str(pm), "--out", str(po)], []):            # files, then the built-in synthetic pair (the same clouds)
+        out = subprocess.run([os.path.join(ROOT, "examples", "registration")] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert "Iterations" in out.stdout and "k = %d" % k in out.stdout
+        assert np.array_equal(T_of(out.stdout).view(np.uint32), o.T.view(np.uint32))
+    moved = np.fromfile(po, "<f4").reshape(-1, 8)
+    assert np.array_equal(moved.view(np.uint32), oracle.transform_q(cloud_m, o.T).view(np.uint32))
+    bad = subprocess.run([os.path.join(ROOT, "examples", "registration"), str(pf), str(tmp_path / "missing.bin")], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "cannot open" in bad.stderr
+    # step by step: 5 iterations in the reference-order modes, against the oracle's 5 steps
+    s5 = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8)
+    s5.write_f(oracle.get_lms(cloud_f)); s5.write_m(oracle.get_lms(cloud_m)); s5.build_rbc()
+    for _ in range(5):
+        s5.step()
+    out = subprocess.run([os.path.join(ROOT, "examples", "step_by_step"), "5", str(pf), str(pm), "--reference-order"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.count("Iteration k = ") == 5
+    assert np.array_equal(T_of(out.stdout).view(np.uint32), s5.T.view(np.uint32))
+
+
 def test_get_lms_and_cloud_transform(engine, oracle):
     cloud_f = engine.synth_cloud_vga(moved=False)
     cloud_m = engine.synth_cloud_vga(moved=True)

@@ -143,18 +143,32 @@ typedef float float2v __attribute__ ((ext_vector_type (2)));
         asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
         if (tid == 0 && p.dbg) p.dbg[(size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = t_;    \
     }
+#elif defined (ICP_DBG_EXIT_AFTER)
+// diagnostic builds (tests/diag_phase_insts.sh): the search kernel ends behind phase k — the instruction counters of a PMC run
+// then hold the phases up to k, and differences between builds are the phases themselves (every thread of a block gets here)
+#define KS_STAMP(k) { if ((k) == ICP_DBG_EXIT_AFTER) return; }
+#define KS_KEEP(a, b) asm volatile ("" :: "v"(a), "v"(b));      // (the phase's results count as used: nothing of it is optimised away)
 #else
 #define KS_STAMP(k)
+#endif
+#ifndef KS_KEEP
+#define KS_KEEP(a, b)
 #endif
 
 // minimum over each group of LPQ (8 or 16) consecutive lanes, returned in all of them (min is exact: any pairing
 // gives the same bits)
+// One v_min_f32 whose first operand comes through DPP per step: fminf (v, dpp (v)) compiles to a DPP move, two canonicalising
+// v_max and the v_min — the values here are results of arithmetic (never signalling NaNs) and v_min_f32 returns the other
+// operand for a quiet NaN exactly as fminf does, so the one instruction gives the same bits (tests: every distance bit for bit).
+// (s_nop 1: a DPP operand must not be read for two wait states after a VALU wrote it; the assembler text is opaque to the
+// compiler's hazard pass.)
+#define KS_MIN_DPP(v, CTRL) asm ("s_nop 1\n\tv_min_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(v) : "v"(v))
 template <int LPQ> static __device__ __forceinline__ float ks_grp_min_f (float v)
 {
-    v = fminf (v, icp_dpp<0xB1> (v));                // quad_perm [1,0,3,2]
-    v = fminf (v, icp_dpp<0x4E> (v));                // quad_perm [2,3,0,1]
-    v = fminf (v, icp_dpp<0x141> (v));               // row_half_mirror: lane i <-> 7 - i
-    if (LPQ == 16) v = fminf (v, icp_dpp<0x140> (v));   // row_mirror: lane i <-> 15 - i
+    KS_MIN_DPP (v, "quad_perm:[1,0,3,2]");
+    KS_MIN_DPP (v, "quad_perm:[2,3,0,1]");
+    KS_MIN_DPP (v, "row_half_mirror");               // lane i <-> 7 - i
+    if (LPQ == 16) KS_MIN_DPP (v, "row_mirror");     // lane i <-> 15 - i
     return v;
 }
 template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint32_t v)
@@ -737,7 +751,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
                 const uint32_t P = (KS_SPLIT == 8 && gt_lg1) ? (((4u * (gl >> (gt_lg1 - 1u)) + (ss >> 1)) << gt_lg1) + 2u * (gl & ((1u << (gt_lg1 - 1u)) - 1u)) + (ss & 1u))
                                                               : gl * KS_SPLIT + ss;
                 if (P < npair_) {
-                    float4 A = s_pair[hb_ * PB + 3 * P], B = s_pair[hb_ * PB + 3 * P + 1], C = s_pair[hb_ * PB + 3 * P + 2];
+                    const uint32_t P3 = hb_ * PB + __umul24 (P, 3u);       // (24-bit multiply: full rate; a 32-bit v_mul_lo costs four issue slots)
+                    float4 A = s_pair[P3], B = s_pair[P3 + 1], C = s_pair[P3 + 2];
                     float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
                     float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
                     float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
@@ -936,6 +951,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             }
         }
     }
+    KS_KEEP (best, bid)
     KS_STAMP (2)
     const float dr = ks_grp_min_f<KS_SPLIT> (best);           // the query's nearest representative: smallest distance,
     uint32_t rstar = ks_grp_min_u<KS_SPLIT> (best == dr ? bid : 0xFFFFFFFFu);     // ties -> lowest index
@@ -966,6 +982,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         if (ss == 0u && valid) p.owner[(size_t) b * m + i] = rstar;
         return;
     }
+    KS_KEEP (dr, rstar)
     KS_STAMP (3)
     // list offset / size of the winner.  One tile (always the case for the MINW == 2 variants, see icp_launch_search):
     // from LDS; the compile-time split keeps the compiler from merging the two sources into flat loads.
@@ -1099,31 +1116,34 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         // nor evaluated, at the cost of scalar compares only (the scan is bound by the vector-memory issue rate).
         constexpr uint32_t KS_DEPTH = (KS_SPLIT == 16) ? ICP_S2_DEPTH16 : 4u;
         const uint32_t je = valid ? o + n : o;       // (invalid queries: an empty range)
-        uint32_t ntrips = 0u;
-#pragma unroll
-        for (uint32_t gq = 0; gq < KS_QPW; ++gq) {
-            const uint32_t ng_ = (uint32_t) __builtin_amdgcn_readlane ((int) (je - o), (int) (gq * KS_SPLIT));
-            ntrips = max (ntrips, (ng_ + KS_SPLIT - 1u) / KS_SPLIT);
-        }
+        // the wave's trip count = its longest list: the lanes of a query hold the same count, so one mirror inside the 16-lane rows
+        // (two queries per row at 8 lanes per query) and the two row broadcasts of a wave reduction leave the maximum in lane 63
+        uint32_t nl = (je - o + KS_SPLIT - 1u) / KS_SPLIT;
+        if (KS_SPLIT == 8) nl = max (nl, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) nl, 0x140, 0xF, 0xF, true));        // row_mirror
+        nl = max (nl, (uint32_t) __builtin_amdgcn_update_dpp ((int) nl, (int) nl, 0x142, 0xA, 0xF, false));                   // row_bcast:15 -> rows 1, 3
+        nl = max (nl, (uint32_t) __builtin_amdgcn_update_dpp ((int) nl, (int) nl, 0x143, 0xC, 0xF, false));                   // row_bcast:31 -> rows 2, 3
+        const uint32_t ntrips = (uint32_t) __builtin_amdgcn_readlane ((int) nl, 63);
+        // byte offsets from the uniform base (m <= 2^20: < 2^25 bytes); a position past the list's end is clamped to its last
+        // element, whose (distance, position) some lane holds anyway — a duplicate changes neither the minimum nor the lowest
+        // position among equals, so there is no tail test.  The lane keeps the TRIP of its best candidate (a scalar + constant per
+        // candidate instead of a recomputed position); trips ascend, so a strict '<' keeps the lane's lowest position.
+        const uint32_t alast = (max (je, 1u) - 1u) << 5;
         for (uint32_t tb = 0; tb < ntrips; tb += KS_DEPTH) {
-            const uint32_t j0 = o + ss + tb * KS_SPLIT, nt = min (KS_DEPTH, ntrips - tb);
+            const uint32_t a0 = (o + ss + tb * KS_SPLIT) << 5, nt = min (KS_DEPTH, ntrips - tb);
             float4 g[KS_DEPTH], c[KS_DEPTH];
 #pragma unroll
             for (uint32_t t = 0; t < KS_DEPTH; ++t) {
                 if (t >= nt) break;
-                const uint32_t j = min (j0 + t * KS_SPLIT, max (je, 1u) - 1u);
-                const char *rec = XQb + (j << 5);     // 32-bit byte offset from a uniform base (m <= 2^20: < 2^25 bytes)
+                const char *rec = XQb + min (a0 + t * (KS_SPLIT * 32u), alast);
                 g[t] = *reinterpret_cast<const float4 *> (rec); c[t] = *reinterpret_cast<const float4 *> (rec + 16);
             }
 #pragma unroll
             for (uint32_t t = 0; t < KS_DEPTH; ++t) {
                 if (t >= nt) break;
-                // no tail test: a position past the list's end was clamped to its last element, whose (distance, position)
-                // some lane holds anyway — a duplicate changes neither the minimum nor the lowest position among equals
-                const uint32_t j = min (j0 + t * KS_SPLIT, max (je, 1u) - 1u);
-                KS_CAND (g[t], c[t], j);
+                KS_CAND (g[t], c[t], tb + t);
             }
         }
+        if (bj != 0xFFFFFFFFu) bj = min (o + ss + bj * KS_SPLIT, max (je, 1u) - 1u);     // trip -> list position
         if (je == o) { best2 = __builtin_inff (); bj = 0xFFFFFFFFu; }      // empty list / invalid query: nothing above was a candidate
     }
     KS_STAMP (4)
@@ -1132,6 +1152,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     dmin = ks_grp_min_f<KS_SPLIT> (best2);
     jmin = ks_grp_min_u<KS_SPLIT> (best2 == dmin ? bj : 0xFFFFFFFFu);
     }
+    KS_KEEP (dmin, jmin)
     KS_STAMP (5)
     // Hand-off: lane 0 of every query leaves (q, distance, winner position, representative, flags) in LDS, and ONE wave
     // finishes all 64 queries of the block with every lane active (lane e = query e): the winner's record, the weight,
@@ -1445,6 +1466,9 @@ template <int ROT>
 __global__ __launch_bounds__ (1024) void k_finalize_fused (const double *gmom, icp_reg_state *gst, uint32_t nb, uint32_t check, icp_params p)
 {
     // (the leading scalars: see k_search)
+#ifdef ICP_DBG_EXIT_AFTER
+    return;                                          // (phase-count builds: the transform stays what it is, every iteration sees the same queries)
+#endif
     const uint32_t b = blockIdx.x;
     icp_reg_state *st = gst + b;
     FF_STAMP (14)

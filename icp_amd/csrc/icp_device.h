@@ -176,9 +176,14 @@ __device__ __forceinline__ float pmq_normalize (float y)
 __device__ __forceinline__ void pmq_rescale (float *Brow)
 {   // exact power-of-two rescale so that max|entry| lies in [1,2)
     // (oracle rescale16; max is exact in any order: the quad's rows are combined with two DPP steps)
-    float mx = fmaxf (fmaxf (fabsf (Brow[0]), fabsf (Brow[1])), fmaxf (fabsf (Brow[2]), fabsf (Brow[3])));
-    mx = fmaxf (mx, icp_dpp<0xB1> (mx));             // quad_perm [1,0,3,2]
-    mx = fmaxf (mx, icp_dpp<0x4E> (mx));             // quad_perm [2,3,0,1]
+    // (four instructions, written out: fmaxf / fabsf compile to a canonicalising v_max per operand and a DPP move per step —
+    // twelve instructions on the one wave the whole grid waits for; v_max3 / v_max return the non-NaN operand as fmaxf does, the
+    // entries are results of arithmetic (no signalling NaNs).  s_nop 1: DPP operand hazard, opaque to the compiler's hazard pass.)
+    float mx;
+    asm ("v_max3_f32 %0, |%1|, |%2|, |%3|\n\tv_max_f32_e64 %0, %0, |%4|\n\ts_nop 1\n\t"
+         "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+         "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+         : "=&v"(mx) : "v"(Brow[0]), "v"(Brow[1]), "v"(Brow[2]), "v"(Brow[3]));
     const uint32_t e = (__float_as_uint (mx) >> 23) & 0xFFu;
     const float sc = (e == 0u || e >= 254u) ? 1.f : __uint_as_float ((254u - e) << 23);    // zero / subnormal / inf / nan: leave
     Brow[0] = Brow[0] * sc; Brow[1] = Brow[1] * sc; Brow[2] = Brow[2] * sc; Brow[3] = Brow[3] * sc;

@@ -361,6 +361,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     p.nsp = (p.G + 511u) / 512u; if (p.nsp != 1 && (p.nsp % 4)) p.nsp += 4 - p.nsp % 4;   // :140-142
     p.nchunk = (m + ICP_CHUNK - 1) / ICP_CHUNK;
     p.nb = (m + 63u) / 64u;
+    { const uint32_t ng = (p.nb + 127u) / 128u; p.ng_magic = ng > 1u ? (uint32_t) ((1ull << 32) / ng + 1ull) : 0u; }    // (tasks: 18 ng < 2^16)
 
     const size_t B = batch;
     float *F = nullptr, *M = nullptr;

@@ -26,6 +26,7 @@ struct icp_params {
     // problem
     uint32_t m, nr, batch;
     uint32_t side, nrx, nry;     // landmark grid side and representative grid (getReps)
+    uint32_t ng_magic;                               // floor (2^32 / ng) + 1 for ng = groups of 128 block moments: task / ng = umulhi (task, magic)
     uint32_t side_magic, cellw_magic, cellh_magic;   // floor (2^32 / d) + 1 for d = side, side / nrx, side / nry (0: the set is no square grid): n / d = umulhi (n, magic)
     float a, c;
     float dist_scale;            // f_g of the metric text: reported distance (NN_ID.dist, the weights' input) = dist_scale * (geo + a pho); default 1

@@ -1495,12 +1495,12 @@ __global__ __launch_bounds__ (1024) void k_finalize_fused (const double *gmom, i
 // First tree level of the moments for large sets (|F| / 64 blocks > 128 * ICP_L1_MIN_GROUPS): one 16-lane row per
 // (moment k, group g) task, 16 tasks per block, spread over the chip — k_finalize_fused alone would walk the
 // 18 x ceil (nb / 128) tasks 64 at a time (config C: 36 dependent passes, 39 us).  Same tree, same bits.
-__global__ __launch_bounds__ (256) void k_moment_level1 (const double *gmom, const icp_reg_state *gst, uint32_t nb, uint32_t check, icp_params p)
+__global__ __launch_bounds__ (256) void k_moment_level1 (const double *gmom, const icp_reg_state *gst, uint32_t nb, uint32_t check, uint32_t ng_magic, icp_params p)
 {
     const uint32_t b = blockIdx.y, l = threadIdx.x & 15u, row = threadIdx.x >> 4;
     if (check && gst[b].done) return;
     const uint32_t ng = (nb + 127u) / 128u, ntask = ICP_NMOM * ng;
-    const uint32_t task = min (blockIdx.x * 16u + row, ntask - 1u), k = task / ng, g = task - k * ng;
+    const uint32_t task = min (blockIdx.x * 16u + row, ntask - 1u), k = ng_magic ? __umulhi (task, ng_magic) : task, g = task - k * ng;   // (ng_magic = floor (2^32 / ng) + 1, a preloaded scalar: no runtime division in front of the loads)
     const double *src = gmom + (size_t) b * 2 * ICP_NMOM * nb + (size_t) k * nb;
     double a[8];
 #pragma unroll
@@ -1637,7 +1637,7 @@ void icp_launch_finalize (const icp_params &p, hipStream_t s)
     if (p.fused) {
         const uint32_t ng = (p.nb + 127u) / 128u;
         if (ng > ICP_L1_MIN_GROUPS && p.ml1)
-            hipLaunchKernelGGL (k_moment_level1, dim3 ((ICP_NMOM * ng + 15u) / 16u, p.batch), dim3 (256), 0, s, (const double *) p.mom, (const icp_reg_state *) p.st, p.nb, (uint32_t) p.check, p);
+            hipLaunchKernelGGL (k_moment_level1, dim3 ((ICP_NMOM * ng + 15u) / 16u, p.batch), dim3 (256), 0, s, (const double *) p.mom, (const icp_reg_state *) p.st, p.nb, (uint32_t) p.check, p.ng_magic, p);
         if (p.rot == 1) hipLaunchKernelGGL (k_finalize_fused<1>, dim3 (p.batch), dim3 (1024), 0, s, (const double *) p.mom, p.st, p.nb, (uint32_t) p.check, p);
         else hipLaunchKernelGGL (k_finalize_fused<0>, dim3 (p.batch), dim3 (1024), 0, s, (const double *) p.mom, p.st, p.nb, (uint32_t) p.check, p);
     } else {

@@ -41,7 +41,7 @@ shutil.copy(os.path.join(ROOT, "gpurun_out", "%s_profile_summary.json" % tag), o
 for cfg in ("A", "B", "C", "Ax64", "REF"):
     src = os.path.join(ROOT, "gpurun_out", "%s_%s_kernel_stats.csv" % (tag, cfg))
     if os.path.exists(src):
-        shutil.copy(src, os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)))
+        shutil.copy(src, os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, "reference_order" if cfg == "REF" else cfg)))
 for k, v in out.items():
     if k.startswith("detail_"):
         print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()})

@@ -893,7 +893,9 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             const float qnan = __builtin_nanf ("");
             dst[0] = qnan; dst[2] = qnan; dst[4] = qnan; dst[6] = qnan; dst[8] = qnan; dst[10] = qnan;
         }
-        __syncthreads ();
+        // (chained variant, queries handed over inside the finalize: its closing barrier already stands behind every LDS write of
+        // the prologue — representatives, list headers, boxes, queries —; a second one here would only be waited for)
+        if (!(CHAIN && handed && t0 == 0u && !(tn & 1u))) __syncthreads ();
         if (t0 == 0) {                               // the query prepared by the query wave
             const float4 a4 = s_qa[qe], c4 = s_qc[qe];
             qx = a4.x; qy = a4.y; qz = a4.z; i = __float_as_uint (a4.w); valid = i < m;

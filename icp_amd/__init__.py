@@ -103,6 +103,10 @@ def lib():
     sig("icp_build_rbc", i32, vp)
     sig("icp_step", i32, vp, i32)
     sig("icp_run", i32, vp, C.POINTER(u32))
+    sig("icp_run_stats", i32, vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32))
+    sig("icp_set_run_depth", i32, vp, u32, i32)
+    sig("icp_run_timeline", i32, vp, C.POINTER(f64))
+    sig("icp_set_output_mode", i32, vp, i32)
     sig("icp_run_fixed", i32, vp, u32)
     sig("icp_run_fixed_fresh", i32, vp, u32)
     sig("icp_sync", i32, vp)
@@ -666,6 +670,26 @@ class ICP(ICPStep):
 
     def step(self, config=False):
         ICPStep.run(self, config)
+
+    def run_stats(self):
+        """(iteration launches enqueued, final k, launches past the last live iteration) of the last finished checked run."""
+        n, k, d = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self._L.icp_run_stats(self._h, C.byref(n), C.byref(k), C.byref(d)))
+        return n.value, k.value, d.value
+
+    def run_timeline(self):
+        """Host timeline of the last run() in us: [0, launches enqueued, first progress seen, decided, end enqueued, FINAL seen]."""
+        t = (C.c_double * 6)()
+        self._chk(self._L.icp_run_timeline(self._h, t))
+        return [float(x) for x in t]
+
+    def set_output_mode(self, every_iteration=False):
+        """Per-query outputs of checked runs: stored by every iteration, or (default) reproduced on the first read (icp_set_output_mode)."""
+        self._chk(self._L.icp_set_output_mode(self._h, int(every_iteration)))
+
+    def set_run_depth(self, depth=3, adaptive=True):
+        """Launches kept queued behind the one in flight by checked runs; adaptive=False: one graph of max_iterations launches."""
+        self._chk(self._L.icp_set_run_depth(self._h, depth, int(adaptive)))
 
     def getMaxIterations(self):
         v = C.c_uint32()

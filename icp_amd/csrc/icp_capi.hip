@@ -10,6 +10,8 @@
 #include "../../include/icp_amd.h"
 #include "icp_kernels.h"
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,12 +19,36 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <immintrin.h>
 
 namespace {
 
 thread_local std::string g_create_error;
 
-struct graph_entry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+struct graph_entry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t used = 0, gen = 0; };
+
+// A checked run (ICP::run — src/ICP/algorithms.cpp:4806-4834: iterate until check () says stop) that the HOST drives, launch by launch.
+// The device publishes every new transform's (k, done) as one 8-byte store into fine-grained host memory (icp_params::hmirror); the
+// host keeps `depth` launches queued behind the one in flight and stops enqueueing the moment `done` shows: a run costs k launches
+// (+ at most `depth` that leave at their first load), not max_iterations.  Plain launches, not graphs: back to back they run at the
+// graph's rate (8.77 against 8.73 us per iteration at |F| = 16384) and every graph boundary costs 4 - 8 us (profiles/r04_segments.txt).
+// The end kernel leaves the final state in host memory too (icp_params::hstate) and sets the word's FINAL bit: the caller polls that
+// instead of synchronising the stream.  At most one run per handle is open; tracking keeps it open across calls (icp_track_submit
+// returns with a frame's predicted launches enqueued, the next call tops it up).
+struct run_ctl {
+    bool active = false, decided = false, chained = false, fresh = false;
+    icp_params p {};
+    uint32_t enq = 0, maxit = 0, depth = 0, k_seen = 0, k_final = 0;
+    int done_seen = 0;
+    bool final_seen = false;                            // every registration's final state has arrived with its converged flag: no end kernel
+    volatile unsigned long long *mirror = nullptr;      // host view of p.hmirror
+    int track_slot = -1;                                // tracking: the ring slot whose evDone follows the end kernel
+    // host timeline of the run (icp_run_timeline), seconds on the steady clock: begin, blind launches enqueued, first progress word seen,
+    // decided, end kernel enqueued
+    double t[5] = { 0, 0, 0, 0, 0 };
+};
+
+inline double now_s () { return std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count (); }
 
 }  // namespace
 
@@ -39,9 +65,23 @@ struct icp_context {
     float *dF = nullptr, *dM = nullptr;          // may be adopted
     bool ownF = true, ownM = true;
     float *hF = nullptr, *hM = nullptr, *hT = nullptr;   // pinned staging (H_IN_F / H_IN_M / H_IO_T)
-    icp_reg_state *hState = nullptr;             // pinned mirror of the registration states: every run graph ends with a copy into it
-    bool hstate_fresh = false;                   // the mirror is what the device holds once the stream has drained (a run graph was the
-                                                 // last state-changing thing enqueued)
+    icp_reg_state *hState = nullptr;             // pinned (fine-grained) mirror of the registration states: the end kernel of a checked run stores into it
+    bool hstate_fresh = false;                   // the mirror is what the device holds (a checked run was the last state-changing thing on the stream)
+    bool hstate_here = false;                    // ... and it has arrived (host-driven run: its FINAL bit was seen); else: once the stream has drained
+    unsigned long long *hMirror = nullptr;       // pinned (fine-grained): progress words of the checked run in flight, [batch] (run_ctl)
+    uint32_t epoch = 0;                          // tag of the last checked run
+    uint32_t run_depth = 3;                      // launches kept queued behind the one in flight (ICP_AMD_RUN_DEPTH)
+    int run_adaptive = 1;                        // 0 (ICP_AMD_RUN_ADAPTIVE=0): checked runs as one graph of max_iterations launches (rounds 1 - 3)
+    run_ctl run;
+    // Per-query outputs (NN_ID, W, NN, QT, RID) of checked runs: fused kernels consume none of them, and a checked run cannot know which
+    // iteration is its last — storing them every iteration costs 0.4 us of every 9 at |F| = 16384.  lazy: the run stores none; every finalize
+    // leaves the transform its search used in p.st_prev, and the first read of such an output re-runs that one search (same T, same
+    // lists: same bits).  Inputs changed in between (F / M written, RBC rebuilt, tracking moved on): the outputs are gone, reads say so.
+    int outputs_lazy = 1;                        // ICP_AMD_OUTPUTS=eager / icp_set_output_mode
+    bool outputs_stale = false, outputs_lost = false;
+    uint32_t stat_launches = 0, stat_k = 0, stat_dead = 0;   // last finished checked run: iteration launches enqueued, final k, launches past the last live one
+    double stat_t[6] = { 0, 0, 0, 0, 0, 0 };     // its host timeline (run_ctl::t) + the moment its FINAL bit was seen
+    uint64_t graph_clock = 0, param_gen = 0;     // LRU stamp of the graph cache; generation of the parameters the cached graphs were captured with
     float *dTin = nullptr;                       // device scratch for write(T)
     float *dCloud = nullptr, *dCloudOut = nullptr; uint32_t cloud_cap = 0;
     std::map<uint64_t, graph_entry> graphs;      // key: iterations << 3 | check << 2 | parity (+ fresh, + kind: see get_graph)
@@ -51,6 +91,9 @@ struct icp_context {
     float *hBand[2] = { nullptr, nullptr }, *dBand[2] = { nullptr, nullptr };     // the part of a frame getLMs reads (ICP_BAND_*), pinned / device
     float *hFrame[2] = { nullptr, nullptr };                 // whole-frame pinned staging handed to the caller (icp_track_staging)
     icp_reg_state *hTrack = nullptr;                         // pinned: final state of the frames in flight (ICP_TRACK_RING slots)
+    unsigned long long *hTrackMirror = nullptr;              // pinned: their progress words
+    uint32_t track_epoch[4] = { 0, 0, 0, 0 };                // epoch of the run in each ring slot
+    uint32_t track_k_hist[2] = { 0, 0 };                     // k of the last two registrations of the sequence (0: none yet): the next frame's blind launches
     hipStream_t copy_stream = nullptr;
     hipEvent_t evUp[2] = { nullptr, nullptr }, evDone[4] = { nullptr, nullptr, nullptr, nullptr };
     hipEvent_t evStage[3] = { nullptr, nullptr, nullptr };   // the last asynchronous copy out of the pinned staging of F / M / T (icp_write)
@@ -91,7 +134,10 @@ void free_all (icp_context *h)
     if (h->hM) (void) hipHostFree (h->hM);
     if (h->hT) (void) hipHostFree (h->hT);
     if (h->hState) (void) hipHostFree (h->hState);
-    h->hState = nullptr; h->hstate_fresh = false;
+    if (h->hMirror) (void) hipHostFree (h->hMirror);
+    if (h->hTrackMirror) (void) hipHostFree (h->hTrackMirror);
+    h->hState = nullptr; h->hMirror = h->hTrackMirror = nullptr; h->hstate_fresh = false;
+    h->run = run_ctl {}; h->track_k_hist[0] = h->track_k_hist[1] = 0;
     if (h->dCloud) (void) hipFree (h->dCloud);
     if (h->dCloudOut) (void) hipFree (h->dCloudOut);
     h->hF = h->hM = h->hT = nullptr; h->dCloud = h->dCloudOut = nullptr; h->cloud_cap = 0;
@@ -139,11 +185,20 @@ bool reps_grid (uint32_t m, uint32_t nr, uint32_t *nrx, uint32_t *nry, uint32_t 
     return true;
 }
 
-int need (icp_context *h, bool built)
+int run_finish (icp_context *h);
+void note_outputs_stored (icp_context *h);
+
+// keep_run: the caller is one of the tracking entries, which carry an open checked run (run_ctl) across calls themselves; everything
+// else that touches the handle's stream first brings an open run to its end (its remaining launches must not interleave with others)
+int need (icp_context *h, bool built, bool keep_run = false)
 {
     if (!h) return ICP_EINVAL;
     if (!h->inited) return fail (h, ICP_ESTATE, "icp_init has not been called");
     if (built && !h->built) return fail (h, ICP_ESTATE, "icp_build_rbc has not been called");
+    if (!keep_run && h->run.active) {
+        if (hipSetDevice (h->device) != hipSuccess) return fail (h, ICP_EHIP, "hipSetDevice");
+        int rc = run_finish (h); if (rc) return rc;
+    }
     return ICP_OK;
 }
 
@@ -153,10 +208,10 @@ int set_device (icp_context *h)
     return ICP_OK;
 }
 
-// Captures the launches `launches ()` enqueues on the handle's stream into an instantiated graph.  Whatever fails,
-// the stream has left capture mode and nothing is leaked when this returns.
+// Captures the launches `launches ()` enqueues on the handle's stream into a graph (instantiate: also into an executable one).
+// Whatever fails, the stream has left capture mode and nothing is leaked when this returns.
 template <typename Fn>
-int capture_graph (icp_context *h, Fn &&launches, graph_entry *out)
+int capture_graph (icp_context *h, Fn &&launches, graph_entry *out, bool instantiate = true)
 {
     graph_entry ge;
     HIPCHK (h, hipStreamBeginCapture (h->stream, hipStreamCaptureModeThreadLocal));
@@ -168,28 +223,33 @@ int capture_graph (icp_context *h, Fn &&launches, graph_entry *out)
         if (ge.graph) (void) hipGraphDestroy (ge.graph);
         return fail (h, ICP_EHIP, std::string ("graph capture: ") + hipGetErrorString (e));
     }
-    e = hipGraphInstantiate (&ge.exec, ge.graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) {
-        (void) hipGraphDestroy (ge.graph);
-        return fail (h, ICP_EHIP, std::string ("hipGraphInstantiate: ") + hipGetErrorString (e));
+    if (instantiate) {
+        e = hipGraphInstantiate (&ge.exec, ge.graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            (void) hipGraphDestroy (ge.graph);
+            return fail (h, ICP_EHIP, std::string ("hipGraphInstantiate: ") + hipGetErrorString (e));
+        }
     }
     *out = ge;
     return ICP_OK;
 }
 
-// Capture `iterations` iterations into a graph (cached until a parameter changes).
+#define ICP_GRAPH_CACHE 8u       // cached run graphs per handle (least recently used goes first)
+
+// Graph of `iterations` iterations, cached (fixed-length runs: icp_run_fixed*, the timing entries; checked runs only with
+// ICP_AMD_RUN_ADAPTIVE=0).  A parameter change (setAlpha, setScaling, thresholds, modes) does not throw the executable graphs away: an
+// entry of an older parameter generation is re-captured and its executable graph UPDATED in place (hipGraphExecUpdate: the kernel
+// nodes' arguments; instantiating anew costs milliseconds) — same topology by construction, re-instantiated only if the update is refused.
 // fresh: the graph starts the registration from the identity transform (icp_reset_transform + the run as one graph; the
-// chained form folds the reset into its first launch).  with_build: buildRBC in front of the run, one graph for a whole
-// registration (tracking: one graph launch per frame).
+// chained form folds the reset into its first launch).  with_build: buildRBC in front of the run.
 int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *out, bool fresh = false, bool with_build = false)
 {
     uint64_t key = ((uint64_t) iterations << 3) | (uint64_t) (check ? 4 : 0) | (uint64_t) h->parity | ((uint64_t) (fresh ? 1 : 0) << 62) | ((uint64_t) (with_build ? 1 : 0) << 61);
     auto it = h->graphs.find (key);
-    if (it != h->graphs.end ()) { *out = it->second.exec; return ICP_OK; }
+    if (it != h->graphs.end () && it->second.gen == h->param_gen) { it->second.used = ++h->graph_clock; *out = it->second.exec; return ICP_OK; }
     icp_params p = h->p;
-    p.check = check;
-    graph_entry ge;
-    int rc = capture_graph (h, [&] {
+    p.check = check; p.hmirror = nullptr; p.hstate = nullptr;
+    auto launches = [&] {
         if (with_build) icp_launch_build_rbc (p, h->stream);
         if (fresh && !icp_chain_supported (p)) icp_launch_reset_state (p, h->stream, 1);
         if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations, fresh);   // one launch per iteration
@@ -197,15 +257,169 @@ int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *o
             p.emit = (check || k + 1 == iterations) ? 1 : 0;            // (with checks on, any iteration may be the last executed)
             icp_launch_iteration (p, h->stream);
         }
-        // ICP::run () (checked graphs: the blocking call whose caller wants k and the state): the states travel to the pinned
-        // mirror as the last node of the graph, so that neither the call nor the pull of the public members costs a copy of
-        // its own (two blocking 248-byte hipMemcpy calls were 25 us of a 420 us run).  Fixed-length graphs are enqueue-only
-        // and stay without it (3 us per graph).
+        // checked graphs: the states travel to the pinned mirror as the last node of the graph
         if (check) (void) hipMemcpyAsync (h->hState, p.st, sizeof (icp_reg_state) * p.batch, hipMemcpyDeviceToHost, h->stream);
-    }, &ge);
+    };
+    if (it != h->graphs.end ()) {                                       // stale parameters: update the executable graph in place
+        graph_entry ng;
+        int rc = capture_graph (h, launches, &ng, false);
+        if (rc) return rc;
+        hipGraphNode_t bad = nullptr; hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
+        hipError_t e = hipGraphExecUpdate (it->second.exec, ng.graph, &bad, &res);
+        if (e != hipSuccess || res != hipGraphExecUpdateSuccess) {
+            (void) hipGetLastError ();
+            (void) hipGraphExecDestroy (it->second.exec); it->second.exec = nullptr;
+            e = hipGraphInstantiate (&it->second.exec, ng.graph, nullptr, nullptr, 0);
+            if (e != hipSuccess) {
+                (void) hipGraphDestroy (ng.graph); (void) hipGraphDestroy (it->second.graph);
+                h->graphs.erase (it);
+                return fail (h, ICP_EHIP, std::string ("hipGraphInstantiate: ") + hipGetErrorString (e));
+            }
+        }
+        (void) hipGraphDestroy (it->second.graph);
+        it->second.graph = ng.graph; it->second.gen = h->param_gen; it->second.used = ++h->graph_clock;
+        *out = it->second.exec;
+        return ICP_OK;
+    }
+    graph_entry ge;
+    int rc = capture_graph (h, launches, &ge);
     if (rc) return rc;
+    ge.gen = h->param_gen; ge.used = ++h->graph_clock;
+    if (h->graphs.size () >= ICP_GRAPH_CACHE) {                          // bounded: the least recently used entry goes
+        auto lru = h->graphs.begin ();
+        for (auto jt = h->graphs.begin (); jt != h->graphs.end (); ++jt) if (jt->second.used < lru->second.used) lru = jt;
+        // (an executable graph may still be queued on the stream: the runtime keeps what a launched graph needs until it has run)
+        if (lru->second.exec) (void) hipGraphExecDestroy (lru->second.exec);
+        if (lru->second.graph) (void) hipGraphDestroy (lru->second.graph);
+        h->graphs.erase (lru);
+    }
     h->graphs[key] = ge;
     *out = ge.exec;
+    return ICP_OK;
+}
+
+// ---- host-driven checked runs (run_ctl) ------------------------------------------------------------------------------------------
+
+void run_launch_one (icp_context *h)
+{
+    run_ctl &r = h->run;
+    if (r.chained) icp_launch_chain_one (r.p, h->stream, r.enq, r.fresh, r.p.emit != 0);
+    else icp_launch_iteration (r.p, h->stream);
+    ++r.enq;
+}
+
+// Opens a checked run on the handle's stream with `blind` iterations enqueued at once (at least one).  p: the parameters of THIS run
+// (tracking passes the frame's own landmark buffers); mirror / hstate: the host memory its words and final state go to.
+int run_begin (icp_context *h, const icp_params &p, bool fresh, bool with_build, uint32_t blind,
+               unsigned long long *mirror, icp_reg_state *hstate, int track_slot)
+{
+    run_ctl &r = h->run;
+    r = run_ctl {};
+    r.t[0] = now_s ();
+    r.p = p; r.p.check = 1;
+    r.p.emit = (h->outputs_lazy && p.fused) ? 0 : 1;                    // (reference-order kernels read the outputs themselves: always stored)
+    h->outputs_stale = r.p.emit == 0; h->outputs_lost = false;
+    if (++h->epoch == 0u) h->epoch = 1u;
+    r.p.epoch = h->epoch; r.p.hmirror = mirror; r.p.hstate = hstate;    // (fine-grained host allocations: the host pointer is the device pointer)
+    r.mirror = mirror; r.track_slot = track_slot;
+    for (uint32_t b = 0; b < p.batch; ++b) mirror[b] = 0ull;
+    std::atomic_thread_fence (std::memory_order_seq_cst);
+    r.chained = icp_chain_supported (r.p); r.fresh = fresh;
+    r.maxit = h->max_iterations; r.depth = h->run_depth ? h->run_depth : 1u;
+    if (with_build) icp_launch_build_rbc (r.p, h->stream);
+    if (fresh && !r.chained) icp_launch_reset_state (r.p, h->stream, 1);
+    r.active = true;
+    const uint32_t n = std::min (std::max (blind, 1u), r.maxit);
+    while (r.enq < n) run_launch_one (h);
+    if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit; }
+    HIPCHK (h, hipGetLastError ());
+    h->hstate_fresh = false; h->hstate_here = false;
+    r.t[1] = now_s ();
+    return ICP_OK;
+}
+
+// One look at the run's words, then the queue topped up to `depth` launches behind the one in flight.  Returns true once the run is
+// decided: every registration has converged, or max_iterations launches are enqueued (nothing more will be).
+bool run_pump (icp_context *h)
+{
+    run_ctl &r = h->run;
+    if (r.decided) return true;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u; bool all_done = true, all_final = true;
+    for (uint32_t b = 0; b < r.p.batch; ++b) {
+        const unsigned long long w = r.mirror[b];
+        const bool mine = (uint32_t) (w >> 32) == r.p.epoch;
+        const uint32_t k = mine ? (uint32_t) (w & 0xFFFFFFull) : 0u;
+        const bool done = mine && (w & ICP_MIRROR_DONE);
+        kmax = std::max (kmax, k);
+        if (!done) { all_done = false; kmin = std::min (kmin, k); }
+        if (!(mine && (w & ICP_MIRROR_FINAL))) all_final = false;
+    }
+    if (all_done) { r.decided = true; r.done_seen = 1; r.final_seen = all_final; r.k_seen = kmax; r.k_final = kmax; return true; }
+    if (kmin && !r.k_seen) r.t[2] = now_s ();
+    r.k_seen = kmin;
+    // launch (chained) / search (separate launches) j publishes k = j in its prologue: k_seen = the iteration in flight, `depth`
+    // iterations are kept queued behind it
+    while (r.enq < r.maxit && r.enq < r.k_seen + 1u + r.depth) run_launch_one (h);
+    if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit; }
+    return r.decided;
+}
+
+// Drives the open run to its decision (the calling thread polls; bounded wait on a device that has stopped answering), then
+// enqueues its end kernel — final state -> p.st and -> host memory, FINAL bit — and closes it.
+int run_finish (icp_context *h)
+{
+    run_ctl &r = h->run;
+    if (!r.active) return ICP_OK;
+    uint32_t spins = 0, k_last = 0xFFFFFFFFu;
+    auto t_last = std::chrono::steady_clock::now ();
+    while (!run_pump (h)) {
+        _mm_pause ();
+        if ((++spins & 0x3FFu) == 0u) {
+            const auto now = std::chrono::steady_clock::now ();
+            if (r.k_seen != k_last) { k_last = r.k_seen; t_last = now; }
+            else if (std::chrono::duration<double> (now - t_last).count () > 20.0) {
+                r.active = false;
+                return fail (h, ICP_EHIP, "checked run: the device has published no progress for 20 s");
+            }
+        }
+    }
+    r.t[3] = now_s ();
+    // (converged in the fused forms: the finalize that set the flag has left the final state in p.st and in host memory already)
+    if (!r.final_seen) {
+        if (r.chained) icp_launch_chain_end (r.p, h->stream, r.enq);
+        else icp_launch_publish_state (r.p, h->stream);
+    }
+    r.t[4] = now_s ();
+    for (int i = 0; i < 5; ++i) h->stat_t[i] = r.t[i];
+    r.active = false;
+    h->stat_launches = r.enq; h->stat_k = r.k_final;
+    // iterations enqueued past the one that found out (converged at k: iterations 0 .. k - 1 ran, launch k saw the flag — in the chained form it
+    // is the one that sets it —, the rest leave at their first load)
+    h->stat_dead = r.done_seen ? r.enq - std::min (r.enq, r.k_final + 1u) : 0u;
+    HIPCHK (h, hipGetLastError ());
+    if (r.track_slot >= 0) HIPCHK (h, hipEventRecord (h->evDone[r.track_slot], h->stream));
+    return ICP_OK;
+}
+
+// Waits for the FINAL bit of `n` words of epoch `epoch` (the end kernel's last store: the final states are in host memory).
+int run_wait_final (icp_context *h, volatile unsigned long long *mirror, uint32_t n, uint32_t epoch)
+{
+    uint32_t spins = 0;
+    const auto t0 = std::chrono::steady_clock::now ();
+    for (uint32_t b = 0; b < n; ++b) {
+        for (;;) {
+            const unsigned long long w = mirror[b];
+            if ((uint32_t) (w >> 32) == epoch && (w & ICP_MIRROR_FINAL)) break;
+            _mm_pause ();
+            if ((++spins & 0x3FFFu) == 0u && std::chrono::duration<double> (std::chrono::steady_clock::now () - t0).count () > 60.0) {
+                // (is the stream in error?  hipStreamQuery reports a faulted queue)
+                const hipError_t e = hipStreamQuery (h->stream);
+                if (e != hipSuccess && e != hipErrorNotReady) return fail (h, ICP_EHIP, std::string ("checked run: ") + hipGetErrorString (e));
+                return fail (h, ICP_EHIP, "checked run: the final state has not arrived after 60 s");
+            }
+        }
+    }
+    std::atomic_thread_fence (std::memory_order_acquire);
     return ICP_OK;
 }
 
@@ -215,14 +429,15 @@ int launch_run (icp_context *h, uint32_t iterations, int check, bool fresh = fal
     {   // diagnostic (ICP_AMD_RUN_GRAPH=0): the same launches enqueued one by one instead of as a cached graph
         static const char *e = std::getenv ("ICP_AMD_RUN_GRAPH");
         if (e && e[0] == '0') {
-            icp_params p = h->p; p.check = check;
+            icp_params p = h->p; p.check = check; p.hmirror = nullptr; p.hstate = nullptr;
             if (with_build) icp_launch_build_rbc (p, h->stream);
             if (fresh && !icp_chain_supported (p)) icp_launch_reset_state (p, h->stream, 1);
             if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations, fresh);
             else for (uint32_t k = 0; k < iterations; ++k) { p.emit = (check || k + 1 == iterations) ? 1 : 0; icp_launch_iteration (p, h->stream); }
             if (check) HIPCHK (h, hipMemcpyAsync (h->hState, p.st, sizeof (icp_reg_state) * p.batch, hipMemcpyDeviceToHost, h->stream));
             HIPCHK (h, hipGetLastError ());
-            h->hstate_fresh = check != 0;
+            h->hstate_fresh = check != 0; h->hstate_here = false;
+            note_outputs_stored (h);
             return ICP_OK;
         }
     }
@@ -230,7 +445,8 @@ int launch_run (icp_context *h, uint32_t iterations, int check, bool fresh = fal
     int rc = get_graph (h, iterations, check, &exec, fresh, with_build);
     if (rc) return rc;
     HIPCHK (h, hipGraphLaunch (exec, h->stream));
-    h->hstate_fresh = check != 0;
+    h->hstate_fresh = check != 0; h->hstate_here = false;
+    note_outputs_stored (h);
     return ICP_OK;
 }
 
@@ -242,7 +458,31 @@ int settle (icp_context *h)
 }
 
 // every state-changing enqueue that is not a checked run graph: the pinned mirror of the states is stale from here on
-void note_enqueue (icp_context *h) { h->hstate_fresh = false; }
+void note_enqueue (icp_context *h) { h->hstate_fresh = false; h->hstate_here = false; }
+
+// the inputs of the last checked run are about to change (F / M / the RBC): per-query outputs it did not store can no longer be reproduced
+void note_inputs_change (icp_context *h) { if (h->outputs_stale) { h->outputs_stale = false; h->outputs_lost = true; } }
+// an enqueue that stores the per-query outputs itself (single steps, fixed-length runs: their last iteration)
+void note_outputs_stored (icp_context *h) { h->outputs_stale = false; h->outputs_lost = false; }
+
+bool is_query_output (int mem) { return mem == ICP_MEM_NN_ID || mem == ICP_MEM_W || mem == ICP_MEM_NN || mem == ICP_MEM_QT || mem == ICP_MEM_RID; }
+
+// Per-query outputs of a checked run that stored none: the search of its last executed iteration again — p.st_prev holds the transform it
+// used — with the stores on.  The moments it leaves are nobody's (the run is over); the state is not touched.
+int materialize_outputs (icp_context *h, int mem)
+{
+    if (!is_query_output (mem)) return ICP_OK;
+    if (h->outputs_lost)
+        return fail (h, ICP_ESTATE, "the per-query outputs of the last checked run were not stored (lazy outputs) and its inputs have changed since: "
+                                    "read them before F / M / the RBC change, or switch to icp_set_output_mode (h, ICP_OUTPUTS_EVERY_ITERATION)");
+    if (!h->outputs_stale) return ICP_OK;
+    icp_params q = h->p;
+    q.st = q.st_prev; q.check = 0; q.emit = 1; q.hmirror = nullptr; q.hstate = nullptr;
+    icp_launch_search (q, h->stream);
+    HIPCHK (h, hipGetLastError ());
+    h->outputs_stale = false;
+    return ICP_OK;
+}
 
 }  // namespace
 
@@ -287,6 +527,9 @@ int icp_create (icp_handle *out, int device, int rot, int weighted)
     h->p.dist_scale = 1.f;
     { const char *e = std::getenv ("ICP_AMD_MODE"); if (e && (e[0] == 'r' || e[0] == 'R')) { h->p.power_mode = ICP_POWER_LITERAL; h->p.fused = ICP_REDUCE_REFERENCE_ORDER; } }
     { const char *e = std::getenv ("ICP_AMD_CHAIN"); h->p.chain = !e ? 1 : (e[0] == '1') ? 2 : (e[0] == '0') ? 0 : 1; }   // see icp_chain_supported
+    { const char *e = std::getenv ("ICP_AMD_RUN_ADAPTIVE"); if (e && e[0] == '0') h->run_adaptive = 0; }                  // see run_ctl
+    { const char *e = std::getenv ("ICP_AMD_OUTPUTS"); if (e && (e[0] == 'e' || e[0] == 'E')) h->outputs_lazy = 0; }
+    { const char *e = std::getenv ("ICP_AMD_RUN_DEPTH"); if (e) { const int d = std::atoi (e); if (d >= 1 && d <= 64) h->run_depth = (uint32_t) d; } }
     e = hipSetDevice (device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags (&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags (&h->copy_stream, hipStreamNonBlocking);
@@ -304,6 +547,7 @@ int icp_destroy (icp_handle h)
 {
     if (!h) return ICP_EINVAL;
     (void) hipSetDevice (h->device);
+    if (h->run.active) (void) run_finish (h);
     if (h->copy_stream) (void) hipStreamSynchronize (h->copy_stream);
     if (h->stream) (void) hipStreamSynchronize (h->stream);
     free_all (h);
@@ -336,6 +580,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if (nr > 32768u) return fail (h, ICP_EINVAL, "nr must be <= 32768");
     if (m > (1u << 20)) return fail (h, ICP_EINVAL, "m must be <= 2^20");
     int rc = set_device (h); if (rc) return rc;
+    if (h->run.active && (rc = run_finish (h))) return rc;
     if (h->copy_stream) HIPCHK (h, hipStreamSynchronize (h->copy_stream));
     if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
     int rot = h->p.rot, weighted = h->p.weighted, pmode = h->p.power_mode, fused = h->p.fused, chain = h->p.chain;
@@ -401,11 +646,15 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &p.ml1, B * 18 * ((p.nb + 127u) / 128u)))) return rc;
     if ((rc = dalloc (h, &p.cst, B * 2))) return rc;
     if ((rc = dalloc (h, &p.st, B))) return rc;
+    if ((rc = dalloc (h, &p.st_prev, B))) return rc;
     if (!h->dTin) HIPCHK (h, hipMalloc ((void **) &h->dTin, 8 * sizeof (float)));
     HIPCHK (h, hipHostMalloc ((void **) &h->hF, B * m * 8 * sizeof (float), hipHostMallocDefault));
     HIPCHK (h, hipHostMalloc ((void **) &h->hM, B * m * 8 * sizeof (float), hipHostMallocDefault));
     HIPCHK (h, hipHostMalloc ((void **) &h->hT, 64 * sizeof (float), hipHostMallocDefault));
-    HIPCHK (h, hipHostMalloc ((void **) &h->hState, B * sizeof (icp_reg_state), hipHostMallocDefault));
+    // (fine-grained: the device stores into these while the host polls them — run_ctl)
+    HIPCHK (h, hipHostMalloc ((void **) &h->hState, B * sizeof (icp_reg_state), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK (h, hipHostMalloc ((void **) &h->hMirror, B * sizeof (unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset (h->hMirror, 0, B * sizeof (unsigned long long));
     icp_launch_reset_state (p, h->stream, 1);
     HIPCHK (h, hipGetLastError ());
     HIPCHK (h, hipStreamSynchronize (h->stream));
@@ -433,6 +682,7 @@ int icp_write_b (icp_handle h, uint32_t b, int mem, const void *host_ptr, int bl
             // the staging buffer may still feed an earlier asynchronous copy of the same kind: wait for THAT copy (an event of a
             // never-recorded event returns at once), not for whatever else the stream holds (a run in flight keeps going)
             hipEvent_t ev = h->evStage[mem == ICP_MEM_F ? 0 : 1];
+            note_inputs_change (h);
             HIPCHK (h, hipEventSynchronize (ev));
             if (host_ptr) std::memcpy (stage, host_ptr, fm);           // algorithms.cpp:4604-4606
             HIPCHK (h, hipMemcpyAsync (dst, stage, fm, hipMemcpyHostToDevice, h->stream));
@@ -518,6 +768,7 @@ int icp_read_b (icp_handle h, uint32_t b, int mem, void *host_dst, size_t bytes)
     if ((rc = set_device (h))) return rc;
     const void *src = nullptr;
     if ((rc = mem_ptr (h, b, mem, &src))) return rc;
+    if ((rc = materialize_outputs (h, mem))) return rc;
     if (mem == ICP_MEM_W) {                        // weights live in the .w lane of the matched points
         size_t rows = bytes / 4;
         HIPCHK (h, hipMemcpy2DAsync (host_dst, 4, src, 16, 4, rows, hipMemcpyDeviceToHost, h->stream));
@@ -535,6 +786,8 @@ int icp_device_ptr (icp_handle h, int mem, void **dptr)
     if (!dptr) return fail (h, ICP_EINVAL, "null pointer");
     const void *src = nullptr;
     if ((rc = mem_ptr (h, 0, mem, &src))) return rc;
+    if ((rc = set_device (h))) return rc;
+    if ((rc = materialize_outputs (h, mem))) return rc;
     *dptr = const_cast<void *> (src);
     return ICP_OK;
 }
@@ -546,6 +799,7 @@ int icp_adopt_device_buffer (icp_handle h, int mem, void *dptr)
     if (mem == ICP_MEM_F) { h->dF = static_cast<float *> (dptr); h->p.F = h->dF; h->ownF = false; h->built = false; }
     else if (mem == ICP_MEM_M) { h->dM = static_cast<float *> (dptr); h->p.M = h->dM; h->ownM = false; }
     else return fail (h, ICP_EINVAL, "only ICP_MEM_F and ICP_MEM_M can be adopted");
+    note_inputs_change (h);
     drop_graphs (h);
     return ICP_OK;
 }
@@ -554,6 +808,7 @@ int icp_build_rbc (icp_handle h)
 {
     int rc = need (h, false); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
+    note_inputs_change (h);
     // The two (latency-bound sizes) to six launches of the construction are enqueued as they are: a graph of so few nodes costs more
     // at its head and tail than it saves between them — same box, back to back, graph against plain launches: A 22.3 -> 13.6 us,
     // B 46.9 -> 39.8, C 193 -> 185, A x 64 115 -> 106 us (ICP_AMD_BUILD_GRAPH=1 brings the cached graph back for the comparison).
@@ -588,8 +843,8 @@ int icp_step (icp_handle h, int config)
     (void) config;   // the reference sizes the list-scan launch from a host read when config is set; nothing to configure here
     int rc = need (h, true); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
-    icp_params p = h->p; p.check = 0;
-    note_enqueue (h);
+    icp_params p = h->p; p.check = 0; p.hmirror = nullptr; p.hstate = nullptr;
+    note_enqueue (h); note_outputs_stored (h);
     icp_launch_iteration (p, h->stream);
     HIPCHK (h, hipGetLastError ());
     return ICP_OK;
@@ -615,16 +870,60 @@ int icp_run (icp_handle h, uint32_t *k)
 {
     int rc = need (h, true); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
-    if ((rc = launch_run (h, h->max_iterations, 1))) return rc;
-    if ((rc = settle (h))) return rc;                                // queue.finish () — :4813
+    if (!h->run_adaptive) {                                              // rounds 1 - 3: one graph of max_iterations launches
+        if ((rc = launch_run (h, h->max_iterations, 1))) return rc;
+        if ((rc = settle (h))) return rc;                                // queue.finish () — :4813
+        h->stat_launches = h->max_iterations; h->stat_k = h->hState[0].k; h->stat_dead = 0;
+    } else {
+        // the host loop of the reference (:4806-4814: run one step, check (), stop), with the check on the device and the host `run_depth`
+        // launches ahead of it: the calling thread polls the registration's progress word and tops the queue up
+        if ((rc = run_begin (h, h->p, false, false, h->run_depth + 1u, h->hMirror, h->hState, -1))) return rc;
+        if ((rc = run_finish (h))) return rc;
+        if ((rc = run_wait_final (h, h->hMirror, h->p.batch, h->run.p.epoch))) return rc;      // (the end kernel is the last thing on the stream: queue.finish ())
+        h->stat_t[5] = now_s ();
+        h->hstate_fresh = true; h->hstate_here = true;
+    }
     if (k) {
-        if (h->hstate_fresh) *k = h->hState[0].k;                    // (the graph's last node left the states in the pinned mirror)
+        if (h->hstate_fresh) *k = h->hState[0].k;                        // (the run left the states in the pinned mirror)
         else {
             icp_reg_state st;
             HIPCHK (h, hipMemcpy (&st, h->p.st, sizeof st, hipMemcpyDeviceToHost));
             *k = st.k;
         }
     }
+    return ICP_OK;
+}
+
+int icp_run_stats (icp_handle h, uint32_t *launches, uint32_t *k, uint32_t *dead)
+{
+    if (!h) return ICP_EINVAL;
+    if (launches) *launches = h->stat_launches;
+    if (k) *k = h->stat_k;
+    if (dead) *dead = h->stat_dead;
+    return ICP_OK;
+}
+
+int icp_set_output_mode (icp_handle h, int mode)
+{
+    if (!h) return ICP_EINVAL;
+    if (mode != ICP_OUTPUTS_LAZY && mode != ICP_OUTPUTS_EVERY_ITERATION) return fail (h, ICP_EINVAL, "unknown output mode");
+    h->outputs_lazy = mode == ICP_OUTPUTS_LAZY;
+    return ICP_OK;
+}
+
+int icp_run_timeline (icp_handle h, double *us6)
+{
+    if (!h || !us6) return ICP_EINVAL;
+    for (int i = 0; i < 6; ++i) us6[i] = (h->stat_t[i] - h->stat_t[0]) * 1e6;
+    return ICP_OK;
+}
+
+int icp_set_run_depth (icp_handle h, uint32_t depth, int adaptive)
+{
+    if (!h) return ICP_EINVAL;
+    if (depth == 0 || depth > 64u) return fail (h, ICP_EINVAL, "icp_set_run_depth: depth must be in [1, 64]");
+    if (h->run.active) { int rc = set_device (h); if (rc) return rc; if ((rc = run_finish (h))) return rc; }
+    h->run_depth = depth; h->run_adaptive = adaptive ? 1 : 0;
     return ICP_OK;
 }
 
@@ -636,21 +935,23 @@ int icp_sync (icp_handle h)
 }
 
 int icp_get_alpha (icp_handle h, float *a) { if (!h || !a) return ICP_EINVAL; *a = h->p.a; return ICP_OK; }
+// The setters change a number in the handle's parameters and nothing else: checked runs are plain launches that read the parameters as they
+// are, and a cached fixed-length graph of an older parameter generation is updated in place when it is next used (get_graph).
 int icp_set_alpha (icp_handle h, float a)
 {   // setAlpha updates construct and search (src/ICP/algorithms.cpp:4712-4717); lists must be rebuilt by the caller
     if (!h) return ICP_EINVAL;
     if (a == 0.f) return fail (h, ICP_EINVAL, "The alpha parameter cannot be equal to zero");
-    h->p.a = a; drop_graphs (h); return ICP_OK;
+    h->p.a = a; ++h->param_gen; return ICP_OK;
 }
 int icp_set_metric_scale (icp_handle h, float f_g)
 {
     if (!h) return ICP_EINVAL;
     if (!(f_g > 0.f) || !std::isfinite (f_g)) return fail (h, ICP_EINVAL, "the metric scale must be positive and finite");
-    h->p.dist_scale = f_g; drop_graphs (h); return ICP_OK;
+    h->p.dist_scale = f_g; ++h->param_gen; return ICP_OK;
 }
 int icp_get_metric_scale (icp_handle h, float *f_g) { if (!h || !f_g) return ICP_EINVAL; *f_g = h->p.dist_scale; return ICP_OK; }
 int icp_get_scaling (icp_handle h, float *c) { if (!h || !c) return ICP_EINVAL; *c = h->p.c; return ICP_OK; }
-int icp_set_scaling (icp_handle h, float c) { if (!h) return ICP_EINVAL; h->p.c = c; drop_graphs (h); return ICP_OK; }
+int icp_set_scaling (icp_handle h, float c) { if (!h) return ICP_EINVAL; h->p.c = c; ++h->param_gen; return ICP_OK; }
 int icp_get_max_iterations (icp_handle h, uint32_t *n) { if (!h || !n) return ICP_EINVAL; *n = h->max_iterations; return ICP_OK; }
 int icp_set_max_iterations (icp_handle h, uint32_t n)
 {
@@ -662,19 +963,19 @@ int icp_get_angle_threshold (icp_handle h, double *d) { if (!h || !d) return ICP
 int icp_set_angle_threshold (icp_handle h, double d)
 {
     if (!h) return ICP_EINVAL;
-    h->angle_threshold = d; h->p.tan_half_thr = std::tan (d * M_PI / 360.0); drop_graphs (h); return ICP_OK;
+    h->angle_threshold = d; h->p.tan_half_thr = std::tan (d * M_PI / 360.0); ++h->param_gen; return ICP_OK;
 }
 int icp_get_translation_threshold (icp_handle h, double *d) { if (!h || !d) return ICP_EINVAL; *d = h->translation_threshold; return ICP_OK; }
 int icp_set_translation_threshold (icp_handle h, double d)
 {
     if (!h) return ICP_EINVAL;
-    h->translation_threshold = d; h->p.trans_thr = d; drop_graphs (h); return ICP_OK;
+    h->translation_threshold = d; h->p.trans_thr = d; ++h->param_gen; return ICP_OK;
 }
 int icp_set_power_mode (icp_handle h, int mode)
 {
     if (!h) return ICP_EINVAL;
     if (mode != ICP_POWER_LITERAL && mode != ICP_POWER_SQUARED) return fail (h, ICP_EINVAL, "unknown power mode");
-    h->p.power_mode = mode; drop_graphs (h); return ICP_OK;
+    h->p.power_mode = mode; ++h->param_gen; return ICP_OK;
 }
 
 int icp_set_reduce_mode (icp_handle h, int mode)
@@ -691,8 +992,8 @@ int icp_state_b (icp_handle h, uint32_t b, icp_state_t *out)
     if (b >= h->p.batch) return fail (h, ICP_EINVAL, "batch index out of range");
     if ((rc = set_device (h))) return rc;
     icp_reg_state st;
-    if (h->hstate_fresh) {                       // a run graph was the last thing that changed the states: its final copy node
-        HIPCHK (h, hipStreamSynchronize (h->stream));
+    if (h->hstate_fresh) {                       // a checked run was the last thing that changed the states: its end left them in the mirror
+        if (!h->hstate_here) HIPCHK (h, hipStreamSynchronize (h->stream));
         st = h->hState[b];
     } else {
         HIPCHK (h, hipMemcpyAsync (&st, h->p.st + b, sizeof st, hipMemcpyDeviceToHost, h->stream));
@@ -723,6 +1024,7 @@ int icp_write_cloud (icp_handle h, int which, const void *cloud, int block)
         HIPCHK (h, hipMalloc ((void **) &h->dCloudOut, (size_t) n * 32));
         h->cloud_cap = n;
     }
+    note_inputs_change (h);
     HIPCHK (h, hipMemcpyAsync (h->dCloud, cloud, (size_t) n * 32, hipMemcpyHostToDevice, h->stream));
     icp_launch_get_lms (h->dCloud, which == ICP_MEM_F ? h->dF : h->dM, h->stream);
     HIPCHK (h, hipGetLastError ());
@@ -769,7 +1071,11 @@ static int track_prepare (icp_context *h)
         if (!h->hBand[k]) HIPCHK (h, hipHostMalloc ((void **) &h->hBand[k], ICP_BAND_BYTES, hipHostMallocDefault));
         if (!h->dBand[k]) HIPCHK (h, hipMalloc ((void **) &h->dBand[k], ICP_BAND_BYTES));
     }
-    if (!h->hTrack) HIPCHK (h, hipHostMalloc ((void **) &h->hTrack, ICP_TRACK_RING * sizeof (icp_reg_state), hipHostMallocDefault));
+    if (!h->hTrack) HIPCHK (h, hipHostMalloc ((void **) &h->hTrack, ICP_TRACK_RING * sizeof (icp_reg_state), hipHostMallocMapped | hipHostMallocCoherent));
+    if (!h->hTrackMirror) {
+        HIPCHK (h, hipHostMalloc ((void **) &h->hTrackMirror, ICP_TRACK_RING * sizeof (unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset (h->hTrackMirror, 0, ICP_TRACK_RING * sizeof (unsigned long long));
+    }
     return ICP_OK;
 }
 
@@ -777,32 +1083,47 @@ int icp_track_reset (icp_handle h)
 {
     if (!h) return ICP_EINVAL;
     int rc = set_device (h); if (rc) return rc;
+    if (h->run.active && (rc = run_finish (h))) return rc;
     if (h->copy_stream) HIPCHK (h, hipStreamSynchronize (h->copy_stream));
     if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
     h->track_submitted = h->track_collected = 0;
+    h->track_k_hist[0] = h->track_k_hist[1] = 0;
     return ICP_OK;
 }
 
 int icp_track_staging (icp_handle h, uint32_t slot, void **host_ptr)
 {
-    int rc = need (h, false); if (rc) return rc;
+    int rc = need (h, false, true); if (rc) return rc;
     if (slot > 1u || !host_ptr) return fail (h, ICP_EINVAL, "icp_track_staging: slot must be 0 or 1");
     if ((rc = set_device (h))) return rc;
     if (!h->hFrame[slot]) HIPCHK (h, hipHostMalloc ((void **) &h->hFrame[slot], (size_t) 640 * 480 * 32, hipHostMallocDefault));
+    // the buffer is handed out once the band of the frame it last held has left it (its upload may still be queued on the copy stream
+    // when more than two frames are in flight; an event that was never recorded returns at once)
+    HIPCHK (h, hipEventSynchronize (h->evUp[slot]));
     *host_ptr = h->hFrame[slot];
     return ICP_OK;
 }
 
-int icp_track_submit (icp_handle h, const void *cloud, int warm_start)
+// Tracking: blind launches of a frame's registration — what is enqueued before icp_track_submit returns (the caller is away until its
+// next call: copying the next frame, typically).  The smaller of the last two registrations' k + the launch that finds out; a first
+// registration of a sequence gets depth + 1 and is topped up by the next call.
+static uint32_t track_blind (const icp_context *h)
 {
-    int rc = need (h, false); if (rc) return rc;
+    const uint32_t a = h->track_k_hist[0], b = h->track_k_hist[1];
+    const uint32_t k = a && b ? std::min (a, b) : (a ? a : b);
+    return k ? k + 1u : h->run_depth + 1u;
+}
+
+static int track_submit (icp_context *h, const void *cloud, int warm_start, bool blocking)
+{
+    int rc = need (h, false, true); if (rc) return rc;
     if (!cloud) return fail (h, ICP_EINVAL, "null pointer");
     if ((rc = set_device (h))) return rc;
     if ((rc = track_prepare (h))) return rc;                            // (everything that can fail for lack of memory comes first)
     if (h->track_submitted - h->track_collected >= ICP_TRACK_RING)
         return fail (h, ICP_ESTATE, "icp_track_submit: four frames are in flight: collect a result first (icp_track_collect)");
     const uint64_t f = h->track_submitted;
-    const uint32_t s = (uint32_t) (f & 1u), buf = (uint32_t) (f % 3u);
+    const uint32_t s = (uint32_t) (f & 1u), buf = (uint32_t) (f % 3u), ring = (uint32_t) (f % ICP_TRACK_RING);
     const char *src = static_cast<const char *> (cloud) + ((size_t) ICP_BAND_ROW0 * 640u + ICP_BAND_COL0) * 32u;
     const size_t spitch = (size_t) ICP_BAND_ROW_STEP * 640u * 32u;
     // the copy stream: not before registration f - 2 (the last reader of lm[buf], as its fixed set) is done
@@ -821,36 +1142,70 @@ int icp_track_submit (icp_handle h, const void *cloud, int warm_start)
     icp_launch_get_lms_band (h->dBand[s], h->lm[buf], h->copy_stream);
     HIPCHK (h, hipGetLastError ());
     HIPCHK (h, hipEventRecord (h->evUp[s], h->copy_stream));
-    // the main stream: this frame's landmarks, then (from the second frame on) the registration against the previous frame's
-    HIPCHK (h, hipStreamWaitEvent (h->stream, h->evUp[s], 0));
-    h->dM = h->lm[buf]; h->p.M = h->dM;
-    h->dF = h->lm[(f + 2u) % 3u]; h->p.F = h->dF;                       // (f - 1) mod 3: the previous frame's landmarks (first frame: a buffer that is not M)
-    h->parity = 1u + buf;                                               // graphs hold the pointers: one cached set per rotation step (0: the buffers of icp_init)
-    h->built = false;
-    if (f > 0u) {
-        note_enqueue (h);
-        if (warm_start) { icp_launch_set_T (h->p, 0, h->p.st->T, h->stream); HIPCHK (h, hipGetLastError ()); }   // as write (D_IO_T) of the previous T
-        if ((rc = launch_run (h, h->max_iterations, 1, !warm_start, true))) return rc;      // buildRBC + ICP::run, one graph
-        h->built = true;
-        HIPCHK (h, hipMemcpyAsync (&h->hTrack[f % ICP_TRACK_RING], h->p.st, sizeof (icp_reg_state), hipMemcpyDeviceToHost, h->stream));
+    // the main stream.  The previous frame's registration may still be open (its blind launches enqueued, the rest not): bring it to
+    // its end first — its end kernel and evDone go in front of this frame's work
+    if (h->run.active) {
+        if ((rc = run_finish (h))) return rc;
+        h->track_k_hist[1] = h->track_k_hist[0]; h->track_k_hist[0] = h->run.k_final;
     }
-    HIPCHK (h, hipEventRecord (h->evDone[f % ICP_TRACK_RING], h->stream));
+    // this frame's landmarks, then (from the second frame on) the registration against the previous frame's: buildRBC + ICP::run
+    HIPCHK (h, hipStreamWaitEvent (h->stream, h->evUp[s], 0));
+    note_inputs_change (h);
+    float *newM = h->lm[buf], *newF = h->lm[(f + 2u) % 3u];             // (f - 1) mod 3: the previous frame's landmarks (first frame: a buffer that is not M)
+    if (f > 0u) {
+        icp_params p = h->p; p.M = newM; p.F = newF;
+        note_enqueue (h);
+        // warm start: from the previous hop's transform, as by write (D_IO_T) — the first registration of a sequence has no previous hop
+        // and starts from the identity whatever the state holds (an earlier sequence's last transform, an icp_run before the reset)
+        const bool warm = warm_start && f > 1u;
+        if (warm) { icp_launch_set_T (p, 0, p.st->T, h->stream); HIPCHK (h, hipGetLastError ()); }
+        if (h->run_adaptive) {
+            const uint32_t blind = blocking ? h->run_depth + 1u : track_blind (h);
+            if ((rc = run_begin (h, p, !warm, true, blind, h->hTrackMirror + ring, h->hTrack + ring, (int) ring))) return rc;
+            h->track_epoch[ring] = h->run.p.epoch;
+        } else {
+            // rounds 1 - 3: buildRBC + a checked run of max_iterations launches as one cached graph (the graphs hold the buffer pointers)
+            float *oF = h->dF, *oM = h->dM; const float *opF = h->p.F, *opM = h->p.M; const uint32_t opar = h->parity;
+            h->dM = newM; h->p.M = newM; h->dF = newF; h->p.F = newF; h->parity = 1u + buf;
+            rc = launch_run (h, h->max_iterations, 1, !warm, true);
+            if (rc) { h->dF = oF; h->dM = oM; h->p.F = opF; h->p.M = opM; h->parity = opar; return rc; }
+            HIPCHK (h, hipMemcpyAsync (&h->hTrack[ring], h->p.st, sizeof (icp_reg_state), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK (h, hipEventRecord (h->evDone[ring], h->stream));
+            h->track_epoch[ring] = 0u;
+        }
+    } else HIPCHK (h, hipEventRecord (h->evDone[ring], h->stream));
+    // everything that can fail is behind us: the handle now points at this frame's buffers
+    h->dM = newM; h->p.M = newM; h->dF = newF; h->p.F = newF;
+    h->parity = 1u + buf;                                               // graphs hold the pointers: one cached set per rotation step (0: the buffers of icp_init)
+    h->built = f > 0u;
     h->track_submitted = f + 1u;
     return ICP_OK;
 }
 
+int icp_track_submit (icp_handle h, const void *cloud, int warm_start) { return track_submit (h, cloud, warm_start, false); }
+
 int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered)
 {
-    int rc = need (h, false); if (rc) return rc;
+    int rc = need (h, false, true); if (rc) return rc;
     if (h->track_collected >= h->track_submitted) return fail (h, ICP_ESTATE, "icp_track_collect: no frame in flight");
     if ((rc = set_device (h))) return rc;
     const uint64_t f = h->track_collected;
-    HIPCHK (h, hipEventSynchronize (h->evDone[f % ICP_TRACK_RING]));
+    const uint32_t ring = (uint32_t) (f % ICP_TRACK_RING);
+    if (h->run.active && h->run.track_slot == (int) ring) {             // the frame's registration is still open: top it up to its end
+        if ((rc = run_finish (h))) return rc;
+        h->track_k_hist[1] = h->track_k_hist[0]; h->track_k_hist[0] = h->run.k_final;
+    }
+    if (f > 0u && h->track_epoch[ring]) { if ((rc = run_wait_final (h, h->hTrackMirror + ring, 1u, h->track_epoch[ring]))) return rc; }
+    else HIPCHK (h, hipEventSynchronize (h->evDone[ring]));
     h->track_collected = f + 1u;
+    if (f + 1u == h->track_submitted && f > 0u && h->track_epoch[ring]) {
+        // nothing behind this frame: the handle's state is this registration's final state, and the host holds it
+        h->hState[0] = h->hTrack[ring]; h->hstate_fresh = true; h->hstate_here = true;
+    }
     if (k) *k = 0;
     if (registered) *registered = f > 0u ? 1 : 0;
     if (f > 0u) {
-        const icp_reg_state &st = h->hTrack[f % ICP_TRACK_RING];
+        const icp_reg_state &st = h->hTrack[ring];
         if (k) *k = st.k;
         if (T8) std::memcpy (T8, st.T, 8 * sizeof (float));
     } else if (T8) { const float T0[8] = { 0, 0, 0, 1, 0, 0, 0, 1 }; std::memcpy (T8, T0, sizeof T0); }
@@ -861,12 +1216,13 @@ int icp_track_next (icp_handle h, const void *cloud, int warm_start, uint32_t *k
 {
     if (k) *k = 0;
     if (registered) *registered = 0;
-    int rc = need (h, false); if (rc) return rc;
+    int rc = need (h, false, true); if (rc) return rc;
     while (h->track_collected < h->track_submitted)                     // (results of an earlier pipelined use nobody collected)
         if ((rc = icp_track_collect (h, nullptr, nullptr, nullptr))) return rc;
-    if ((rc = icp_track_submit (h, cloud, warm_start))) return rc;
+    if ((rc = track_submit (h, cloud, warm_start, true))) return rc;
     if ((rc = icp_track_collect (h, k, nullptr, registered))) return rc;
-    return settle (h);
+    if (!h->run_adaptive) return settle (h);
+    return ICP_OK;
 }
 
 int icp_transform_cloud_ex (icp_handle h, int kind, const float *T, const void *host_in, void *host_out, uint32_t n)
@@ -940,7 +1296,7 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int fr
     if ((rc = get_graph (h, iterations, 0, &exec, from_identity != 0))) return rc;     // from_identity: every pass is a fresh registration
     HIPCHK (h, hipEventRecord (h->ev0, h->stream));
     for (uint32_t r = 0; r < reps; ++r) HIPCHK (h, hipGraphLaunch (exec, h->stream));
-    h->hstate_fresh = false;
+    h->hstate_fresh = false; note_outputs_stored (h);
     HIPCHK (h, hipEventRecord (h->ev1, h->stream));
     HIPCHK (h, hipStreamSynchronize (h->stream));                       // (not hipEventSynchronize: its wake-up now and then takes 0.5 ms, tests/diag_overhead.py)
     HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));
@@ -961,7 +1317,7 @@ int icp_time_run_fixed_tail (icp_handle h, uint32_t iterations, uint32_t reps, i
     if (lead) HIPCHK (h, hipGraphLaunch (exec, h->stream));
     HIPCHK (h, hipEventRecord (h->ev0, h->stream));
     for (uint32_t r = lead; r < reps; ++r) HIPCHK (h, hipGraphLaunch (exec, h->stream));
-    h->hstate_fresh = false;
+    h->hstate_fresh = false; note_outputs_stored (h);
     HIPCHK (h, hipEventRecord (h->ev1, h->stream));
     HIPCHK (h, hipStreamSynchronize (h->stream));                       // (not hipEventSynchronize: its wake-up now and then takes 0.5 ms, tests/diag_overhead.py)
     HIPCHK (h, hipEventElapsedTime (ms_timed, h->ev0, h->ev1));
@@ -1001,8 +1357,8 @@ int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t 
     int rc = need (h, true); if (rc) return rc;
     if (!ms_total || iterations == 0 || reps == 0 || mask == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
-    icp_params p = h->p; p.check = 0;
-    note_enqueue (h);                                                   // (the masked graphs change the device state: the pinned mirror is stale)
+    icp_params p = h->p; p.check = 0; p.hmirror = nullptr; p.hstate = nullptr;
+    note_enqueue (h); note_outputs_stored (h);                          // (the masked graphs change the device state: the pinned mirror is stale)
     graph_entry ge;
     // (the per-query outputs follow the policy of the fixed-length graphs: stored by the last iteration only in fused mode)
     if ((rc = capture_graph (h, [&] {
@@ -1027,8 +1383,8 @@ int icp_debug_stamps (icp_handle h, unsigned long long *out, uint32_t nblocks)
     unsigned long long *d = nullptr;
     HIPCHK (h, hipMalloc ((void **) &d, (size_t) nblocks * 16 * 8));
     hipError_t e = hipMemset (d, 0, (size_t) nblocks * 16 * 8);
-    icp_params p = h->p; p.check = 0; p.dbg = d;
-    note_enqueue (h);
+    icp_params p = h->p; p.check = 0; p.dbg = d; p.hmirror = nullptr; p.hstate = nullptr;
+    note_enqueue (h); note_outputs_stored (h);
     if (e == hipSuccess) {
         if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, 2);
         else { icp_launch_search (p, h->stream); if (p.fused) icp_launch_finalize (p, h->stream); }
@@ -1046,8 +1402,8 @@ int icp_profile_run (icp_handle h, uint32_t iterations, float *out_ms, float *to
     int rc = need (h, true); if (rc) return rc;
     if (!out_ms || iterations == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
-    icp_params p = h->p; p.check = 0; p.emit = 1;
-    note_enqueue (h);
+    icp_params p = h->p; p.check = 0; p.emit = 1; p.hmirror = nullptr; p.hstate = nullptr;
+    note_enqueue (h); note_outputs_stored (h);
     std::vector<hipEvent_t> ev ((size_t) iterations * 5, nullptr);
     hipError_t e = hipSuccess;
     for (auto &x : ev) if (e == hipSuccess) e = hipEventCreate (&x);

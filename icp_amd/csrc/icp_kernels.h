@@ -72,8 +72,21 @@ struct icp_params {
     icp_reg_state *cst;          // [batch][2]  chained fused mode: state slots, launch j reads slot j&1 and writes the other
     uint32_t slot;               // chained fused mode: slot this launch reads
     icp_reg_state *st;           // [batch]
+    icp_reg_state *st_prev;      // [batch]  .T = the transform the last executed search used (stored by every finalize; everything else stays zero):
+                                 // icp_launch_search on it reproduces that iteration's per-query outputs (checked runs do not store them on the way)
     unsigned long long *dbg;     // diagnostic builds only (ICP_DBG_STAMPS): [blocks][16] s_memtime stamps
+    // checked runs driven from the host (icp_run, icp_track_*: see run_ctl in icp_capi.hip): progress words and the final states in
+    // host memory the device writes straight into (fine-grained pinned allocations; nullptr: nobody is watching)
+    unsigned long long *hmirror; // [batch]  ICP_MIRROR_WORD (epoch, done, k) stored by the lane that publishes a registration's state
+    icp_reg_state *hstate;       // [batch]  the final state of a run, stored by its end kernel in front of the word's FINAL bit
+    uint32_t epoch;              // tag of the run the words belong to (a word of another epoch is stale)
 };
+
+// progress word of a checked run: bits 0..23 k (iterations whose transform has been published), bit 30 FINAL (the end kernel has
+// left the state in p.hstate), bit 31 done (ICP::check said stop), bits 32..63 the run's epoch
+#define ICP_MIRROR_FINAL (1ull << 30)
+#define ICP_MIRROR_DONE (1ull << 31)
+#define ICP_MIRROR_WORD(epoch, k, done) (((unsigned long long) (epoch) << 32) | ((done) ? ICP_MIRROR_DONE : 0ull) | (unsigned long long) ((k) & 0xFFFFFFu))
 
 // Index of the fixed point representative r is sampled from (generalised getReps: kernels/icp_kernels.cl:107-113 with the
 // grid side of the set instead of 128).
@@ -96,6 +109,9 @@ void icp_launch_finalize (const icp_params &p, hipStream_t s);
 void icp_launch_iteration (const icp_params &p, hipStream_t s);
 void icp_launch_masked (const icp_params &p, hipStream_t s, unsigned mask);
 void icp_launch_chain (const icp_params &p, hipStream_t s, uint32_t iterations, bool fresh = false);
+void icp_launch_chain_one (const icp_params &p, hipStream_t s, uint32_t j, bool fresh, bool emit);   // launch j of a chain (j = 0: reads the user-visible state)
+void icp_launch_chain_end (const icp_params &p, hipStream_t s, uint32_t launches);                  // after `launches` chained launches: the last moments -> p.st (and p.hstate)
+void icp_launch_publish_state (const icp_params &p, hipStream_t s);                                  // separate launches: p.st -> p.hstate + the FINAL bit
 bool icp_chain_supported (const icp_params &p);
 bool icp_build_lists (const icp_params &p);      // buildRBC = owner search + k_place_lists (2 launches)
 bool icp_dense (const icp_params &p);            // the dense search variant (several blocks per CU, stage-1 pruning)

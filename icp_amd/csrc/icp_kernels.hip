@@ -241,6 +241,12 @@ static __device__ __forceinline__ uint32_t cell_rep_of (const icp_params &p, uin
     return (p.cellh_magic ? __umulhi (y, p.cellh_magic) : y) * p.nrx + (p.cellw_magic ? __umulhi (x, p.cellw_magic) : x);      // (magic 0: cells of one point)
 }
 
+// Progress word of a host-driven checked run (ICP_MIRROR_WORD) -> fine-grained host memory: one 8-byte system-scope store nobody waits for
+static __device__ __forceinline__ void icp_mirror_store (unsigned long long *dst, unsigned long long v)
+{
+    __hip_atomic_store (dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Result of turning one iteration's moments into the next transform: the registration state itself, staged
 // in LDS (one per block) so that one wave publishes it with a single store
 typedef icp_reg_state icp_fin_result;
@@ -306,8 +312,15 @@ template <int NG, int NT, int ROT, bool LEAN = false, typename AFTER = ff_no_hoo
 static __device__ bool fused_finalize_block (const icp_params &p, const double *mom, uint32_t nb, uint32_t check, uint32_t sv,
                                              const double *a0, icp_fin_result *res, double (*s_l1)[NG], double *s_t,
                                              const double *gl1 = nullptr, icp_reg_state *direct = nullptr, AFTER after = AFTER (),
-                                             uint32_t pending_unless_done = 1u)
+                                             uint32_t pending_unless_done = 1u, unsigned long long *mirror = nullptr, bool progress = false,
+                                             icp_reg_state *final_dst = nullptr, icp_reg_state *host_dst = nullptr, icp_reg_state *prev_dst = nullptr)
 {
+    // Host-driven checked runs (run_ctl in icp_capi.hip; mirror != nullptr on the lane that publishes): `progress` — every new (k, done) goes
+    // to the registration's word in host memory (chained form: nothing waits for the store); a CONVERGED registration's final state is stored
+    // to final_dst (chained: the user-visible state, which the launches behind this one no longer touch) and host_dst (host memory) in front
+    // of the word's DONE | FINAL bits: the run needs no end kernel and the host reads the result the moment the flag shows.
+    // prev_dst: the transform the search of this iteration used (T before the composition) — what a later search needs to reproduce the
+    // iteration's per-query outputs, which checked runs do not store on the way (icp_launch_search on p.st_prev).
     // NT = threads of the calling block (compile-time: reading blockDim costs a dependent cold load at kernel start)
     constexpr uint32_t nrow = NT / 16;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, l = tid & 15u, row = tid >> 4;
@@ -413,10 +426,25 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
                         __uint_as_float ((uint32_t) swb), __uint_as_float ((uint32_t) (swb >> 32)),
                         __uint_as_float (kprev + 1u), __uint_as_float (done), __uint_as_float ((uint32_t) iters), __uint_as_float (done ? 0u : pending_unless_done),
                         0.f, 0.f, 0.f, 0.f };
-                    float *dst = reinterpret_cast<float *> (direct);
+                    auto store_image = [&] (icp_reg_state *to) {
+                        float *dst = reinterpret_cast<float *> (to);
 #pragma unroll
-                    for (int k = 0; k < 15; ++k) *reinterpret_cast<f4u *> (dst + 4 * k) = f4u { img[4 * k], img[4 * k + 1], img[4 * k + 2], img[4 * k + 3] };
-                    *reinterpret_cast<f2u *> (dst + 60) = f2u { img[60], img[61] };
+                        for (int k = 0; k < 15; ++k) *reinterpret_cast<f4u *> (dst + 4 * k) = f4u { img[4 * k], img[4 * k + 1], img[4 * k + 2], img[4 * k + 3] };
+                        *reinterpret_cast<f2u *> (dst + 60) = f2u { img[60], img[61] };
+                    };
+                    store_image (direct);
+                    if (prev_dst) {
+                        float *dst = reinterpret_cast<float *> (prev_dst);
+                        *reinterpret_cast<f4u *> (dst) = f4u { Tprev[0], Tprev[1], Tprev[2], Tprev[3] };
+                        *reinterpret_cast<f4u *> (dst + 4) = f4u { Tprev[4], Tprev[5], Tprev[6], Tprev[7] };
+                    }
+                    if (mirror) {
+                        if (done) {
+                            if (final_dst) store_image (final_dst);
+                            if (host_dst) { store_image (host_dst); __threadfence_system (); }
+                            icp_mirror_store (mirror, ICP_MIRROR_WORD (p.epoch, kprev + 1u, 1u) | (host_dst ? ICP_MIRROR_FINAL : 0ull));
+                        } else if (progress) icp_mirror_store (mirror, ICP_MIRROR_WORD (p.epoch, kprev + 1u, 0u));
+                    }
                 }
             }
         } else if (lane == 0) {
@@ -431,6 +459,10 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
             res->sum_w = sw; res->pm_iters = (uint32_t) iters; res->k = kprev + 1u; res->pad0 = 0.f; res->pending = 0u;
             res->reserved0 = 0u; res->reserved1 = 0u;
             res->done = (p.check && icp_check_converged (Tk, p.tan_half_thr, p.trans_thr)) ? 1u : 0u;
+            if (prev_dst) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) prev_dst->T[k] = Tprev[k];
+            }
         }
     }
     __syncthreads ();
@@ -633,6 +665,13 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         if (seed_cell != 0xFFFFFFFFu && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (k)) == 0) seed = seed_cell;    // first search of a registration
     }
     icp_reg_state *sout = CHAIN ? p.cst + (size_t) b * 2 + (p.slot ^ 1u) : st;
+    if constexpr (!OWNER && !CHAIN) {
+        // host-driven checked runs (icp_run; see run_ctl in icp_capi.hip), separate launches: the search of iteration j tells the host that j
+        // iterations are through and whether the last one converged — one 8-byte store into host memory that nothing here waits for
+        if (p.hmirror && blockIdx.x == 0 && tid == 0)
+            icp_mirror_store (p.hmirror + b, ICP_MIRROR_WORD (p.epoch, (uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (k)),
+                                                              __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))));
+    }
     if (!OWNER && check && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))) {    // converged earlier
         if constexpr (CHAIN) {                       // carry the state forward
             if (blockIdx.x == 0 && tid < sizeof (icp_reg_state) / 4) reinterpret_cast<uint32_t *> (sout)[tid] = sv;
@@ -681,7 +720,9 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
                 s_qc[lane] = make_float4 (mc.x, mc.y, mc.z, __uint_as_float (seed));
             };
             fused_finalize_block<32, 64 * LPQ, ROT, true> (p, gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, 0u, sv, ma0, &s_fin, s_l1, s_t, nullptr,
-                                                           blockIdx.x == 0 ? sout : nullptr, hand_over);
+                                                           blockIdx.x == 0 ? sout : nullptr, hand_over, 1u,
+                                                           (blockIdx.x == 0 && p.hmirror) ? p.hmirror + b : nullptr, true, p.st + b,
+                                                           p.hstate ? p.hstate + b : nullptr, p.st_prev ? p.st_prev + b : nullptr);
             handed = true;
             KS_STAMP (9)
             if (s_fin.done) return;
@@ -934,7 +975,6 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         if (prune) {
             // coarse pass: a group = the 2 * LPQ representatives of one trip of the query's lanes; lane ss tests the
             // groups ss, ss + LPQ, ..  (further tiles: done above, before the tile was staged)
-            const uint32_t ngt = (npair + KS_SPLIT - 1u) / KS_SPLIT;
             if (t0 == 0 && __ballot (tile_near (lim))) cmask = coarse_pass (tn, lim);
             fine_pass (t0, npair, cmask);
             s1_lim = fminf (lim, ks_grp_min_f<KS_SPLIT> (best));
@@ -1450,6 +1490,10 @@ __global__ __launch_bounds__ (192) void k_finalize (const float *gspart, icp_reg
     else icp_svd_rotation (S, means, Rk, Tk);
 
     if (lane == 0) {
+        if (p.st_prev) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p.st_prev[b].T[k] = st->T[k];
+        }
         icp_compose (st, Tk, Rk, ROT != 1);
 #pragma unroll
         for (int k = 0; k < 11; ++k) st->S[k] = S[k];
@@ -1491,7 +1535,12 @@ __global__ __launch_bounds__ (1024) void k_finalize_fused (const double *gmom, i
     for (int q = 0; q < 8; ++q) a0[q] = 0.0;
     if (!gl1) fused_moment_loads<1024> (mom, nb, 0u, a0);
     // (the state goes to memory straight from the composing lane's registers: no LDS image, no second pass)
-    fused_finalize_block<128, 1024, ROT, true> (p, mom, nb, check, sv, a0, &s_fin, s_l1, s_t, gl1, st, ff_no_hook (), 0u);
+    // (host-driven checked runs: the new (k, done) is published by the NEXT search's prologue, not here — a store into host memory at the
+    // end of this kernel is waited for by the kernel's end, and the next search by that: |F| = 65536, 18.7 -> 19.8 us per iteration)
+    // A registration that converges here leaves its final state in host memory too, in front of the word's DONE | FINAL bits.
+    fused_finalize_block<128, 1024, ROT, true> (p, mom, nb, check, sv, a0, &s_fin, s_l1, s_t, gl1, st, ff_no_hook (), 0u,
+                                                p.hmirror ? p.hmirror + b : nullptr, false, nullptr, p.hstate ? p.hstate + b : nullptr,
+                                                p.st_prev ? p.st_prev + b : nullptr);
 }
 
 // First tree level of the moments for large sets (|F| / 64 blocks > 128 * ICP_L1_MIN_GROUPS): one 16-lane row per
@@ -1517,6 +1566,16 @@ __global__ __launch_bounds__ (256) void k_moment_level1 (const double *gmom, con
 
 // chain end: finalize the last iteration's moments (slot given by p.slot) into the user-visible state.  (There is no
 // begin kernel: the first launch of a chain reads the user-visible state itself.)
+// The final state of a host-driven checked run -> the host (p.hstate: fine-grained pinned memory), then the word's FINAL bit: one wave,
+// so that the wave's own wait (the fence) covers every lane's stores before the word goes out.  v = dword t of the state.
+static __device__ __forceinline__ void state_to_host (const icp_params &p, uint32_t b, uint32_t t, uint32_t v, uint32_t k, uint32_t done)
+{
+    if (!p.hstate) return;                              // (kernel-uniform)
+    if (t < sizeof (icp_reg_state) / 4) reinterpret_cast<uint32_t *> (p.hstate + b)[t] = v;
+    __threadfence_system ();
+    if (t == 0 && p.hmirror) icp_mirror_store (p.hmirror + b, ICP_MIRROR_WORD (p.epoch, k, done) | ICP_MIRROR_FINAL);
+}
+
 template <int ROT>
 __global__ __launch_bounds__ (320) void k_chain_end (icp_params p)
 {
@@ -1527,18 +1586,36 @@ __global__ __launch_bounds__ (320) void k_chain_end (icp_params p)
     __shared__ double s_l1[ICP_NMOM][32];
     __shared__ double s_t[ICP_NMOM];
     if ((p.check && sin->done) || !sin->pending) {
-        if (threadIdx.x < sizeof (icp_reg_state) / 4) {
-            uint32_t v = reinterpret_cast<const uint32_t *> (sin)[threadIdx.x];
-            if (threadIdx.x == offsetof (icp_reg_state, pending) / 4) v = 0u;
-            reinterpret_cast<uint32_t *> (st)[threadIdx.x] = v;
+        if (threadIdx.x < 64) {
+            const uint32_t t = threadIdx.x;
+            uint32_t v = reinterpret_cast<const uint32_t *> (sin)[min (t, (uint32_t) sizeof (icp_reg_state) / 4u - 1u)];
+            if (t == offsetof (icp_reg_state, pending) / 4) v = 0u;
+            if (t < sizeof (icp_reg_state) / 4) reinterpret_cast<uint32_t *> (st)[t] = v;
+            state_to_host (p, b, t, v, sin->k, sin->done);
         }
         return;
     }
     const double *mom = p.mom + ((size_t) b * 2 + p.slot) * ICP_NMOM * p.nb;
     double a0[8];
     fused_moment_loads<320> (mom, p.nb, 0u, a0);
-    fused_finalize_block<32, 320, ROT> (p, mom, p.nb, 0u, state_load_lanes (sin), a0, &s_fin, s_l1, s_t);
+    fused_finalize_block<32, 320, ROT> (p, mom, p.nb, 0u, state_load_lanes (sin), a0, &s_fin, s_l1, s_t, nullptr, nullptr, ff_no_hook (), 1u,
+                                        nullptr, false, nullptr, nullptr, p.st_prev ? p.st_prev + b : nullptr);
     fin_result_to_state (&s_fin, st, 0u);
+    if (threadIdx.x < 64) {
+        const uint32_t t = threadIdx.x;
+        uint32_t v = reinterpret_cast<const uint32_t *> (&s_fin)[min (t, (uint32_t) sizeof (icp_reg_state) / 4u - 1u)];
+        if (t == offsetof (icp_reg_state, pending) / 4) v = 0u;
+        state_to_host (p, b, t, v, s_fin.k, s_fin.done);
+    }
+}
+
+// separate launches (dense sizes, reference order): the end of a host-driven checked run — p.st -> p.hstate + the FINAL bit
+__global__ __launch_bounds__ (64) void k_publish_state (icp_params p)
+{
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    const icp_reg_state *st = p.st + b;
+    const uint32_t v = reinterpret_cast<const uint32_t *> (st)[min (t, (uint32_t) sizeof (icp_reg_state) / 4u - 1u)];
+    state_to_host (p, b, t, v, st->k, st->done);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1670,28 +1747,43 @@ bool icp_chain_supported (const icp_params &p)
     return p.fused && p.nb <= 4096u && p.nr <= 1024u && (p.chain == 2 || (p.chain == 1 && !icp_dense (p)));
 }
 
-void icp_launch_chain (const icp_params &p0, hipStream_t s, uint32_t iterations, bool fresh)
+// launch j of a chain: reads state slot / moments buffer j & 1 and leaves the other (j = 0: reads the user-visible state, nothing to finalize yet)
+void icp_launch_chain_one (const icp_params &p0, hipStream_t s, uint32_t j, bool fresh, bool emit)
 {
     icp_params p = p0;
-    if (iterations == 0) return;
+    p.slot = j & 1u;
+    p.emit = emit ? 1 : 0;
     const uint32_t first_flags = 2u | (fresh ? 16u : 0u);             // (fresh: the run starts from the identity, see k_search)
-    for (uint32_t j = 0; j < iterations; ++j) {
-        p.slot = j & 1u;
-        p.emit = (p.check || j + 1 == iterations) ? 1 : 0;          // (with checks on, any iteration may be the last executed)
-        // the first launch reads the user-visible state directly (pending == 0 there: nothing to finalize yet)
-        if (p.rot == 1) {
-            if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 1>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, (const double *) p.mom,
-                                            p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | first_flags, p);
-            else hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 1>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
-        } else {
-            if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 0>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, (const double *) p.mom,
-                                            p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | first_flags, p);
-            else hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 0>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
-        }
+    if (p.rot == 1) {
+        if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 1>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, (const double *) p.mom,
+                                        p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | first_flags, p);
+        else hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 1>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
+    } else {
+        if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 0>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, (const double *) p.mom,
+                                        p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | first_flags, p);
+        else hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 0>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
     }
-    p.slot = iterations & 1u;
+}
+
+void icp_launch_chain_end (const icp_params &p0, hipStream_t s, uint32_t launches)
+{
+    icp_params p = p0;
+    p.slot = launches & 1u;
     if (p.rot == 1) hipLaunchKernelGGL (k_chain_end<1>, dim3 (p.batch), dim3 (320), 0, s, p);
     else hipLaunchKernelGGL (k_chain_end<0>, dim3 (p.batch), dim3 (320), 0, s, p);
+}
+
+void icp_launch_publish_state (const icp_params &p, hipStream_t s)
+{
+    hipLaunchKernelGGL (k_publish_state, dim3 (p.batch), dim3 (64), 0, s, p);
+}
+
+void icp_launch_chain (const icp_params &p, hipStream_t s, uint32_t iterations, bool fresh)
+{
+    if (iterations == 0) return;
+    for (uint32_t j = 0; j < iterations; ++j)                       // (with checks on, any iteration may be the last executed: every launch emits)
+        icp_launch_chain_one (p, s, j, fresh, p.check || j + 1 == iterations);
+    icp_launch_chain_end (p, s, iterations);
 }
 
 void icp_launch_iteration (const icp_params &p, hipStream_t s)

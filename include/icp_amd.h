@@ -151,9 +151,36 @@ int icp_step (icp_handle h, int config);
 
 /* ICP::run () — include/ICP/algorithms.hpp:2446, src/ICP/algorithms.cpp:4806-4834: iterate until
  * check() stops; blocking.  *k receives the iteration count (ICP::k) of registration 0 (a batch: icp_state_b gives every
- * registration's own k and converged flag; a registration that has converged is skipped by the remaining launches of
- * the graph, which is always max_iterations launches long). */
+ * registration's own k and converged flag; a registration that has converged is skipped by the launches the others still need).
+ * The loop is the reference's host loop (:4806-4814) with the check on the device: every new transform's (k, converged) reaches
+ * the host as one 8-byte store into pinned memory, the calling thread keeps `depth` launches queued behind the one in flight and
+ * stops enqueueing when the flag shows — a run costs k launches plus at most `depth` that leave at their first load, not
+ * max_iterations; the final state arrives in pinned memory with the end kernel (no stream synchronisation, no copy). */
 int icp_run (icp_handle h, uint32_t *k);
+
+/* The last finished checked run (icp_run, a tracked frame): iteration launches enqueued, its final k, and how many of the launches
+ * ran past the registration's last live iteration.  Any pointer may be NULL. */
+int icp_run_stats (icp_handle h, uint32_t *launches, uint32_t *k, uint32_t *dead_launches);
+
+/* Per-query outputs of checked runs (icp_run, tracked frames: ICP_MEM_NN_ID, _W, _NN, _QT, _RID — the reference's D_OUT_NN_ID etc. of
+ * the last executed iteration).  The fused kernels read none of them, and a checked run cannot know which iteration is its last:
+ *   ICP_OUTPUTS_LAZY (default)     the run stores none; the first icp_read / icp_device_ptr of one re-runs the search of the last executed
+ *                                  iteration with the transform it used (kept on the device): same bits, one extra launch, only when asked.
+ *                                  If F, M or the RBC have changed since the run (icp_write, icp_build_rbc, the next tracked frame), the
+ *                                  read fails with ICP_ESTATE instead;
+ *   ICP_OUTPUTS_EVERY_ITERATION    every iteration stores them (0.4 us of every 9 at |F| = 16384); ICP_AMD_OUTPUTS=eager at icp_create.
+ * Single steps, fixed-length runs and the reference-order mode always store them. */
+typedef enum { ICP_OUTPUTS_LAZY = 0, ICP_OUTPUTS_EVERY_ITERATION = 1 } icp_output_mode;
+int icp_set_output_mode (icp_handle h, int mode);
+
+/* Diagnostic: host timeline of the last icp_run, microseconds after its begin — [0] 0, [1] the first launches enqueued, [2] the first
+ * progress word seen, [3] decided (converged flag seen or max_iterations enqueued), [4] end kernel enqueued, [5] FINAL bit seen. */
+int icp_run_timeline (icp_handle h, double *us6);
+
+/* depth: launches kept queued behind the one in flight by checked runs (default 3; ICP_AMD_RUN_DEPTH at icp_create).
+ * adaptive = 0 brings back rounds 1 - 3's form — one cached graph of max_iterations launches per checked run, converged iterations
+ * leaving early — for comparisons (ICP_AMD_RUN_ADAPTIVE=0 at icp_create). */
+int icp_set_run_depth (icp_handle h, uint32_t depth, int adaptive);
 
 /* ICP::run (timer) — include/ICP/algorithms.hpp:2482-2494: exactly `iterations` steps, no
  * convergence test (the reference's profiling run; 40 there).  Enqueue only. */
@@ -214,14 +241,21 @@ int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint
  * fixed set by a rotation of three landmark buffers (no copy, no host trip).  Only the band of a frame that getLMs reads
  * (128 rows x 509 pixels = 2.08 MB of the 9.83 MB) is uploaded; the landmarks are extracted on the device (kernels/icp_kernels.cl:63-76).
  *
- * icp_track_submit   enqueue only: upload + getLMs on a copy stream, then buildRBC + ICP::run as ONE graph on the handle's
- *                    stream; up to four frames may be in flight, so frame f + 1 is uploaded while frame f registers.
+ * icp_track_submit   upload + getLMs on a copy stream, then buildRBC + ICP::run on the handle's stream; up to four frames may be
+ *                    in flight, so frame f + 1 is uploaded while frame f registers.  The registration is a host-driven checked
+ *                    run (icp_run): the call first brings the PREVIOUS frame's run to its end (polling its progress word,
+ *                    topping up its launches: it returns once that frame is decided), then enqueues this frame's buildRBC and
+ *                    as many iterations as the last two registrations suggest it needs (the smaller k, + 1) and returns; the
+ *                    next icp_track_* call tops it up.  No launch is spent on iterations past the convergence of a frame
+ *                    beyond that prediction / the run depth.
  *                    warm_start != 0: the registration starts from the previous hop's transform (written back as by
- *                    icp_write (ICP_MEM_T): the rotation state is re-derived from it) instead of the identity.
+ *                    icp_write (ICP_MEM_T): the rotation state is re-derived from it) instead of the identity; the first
+ *                    registration of a sequence (after icp_init / icp_track_reset) has no previous hop and starts from the
+ *                    identity.
  *                    `cloud` may be pageable host memory (the band is copied into pinned staging by the calling thread) or one
  *                    of the engine's two pinned frame buffers (icp_track_staging: the band goes by DMA straight from there —
- *                    the reference's mapped staging buffers hPtrInF / hPtrInM, src/ICP/algorithms.cpp:4438-4475; a buffer
- *                    may be refilled once its frame has been collected).
+ *                    the reference's mapped staging buffers hPtrInF / hPtrInM, src/ICP/algorithms.cpp:4438-4475;
+ *                    icp_track_staging returns a buffer only after the band of the frame it last held has left it).
  * icp_track_collect  blocks until the oldest frame in flight is done: *registered = 0 for the first frame after icp_init /
  *                    icp_track_reset (nothing to register against; *k = 0, T8 = identity), else 1, *k = iterations executed and
  *                    T8 = [q | t, s] mapping that frame onto the previous one.  Any output pointer may be NULL.

@@ -338,68 +338,107 @@ def measure_modes(icp_amd, device, g_default, power_mode, reduce_mode):
     return out
 
 
-def measure_tracking(icp_amd, device, hops=64):
-    """Frame-to-frame tracking (README.md:4; src/ocl_icp_reg.cpp:128-172 per pair): frames/s over a synthetic VGA sequence (five
-    frames walked back and forth: every hop is one step of 3 degrees / (25, -10, 15) mm), cold start (every hop from the
-    identity) and warm start (from the previous hop's T), three ways: the blocking icp_track_next; icp_track_submit / collect with
-    two frames in flight from pageable host memory (the calling thread copies the band getLMs reads into pinned staging); the same
-    from the engine's two pinned frame buffers (band by DMA, no host copy: two frames alternate)."""
+def _dist(a):
+    import numpy as np
+    a = np.asarray(a, float)
+    return {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "p99": float(np.percentile(a, 99)), "max": float(a.max()),
+            "mean": float(a.mean())}
+
+
+def _track_report(hops, elapsed, gaps_us, lat_us, ks, launches=None):
+    """One tracking variant: frames/s and the distributions of the SAME pass.  `gap` = time between two results reaching the host,
+    `latency` = submit call -> result on the host.  A frame's time follows its iteration count k (a warm start on a sequence that
+    reverses direction needs more iterations at the turning points): `gap_over_same_k` is every frame's gap over the median gap of the
+    frames with the same k — what is left is jitter, not workload."""
+    import numpy as np
+    gaps, ks = np.asarray(gaps_us, float), np.asarray(ks)
+    ratio = []
+    for k in np.unique(ks):
+        sel = gaps[ks == k]
+        if len(sel) >= 4:
+            ratio.extend(sel / np.median(sel))
+    out = {"frames": hops, "frames_per_s": hops / elapsed, "ms_per_frame": elapsed / hops * 1e3,
+           "completion_gap_us": _dist(gaps), "latency_us": _dist(lat_us),
+           "iterations": {"mean": float(ks.mean()), "p50": float(np.percentile(ks, 50)), "max": int(ks.max())},
+           "gap_over_same_k": ({"p99": float(np.percentile(ratio, 99)), "max": float(np.max(ratio)), "frames_compared": len(ratio)} if ratio else None),
+           "frames_above_1.25x_median_gap": int((gaps > 1.25 * np.median(gaps)).sum()),
+           "first_8_gaps_us": [float(x) for x in gaps[:8]]}
+    if launches is not None:
+        L = np.asarray(launches, float)
+        out["launches_per_frame"] = {"mean": float(L[:, 0].mean()), "past_the_last_live_iteration_mean": float(L[:, 2].mean()),
+                                     "note": "iteration launches enqueued per frame (icp_run_stats): k live + the one that finds out + what the "
+                                             "blind prediction / run depth put behind it; rounds 1 - 3 always launched max_iterations = 40"}
+    return out
+
+
+def measure_tracking(icp_amd, device, hops=256):
+    """Frame-to-frame tracking (README.md:4; src/ocl_icp_reg.cpp:128-172 per pair): ONE pass of `hops` frames per variant over a synthetic VGA
+    sequence (five frames walked back and forth: every hop is one step of 3 degrees / (25, -10, 15) mm), frames/s and the per-frame
+    distributions from that pass — cold start (every hop from the identity) and warm start (from the previous hop's T), three ways: the
+    blocking icp_track_next; icp_track_submit / collect with two frames in flight from pageable host memory (the calling thread copies
+    the band getLMs reads into pinned staging); the same from the engine's two pinned frame buffers (band by DMA, no host copy: two
+    frames alternate)."""
     import numpy as np
     frames = [icp_amd.synth_cloud_vga(moved=f) for f in range(5)]
     order = [0, 1, 2, 3, 4, 3, 2, 1]
     seq = [frames[order[i % len(order)]] for i in range(hops + 8)]
     out = {"frames": hops, "frame": "640 x 480 float8 (9.83 MB in host memory; the 2.08 MB band getLMs reads is uploaded), 16384 landmarks, |R| = 256",
-           "per_frame": "upload + getLMs + buildRBC + ICP::run to convergence (checked graph), result collected on the host"}
+           "per_frame": "upload + getLMs + buildRBC + ICP::run to convergence (host-driven checked run: k launches, not max_iterations), result collected on the host",
+           "timing": "one pass of %d frames per variant after 8 untimed frames; no pass is dropped or repeated" % hops}
+    pc = time.perf_counter
     for name, warm in (("cold_start", False), ("warm_start", True)):
         g = icp_amd.ICP(device)
         g.init(16384, 256, ALPHA, SCALING)
         res = {}
-        def best_of_two(run):
-            """(elapsed s, results) of the faster of two timed passes: interleaved copy-stream uploads and graph launches now and then run a
-            whole pass at a third of the speed (seen with plain icp_write + run as well); both times are kept in `passes_ms_per_frame`."""
-            got = []
-            for _ in range(2):
-                g.sync()
-                t0 = time.perf_counter()
-                r = run()
-                g.sync()
-                got.append((time.perf_counter() - t0, r))
-            return min(got, key=lambda x: x[0]) + ([x[0] / hops * 1e3 for x in got],)
-
-        for f in seq[:8]:                             # warm-up: the graphs of the three rotation steps captured
+        for f in seq[:8]:
             g.track_next(f, warm_start=warm)
-        el, ks, both = best_of_two(lambda: [g.track_next(f, warm_start=warm) for f in seq[8:]])
-        res["blocking"] = {"frames_per_s": hops / el, "ms_per_frame": el / hops * 1e3, "mean_iterations": float(np.mean(ks)), "passes_ms_per_frame": both}
-        g.track_reset()
-        g.track_pipelined(seq[:8], warm_start=warm)
-        el, r, both = best_of_two(lambda: g.track_pipelined(seq[8:], warm_start=warm, depth=2))
-        res["pipelined_pageable"] = {"frames_per_s": hops / el, "ms_per_frame": el / hops * 1e3, "mean_iterations": float(np.mean([x[0] for x in r if x])),
-                                     "passes_ms_per_frame": both}
-        if warm:                                      # (two alternating frames make every warm start the inverse of what is needed: cold only)
-            out[name] = res
-            g.close()
-            continue
-        g.track_reset()
-        g.track_staging(0)[...] = frames[1]
-        g.track_staging(1)[...] = frames[2]
-        for i in range(8):
-            g.track_submit(i & 1, warm)
-            g.track_collect()
+        g.sync()
+        ks, stamps, lat, st = [], [], [], []
+        t0 = pc()
+        for f in seq[8:]:
+            ts = pc()
+            ks.append(g.track_next(f, warm_start=warm))
+            te = pc()
+            stamps.append(te); lat.append((te - ts) * 1e6); st.append(g.run_stats())
+        el = pc() - t0
+        res["blocking"] = _track_report(hops, el, np.diff(np.array([t0] + stamps)) * 1e6, lat, ks, st)
+        res["blocking"]["host_launch_calls"] = dict(zip(("longest_us", "slower_than_10us", "calls"), g.launch_stats(reset=True)))
 
-        def pinned_pass():
-            g.track_submit(0, warm)
-            r = []
-            for i in range(1, hops):
+        def pipelined(submit_of, n):
+            """Two frames in flight: submit frame i, then collect frame i - 1."""
+            sub, stamps, ks = [], [], []
+            t0 = pc()
+            for i in range(n):
+                sub.append(pc())
+                submit_of(i)
+                if i >= 1:
+                    ks.append(g.track_collect()[0]); stamps.append(pc())
+            ks.append(g.track_collect()[0]); stamps.append(pc())
+            el = pc() - t0
+            return el, np.diff(np.array([t0] + stamps)) * 1e6, (np.array(stamps) - np.array(sub)) * 1e6, ks
+
+        g.track_reset()
+        g.track_pipelined(seq[:8], warm_start=warm)            # (the first frame of a sequence registers against nothing: it is in the warm-up)
+        g.sync()
+        g.launch_stats(reset=True)
+        # the warm-up's last frame is frame 7 of the sequence: the pass continues it
+        tail = seq[8:]
+        el, gaps, lats, ks = pipelined(lambda i: g.track_submit(tail[i], warm), hops)
+        res["pipelined_pageable"] = _track_report(hops, el, gaps, lats, ks)
+        res["pipelined_pageable"]["host_launch_calls"] = dict(zip(("longest_us", "slower_than_10us", "calls"), g.launch_stats(reset=True)))
+        if not warm:                                  # (two alternating frames make every warm start the inverse of what is needed: cold only)
+            g.track_reset()
+            g.track_staging(0)[...] = frames[1]
+            g.track_staging(1)[...] = frames[2]
+            for i in range(8):
                 g.track_submit(i & 1, warm)
-                r.append(g.track_collect())
-            r.append(g.track_collect())
-            return r
-
-        el, r, both = best_of_two(pinned_pass)
-        res["pipelined_pinned"] = {"frames_per_s": hops / el, "ms_per_frame": el / hops * 1e3, "mean_iterations": float(np.mean([x[0] for x in r if x])),
-                                   "passes_ms_per_frame": both,
-                                   "note": "two frames one step apart alternate in the engine's pinned frame buffers (icp_track_staging); a frame's buffer is "
-                                           "resubmitted after its previous use has been collected"}
+                g.track_collect()
+            g.sync()
+            el, gaps, lats, ks = pipelined(lambda i: g.track_submit(i & 1, warm), hops)
+            res["pipelined_pinned"] = _track_report(hops, el, gaps, lats, ks)
+            res["pipelined_pinned"]["host_launch_calls"] = dict(zip(("longest_us", "slower_than_10us", "calls"), g.launch_stats(reset=True)))
+            res["pipelined_pinned"]["note"] = ("two frames one step apart alternate in the engine's pinned frame buffers (icp_track_staging): what a capture "
+                                               "loop that writes its frames there would see")
         out[name] = res
         g.close()
     return out

@@ -107,6 +107,7 @@ def lib():
     sig("icp_set_run_depth", i32, vp, u32, i32)
     sig("icp_run_timeline", i32, vp, C.POINTER(f64))
     sig("icp_set_output_mode", i32, vp, i32)
+    sig("icp_launch_stats", i32, vp, C.POINTER(f64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32)
     sig("icp_run_fixed", i32, vp, u32)
     sig("icp_run_fixed_fresh", i32, vp, u32)
     sig("icp_sync", i32, vp)
@@ -682,6 +683,12 @@ class ICP(ICPStep):
         t = (C.c_double * 6)()
         self._chk(self._L.icp_run_timeline(self._h, t))
         return [float(x) for x in t]
+
+    def launch_stats(self, reset=False):
+        """(longest launch call in us, calls slower than 10 us, calls) of the checked runs since init / the last reset."""
+        mx, slow, tot = C.c_double(), C.c_uint64(), C.c_uint64()
+        self._chk(self._L.icp_launch_stats(self._h, C.byref(mx), C.byref(slow), C.byref(tot), int(reset)))
+        return mx.value, slow.value, tot.value
 
     def set_output_mode(self, every_iteration=False):
         """Per-query outputs of checked runs: stored by every iteration, or (default) reproduced on the first read (icp_set_output_mode)."""

@@ -46,6 +46,7 @@ struct run_ctl {
     // host timeline of the run (icp_run_timeline), seconds on the steady clock: begin, blind launches enqueued, first progress word seen,
     // decided, end kernel enqueued
     double t[5] = { 0, 0, 0, 0, 0 };
+    double launch_max_us = 0.0; uint32_t launch_slow = 0;   // the host's own launch calls: the longest, and how many took more than 10 us
 };
 
 inline double now_s () { return std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count (); }
@@ -81,6 +82,7 @@ struct icp_context {
     bool outputs_stale = false, outputs_lost = false;
     uint32_t stat_launches = 0, stat_k = 0, stat_dead = 0;   // last finished checked run: iteration launches enqueued, final k, launches past the last live one
     double stat_t[6] = { 0, 0, 0, 0, 0, 0 };     // its host timeline (run_ctl::t) + the moment its FINAL bit was seen
+    double stat_launch_max_us = 0.0; uint64_t stat_launch_slow = 0, stat_launch_total = 0;   // launch calls of all checked runs since icp_init
     uint64_t graph_clock = 0, param_gen = 0;     // LRU stamp of the graph cache; generation of the parameters the cached graphs were captured with
     float *dTin = nullptr;                       // device scratch for write(T)
     float *dCloud = nullptr, *dCloudOut = nullptr; uint32_t cloud_cap = 0;
@@ -185,7 +187,7 @@ bool reps_grid (uint32_t m, uint32_t nr, uint32_t *nrx, uint32_t *nry, uint32_t 
     return true;
 }
 
-int run_finish (icp_context *h);
+int run_finish (icp_context *h, bool defer_event = false);
 void note_outputs_stored (icp_context *h);
 
 // keep_run: the caller is one of the tracking entries, which carry an open checked run (run_ctl) across calls themselves; everything
@@ -303,15 +305,23 @@ int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *o
 void run_launch_one (icp_context *h)
 {
     run_ctl &r = h->run;
+    const double t0 = now_s ();
     if (r.chained) icp_launch_chain_one (r.p, h->stream, r.enq, r.fresh, r.p.emit != 0);
     else icp_launch_iteration (r.p, h->stream);
+    const double us = (now_s () - t0) * 1e6;
+    if (us > r.launch_max_us) r.launch_max_us = us;
+    if (us > 10.0) ++r.launch_slow;
     ++r.enq;
 }
 
 // Opens a checked run on the handle's stream with `blind` iterations enqueued at once (at least one).  p: the parameters of THIS run
 // (tracking passes the frame's own landmark buffers); mirror / hstate: the host memory its words and final state go to.
+// between (): enqueued after the RBC construction and in front of the first iteration (tracking: the waits and records that need not
+// hold the construction back).
+struct run_no_hook { int operator() () const { return ICP_OK; } };
+template <typename BETWEEN = run_no_hook>
 int run_begin (icp_context *h, const icp_params &p, bool fresh, bool with_build, uint32_t blind,
-               unsigned long long *mirror, icp_reg_state *hstate, int track_slot)
+               unsigned long long *mirror, icp_reg_state *hstate, int track_slot, BETWEEN between = BETWEEN ())
 {
     run_ctl &r = h->run;
     r = run_ctl {};
@@ -327,6 +337,7 @@ int run_begin (icp_context *h, const icp_params &p, bool fresh, bool with_build,
     r.chained = icp_chain_supported (r.p); r.fresh = fresh;
     r.maxit = h->max_iterations; r.depth = h->run_depth ? h->run_depth : 1u;
     if (with_build) icp_launch_build_rbc (r.p, h->stream);
+    { int rc = between (); if (rc) return rc; }
     if (fresh && !r.chained) icp_launch_reset_state (r.p, h->stream, 1);
     r.active = true;
     const uint32_t n = std::min (std::max (blind, 1u), r.maxit);
@@ -366,7 +377,7 @@ bool run_pump (icp_context *h)
 
 // Drives the open run to its decision (the calling thread polls; bounded wait on a device that has stopped answering), then
 // enqueues its end kernel — final state -> p.st and -> host memory, FINAL bit — and closes it.
-int run_finish (icp_context *h)
+int run_finish (icp_context *h, bool defer_event)
 {
     run_ctl &r = h->run;
     if (!r.active) return ICP_OK;
@@ -391,13 +402,14 @@ int run_finish (icp_context *h)
     }
     r.t[4] = now_s ();
     for (int i = 0; i < 5; ++i) h->stat_t[i] = r.t[i];
+    h->stat_launch_max_us = std::max (h->stat_launch_max_us, r.launch_max_us); h->stat_launch_slow += r.launch_slow; h->stat_launch_total += r.enq;
     r.active = false;
     h->stat_launches = r.enq; h->stat_k = r.k_final;
     // iterations enqueued past the one that found out (converged at k: iterations 0 .. k - 1 ran, launch k saw the flag — in the chained form it
     // is the one that sets it —, the rest leave at their first load)
     h->stat_dead = r.done_seen ? r.enq - std::min (r.enq, r.k_final + 1u) : 0u;
     HIPCHK (h, hipGetLastError ());
-    if (r.track_slot >= 0) HIPCHK (h, hipEventRecord (h->evDone[r.track_slot], h->stream));
+    (void) defer_event;                                                 // (host-driven tracked frames carry no event: see track_submit)
     return ICP_OK;
 }
 
@@ -903,6 +915,16 @@ int icp_run_stats (icp_handle h, uint32_t *launches, uint32_t *k, uint32_t *dead
     return ICP_OK;
 }
 
+int icp_launch_stats (icp_handle h, double *max_us, uint64_t *slower_than_10us, uint64_t *total, int reset)
+{
+    if (!h) return ICP_EINVAL;
+    if (max_us) *max_us = h->stat_launch_max_us;
+    if (slower_than_10us) *slower_than_10us = h->stat_launch_slow;
+    if (total) *total = h->stat_launch_total;
+    if (reset) { h->stat_launch_max_us = 0.0; h->stat_launch_slow = h->stat_launch_total = 0; }
+    return ICP_OK;
+}
+
 int icp_set_output_mode (icp_handle h, int mode)
 {
     if (!h) return ICP_EINVAL;
@@ -1126,8 +1148,15 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     const uint32_t s = (uint32_t) (f & 1u), buf = (uint32_t) (f % 3u), ring = (uint32_t) (f % ICP_TRACK_RING);
     const char *src = static_cast<const char *> (cloud) + ((size_t) ICP_BAND_ROW0 * 640u + ICP_BAND_COL0) * 32u;
     const size_t spitch = (size_t) ICP_BAND_ROW_STEP * 640u * 32u;
-    // the copy stream: not before registration f - 2 (the last reader of lm[buf], as its fixed set) is done
-    if (f >= 2u) HIPCHK (h, hipStreamWaitEvent (h->copy_stream, h->evDone[(f - 2u) % ICP_TRACK_RING], 0));
+    // the copy stream: not before registration f - 2 (the last reader of lm[buf], as its fixed set) is done.  Host-driven runs: the host
+    // knows — the FINAL bit of that frame's word (it is there long before: that registration was decided before frame f - 1 was even
+    // begun) —, and neither stream carries an event for it (a record + a cross-stream wait cost the main stream ~10 us per frame between
+    // the RBC construction and the first iteration, profiles/r04_track_trace.txt)
+    if (f >= 2u) {
+        const uint32_t r2 = (uint32_t) ((f - 2u) % ICP_TRACK_RING);
+        if (h->track_epoch[r2]) { if ((rc = run_wait_final (h, h->hTrackMirror + r2, 1u, h->track_epoch[r2]))) return rc; }
+        else HIPCHK (h, hipStreamWaitEvent (h->copy_stream, h->evDone[r2], 0));
+    }
     const bool pinned = cloud == h->hFrame[0] || cloud == h->hFrame[1];
     if (pinned) {
         // the caller filled one of the engine's pinned frame buffers (icp_track_staging): the band goes by DMA straight from there
@@ -1135,21 +1164,29 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     } else {
         // pageable source: the band's 128 row segments into the slot's pinned staging (free once the upload of frame f - 2 is through)
         if (f >= 2u) HIPCHK (h, hipEventSynchronize (h->evUp[s]));
-        for (uint32_t j = 0; j < ICP_BAND_ROWS; ++j)
+        for (uint32_t j = 0; j < ICP_BAND_ROWS; ++j) {
             std::memcpy (reinterpret_cast<char *> (h->hBand[s]) + (size_t) j * ICP_BAND_ROW_BYTES, src + (size_t) j * spitch, ICP_BAND_ROW_BYTES);
+            // (the copy takes ~60 us: the previous frame's open registration is looked after on the way — a word read, a launch if it needs one)
+            if ((j & 7u) == 7u && h->run.active) (void) run_pump (h);
+        }
         HIPCHK (h, hipMemcpyAsync (h->dBand[s], h->hBand[s], ICP_BAND_BYTES, hipMemcpyHostToDevice, h->copy_stream));
     }
     icp_launch_get_lms_band (h->dBand[s], h->lm[buf], h->copy_stream);
     HIPCHK (h, hipGetLastError ());
     HIPCHK (h, hipEventRecord (h->evUp[s], h->copy_stream));
     // the main stream.  The previous frame's registration may still be open (its blind launches enqueued, the rest not): bring it to
-    // its end first — its end kernel and evDone go in front of this frame's work
+    // its end first.  Its evDone — "the landmark buffers it read are free" — is recorded behind this frame's RBC construction: the device
+    // has run dry by the time the host sees the converged flag, and the first kernel of this frame is what it is waiting for
+    int prev_slot = -1;
     if (h->run.active) {
-        if ((rc = run_finish (h))) return rc;
+        prev_slot = h->run.track_slot;
+        if ((rc = run_finish (h, true))) return rc;
         h->track_k_hist[1] = h->track_k_hist[0]; h->track_k_hist[0] = h->run.k_final;
     }
-    // this frame's landmarks, then (from the second frame on) the registration against the previous frame's: buildRBC + ICP::run
-    HIPCHK (h, hipStreamWaitEvent (h->stream, h->evUp[s], 0));
+    // (rounds 1 - 3's form only: host-driven runs order the streams from the host, see above)
+    auto record_prev = [&] () -> int { if (prev_slot >= 0 && !h->track_epoch[prev_slot]) { HIPCHK (h, hipEventRecord (h->evDone[prev_slot], h->stream)); } prev_slot = -1; return ICP_OK; };
+    // this frame's upload: waited for on the stream only if it is not through yet (it is, whenever a registration takes longer than an upload)
+    auto wait_upload = [&] () -> int { if (hipEventQuery (h->evUp[s]) != hipSuccess) { (void) hipGetLastError (); HIPCHK (h, hipStreamWaitEvent (h->stream, h->evUp[s], 0)); } return ICP_OK; };
     note_inputs_change (h);
     float *newM = h->lm[buf], *newF = h->lm[(f + 2u) % 3u];             // (f - 1) mod 3: the previous frame's landmarks (first frame: a buffer that is not M)
     if (f > 0u) {
@@ -1158,13 +1195,23 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
         // warm start: from the previous hop's transform, as by write (D_IO_T) — the first registration of a sequence has no previous hop
         // and starts from the identity whatever the state holds (an earlier sequence's last transform, an icp_run before the reset)
         const bool warm = warm_start && f > 1u;
-        if (warm) { icp_launch_set_T (p, 0, p.st->T, h->stream); HIPCHK (h, hipGetLastError ()); }
         if (h->run_adaptive) {
             const uint32_t blind = blocking ? h->run_depth + 1u : track_blind (h);
-            if ((rc = run_begin (h, p, !warm, true, blind, h->hTrackMirror + ring, h->hTrack + ring, (int) ring))) return rc;
+            // buildRBC reads the fixed set only — the previous frame's landmarks, resident since that frame's own registration —: this frame's
+            // upload is waited for behind it
+            auto between = [&] () -> int {
+                int rc2 = record_prev (); if (rc2) return rc2;
+                if ((rc2 = wait_upload ())) return rc2;
+                if (warm) { icp_launch_set_T (p, 0, p.st->T, h->stream); HIPCHK (h, hipGetLastError ()); }
+                return ICP_OK;
+            };
+            if ((rc = run_begin (h, p, !warm, true, blind, h->hTrackMirror + ring, h->hTrack + ring, (int) ring, between))) return rc;
             h->track_epoch[ring] = h->run.p.epoch;
         } else {
             // rounds 1 - 3: buildRBC + a checked run of max_iterations launches as one cached graph (the graphs hold the buffer pointers)
+            if ((rc = record_prev ())) return rc;
+            HIPCHK (h, hipStreamWaitEvent (h->stream, h->evUp[s], 0));
+            if (warm) { icp_launch_set_T (p, 0, p.st->T, h->stream); HIPCHK (h, hipGetLastError ()); }
             float *oF = h->dF, *oM = h->dM; const float *opF = h->p.F, *opM = h->p.M; const uint32_t opar = h->parity;
             h->dM = newM; h->p.M = newM; h->dF = newF; h->p.F = newF; h->parity = 1u + buf;
             rc = launch_run (h, h->max_iterations, 1, !warm, true);
@@ -1173,7 +1220,12 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
             HIPCHK (h, hipEventRecord (h->evDone[ring], h->stream));
             h->track_epoch[ring] = 0u;
         }
-    } else HIPCHK (h, hipEventRecord (h->evDone[ring], h->stream));
+    } else {
+        if ((rc = record_prev ())) return rc;
+        HIPCHK (h, hipStreamWaitEvent (h->stream, h->evUp[s], 0));      // this frame's landmarks (nothing to register against yet)
+        HIPCHK (h, hipEventRecord (h->evDone[ring], h->stream));
+        h->track_epoch[ring] = 0u;
+    }
     // everything that can fail is behind us: the handle now points at this frame's buffers
     h->dM = newM; h->p.M = newM; h->dF = newF; h->p.F = newF;
     h->parity = 1u + buf;                                               // graphs hold the pointers: one cached set per rotation step (0: the buffers of icp_init)

@@ -162,6 +162,10 @@ int icp_run (icp_handle h, uint32_t *k);
  * ran past the registration's last live iteration.  Any pointer may be NULL. */
 int icp_run_stats (icp_handle h, uint32_t *launches, uint32_t *k, uint32_t *dead_launches);
 
+/* Diagnostic: the host's own kernel-launch calls inside checked runs since icp_init (or the last reset): the longest one, how many took
+ * more than 10 us, how many there were.  A host-driven run is as good as the host is punctual. */
+int icp_launch_stats (icp_handle h, double *max_us, uint64_t *slower_than_10us, uint64_t *total, int reset);
+
 /* Per-query outputs of checked runs (icp_run, tracked frames: ICP_MEM_NN_ID, _W, _NN, _QT, _RID — the reference's D_OUT_NN_ID etc. of
  * the last executed iteration).  The fused kernels read none of them, and a checked run cannot know which iteration is its last:
  *   ICP_OUTPUTS_LAZY (default)     the run stores none; the first icp_read / icp_device_ptr of one re-runs the search of the last executed

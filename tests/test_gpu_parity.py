@@ -4,9 +4,12 @@ Bar: bit-exact for indices AND for every float the iteration produces (the canon
 DESIGN.md §3 makes the fp32 reductions reproducible), so comparisons are on the raw bit patterns.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -372,17 +375,37 @@ def test_fused_run_and_cross_mode_tolerance(engine, oracle):
     kr = r.run()
     Tr = r.read(engine.Memory.T)
     assert abs(kr - kg) <= 1
-    # The contract ("1e-5 relative"): each block of [q | t, s] against its own magnitude — |q| = 1, the
-    # scene scale for t (largest coordinate, ~1900 mm: what the translation is resolved against), s itself.
-    scale = float(np.abs(F[:, :3]).max())
-    assert np.abs(T[:4] - Tr[:4]).max() < 1e-5
-    assert np.abs(T[4:7] - Tr[4:7]).max() < 1e-5 * scale
-    assert abs(T[7] - Tr[7]) < 1e-5 * abs(Tr[7])
-    # What is measured (free-running trajectories differ at the fp32 noise level of the coordinates, ulp(1500 mm) =
-    # 1.2e-4 mm, and a handful of near-tie correspondences flip): pinned ~2x above it so that a regression shows
+    # The contract ("final R|t within 1e-5 relative", north star), under a float64 solution: every mode's result against the
+    # float64 restatement of its own iterations (tests/float64_ref.py, fed the correspondences the ENGINE found in each iteration), each
+    # block of [q | t, s] against its own magnitude — |q| = 1, |t| (25 mm here), s.
+    import float64_ref as R64
+    scene = float(np.abs(F[:, :3]).max())
+
+    def against_float64(h, k, Tend):
+        h.reset_transform(); h.buildRBC()
+        f = R64.Float64ICP(F, M, 2e2, 1e-6)
+        for _ in range(k):
+            h.step()
+            f.step(h.read(engine.Memory.NN_ID)["id"])
+        assert_bits(h.read(engine.Memory.T), Tend, "step by step = run ()")
+        return R64.errors_against(Tend, f.T, scene), f.T
+
+    ef, T64f = against_float64(g, kg, T)
+    er, T64r = against_float64(r, kr, Tr)
+    for e in (ef, er):
+        assert e["dq"] < 1e-5 and e["dt_over_t"] < 1e-5 and e["ds_over_s"] < 1e-5, e
+    for key in ("dq", "dt_mm", "ds_over_s"):                             # the default mode is the closer one, in every component
+        assert ef[key] <= er[key], (key, ef, er)
+    # BETWEEN the modes the same norm reads ~2.4e-5 in t: that is the one near-tie correspondence (of 16384) the two runs end up
+    # disagreeing on — the float64 solutions of the two correspondence sets are as far apart as the two fp32 results
+    b32, b64 = R64.errors_against(T, Tr, scene), R64.errors_against(T64f, T64r, scene)
+    assert abs(b32["dt_mm"] - b64["dt_mm"]) < 0.25 * b64["dt_mm"], (b32, b64)
+    # What is measured between the modes, pinned ~2x above it so that a regression shows
     assert np.abs(T[:4] - Tr[:4]).max() < 2e-6, np.abs(T[:4] - Tr[:4]).max()
     assert np.abs(T[4:7] - Tr[4:7]).max() < 2e-3, np.abs(T[4:7] - Tr[4:7]).max()          # mm
     assert abs(T[7] - Tr[7]) < 2e-6
+    g.reset_transform(); g.buildRBC(); g.run()                           # (the final correspondences of the two runs)
+    r.reset_transform(); r.buildRBC(); r.run()
     ids_f, ids_r = g.read(engine.Memory.NN_ID)["id"], r.read(engine.Memory.NN_ID)["id"]
     assert np.mean(ids_f == ids_r) > 0.999
     g.close()

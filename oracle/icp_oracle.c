@@ -105,6 +105,8 @@ int orc_get_reps (const float *F, uint32_t m, uint32_t nr, float *R, uint32_t *r
 /* ======================================================================================= */
 /* a3  icpTransform_Quaternion — kernels/icp_kernels.cl:772-802, twin helper_funcs.hpp:451   */
 /* ======================================================================================= */
+static int g_threads = 1;      /* OpenMP team size of the current call (orc_icp_set_threads) */
+
 static void transform_point (const float *T, const float *p, float *tp)
 {
     const float *q = T;
@@ -121,6 +123,7 @@ static void transform_point (const float *T, const float *p, float *tp)
 
 void orc_transform_q (const float *M, float *tM, const float *T, uint32_t m)
 {
+    #pragma omp parallel for schedule(static) num_threads(g_threads) if (m >= 4096)
     for (uint32_t i = 0; i < m; ++i) {
         float tp[3]; transform_point (T, M + (size_t) i * 8, tp);
         tM[i * 8 + 0] = tp[0]; tM[i * 8 + 1] = tp[1]; tM[i * 8 + 2] = tp[2];
@@ -186,7 +189,6 @@ float orc_metric8 (const float *x, const float *y, float a)
     return fmaf (a, p, g);
 }
 
-static int g_threads = 1;
 
 /* owner(x) = argmin_r d(x, R[r]), ties -> lowest r */
 static uint32_t nearest_rep (const float *x, const float *R, uint32_t nr, float a, float *dist)
@@ -235,7 +237,7 @@ void orc_rbc_search (const float *Q, uint32_t nq, const float *R, uint32_t nr,
                      const uint32_t *N, const uint32_t *rep_src, float a,
                      orc_dist_id *nn_id, float *NN, uint32_t *rid)
 {
-    #pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    #pragma omp parallel for schedule(dynamic, 64) num_threads(g_threads)
     for (int64_t i = 0; i < (int64_t) nq; ++i) {
         const float *q = Q + (size_t) i * 8;
         float dr; uint32_t r = nearest_rep (q, R, nr, a, &dr);
@@ -790,8 +792,11 @@ void orc_moments_fused (const float *NN, const float *tM, const float *Wt, uint3
 {
     uint32_t nb = (m + 63u) / 64u;
     double *part = (double *) calloc ((size_t) nb * NMOM, sizeof (double));
-    double data[NMOM][64];
+    /* the block partials are independent of each other (a fixed tree per block): any thread may compute any block — deterministic
+     * per-thread partials, the same bits as the serial loop (bench.py's cpu_baseline runs this on all host cores) */
+    #pragma omp parallel for schedule(static) num_threads(g_threads) if (nb >= 64)
     for (uint32_t b = 0; b < nb; ++b) {
+        double data[NMOM][64];
         for (uint32_t e = 0; e < 64; ++e) {
             uint32_t i = orc_fused_query (m, side, b, e);
             double t[NMOM];
@@ -980,9 +985,13 @@ void orc_icp_step (orc_icp *h)
                     h->nn_id, h->NN, h->rid);                                      /* rbcS.run      */
     /* absolute scale of the metric (ASSUMPTION-METRIC, second half): the search runs on geo + a pho (argmin and ties do not
      * depend on a positive common factor f_g); the distance it reports, which feeds the weights, is f_g times that */
+    #pragma omp parallel for schedule(static) num_threads(g_threads) if (h->m >= 4096)
     for (uint32_t i = 0; i < h->m; ++i) h->nn_id[i].dist = h->dist_scale * h->nn_id[i].dist;
     if (h->fused) {
-        if (h->weighted) for (uint32_t i = 0; i < h->m; ++i) h->W[i] = 100.f / (100.f + h->nn_id[i].dist);
+        if (h->weighted) {
+            #pragma omp parallel for schedule(static) num_threads(g_threads) if (h->m >= 4096)
+            for (uint32_t i = 0; i < h->m; ++i) h->W[i] = 100.f / (100.f + h->nn_id[i].dist);
+        }
         orc_moments_fused (h->NN, h->tM, h->weighted ? h->W : NULL, h->m, h->side, h->c, &h->sum_w, h->means, h->S);
     } else {
     if (h->weighted) {

@@ -416,6 +416,67 @@ def test_bench_gpus_2_plain_python_in_process():
     assert bad.returncode != 0 and "device(s) are visible" in bad.stderr
 
 
+def test_config4_at_its_real_shape_on_one_gpu(engine):
+    """BASELINE config 4 as the 8-GPU node will see it — 512 registrations, 8 device slots x 64 — rehearsed with all eight slots on GPU 0:
+    `python bench.py --gpus 8` (in-process form, ICP_BENCH_DEVICES=0,0,0,0,0,0,0,0) prints a line with n_gpus 8 and eight per-GPU
+    rates; then an ICPBatch over the same eight slots runs the 512 pairs to convergence and the registrations the fixture holds
+    (tests/golden/config4_vectors.npz: job indices 0, 9, .., 63 = slot i mod 8, entry i / 8) come out bit for bit."""
+    import json
+    import sys
+    from icp_amd import workloads as C4
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["ICP_BENCH_DEVICES"] = "0,0,0,0,0,0,0,0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["registrations_per_gpu"] == 64 and d["config"]["devices"] == [0] * 8
+    assert len(d["per_gpu_iterations_per_s"]) == 8 and all(v > 0 for v in d["per_gpu_iterations_per_s"])
+    assert d["value"] == pytest.approx(512 * 2 * 40 / (d["ms_per_step"] * 2 * 1e-3), rel=1e-6)        # 512 registrations x 2 steps x 40 iterations
+    assert d["config4_per_gpu_value"] == pytest.approx(d["value"] / 8)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "config4_vectors.npz"))
+    B = engine.ICPBatch([0] * 8)
+    B.init(512, C4.M_POINTS, C4.NR, C4.A, C4.C_)
+    for i in range(512):
+        F, M = C4.pair(engine, i)
+        B.write(i, engine.Memory.F, F)
+        B.write(i, engine.Memory.M, M)
+        assert engine.batch_partition(512, 8, i) == (i % 8, i // 8, 64)
+    B.buildRBC()
+    B.run()
+    for i in C4.CHECKED:
+        st = B.state(i)
+        T, ids = B.read(i, engine.Memory.T), B.read(i, engine.Memory.NN_ID)["id"]
+        assert (st.k, int(st.converged)) == tuple(int(v) for v in gold["r%d_run" % i]), i
+        assert np.array_equal(T.view(np.uint32), gold["r%d_run_T" % i].view(np.uint32)), i
+        assert np.array_equal(ids[:256], gold["r%d_run_ids_head" % i]) and np.array_equal(C4.ids_digest(ids), gold["r%d_run_ids_digest" % i]), i
+    B.close()
+
+
+def test_bench_six_gloo_ranks_on_one_gpu():
+    """The driver's launch form with as many ranks as one GPU box admits (six processes may hold the card at once; the node runs
+    eight, one per GPU): torch.distributed.run, the DEFAULT backend of the rank path (gloo — the engine's contract is no RCCL), every
+    rank its own 64 registrations of config 4, one line with n_gpus 6."""
+    import json
+    import socket
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k != "ICP_BENCH_BACKEND"}
+    env.update(ICP_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "6", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "6", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 6 and d["config"]["registrations_per_gpu"] == 64 and "gloo" in d["config"]["parallelism"]
+    assert d["value"] == pytest.approx(6 * 64 * 2 * 40 / (d["ms_per_step"] * 2 * 1e-3), rel=1e-6)
+    assert len(d["per_gpu_iterations_per_s"]) == 6 and d["config4_per_gpu_value"] == pytest.approx(d["value"] / 6)
+
+
 @pytest.mark.parametrize("warm", [False, True])
 def test_tracking_on_device_four_frames(engine, oracle, warm):
     """icp_track_next: a 4-frame synthetic sequence; every hop's T, k and correspondences equal the oracle's bit for bit,

@@ -388,3 +388,27 @@ def test_host_sanitizer_build_is_clean():
     r = subprocess.run(["make", "-C", root, "-s", "asan"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "asan_host: clean" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def test_oracle_bits_do_not_depend_on_the_thread_count(oracle, engine):
+    """bench.py's cpu_baseline sweeps the OpenMP team size: the parallel loops are over independent queries and over the independent
+    64-pair blocks of the moment reduction (fixed trees), so every team size gives the same bits — both modes, whole runs."""
+    F, M = engine.synth_pair(128)
+    for kw in (dict(power_fast=True, fused=True), dict()):
+        res = []
+        for t in (1, 3, 8):
+            o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=t, **kw)
+            o.write_f(F); o.write_m(M); o.build_rbc()
+            k = o.run()
+            res.append((k, o.T.tobytes(), o.S.tobytes(), o.means.tobytes(), o.nn_id["id"].tobytes(), o.nn_id["dist"].tobytes()))
+        assert res[0] == res[1] == res[2]
+
+
+def test_cpu_baseline_reports_a_thread_sweep(engine):
+    """bench.py's cpu_baseline: a bounded thread sweep, the best count as `value`, the host's core count beside it."""
+    import bench
+    F, M = engine.synth_pair(64)
+    r = bench.cpu_baseline(F, M, 4096, 64, True, budget_s=1.0)
+    assert r["kind"] == "port" and r["host_cores"] == os.cpu_count() and r["unit"] == "iterations/s"
+    assert [x["threads"] for x in r["sweep"]] == sorted({t for t in (1, 8, 16, 64, os.cpu_count()) if t <= os.cpu_count()})
+    assert r["value"] == max(x["iterations_per_s"] for x in r["sweep"]) and r["cores"] in [x["threads"] for x in r["sweep"]]

@@ -455,26 +455,26 @@ def test_config4_at_its_real_shape_on_one_gpu(engine):
     B.close()
 
 
-def test_bench_six_gloo_ranks_on_one_gpu():
-    """The driver's launch form with as many ranks as one GPU box admits (six processes may hold the card at once; the node runs
-    eight, one per GPU): torch.distributed.run, the DEFAULT backend of the rank path (gloo — the engine's contract is no RCCL), every
-    rank its own 64 registrations of config 4, one line with n_gpus 6."""
+def test_bench_four_gloo_ranks_on_one_gpu():
+    """The driver's launch form with as many ranks as one GPU box admits beside the test process and the launcher (six processes may hold
+    the card at once; the node runs eight ranks, one per GPU): torch.distributed.run, the DEFAULT backend of the rank path (gloo — the
+    engine's contract is no RCCL), every rank its own 64 registrations of config 4, one line with n_gpus 4."""
     import json
     import socket
     import sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = {k: v for k, v in os.environ.items() if k != "ICP_BENCH_BACKEND"}
     env.update(ICP_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "6", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "6", "--steps", "2", "--warmup", "1"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 6 and d["config"]["registrations_per_gpu"] == 64 and "gloo" in d["config"]["parallelism"]
-    assert d["value"] == pytest.approx(6 * 64 * 2 * 40 / (d["ms_per_step"] * 2 * 1e-3), rel=1e-6)
-    assert len(d["per_gpu_iterations_per_s"]) == 6 and d["config4_per_gpu_value"] == pytest.approx(d["value"] / 6)
+    assert d["n_gpus"] == 4 and d["config"]["registrations_per_gpu"] == 64 and "gloo" in d["config"]["parallelism"]
+    assert d["value"] == pytest.approx(4 * 64 * 2 * 40 / (d["ms_per_step"] * 2 * 1e-3), rel=1e-6)
+    assert len(d["per_gpu_iterations_per_s"]) == 4 and d["config4_per_gpu_value"] == pytest.approx(d["value"] / 4)
 
 
 @pytest.mark.parametrize("warm", [False, True])

@@ -396,10 +396,15 @@ def test_fused_run_and_cross_mode_tolerance(engine, oracle):
         assert e["dq"] < 1e-5 and e["dt_over_t"] < 1e-5 and e["ds_over_s"] < 1e-5, e
     for key in ("dq", "dt_mm", "ds_over_s"):                             # the default mode is the closer one, in every component
         assert ef[key] <= er[key], (key, ef, er)
-    # BETWEEN the modes the same norm reads ~2.4e-5 in t: that is the one near-tie correspondence (of 16384) the two runs end up
-    # disagreeing on — the float64 solutions of the two correspondence sets are as far apart as the two fp32 results
+    # BETWEEN two free-running modes: when they find the same correspondences all the way (these two do: both with the squared power start),
+    # what separates them is arithmetic alone and the strict 1e-5 holds between them as well (measured: |dt| / |t| = 6e-7); when a
+    # near-tie correspondence flips (the literal power method against this one: 1 id of 16384, tests/test_float64_contract.py), the
+    # float64 solutions of the two correspondence sets are as far apart as the two fp32 results
     b32, b64 = R64.errors_against(T, Tr, scene), R64.errors_against(T64f, T64r, scene)
-    assert abs(b32["dt_mm"] - b64["dt_mm"]) < 0.25 * b64["dt_mm"], (b32, b64)
+    if b64["dt_over_t"] < 1e-7:
+        assert b32["dq"] < 1e-5 and b32["dt_over_t"] < 1e-5 and b32["ds_over_s"] < 1e-5, b32
+    else:
+        assert abs(b32["dt_mm"] - b64["dt_mm"]) < 0.25 * b64["dt_mm"], (b32, b64)
     # What is measured between the modes, pinned ~2x above it so that a regression shows
     assert np.abs(T[:4] - Tr[:4]).max() < 2e-6, np.abs(T[:4] - Tr[:4]).max()
     assert np.abs(T[4:7] - Tr[4:7]).max() < 2e-3, np.abs(T[4:7] - Tr[4:7]).max()          # mm

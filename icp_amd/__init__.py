@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["ICP", "ICPStep", "ICPError", "Memory", "ICPStepConfigT", "ICPStepConfigW",
-           "PowerMode", "ReduceMode", "TransformKind", "ICPBatch", "batch_partition", "power_method", "kernel_lms", "kernel_reps", "kernel_weights", "kernel_mean", "kernel_devs", "kernel_s", "ReduceScan", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
+           "PowerMode", "ReduceMode", "TransformKind", "ICPBatch", "batch_partition", "power_method", "KernelObject", "kernel_lms", "kernel_reps", "kernel_weights", "kernel_mean", "kernel_devs", "kernel_s", "ReduceScan", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("ICP_AMD_LIB", os.path.join(_HERE, "libicp_amd.so"))   # override: A/B builds of the same ABI
@@ -167,6 +167,15 @@ def lib():
     sig("icp_kernel_devs", i32, i32, vp, vp, vp, u32, vp, vp)
     sig("icp_kernel_s", i32, i32, i32, vp, vp, vp, u32, f32, vp)
     sig("icp_kernel_last_error", C.c_char_p)
+    sig("icp_ko_create", i32, C.POINTER(vp), i32, i32, u32, u32, f32)
+    sig("icp_ko_destroy", i32, vp)
+    sig("icp_ko_adopt", i32, vp, i32, vp)
+    sig("icp_ko_device_ptr", i32, vp, i32, C.POINTER(vp))
+    sig("icp_ko_slot_bytes", C.c_size_t, vp, i32)
+    sig("icp_ko_write", i32, vp, i32, vp)
+    sig("icp_ko_read", i32, vp, i32, vp)
+    sig("icp_ko_run", i32, vp)
+    sig("icp_ko_set_scaling", i32, vp, f32)
     sig("icp_reduce", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_scan", i32, i32, i32, vp, u32, u32, vp)
     sig("icp_reduce_scan_last_error", C.c_char_p)
@@ -338,6 +347,52 @@ def kernel_s(DM, DF, W=None, c=1e-6, device=0):
     out = np.empty(11, np.float32)
     _kchk(lib().icp_kernel_s(device, int(W is not None), _p(DM), _p(DF), None if Wp is None else _p(Wp), DM.shape[0], c, _p(out)))
     return out
+
+
+class KernelObject:
+    """Resident per-kernel object (icp_ko_*): the reference's ICPLMs / ICPReps / ICPWeights / ICPMean<> / ICPDevs / ICPS<> with device
+    buffers that live with the object.  kind: "lms", "reps", "weights", "mean", "mean_weighted", "devs", "s", "s_weighted"; slots (Memory
+    objects) as listed in include/icp_amd.h.  get(slot) = the device pointer; adopt(slot, ptr) before the slot's first use wires another
+    object's buffer in (no copy); run() enqueues kernels only."""
+    KINDS = {"lms": 0, "reps": 1, "weights": 2, "mean": 3, "mean_weighted": 4, "devs": 5, "s": 6, "s_weighted": 7}
+
+    def __init__(self, kind, n=0, aux=0, c=1e-6, device=0):
+        self._L = lib()
+        self._k = C.c_void_p()
+        _kchk(self._L.icp_ko_create(C.byref(self._k), device, self.KINDS[kind], n, aux, c))
+
+    def close(self):
+        if getattr(self, "_k", None):
+            self._L.icp_ko_destroy(self._k)
+            self._k = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get(self, slot):
+        p = C.c_void_p()
+        _kchk(self._L.icp_ko_device_ptr(self._k, slot, C.byref(p)))
+        return p.value
+
+    def adopt(self, slot, device_ptr):
+        _kchk(self._L.icp_ko_adopt(self._k, slot, C.c_void_p(device_ptr)))
+
+    def write(self, slot, a):
+        a = np.ascontiguousarray(a)
+        if a.nbytes != self._L.icp_ko_slot_bytes(self._k, slot):
+            raise ValueError("slot %d holds %d bytes, got %d" % (slot, self._L.icp_ko_slot_bytes(self._k, slot), a.nbytes))
+        _kchk(self._L.icp_ko_write(self._k, slot, _p(a)))
+
+    def read(self, slot, dtype=np.float32):
+        out = np.empty(self._L.icp_ko_slot_bytes(self._k, slot) // np.dtype(dtype).itemsize, dtype)
+        _kchk(self._L.icp_ko_read(self._k, slot, _p(out)))
+        return out
+
+    def run(self):
+        _kchk(self._L.icp_ko_run(self._k))
 
 
 def device_count():

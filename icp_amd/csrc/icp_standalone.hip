@@ -1,4 +1,6 @@
-// icp_standalone.hip — the reference's per-kernel wrapper classes as stand-alone operations (host in, host out, one call each):
+// icp_standalone.hip — the reference's per-kernel wrapper classes as RESIDENT objects (icp_ko_*: device buffers live with the object,
+// get (Memory) = a device pointer another object can adopt before its own buffers exist, run () = kernels only — the way ICPStep::init wires
+// the reference's objects by shared cl::Buffers, src/ICP/algorithms.cpp:4499-4581) and, on top of them, as one-call operations (host in, host out):
 // ICPLMs, ICPReps, ICPWeights, ICPMean<REGULAR | WEIGHTED>, ICPDevs, ICPS<REGULAR | WEIGHTED> (include/ICP/algorithms.hpp:397-1183,
 // src/ICP/algorithms.cpp:621-2547, kernels/icp_kernels.cl:63-743, kernels/reduce_kernels.cl:230-264).  The iteration itself runs
 // none of this — it fuses these steps into k_search / k_means / k_sij / k_finalize (icp_kernels.hip) —; the classes exist because a
@@ -100,6 +102,13 @@ __global__ void k_sa_mean_scale (const float *F, const float *M, const float *W,
     }
 }
 
+// the last level of the mean trees leaves [set][k] (six floats): -> [mean_F, 0 | mean_M, 0] (the layout ICPDevs and the power method read)
+__global__ void k_sa_pack_mean8 (const float *six, float *mean8)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < 8u) mean8[t] = (t & 3u) == 3u ? 0.f : six[(t >> 2) * 3u + (t & 3u)];
+}
+
 // ICPDevs (icpSubtractMean :588-602): float4 subtract, xyz - mean, .w = 1 - 0
 __global__ void k_sa_devs (const float4 *F, const float4 *M, const float *mean8, uint32_t n, float4 *DF, float4 *DM)
 {
@@ -158,22 +167,6 @@ __global__ void k_sa_get_reps (const float4 *F, float4 *R, icp_params p)
     R[2 * r] = F[2 * (size_t) src]; R[2 * r + 1] = F[2 * (size_t) src + 1];
 }
 
-struct dev_scope {                                   // device selection + a bag of allocations freed on the way out
-    std::vector<void *> allocs;
-    bool ok = true; std::string err;
-    ~dev_scope () { for (void *q : allocs) (void) hipFree (q); }
-    template <typename T> T *alloc (size_t count)
-    {
-        void *q = nullptr;
-        if (!ok) return nullptr;
-        hipError_t e = hipMalloc (&q, (count ? count : 1) * sizeof (T));
-        if (e != hipSuccess) { ok = false; err = std::string ("hipMalloc: ") + hipGetErrorString (e); return nullptr; }
-        allocs.push_back (q);
-        return static_cast<T *> (q);
-    }
-    void chk (hipError_t e, const char *what) { if (ok && e != hipSuccess) { ok = false; err = std::string (what) + ": " + hipGetErrorString (e); } }
-};
-
 int sa_device (int device)
 {
     int count = 0;
@@ -188,19 +181,53 @@ int sa_device (int device)
 
 uint32_t pad4 (uint32_t x) { return (x != 1u && (x % 4u)) ? x + 4u - x % 4u : x; }
 
-// row-wise reduce_sum_f of a rows x cols device array (cols % 4 == 0) until one value per row; returns the device pointer of the result
-const float *sa_reduce_rows (dev_scope &d, const float *in, uint32_t cols, uint32_t rows)
+}  // namespace
+
+// A resident kernel object: `slots` are its Memory objects on the device (inputs and outputs; a slot another object's buffer was adopted
+// for is not owned), `scratch` the intermediate levels of its trees, sized at creation; run () enqueues kernels on the device's null
+// stream — one in-order queue for all kernel objects of a device, like the reference's command queue — and nothing else.
+struct icp_ko {
+    int device = 0, kind = 0;
+    uint32_t n = 0, aux = 0; float c = 1e-6f;
+    icp_params p {};                                 // REPS: the grids
+    static constexpr int MAXS = 5;
+    void *slot[MAXS] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    size_t bytes[MAXS] = { 0, 0, 0, 0, 0 };
+    bool owned[MAXS] = { false, false, false, false, false };
+    int nslots = 0;
+    std::vector<void *> scratch;                     // owned
+    std::vector<uint32_t> level_cols;                // reduce levels (S) / group counts (mean)
+};
+
+namespace {
+
+int ko_alloc (icp_ko *k, void **out, size_t bytes, bool zero)
 {
-    const float *cur = in; uint32_t ccols = cols;
-    for (;;) {
-        const uint32_t wgp = pad4 ((ccols + 511u) / 512u);
-        float *nxt = d.alloc<float> ((size_t) rows * wgp);
-        if (!d.ok) return nullptr;
-        d.chk (hipMemset (nxt, 0, (size_t) rows * wgp * sizeof (float)), "hipMemset");
-        hipLaunchKernelGGL (k_sa_sum_level, dim3 ((wgp + 3u) / 4u, rows), dim3 (64), 0, 0, cur, ccols, wgp, nxt);
-        cur = nxt; ccols = wgp;
-        if (wgp == 1u) return cur;
+    void *q = nullptr;
+    hipError_t e = hipMalloc (&q, bytes ? bytes : 1);
+    if (e != hipSuccess) return sa_fail (ICP_ENOMEM, std::string ("hipMalloc: ") + hipGetErrorString (e));
+    if (zero && (e = hipMemset (q, 0, bytes ? bytes : 1)) != hipSuccess) { (void) hipFree (q); return sa_fail (ICP_EHIP, std::string ("hipMemset: ") + hipGetErrorString (e)); }
+    *out = q;
+    (void) k;
+    return ICP_OK;
+}
+
+// slots of every kind: (bytes, is it an input)
+int ko_layout (icp_ko *k)
+{
+    const size_t n = k->n;
+    switch (k->kind) {
+        case ICP_KO_LMS:     k->nslots = 2; k->bytes[0] = (size_t) 640 * 480 * 32; k->bytes[1] = (size_t) 16384 * 32; break;
+        case ICP_KO_REPS:    k->nslots = 2; k->bytes[0] = n * 32; k->bytes[1] = (size_t) k->aux * 32; break;
+        case ICP_KO_WEIGHTS: k->nslots = 3; k->bytes[0] = n * 8; k->bytes[1] = n * 4; k->bytes[2] = 8; break;
+        case ICP_KO_MEAN: case ICP_KO_MEAN_WEIGHTED:
+                             k->nslots = 5; k->bytes[0] = n * 32; k->bytes[1] = n * 32; k->bytes[2] = n * 4; k->bytes[3] = 8; k->bytes[4] = 32; break;
+        case ICP_KO_DEVS:    k->nslots = 5; k->bytes[0] = n * 32; k->bytes[1] = n * 32; k->bytes[2] = 32; k->bytes[3] = n * 16; k->bytes[4] = n * 16; break;
+        case ICP_KO_S: case ICP_KO_S_WEIGHTED:
+                             k->nslots = 4; k->bytes[0] = n * 16; k->bytes[1] = n * 16; k->bytes[2] = n * 4; k->bytes[3] = 44; break;
+        default: return sa_fail (ICP_EINVAL, "unknown kernel object kind");
     }
+    return ICP_OK;
 }
 
 }  // namespace
@@ -209,132 +236,248 @@ extern "C" {
 
 const char *icp_kernel_last_error (void) { return g_sa_error.c_str (); }
 
+int icp_ko_create (icp_ko_handle *out, int device, int kind, uint32_t n, uint32_t aux, float c)
+{
+    if (!out) return sa_fail (ICP_EINVAL, "null pointer");
+    *out = nullptr;
+    int rc = sa_device (device); if (rc) return rc;
+    icp_ko *k = new icp_ko ();
+    k->device = device; k->kind = kind; k->n = n; k->aux = aux; k->c = c;
+    auto bail = [&] (int code) { (void) icp_ko_destroy (k); return code; };
+    switch (kind) {
+        case ICP_KO_LMS: k->n = 640u * 480u; break;
+        case ICP_KO_REPS: {
+            // the representative grid — src/ICP/algorithms.cpp:842-854 generalised to a sqrt (m) x sqrt (m) landmark grid
+            const uint32_t m = n, nr = aux;
+            if (m == 0 || nr == 0 || nr > m || (nr & (nr - 1))) return bail (sa_fail (ICP_EINVAL, "nr must be a power of two, at most m"));
+            const uint32_t side = (uint32_t) std::floor (std::sqrt ((double) m) + 0.5);
+            if ((uint64_t) side * side != m) return bail (sa_fail (ICP_EINVAL, "m must be a square number (the landmark grid)"));
+            uint32_t pw = 0; while ((1u << (pw + 1)) <= nr) ++pw;
+            k->p.m = m; k->p.nr = nr; k->p.side = side; k->p.nrx = 1u << (pw - pw / 2); k->p.nry = 1u << (pw / 2);
+            if (side % k->p.nrx || side % k->p.nry) return bail (sa_fail (ICP_EINVAL, "the representative grid must tile the landmark grid"));
+            break;
+        }
+        case ICP_KO_WEIGHTS: case ICP_KO_MEAN: case ICP_KO_MEAN_WEIGHTED:
+            if (n == 0 || (n % 2)) return bail (sa_fail (ICP_EINVAL, "The number of points in the array must be a (positive) multiple of 2"));      // src/ICP/algorithms.cpp:1050, :1306, :1573
+            break;
+        case ICP_KO_DEVS: case ICP_KO_S: case ICP_KO_S_WEIGHTED:
+            if (n == 0) return bail (sa_fail (ICP_EINVAL, "The array cannot have zero points"));
+            break;
+        default: return bail (sa_fail (ICP_EINVAL, "unknown kernel object kind"));
+    }
+    if ((rc = ko_layout (k))) return bail (rc);
+    // scratch: the levels of the trees
+    auto scratch = [&] (size_t bytes) -> int { void *q = nullptr; int r = ko_alloc (k, &q, bytes, true); if (!r) k->scratch.push_back (q); return r; };
+    if (kind == ICP_KO_WEIGHTS) {
+        const uint32_t wgp = pad4 ((n + 127u) / 128u), npad = wgp * 128u;
+        if ((rc = scratch ((size_t) npad * 4)) || (rc = scratch ((size_t) wgp * 4))) return bail (rc);
+    } else if (kind == ICP_KO_MEAN || kind == ICP_KO_MEAN_WEIGHTED) {
+        const uint32_t npad = ((n + 127u) / 128u) * 128u;
+        if ((rc = scratch ((size_t) 6 * npad * 4))) return bail (rc);
+        for (uint32_t cnt = npad;;) {               // block means (one per 128 pairs), then icpGMean (:530-566) until one vector per set remains
+            const uint32_t ng = (cnt + 127u) / 128u;
+            if ((rc = scratch ((size_t) 6 * ng * 4))) return bail (rc);
+            k->level_cols.push_back (ng);
+            cnt = ng;
+            if (ng == 1u) break;
+        }
+    } else if (kind == ICP_KO_S || kind == ICP_KO_S_WEIGHTED) {
+        uint32_t n4 = n; if (n4 % 4u) n4 += 4u - n4 % 4u;
+        const uint32_t G = n4 / 4u, Gp = (G + 3u) & ~3u;                    // src/ICP/algorithms.cpp:2344-2346; columns padded to float4
+        if ((rc = scratch ((size_t) 11 * Gp * 4))) return bail (rc);
+        for (uint32_t cols = Gp;;) {                // reduce_sum_f until one value per row
+            const uint32_t wgp = pad4 ((cols + 511u) / 512u);
+            if ((rc = scratch ((size_t) 11 * wgp * 4))) return bail (rc);
+            k->level_cols.push_back (wgp);
+            cols = wgp;
+            if (wgp == 1u) break;
+        }
+    }
+    *out = k;
+    return ICP_OK;
+}
+
+int icp_ko_destroy (icp_ko_handle k)
+{
+    if (!k) return ICP_EINVAL;
+    (void) hipSetDevice (k->device);
+    (void) hipDeviceSynchronize ();
+    for (int s = 0; s < icp_ko::MAXS; ++s) if (k->owned[s] && k->slot[s]) (void) hipFree (k->slot[s]);
+    for (void *q : k->scratch) (void) hipFree (q);
+    delete k;
+    return ICP_OK;
+}
+
+// A slot's buffer comes into being at its first use (write, device_ptr, run): until then another object's device pointer can take its
+// place (icp_ko_adopt — the reference: `get (Memory)` assigned before `init`, include/ICP/algorithms.hpp:2214-2220).
+static int ko_ensure (icp_ko *k, int s)
+{
+    if (k->slot[s]) return ICP_OK;
+    int rc = ko_alloc (k, &k->slot[s], k->bytes[s], true);
+    if (!rc) k->owned[s] = true;
+    return rc;
+}
+
+int icp_ko_adopt (icp_ko_handle k, int s, void *dptr)
+{
+    if (!k || !dptr || s < 0 || s >= k->nslots) return sa_fail (ICP_EINVAL, "icp_ko_adopt: bad arguments");
+    if (hipSetDevice (k->device) != hipSuccess) return sa_fail (ICP_EHIP, "hipSetDevice failed");
+    if (k->owned[s] && k->slot[s]) { (void) hipDeviceSynchronize (); (void) hipFree (k->slot[s]); }
+    k->slot[s] = dptr; k->owned[s] = false;
+    return ICP_OK;
+}
+
+int icp_ko_device_ptr (icp_ko_handle k, int s, void **dptr)
+{
+    if (!k || !dptr || s < 0 || s >= k->nslots) return sa_fail (ICP_EINVAL, "icp_ko_device_ptr: bad arguments");
+    if (hipSetDevice (k->device) != hipSuccess) return sa_fail (ICP_EHIP, "hipSetDevice failed");
+    int rc = ko_ensure (k, s); if (rc) return rc;
+    *dptr = k->slot[s];
+    return ICP_OK;
+}
+
+size_t icp_ko_slot_bytes (icp_ko_handle k, int s) { return (k && s >= 0 && s < k->nslots) ? k->bytes[s] : 0; }
+
+int icp_ko_write (icp_ko_handle k, int s, const void *host)
+{
+    if (!k || !host || s < 0 || s >= k->nslots) return sa_fail (ICP_EINVAL, "icp_ko_write: bad arguments");
+    if (hipSetDevice (k->device) != hipSuccess) return sa_fail (ICP_EHIP, "hipSetDevice failed");
+    int rc = ko_ensure (k, s); if (rc) return rc;
+    hipError_t e = hipMemcpy (k->slot[s], host, k->bytes[s], hipMemcpyHostToDevice);
+    return e == hipSuccess ? ICP_OK : sa_fail (ICP_EHIP, std::string ("hipMemcpy: ") + hipGetErrorString (e));
+}
+
+int icp_ko_read (icp_ko_handle k, int s, void *host)
+{
+    if (!k || !host || s < 0 || s >= k->nslots) return sa_fail (ICP_EINVAL, "icp_ko_read: bad arguments");
+    if (hipSetDevice (k->device) != hipSuccess) return sa_fail (ICP_EHIP, "hipSetDevice failed");
+    int rc = ko_ensure (k, s); if (rc) return rc;
+    hipError_t e = hipMemcpy (host, k->slot[s], k->bytes[s], hipMemcpyDeviceToHost);       // (blocking: behind the kernels on the null stream)
+    return e == hipSuccess ? ICP_OK : sa_fail (ICP_EHIP, std::string ("hipMemcpy: ") + hipGetErrorString (e));
+}
+
+int icp_ko_set_scaling (icp_ko_handle k, float c) { if (!k) return ICP_EINVAL; k->c = c; return ICP_OK; }
+
+int icp_ko_run (icp_ko_handle k)
+{
+    if (!k) return sa_fail (ICP_EINVAL, "null handle");
+    if (hipSetDevice (k->device) != hipSuccess) return sa_fail (ICP_EHIP, "hipSetDevice failed");
+    for (int s = 0; s < k->nslots; ++s) { int rc = ko_ensure (k, s); if (rc) return rc; }
+    const uint32_t n = k->n;
+    switch (k->kind) {
+        case ICP_KO_LMS:
+            hipLaunchKernelGGL (k_sa_get_lms, dim3 (128), dim3 (256), 0, 0, (const float4 *) k->slot[0], (float4 *) k->slot[1]);
+            break;
+        case ICP_KO_REPS:
+            hipLaunchKernelGGL (k_sa_get_reps, dim3 ((k->aux + 255u) / 256u), dim3 (256), 0, 0, (const float4 *) k->slot[0], (float4 *) k->slot[1], k->p);
+            break;
+        case ICP_KO_WEIGHTS: {
+            const uint32_t wgp = pad4 ((n + 127u) / 128u), npad = wgp * 128u;
+            float *plane = (float *) k->scratch[0], *part = (float *) k->scratch[1];
+            hipLaunchKernelGGL (k_sa_weights, dim3 ((npad + 255u) / 256u), dim3 (256), 0, 0, (const icp_dist_id *) k->slot[0], n, npad, (float *) k->slot[1], plane);
+            hipLaunchKernelGGL (k_sa_tree128, dim3 ((wgp + 3u) / 4u, 1), dim3 (64), 0, 0, plane, npad, npad, wgp, wgp, part);
+            hipLaunchKernelGGL (k_sa_sum_fd, dim3 (1), dim3 (64), 0, 0, part, wgp, (double *) k->slot[2]);
+            break;
+        }
+        case ICP_KO_MEAN: case ICP_KO_MEAN_WEIGHTED: {
+            const uint32_t npad = ((n + 127u) / 128u) * 128u;
+            float *planes = (float *) k->scratch[0];
+            hipLaunchKernelGGL (k_sa_mean_scale, dim3 ((npad + 255u) / 256u), dim3 (256), 0, 0, (const float *) k->slot[0], (const float *) k->slot[1],
+                                (const float *) k->slot[2], (const double *) k->slot[3], n, npad, k->kind == ICP_KO_MEAN_WEIGHTED ? 1 : 0, planes);
+            const float *cur = planes; uint32_t cnt = npad, stride = npad;
+            for (size_t l = 0; l < k->level_cols.size (); ++l) {
+                const uint32_t ng = k->level_cols[l];
+                float *nxt = (float *) k->scratch[1 + l];
+                hipLaunchKernelGGL (k_sa_tree128, dim3 ((ng + 3u) / 4u, 6), dim3 (64), 0, 0, cur, cnt, stride, ng, ng, nxt);
+                cur = nxt; cnt = ng; stride = ng;
+            }
+            hipLaunchKernelGGL (k_sa_pack_mean8, dim3 (1), dim3 (64), 0, 0, cur, (float *) k->slot[4]);
+            break;
+        }
+        case ICP_KO_DEVS:
+            hipLaunchKernelGGL (k_sa_devs, dim3 ((n + 255u) / 256u), dim3 (256), 0, 0, (const float4 *) k->slot[0], (const float4 *) k->slot[1],
+                                (const float *) k->slot[2], n, (float4 *) k->slot[3], (float4 *) k->slot[4]);
+            break;
+        case ICP_KO_S: case ICP_KO_S_WEIGHTED: {
+            uint32_t n4 = n; if (n4 % 4u) n4 += 4u - n4 % 4u;
+            const uint32_t G = n4 / 4u, Gp = (G + 3u) & ~3u;
+            float *Sij = (float *) k->scratch[0];
+            hipLaunchKernelGGL (k_sa_sij, dim3 ((G + 255u) / 256u), dim3 (256), 0, 0, (const float4 *) k->slot[0], (const float4 *) k->slot[1],
+                                (const float *) k->slot[2], n, G, Gp, k->c, k->kind == ICP_KO_S_WEIGHTED ? 1 : 0, Sij);
+            const float *cur = Sij; uint32_t cols = Gp;
+            for (size_t l = 0; l < k->level_cols.size (); ++l) {
+                const uint32_t wgp = k->level_cols[l];
+                float *nxt = (float *) k->scratch[1 + l];
+                hipLaunchKernelGGL (k_sa_sum_level, dim3 ((wgp + 3u) / 4u, 11), dim3 (64), 0, 0, cur, cols, wgp, nxt);
+                cur = nxt; cols = wgp;
+            }
+            (void) hipMemcpyAsync (k->slot[3], cur, 44, hipMemcpyDeviceToDevice, 0);
+            break;
+        }
+        default: return sa_fail (ICP_EINVAL, "unknown kernel object kind");
+    }
+    hipError_t e = hipGetLastError ();
+    return e == hipSuccess ? ICP_OK : sa_fail (ICP_EHIP, std::string ("icp_ko_run: ") + hipGetErrorString (e));
+}
+
+// ---- the one-call forms: create, upload, run, download, destroy ----------------------------------------------------------------------
+
+namespace {
+struct ko_guard { icp_ko_handle k = nullptr; ~ko_guard () { if (k) (void) icp_ko_destroy (k); } };
+}
+
 int icp_kernel_lms (int device, const void *cloud, void *lms)
 {
     if (!cloud || !lms) return sa_fail (ICP_EINVAL, "null pointer");
-    int rc = sa_device (device); if (rc) return rc;
-    dev_scope d;
-    float4 *dc = d.alloc<float4> ((size_t) 640 * 480 * 2), *dl = d.alloc<float4> (16384 * 2);
-    if (d.ok) d.chk (hipMemcpy (dc, cloud, (size_t) 640 * 480 * 32, hipMemcpyHostToDevice), "hipMemcpy");
-    if (d.ok) { hipLaunchKernelGGL (k_sa_get_lms, dim3 (128), dim3 (256), 0, 0, dc, dl); d.chk (hipGetLastError (), "k_sa_get_lms"); }
-    if (d.ok) d.chk (hipMemcpy (lms, dl, (size_t) 16384 * 32, hipMemcpyDeviceToHost), "hipMemcpy");
-    return d.ok ? ICP_OK : sa_fail (ICP_EHIP, d.err);
+    ko_guard g; int rc;
+    if ((rc = icp_ko_create (&g.k, device, ICP_KO_LMS, 0, 0, 0.f)) || (rc = icp_ko_write (g.k, 0, cloud)) || (rc = icp_ko_run (g.k))) return rc;
+    return icp_ko_read (g.k, 1, lms);
 }
 
 int icp_kernel_reps (int device, const void *F, uint32_t m, uint32_t nr, void *R)
 {
     if (!F || !R) return sa_fail (ICP_EINVAL, "null pointer");
-    // the representative grid — src/ICP/algorithms.cpp:842-854 generalised to a sqrt (m) x sqrt (m) landmark grid
-    if (m == 0 || nr == 0 || nr > m || (nr & (nr - 1))) return sa_fail (ICP_EINVAL, "nr must be a power of two, at most m");
-    const uint32_t side = (uint32_t) std::floor (std::sqrt ((double) m) + 0.5);
-    if ((uint64_t) side * side != m) return sa_fail (ICP_EINVAL, "m must be a square number (the landmark grid)");
-    uint32_t pw = 0; while ((1u << (pw + 1)) <= nr) ++pw;
-    icp_params p {};
-    p.m = m; p.nr = nr; p.side = side; p.nrx = 1u << (pw - pw / 2); p.nry = 1u << (pw / 2);
-    if (side % p.nrx || side % p.nry) return sa_fail (ICP_EINVAL, "the representative grid must tile the landmark grid");
-    int rc = sa_device (device); if (rc) return rc;
-    dev_scope d;
-    float4 *dF = d.alloc<float4> ((size_t) m * 2), *dR = d.alloc<float4> ((size_t) nr * 2);
-    if (d.ok) d.chk (hipMemcpy (dF, F, (size_t) m * 32, hipMemcpyHostToDevice), "hipMemcpy");
-    if (d.ok) { hipLaunchKernelGGL (k_sa_get_reps, dim3 ((nr + 255u) / 256u), dim3 (256), 0, 0, dF, dR, p); d.chk (hipGetLastError (), "k_sa_get_reps"); }
-    if (d.ok) d.chk (hipMemcpy (R, dR, (size_t) nr * 32, hipMemcpyDeviceToHost), "hipMemcpy");
-    return d.ok ? ICP_OK : sa_fail (ICP_EHIP, d.err);
+    ko_guard g; int rc;
+    if ((rc = icp_ko_create (&g.k, device, ICP_KO_REPS, m, nr, 0.f)) || (rc = icp_ko_write (g.k, 0, F)) || (rc = icp_ko_run (g.k))) return rc;
+    return icp_ko_read (g.k, 1, R);
 }
 
 int icp_kernel_weights (int device, const void *nn_id, uint32_t n, float *W, double *sum_w)
 {
     if (!nn_id || !W || !sum_w) return sa_fail (ICP_EINVAL, "null pointer");
-    if (n == 0 || (n % 2)) return sa_fail (ICP_EINVAL, "The number of points in the array must be a (positive) multiple of 2");      // src/ICP/algorithms.cpp:1050
-    int rc = sa_device (device); if (rc) return rc;
-    const uint32_t wg = (n + 127u) / 128u, wgp = pad4 (wg), npad = wgp * 128u;
-    dev_scope d;
-    icp_dist_id *dD = d.alloc<icp_dist_id> (n); float *dW = d.alloc<float> (n), *plane = d.alloc<float> (npad), *part = d.alloc<float> (wgp);
-    double *dsw = d.alloc<double> (1);
-    if (d.ok) d.chk (hipMemcpy (dD, nn_id, (size_t) n * 8, hipMemcpyHostToDevice), "hipMemcpy");
-    if (d.ok) {
-        hipLaunchKernelGGL (k_sa_weights, dim3 ((npad + 255u) / 256u), dim3 (256), 0, 0, dD, n, npad, dW, plane);
-        hipLaunchKernelGGL (k_sa_tree128, dim3 ((wgp + 3u) / 4u, 1), dim3 (64), 0, 0, plane, npad, npad, wgp, wgp, part);
-        hipLaunchKernelGGL (k_sa_sum_fd, dim3 (1), dim3 (64), 0, 0, part, wgp, dsw);
-        d.chk (hipGetLastError (), "weights kernels");
-    }
-    if (d.ok) d.chk (hipMemcpy (W, dW, (size_t) n * 4, hipMemcpyDeviceToHost), "hipMemcpy");
-    if (d.ok) d.chk (hipMemcpy (sum_w, dsw, 8, hipMemcpyDeviceToHost), "hipMemcpy");
-    return d.ok ? ICP_OK : sa_fail (ICP_EHIP, d.err);
+    ko_guard g; int rc;
+    if ((rc = icp_ko_create (&g.k, device, ICP_KO_WEIGHTS, n, 0, 0.f)) || (rc = icp_ko_write (g.k, 0, nn_id)) || (rc = icp_ko_run (g.k))) return rc;
+    if ((rc = icp_ko_read (g.k, 1, W))) return rc;
+    return icp_ko_read (g.k, 2, sum_w);
 }
 
 int icp_kernel_mean (int device, int weighted, const void *F, const void *M, const float *W, double sum_w, uint32_t n, float *mean8)
 {
     if (!F || !M || !mean8 || (weighted && !W)) return sa_fail (ICP_EINVAL, "null pointer");
-    if (n == 0 || (n % 2)) return sa_fail (ICP_EINVAL, "The number of points in the array must be a (positive) multiple of 2");      // :1306, :1573
-    int rc = sa_device (device); if (rc) return rc;
-    const uint32_t wg = (n + 127u) / 128u, npad = wg * 128u;
-    dev_scope d;
-    float *dF = d.alloc<float> ((size_t) n * 8), *dM = d.alloc<float> ((size_t) n * 8), *dW = d.alloc<float> (n), *planes = d.alloc<float> ((size_t) 6 * npad);
-    double *dsw = d.alloc<double> (1);
-    if (d.ok) d.chk (hipMemcpy (dF, F, (size_t) n * 32, hipMemcpyHostToDevice), "hipMemcpy");
-    if (d.ok) d.chk (hipMemcpy (dM, M, (size_t) n * 32, hipMemcpyHostToDevice), "hipMemcpy");
-    if (d.ok && weighted) d.chk (hipMemcpy (dW, W, (size_t) n * 4, hipMemcpyHostToDevice), "hipMemcpy");
-    if (d.ok) d.chk (hipMemcpy (dsw, &sum_w, 8, hipMemcpyHostToDevice), "hipMemcpy");
-    const float *cur = planes; uint32_t cnt = npad, stride = npad;
-    if (d.ok) {
-        hipLaunchKernelGGL (k_sa_mean_scale, dim3 ((npad + 255u) / 256u), dim3 (256), 0, 0, dF, dM, dW, dsw, n, npad, weighted, planes);
-        // block means (one per 128 pairs), then icpGMean (:530-566) until one vector per set remains
-        for (;;) {
-            const uint32_t ng = (cnt + 127u) / 128u;
-            float *nxt = d.alloc<float> ((size_t) 6 * ng);
-            if (!d.ok) break;
-            hipLaunchKernelGGL (k_sa_tree128, dim3 ((ng + 3u) / 4u, 6), dim3 (64), 0, 0, cur, cnt, stride, ng, ng, nxt);
-            cur = nxt; cnt = ng; stride = ng;
-            if (ng == 1u) break;
-        }
-        d.chk (hipGetLastError (), "mean kernels");
-    }
-    float six[6];
-    if (d.ok) d.chk (hipMemcpy (six, cur, sizeof six, hipMemcpyDeviceToHost), "hipMemcpy");
-    if (!d.ok) return sa_fail (ICP_EHIP, d.err);
-    for (int s = 0; s < 2; ++s) { mean8[4 * s] = six[3 * s]; mean8[4 * s + 1] = six[3 * s + 1]; mean8[4 * s + 2] = six[3 * s + 2]; mean8[4 * s + 3] = 0.f; }
-    return ICP_OK;
+    ko_guard g; int rc;
+    if ((rc = icp_ko_create (&g.k, device, weighted ? ICP_KO_MEAN_WEIGHTED : ICP_KO_MEAN, n, 0, 0.f))) return rc;
+    if ((rc = icp_ko_write (g.k, 0, F)) || (rc = icp_ko_write (g.k, 1, M)) || (weighted && (rc = icp_ko_write (g.k, 2, W))) || (rc = icp_ko_write (g.k, 3, &sum_w))) return rc;
+    if ((rc = icp_ko_run (g.k))) return rc;
+    return icp_ko_read (g.k, 4, mean8);
 }
 
 int icp_kernel_devs (int device, const void *F, const void *M, const float *mean8, uint32_t n, float *DF, float *DM)
 {
     if (!F || !M || !mean8 || !DF || !DM) return sa_fail (ICP_EINVAL, "null pointer");
-    if (n == 0) return sa_fail (ICP_EINVAL, "The array cannot have zero points");
-    int rc = sa_device (device); if (rc) return rc;
-    dev_scope d;
-    float4 *dF = d.alloc<float4> ((size_t) n * 2), *dM = d.alloc<float4> ((size_t) n * 2), *dDF = d.alloc<float4> (n), *dDM = d.alloc<float4> (n);
-    float *dmean = d.alloc<float> (8);
-    if (d.ok) d.chk (hipMemcpy (dF, F, (size_t) n * 32, hipMemcpyHostToDevice), "hipMemcpy");
-    if (d.ok) d.chk (hipMemcpy (dM, M, (size_t) n * 32, hipMemcpyHostToDevice), "hipMemcpy");
-    if (d.ok) d.chk (hipMemcpy (dmean, mean8, 32, hipMemcpyHostToDevice), "hipMemcpy");
-    if (d.ok) { hipLaunchKernelGGL (k_sa_devs, dim3 ((n + 255u) / 256u), dim3 (256), 0, 0, dF, dM, dmean, n, dDF, dDM); d.chk (hipGetLastError (), "k_sa_devs"); }
-    if (d.ok) d.chk (hipMemcpy (DF, dDF, (size_t) n * 16, hipMemcpyDeviceToHost), "hipMemcpy");
-    if (d.ok) d.chk (hipMemcpy (DM, dDM, (size_t) n * 16, hipMemcpyDeviceToHost), "hipMemcpy");
-    return d.ok ? ICP_OK : sa_fail (ICP_EHIP, d.err);
+    ko_guard g; int rc;
+    if ((rc = icp_ko_create (&g.k, device, ICP_KO_DEVS, n, 0, 0.f))) return rc;
+    if ((rc = icp_ko_write (g.k, 0, F)) || (rc = icp_ko_write (g.k, 1, M)) || (rc = icp_ko_write (g.k, 2, mean8)) || (rc = icp_ko_run (g.k))) return rc;
+    if ((rc = icp_ko_read (g.k, 3, DF))) return rc;
+    return icp_ko_read (g.k, 4, DM);
 }
 
 int icp_kernel_s (int device, int weighted, const float *DM, const float *DF, const float *W, uint32_t m, float c, float *S11)
 {
     if (!DM || !DF || !S11 || (weighted && !W)) return sa_fail (ICP_EINVAL, "null pointer");
-    if (m == 0) return sa_fail (ICP_EINVAL, "The array cannot have zero points");
-    int rc = sa_device (device); if (rc) return rc;
-    uint32_t n4 = m; if (n4 % 4u) n4 += 4u - n4 % 4u;
-    const uint32_t G = n4 / 4u, Gp = (G + 3u) & ~3u;                        // src/ICP/algorithms.cpp:2344-2346; columns padded to float4
-    dev_scope d;
-    float4 *dDM = d.alloc<float4> (m), *dDF = d.alloc<float4> (m); float *dW = d.alloc<float> (m), *Sij = d.alloc<float> ((size_t) 11 * Gp);
-    if (d.ok) d.chk (hipMemcpy (dDM, DM, (size_t) m * 16, hipMemcpyHostToDevice), "hipMemcpy");
-    if (d.ok) d.chk (hipMemcpy (dDF, DF, (size_t) m * 16, hipMemcpyHostToDevice), "hipMemcpy");
-    if (d.ok && weighted) d.chk (hipMemcpy (dW, W, (size_t) m * 4, hipMemcpyHostToDevice), "hipMemcpy");
-    if (d.ok) d.chk (hipMemset (Sij, 0, (size_t) 11 * Gp * sizeof (float)), "hipMemset");
-    const float *res = nullptr;
-    if (d.ok) {
-        hipLaunchKernelGGL (k_sa_sij, dim3 ((G + 255u) / 256u), dim3 (256), 0, 0, dDM, dDF, dW, m, G, Gp, c, weighted, Sij);
-        d.chk (hipGetLastError (), "k_sa_sij");
-    }
-    if (d.ok) res = sa_reduce_rows (d, Sij, Gp, 11);
-    if (d.ok) d.chk (hipGetLastError (), "reduce_sum_f");
-    if (d.ok) d.chk (hipMemcpy (S11, res, 44, hipMemcpyDeviceToHost), "hipMemcpy");
-    return d.ok ? ICP_OK : sa_fail (ICP_EHIP, d.err);
+    ko_guard g; int rc;
+    if ((rc = icp_ko_create (&g.k, device, weighted ? ICP_KO_S_WEIGHTED : ICP_KO_S, m, 0, c))) return rc;
+    if ((rc = icp_ko_write (g.k, 0, DM)) || (rc = icp_ko_write (g.k, 1, DF)) || (weighted && (rc = icp_ko_write (g.k, 2, W))) || (rc = icp_ko_run (g.k))) return rc;
+    return icp_ko_read (g.k, 3, S11);
 }
 
 }  // extern "C"

@@ -246,26 +246,54 @@ namespace ICP
     enum class ICPMeanConfig : uint8_t { REGULAR, WEIGHTED };
     enum class ICPSConfig : uint8_t { REGULAR, WEIGHTED };
 
-    /*! \brief Base of the per-kernel classes below: the device, the error path (the reference prints and calls `exit ()`). */
+    /*! \brief Base of the per-kernel classes below — each one a RESIDENT object (include/icp_amd.h: icp_ko_*), wired like the reference's:
+     *  `get (Memory)` is a reference to a device pointer; assigned BEFORE `init` (e.g. `mean.get (D_IN_W) = weights.get (D_OUT_W)`) the
+     *  object uses that buffer instead of creating its own (reference note include/ICP/algorithms.hpp:2214-2220; wiring
+     *  src/ICP/algorithms.cpp:4499-4581), after `init` it is the object's own buffer.  `write` uploads a staging buffer, `run` enqueues
+     *  kernels only, `read` downloads.  Errors throw (the reference prints and calls `exit ()`). */
     class KernelClass
     {
+    public:
+        KernelClass (const KernelClass&) = delete;
+        KernelClass& operator= (const KernelClass&) = delete;
+        ~KernelClass () { if (ko) icp_ko_destroy (ko); }
     protected:
-        explicit KernelClass (icp::Env _env) : env (_env) {}
+        explicit KernelClass (icp::Env _env) : env (_env), ko (nullptr) { for (auto &q : dptr) q = nullptr; }
         void chk (int rc, const char *who) { if (rc != ICP_OK) throw std::runtime_error (std::string (who) + ": " + icp_kernel_last_error ()); }
+        /*! creates the device object; slots whose pointer was assigned through get () before are adopted, the others become the object's own */
+        void create (int kind, uint32_t n, uint32_t aux, float c, int nslots, const char *who)
+        {
+            void *preset[5];
+            for (int s = 0; s < 5; ++s) preset[s] = ko ? nullptr : dptr[s];
+            if (ko) { icp_ko_destroy (ko); ko = nullptr; }
+            chk (icp_ko_create (&ko, env.device, kind, n, aux, c), who);
+            for (int s = 0; s < nslots; ++s) {
+                if (preset[s]) chk (icp_ko_adopt (ko, s, preset[s]), who);
+                chk (icp_ko_device_ptr (ko, s, &dptr[s]), who);
+            }
+        }
+        void upload (int slot, const void *host, const char *who) { chk (icp_ko_write (ko, slot, host), who); }
+        void download (int slot, void *host, const char *who) { chk (icp_ko_read (ko, slot, host), who); }
+        void launch (const char *who) { if (!ko) throw std::runtime_error (std::string (who) + ": init has not been called"); chk (icp_ko_run (ko), who); }
         icp::Env env;
+        icp_ko_handle ko;
+        void *dptr[5];
     };
 
     /*! \brief Landmark extraction — mirrors `ICPLMs` (reference include/ICP/algorithms.hpp:312-383, kernel `getLMs`
-     *         kernels/icp_kernels.cl:63-76): 640 x 480 points in, 128 x 128 landmarks out; `init / write / run / read`, `hPtrIn`, `hPtrOut`. */
+     *         kernels/icp_kernels.cl:63-76): 640 x 480 points in, 128 x 128 landmarks out; `get / init / write / run / read`, `hPtrIn`, `hPtrOut`. */
     class ICPLMs : public KernelClass
     {
     public:
         enum class Memory : uint8_t { H_IN, H_OUT, D_IN, D_OUT };
         explicit ICPLMs (icp::Env _env) : KernelClass (_env), hPtrIn (nullptr), hPtrOut (nullptr) {}
-        void init (Staging = Staging::IO) { in.assign ((size_t) 640 * 480 * 8, 0.f); out.assign ((size_t) 16384 * 8, 0.f); hPtrIn = in.data (); hPtrOut = out.data (); }
-        void write (Memory = Memory::D_IN, void *ptr = nullptr, bool = false) { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (float)); }
-        void* read (Memory = Memory::H_OUT, bool = true) { return out.data (); }
-        void run () { chk (icp_kernel_lms (env.device, in.data (), out.data ()), "ICPLMs"); }
+        void*& get (Memory mem) { return dptr[mem == Memory::D_OUT || mem == Memory::H_OUT ? 1 : 0]; }
+        void init (Staging = Staging::IO)
+        { in.assign ((size_t) 640 * 480 * 8, 0.f); out.assign ((size_t) 16384 * 8, 0.f); hPtrIn = in.data (); hPtrOut = out.data (); create (ICP_KO_LMS, 0, 0, 0.f, 2, "ICPLMs"); }
+        /*! uploads the staging buffer (after copying `ptr` into it, if given) — reference `write (D_IN, ptr, block)` */
+        void write (Memory = Memory::D_IN, void *ptr = nullptr, bool = false) { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (float)); upload (0, in.data (), "ICPLMs"); }
+        void* read (Memory = Memory::H_OUT, bool = true) { download (1, out.data (), "ICPLMs"); return out.data (); }
+        void run () { launch ("ICPLMs"); }
         float *hPtrIn, *hPtrOut;
     private:
         std::vector<float> in, out;
@@ -278,11 +306,13 @@ namespace ICP
     public:
         enum class Memory : uint8_t { H_IN, H_OUT, D_IN, D_OUT };
         explicit ICPReps (icp::Env _env) : KernelClass (_env), hPtrIn (nullptr), hPtrOut (nullptr), m (16384), nr (0) {}
+        void*& get (Memory mem) { return dptr[mem == Memory::D_OUT || mem == Memory::H_OUT ? 1 : 0]; }
         void init (unsigned int _nr, Staging = Staging::IO) { init (_nr, 16384u); }
-        void init (unsigned int _nr, unsigned int _m) { m = _m; nr = _nr; in.assign ((size_t) m * 8, 0.f); out.assign ((size_t) nr * 8, 0.f); hPtrIn = in.data (); hPtrOut = out.data (); }
-        void write (Memory = Memory::D_IN, void *ptr = nullptr, bool = false) { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (float)); }
-        void* read (Memory = Memory::H_OUT, bool = true) { return out.data (); }
-        void run () { chk (icp_kernel_reps (env.device, in.data (), m, nr, out.data ()), "ICPReps"); }
+        void init (unsigned int _nr, unsigned int _m)
+        { m = _m; nr = _nr; in.assign ((size_t) m * 8, 0.f); out.assign ((size_t) nr * 8, 0.f); hPtrIn = in.data (); hPtrOut = out.data (); create (ICP_KO_REPS, m, nr, 0.f, 2, "ICPReps"); }
+        void write (Memory = Memory::D_IN, void *ptr = nullptr, bool = false) { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (float)); upload (0, in.data (), "ICPReps"); }
+        void* read (Memory = Memory::H_OUT, bool = true) { download (1, out.data (), "ICPReps"); return out.data (); }
+        void run () { launch ("ICPReps"); }
         float *hPtrIn, *hPtrOut;
     private:
         unsigned int m, nr;
@@ -297,10 +327,13 @@ namespace ICP
         enum class Memory : uint8_t { H_IN, H_OUT_W, H_OUT_SUM_W, D_IN, D_OUT_W, D_GW, D_OUT_SUM_W };
         struct dist_id { float dist; uint32_t id; };                  /*!< `rbc_dist_id` (kernels/icp_kernels.cl:34-38) */
         explicit ICPWeights (icp::Env _env) : KernelClass (_env), hPtrIn (nullptr), hPtrOutW (nullptr), hPtrOutSW (&sw), n (0), sw (0.0) {}
-        void init (unsigned int _n, Staging = Staging::IO) { n = _n; in.assign (n, dist_id { 0.f, 0u }); W.assign (n, 0.f); hPtrIn = in.data (); hPtrOutW = W.data (); }
-        void write (Memory = Memory::D_IN, void *ptr = nullptr, bool = false) { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (dist_id)); }
-        void* read (Memory mem = Memory::H_OUT_SUM_W, bool = true) { return mem == Memory::H_OUT_W ? (void *) W.data () : (void *) &sw; }
-        void run () { chk (icp_kernel_weights (env.device, in.data (), n, W.data (), &sw), "ICPWeights"); }
+        void*& get (Memory mem) { return dptr[(mem == Memory::D_OUT_W || mem == Memory::H_OUT_W) ? 1 : (mem == Memory::D_OUT_SUM_W || mem == Memory::H_OUT_SUM_W) ? 2 : 0]; }
+        void init (unsigned int _n, Staging = Staging::IO)
+        { n = _n; in.assign (n, dist_id { 0.f, 0u }); W.assign (n, 0.f); hPtrIn = in.data (); hPtrOutW = W.data (); create (ICP_KO_WEIGHTS, n, 0, 0.f, 3, "ICPWeights"); }
+        void write (Memory = Memory::D_IN, void *ptr = nullptr, bool = false) { if (ptr) std::memcpy (in.data (), ptr, in.size () * sizeof (dist_id)); upload (0, in.data (), "ICPWeights"); }
+        void* read (Memory mem = Memory::H_OUT_SUM_W, bool = true)
+        { if (mem == Memory::H_OUT_W) { download (1, W.data (), "ICPWeights"); return W.data (); } download (2, &sw, "ICPWeights"); return &sw; }
+        void run () { launch ("ICPWeights"); }
         dist_id *hPtrIn; float *hPtrOutW; double *hPtrOutSW;
     private:
         unsigned int n; double sw;
@@ -315,17 +348,33 @@ namespace ICP
     public:
         enum class Memory : uint8_t { H_IN_F, H_IN_M, H_IN_W, H_IN_SUM_W, H_OUT, D_IN_F, D_IN_M, D_IN_W, D_IN_SUM_W, D_GM, D_OUT };
         explicit ICPMean (icp::Env _env) : KernelClass (_env), hPtrInF (nullptr), hPtrInM (nullptr), hPtrInW (nullptr), hPtrInSW (&sw), hPtrOut (mean), n (0), sw (1.0) { std::memset (mean, 0, sizeof mean); }
-        void init (unsigned int _n, Staging = Staging::IO) { n = _n; F.assign ((size_t) n * 8, 0.f); M.assign ((size_t) n * 8, 0.f); W.assign (n, 0.f); hPtrInF = F.data (); hPtrInM = M.data (); hPtrInW = W.data (); }
+        static int slot_of (Memory mem)
+        {
+            switch (mem) {
+                case Memory::H_IN_M: case Memory::D_IN_M: return 1;
+                case Memory::H_IN_W: case Memory::D_IN_W: return 2;
+                case Memory::H_IN_SUM_W: case Memory::D_IN_SUM_W: return 3;
+                case Memory::H_OUT: case Memory::D_OUT: return 4;
+                default: return 0;
+            }
+        }
+        void*& get (Memory mem) { return dptr[slot_of (mem)]; }
+        void init (unsigned int _n, Staging = Staging::IO)
+        {
+            n = _n; F.assign ((size_t) n * 8, 0.f); M.assign ((size_t) n * 8, 0.f); W.assign (n, 0.f); hPtrInF = F.data (); hPtrInM = M.data (); hPtrInW = W.data ();
+            create (C == ICPMeanConfig::WEIGHTED ? ICP_KO_MEAN_WEIGHTED : ICP_KO_MEAN, n, 0, 0.f, 5, "ICPMean");
+        }
         void write (Memory mem = Memory::D_IN_F, void *ptr = nullptr, bool = false)
         {
-            if (!ptr) return;
-            if (mem == Memory::D_IN_F) std::memcpy (F.data (), ptr, F.size () * sizeof (float));
-            else if (mem == Memory::D_IN_M) std::memcpy (M.data (), ptr, M.size () * sizeof (float));
-            else if (mem == Memory::D_IN_W) std::memcpy (W.data (), ptr, W.size () * sizeof (float));
-            else if (mem == Memory::D_IN_SUM_W) std::memcpy (&sw, ptr, sizeof sw);
+            const int s = slot_of (mem);
+            void *stage = s == 0 ? (void *) F.data () : s == 1 ? (void *) M.data () : s == 2 ? (void *) W.data () : (void *) &sw;
+            const size_t bytes = s <= 1 ? F.size () * sizeof (float) : s == 2 ? W.size () * sizeof (float) : sizeof sw;
+            if (s > 3) return;
+            if (ptr) std::memcpy (stage, ptr, bytes);
+            upload (s, stage, "ICPMean");
         }
-        void* read (Memory = Memory::H_OUT, bool = true) { return mean; }
-        void run () { chk (icp_kernel_mean (env.device, C == ICPMeanConfig::WEIGHTED ? 1 : 0, F.data (), M.data (), W.data (), sw, n, mean), "ICPMean"); }
+        void* read (Memory = Memory::H_OUT, bool = true) { download (4, mean, "ICPMean"); return mean; }
+        void run () { launch ("ICPMean"); }
         float *hPtrInF, *hPtrInM, *hPtrInW; double *hPtrInSW; float *hPtrOut;
     private:
         unsigned int n; double sw; float mean[8];
@@ -338,18 +387,31 @@ namespace ICP
     public:
         enum class Memory : uint8_t { H_IN_F, H_IN_M, H_IN_MEAN, H_OUT_DEV_F, H_OUT_DEV_M, D_IN_F, D_IN_M, D_IN_MEAN, D_OUT_DEV_F, D_OUT_DEV_M };
         explicit ICPDevs (icp::Env _env) : KernelClass (_env), hPtrInF (nullptr), hPtrInM (nullptr), hPtrInMean (mean), hPtrOutDevF (nullptr), hPtrOutDevM (nullptr), n (0) { std::memset (mean, 0, sizeof mean); }
+        static int slot_of (Memory mem)
+        {
+            switch (mem) {
+                case Memory::H_IN_M: case Memory::D_IN_M: return 1;
+                case Memory::H_IN_MEAN: case Memory::D_IN_MEAN: return 2;
+                case Memory::H_OUT_DEV_F: case Memory::D_OUT_DEV_F: return 3;
+                case Memory::H_OUT_DEV_M: case Memory::D_OUT_DEV_M: return 4;
+                default: return 0;
+            }
+        }
+        void*& get (Memory mem) { return dptr[slot_of (mem)]; }
         void init (unsigned int _n, Staging = Staging::IO)
         { n = _n; F.assign ((size_t) n * 8, 0.f); M.assign ((size_t) n * 8, 0.f); DF.assign ((size_t) n * 4, 0.f); DM.assign ((size_t) n * 4, 0.f);
-          hPtrInF = F.data (); hPtrInM = M.data (); hPtrOutDevF = DF.data (); hPtrOutDevM = DM.data (); }
+          hPtrInF = F.data (); hPtrInM = M.data (); hPtrOutDevF = DF.data (); hPtrOutDevM = DM.data (); create (ICP_KO_DEVS, n, 0, 0.f, 5, "ICPDevs"); }
         void write (Memory mem = Memory::D_IN_F, void *ptr = nullptr, bool = false)
         {
-            if (!ptr) return;
-            if (mem == Memory::D_IN_F) std::memcpy (F.data (), ptr, F.size () * sizeof (float));
-            else if (mem == Memory::D_IN_M) std::memcpy (M.data (), ptr, M.size () * sizeof (float));
-            else if (mem == Memory::D_IN_MEAN) std::memcpy (mean, ptr, sizeof mean);
+            const int s = slot_of (mem);
+            if (s > 2) return;
+            void *stage = s == 0 ? (void *) F.data () : s == 1 ? (void *) M.data () : (void *) mean;
+            if (ptr) std::memcpy (stage, ptr, s == 2 ? sizeof mean : F.size () * sizeof (float));
+            upload (s, stage, "ICPDevs");
         }
-        void* read (Memory mem = Memory::H_OUT_DEV_F, bool = true) { return mem == Memory::H_OUT_DEV_M ? DM.data () : DF.data (); }
-        void run () { chk (icp_kernel_devs (env.device, F.data (), M.data (), mean, n, DF.data (), DM.data ()), "ICPDevs"); }
+        void* read (Memory mem = Memory::H_OUT_DEV_F, bool = true)
+        { if (mem == Memory::H_OUT_DEV_M) { download (4, DM.data (), "ICPDevs"); return DM.data (); } download (3, DF.data (), "ICPDevs"); return DF.data (); }
+        void run () { launch ("ICPDevs"); }
         float *hPtrInF, *hPtrInM, *hPtrInMean, *hPtrOutDevF, *hPtrOutDevM;
     private:
         unsigned int n; float mean[8];
@@ -365,19 +427,31 @@ namespace ICP
     public:
         enum class Memory : uint8_t { H_IN_DEV_M, H_IN_DEV_F, H_IN_W, H_OUT, D_IN_DEV_M, D_IN_DEV_F, D_IN_W, D_SIJ, D_OUT };
         explicit ICPS (icp::Env _env) : KernelClass (_env), hPtrInDevM (nullptr), hPtrInDevF (nullptr), hPtrInW (nullptr), hPtrOut (S), m (0), c (1e-6f) { std::memset (S, 0, sizeof S); }
+        static int slot_of (Memory mem)
+        {
+            switch (mem) {
+                case Memory::H_IN_DEV_F: case Memory::D_IN_DEV_F: return 1;
+                case Memory::H_IN_W: case Memory::D_IN_W: return 2;
+                case Memory::H_OUT: case Memory::D_OUT: return 3;
+                default: return 0;
+            }
+        }
+        void*& get (Memory mem) { return dptr[slot_of (mem)]; }
         void init (unsigned int _m, float _c, Staging = Staging::IO)
-        { m = _m; c = _c; DM.assign ((size_t) m * 4, 0.f); DF.assign ((size_t) m * 4, 0.f); W.assign (m, 0.f); hPtrInDevM = DM.data (); hPtrInDevF = DF.data (); hPtrInW = W.data (); }
+        { m = _m; c = _c; DM.assign ((size_t) m * 4, 0.f); DF.assign ((size_t) m * 4, 0.f); W.assign (m, 0.f); hPtrInDevM = DM.data (); hPtrInDevF = DF.data (); hPtrInW = W.data ();
+          create (C == ICPSConfig::WEIGHTED ? ICP_KO_S_WEIGHTED : ICP_KO_S, m, 0, c, 4, "ICPS"); }
         void write (Memory mem = Memory::D_IN_DEV_M, void *ptr = nullptr, bool = false)
         {
-            if (!ptr) return;
-            if (mem == Memory::D_IN_DEV_M) std::memcpy (DM.data (), ptr, DM.size () * sizeof (float));
-            else if (mem == Memory::D_IN_DEV_F) std::memcpy (DF.data (), ptr, DF.size () * sizeof (float));
-            else if (mem == Memory::D_IN_W) std::memcpy (W.data (), ptr, W.size () * sizeof (float));
+            const int s = slot_of (mem);
+            if (s > 2) return;
+            void *stage = s == 0 ? (void *) DM.data () : s == 1 ? (void *) DF.data () : (void *) W.data ();
+            if (ptr) std::memcpy (stage, ptr, (s == 2 ? W.size () : DM.size ()) * sizeof (float));
+            upload (s, stage, "ICPS");
         }
-        void* read (Memory = Memory::H_OUT, bool = true) { return S; }
-        void run () { chk (icp_kernel_s (env.device, C == ICPSConfig::WEIGHTED ? 1 : 0, DM.data (), DF.data (), W.data (), m, c, S), "ICPS"); }
+        void* read (Memory = Memory::H_OUT, bool = true) { download (3, S, "ICPS"); return S; }
+        void run () { launch ("ICPS"); }
         float getScaling () { return c; }
-        void setScaling (float _c) { c = _c; }
+        void setScaling (float _c) { c = _c; if (ko) chk (icp_ko_set_scaling (ko, c), "ICPS"); }
         float *hPtrInDevM, *hPtrInDevF, *hPtrInW, *hPtrOut;
     private:
         unsigned int m; float c; float S[11];

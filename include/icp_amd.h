@@ -306,6 +306,31 @@ int icp_kernel_devs (int device, const void *F, const void *M, const float *mean
 int icp_kernel_s (int device, int weighted, const float *DM, const float *DF, const float *W, uint32_t m, float c, float *S11);
 const char *icp_kernel_last_error (void);
 
+/* The same classes as RESIDENT objects — the reference's L2 classes own cl::Buffers, hand them out through get (Memory) and are wired
+ * by sharing them (include/ICP/algorithms.hpp:312-1537; wiring src/ICP/algorithms.cpp:4499-4581): device buffers live with the object,
+ * icp_ko_device_ptr = get (Memory), icp_ko_adopt = a buffer assigned through get () before init (:2214-2220: the object then does not
+ * own it), icp_ko_run = kernels only on the device's null stream (one in-order queue for all kernel objects), icp_ko_write / _read = the
+ * staged upload / blocking download of one Memory object.  A slot's buffer is created at its first use, so adoption costs no allocation.
+ * Slots (Memory objects) per kind, inputs first:
+ *   ICP_KO_LMS      0 cloud 640 x 480 float8          | 1 landmarks 16384 float8
+ *   ICP_KO_REPS     0 F n float8 (aux = nr)           | 1 R nr float8
+ *   ICP_KO_WEIGHTS  0 {dist, id}[n]                   | 1 W[n], 2 sum of weights (double)
+ *   ICP_KO_MEAN(_WEIGHTED)  0 F, 1 M, 2 W[n], 3 sum of weights (double)  | 4 [mean_F, 0 | mean_M, 0]
+ *   ICP_KO_DEVS     0 F, 1 M, 2 means (8 floats)      | 3 DF n float4, 4 DM n float4
+ *   ICP_KO_S(_WEIGHTED)     0 DM, 1 DF, 2 W[n]        | 3 S[11]     (c: the scaling, icp_ko_set_scaling) */
+typedef struct icp_ko *icp_ko_handle;
+typedef enum { ICP_KO_LMS = 0, ICP_KO_REPS = 1, ICP_KO_WEIGHTS = 2, ICP_KO_MEAN = 3, ICP_KO_MEAN_WEIGHTED = 4, ICP_KO_DEVS = 5, ICP_KO_S = 6,
+               ICP_KO_S_WEIGHTED = 7 } icp_ko_kind;
+int icp_ko_create (icp_ko_handle *out, int device, int kind, uint32_t n, uint32_t aux, float c);
+int icp_ko_destroy (icp_ko_handle k);
+int icp_ko_adopt (icp_ko_handle k, int slot, void *device_ptr);
+int icp_ko_device_ptr (icp_ko_handle k, int slot, void **device_ptr);
+size_t icp_ko_slot_bytes (icp_ko_handle k, int slot);
+int icp_ko_write (icp_ko_handle k, int slot, const void *host);
+int icp_ko_read (icp_ko_handle k, int slot, void *host);
+int icp_ko_run (icp_ko_handle k);
+int icp_ko_set_scaling (icp_ko_handle k, float c);
+
 /* ---- standalone Reduce / Scan classes of the reference ------------------------------ */
 
 /* Reduce<MIN,float> / Reduce<MAX,uint> / Reduce<SUM,float> — include/ICP/algorithms.hpp:52-166,

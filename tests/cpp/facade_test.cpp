@@ -160,28 +160,38 @@ int main (int argc, char **argv)
             printf ("PM %.9g %.9g %.9g %u\n", worst[0], worst[1], worst[2], trips);
         }
 
-        // the per-kernel classes chained by hand the way ICPStep::init wires them (src/ICP/algorithms.cpp:4538-4576): weights -> weighted
-        // means -> deviations -> S, on the synthetic pair with distances made up from the index; the last S goes to the test
+        // the per-kernel classes chained the way ICPStep::init wires them (src/ICP/algorithms.cpp:4538-4576) — by SHARED DEVICE BUFFERS: an
+        // input's get (Memory) is assigned the producer's get (Memory) before init, so nothing travels through the host between the stages
+        // (weights -> weighted means -> deviations -> S; four run () calls enqueue kernels only), on the synthetic pair with distances made
+        // up from the index; the last S goes to the test
         {
             ICPLMs lmsK (env); lmsK.init ();                             // (instantiation only: a VGA cloud is exercised by the Python test)
             ICPReps reps (env); reps.init (r, m); reps.write (ICPReps::Memory::D_IN, F.data ()); reps.run ();
             ICPWeights wts (env); wts.init (m);
             for (unsigned int i = 0; i < m; ++i) { wts.hPtrIn[i].dist = (float) ((i * 2654435761u) % 1000u) * 0.001f; wts.hPtrIn[i].id = i; }
-            wts.run ();
-            ICPMean<ICPMeanConfig::WEIGHTED> mean (env); mean.init (m);
-            mean.write (decltype (mean)::Memory::D_IN_F, F.data ()); mean.write (decltype (mean)::Memory::D_IN_M, M.data ());
-            mean.write (decltype (mean)::Memory::D_IN_W, wts.read (ICPWeights::Memory::H_OUT_W)); mean.write (decltype (mean)::Memory::D_IN_SUM_W, wts.read ());
-            mean.run ();
-            ICPDevs devs (env); devs.init (m);
-            devs.write (ICPDevs::Memory::D_IN_F, F.data ()); devs.write (ICPDevs::Memory::D_IN_M, M.data ()); devs.write (ICPDevs::Memory::D_IN_MEAN, mean.read ());
-            devs.run ();
-            ICPS<ICPSConfig::WEIGHTED> S (env); S.init (m, c);
-            S.write (decltype (S)::Memory::D_IN_DEV_M, devs.read (ICPDevs::Memory::H_OUT_DEV_M)); S.write (decltype (S)::Memory::D_IN_DEV_F, devs.read (ICPDevs::Memory::H_OUT_DEV_F));
-            S.write (decltype (S)::Memory::D_IN_W, wts.read (ICPWeights::Memory::H_OUT_W));
-            S.run ();
+            wts.write ();                                                // staging -> device (reference: write (D_IN, nullptr))
+            typedef ICPMean<ICPMeanConfig::WEIGHTED> MeanW; typedef ICPS<ICPSConfig::WEIGHTED> SW;
+            MeanW mean (env);
+            mean.get (MeanW::Memory::D_IN_W) = wts.get (ICPWeights::Memory::D_OUT_W);
+            mean.get (MeanW::Memory::D_IN_SUM_W) = wts.get (ICPWeights::Memory::D_OUT_SUM_W);
+            mean.init (m);
+            mean.write (MeanW::Memory::D_IN_F, F.data ()); mean.write (MeanW::Memory::D_IN_M, M.data ());
+            ICPDevs devs (env);
+            devs.get (ICPDevs::Memory::D_IN_F) = mean.get (MeanW::Memory::D_IN_F);
+            devs.get (ICPDevs::Memory::D_IN_M) = mean.get (MeanW::Memory::D_IN_M);
+            devs.get (ICPDevs::Memory::D_IN_MEAN) = mean.get (MeanW::Memory::D_OUT);
+            devs.init (m);
+            SW S (env);
+            S.get (SW::Memory::D_IN_DEV_M) = devs.get (ICPDevs::Memory::D_OUT_DEV_M);
+            S.get (SW::Memory::D_IN_DEV_F) = devs.get (ICPDevs::Memory::D_OUT_DEV_F);
+            S.get (SW::Memory::D_IN_W) = wts.get (ICPWeights::Memory::D_OUT_W);
+            S.init (m, c);
+            if (S.get (SW::Memory::D_IN_W) != wts.get (ICPWeights::Memory::D_OUT_W) || devs.get (ICPDevs::Memory::D_IN_MEAN) != mean.get (MeanW::Memory::D_OUT))
+                throw std::runtime_error ("the wired objects do not share their buffers");
+            wts.run (); mean.run (); devs.run (); S.run ();              // kernels only: no host copy between the stages
             const float *s11 = (const float *) S.read (), *r0 = (const float *) reps.read ();
             printf ("KC %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.17g %.9g\n", s11[0], s11[1], s11[2], s11[3], s11[4], s11[5], s11[6], s11[7], s11[8], s11[9], s11[10],
-                    *wts.hPtrOutSW, r0[8 * (r - 1)]);
+                    *(const double *) wts.read (ICPWeights::Memory::H_OUT_SUM_W), r0[8 * (r - 1)]);
         }
 
         // the reference's profiling run: 40 steps, per-stage table (include/ICP/algorithms.hpp:2482-2494)

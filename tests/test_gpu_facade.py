@@ -687,3 +687,47 @@ def test_per_kernel_classes_landmarks_and_representatives(engine, oracle):
         assert np.array_equal(R.view(np.uint32), oracle.get_reps(F, nr)[0].view(np.uint32)), (side, nr)
     with pytest.raises(engine.ICPError):
         engine.kernel_reps(F, 48)
+
+
+@pytest.mark.parametrize("n", [16384, 65664])
+def test_resident_kernel_objects_wired_by_device_buffers(engine, oracle, n):
+    """The per-kernel classes as RESIDENT objects (icp_ko_*), wired the way ICPStep::init wires the reference's (shared device
+    buffers, src/ICP/algorithms.cpp:4538-4576): weights -> weighted means -> deviations -> S with every consumer's input slot ADOPTING the
+    producer's output buffer — no host copy between the stages, four run () calls that enqueue kernels only — and every stage's
+    output equal to the oracle twin fed the oracle's own previous stage, bit for bit.  Run twice with new inputs: the objects are reused."""
+    rng = np.random.default_rng(n + 1)
+    wts = engine.KernelObject("weights", n)
+    mean = engine.KernelObject("mean_weighted", n)
+    devs = engine.KernelObject("devs", n)
+    S = engine.KernelObject("s_weighted", n, c=1e-6)
+    mean.adopt(2, wts.get(1)); mean.adopt(3, wts.get(2))                  # W, sum of weights
+    devs.adopt(0, mean.get(0)); devs.adopt(1, mean.get(1)); devs.adopt(2, mean.get(4))      # F, M, the means
+    S.adopt(0, devs.get(4)); S.adopt(1, devs.get(3)); S.adopt(2, wts.get(1))                # DM, DF, W
+    assert S.get(2) == wts.get(1) and devs.get(2) == mean.get(4) and S.get(0) == devs.get(4)
+    for rep in range(2):
+        nn = np.zeros(n, engine.DIST_ID)
+        nn["dist"] = rng.random(n, dtype=np.float32) * 50
+        nn["id"] = rng.integers(0, n, n)
+        F = (rng.random((n, 8), dtype=np.float32) * 2000 - 1000).astype(np.float32)
+        M = (rng.random((n, 8), dtype=np.float32) * 2000 - 1000).astype(np.float32)
+        wts.write(0, nn); mean.write(0, F); mean.write(1, M)
+        wts.run(); mean.run(); devs.run(); S.run()                       # kernels only
+        Wo, swo = oracle.weights(nn)
+        mo = oracle.mean_weighted(F, M, Wo, swo)
+        DFo, DMo = oracle.devs(F, M, mo)
+        So = oracle.sij(DMo, DFo, Wo, 1e-6)
+        assert np.array_equal(wts.read(1).view(np.uint32), Wo.view(np.uint32)) and wts.read(2, np.float64)[0].tobytes() == np.float64(swo).tobytes()
+        assert np.array_equal(mean.read(4).view(np.uint32), mo.view(np.uint32))
+        assert np.array_equal(devs.read(3).view(np.uint32), DFo.reshape(-1).view(np.uint32)) and np.array_equal(devs.read(4).view(np.uint32), DMo.reshape(-1).view(np.uint32))
+        assert np.array_equal(S.read(3).view(np.uint32), So.view(np.uint32)), rep
+    for k in (S, devs, mean, wts):
+        k.close()
+    lm = engine.KernelObject("lms")                                       # landmarks -> representatives, same wiring
+    reps = engine.KernelObject("reps", 16384, 256)
+    reps.adopt(0, lm.get(1))
+    cloud = engine.synth_cloud_vga()
+    lm.write(0, cloud); lm.run(); reps.run()
+    lo = oracle.get_lms(cloud)
+    assert np.array_equal(lm.read(1).view(np.uint32), lo.reshape(-1).view(np.uint32))
+    assert np.array_equal(reps.read(1).view(np.uint32), oracle.get_reps(lo, 256)[0].reshape(-1).view(np.uint32))
+    reps.close(); lm.close()

@@ -11,6 +11,7 @@
 #include <atomic>
 #include <chrono>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -35,15 +36,22 @@ int bfail (icp_batch_context *b, int code, const std::string &msg)
 }
 
 // runs fn (slot) on one host thread per slot that holds registrations; returns the first failing status
+// started_short (optional): set when not every slot's thread could be started, so that threads waiting for each other give up
 template <typename Fn>
-int for_each_slot (icp_batch_context *b, Fn &&fn)
+int for_each_slot (icp_batch_context *b, Fn &&fn, std::atomic<int> *started_short = nullptr)
 {
     const size_t n = b->slots.size ();
     std::vector<int> rc (n, ICP_OK);
     std::vector<std::thread> th;
-    for (size_t s = 0; s < n; ++s)
-        if (b->count[s]) th.emplace_back ([&, s] { rc[s] = fn (s); });
+    bool spawn_failed = false;
+    for (size_t s = 0; s < n && !spawn_failed; ++s) {
+        if (!b->count[s]) continue;
+        try { th.emplace_back ([&, s] { rc[s] = fn (s); }); }
+        catch (const std::system_error &) { spawn_failed = true; }     // (resource exhaustion: the threads already started are joined, never abandoned)
+    }
+    if (spawn_failed && started_short) started_short->store (1, std::memory_order_release);
     for (auto &t : th) t.join ();
+    if (spawn_failed) return bfail (b, ICP_ENOMEM, "a host thread per device slot could not be started");
     for (size_t s = 0; s < n; ++s)
         if (rc[s] != ICP_OK) return bfail (b, rc[s], "slot " + std::to_string (s) + " (device " + std::to_string (b->devices[s]) + "): " + icp_last_error (b->slots[s]));
     return ICP_OK;
@@ -194,28 +202,28 @@ int icp_batch_time_run_fixed_slots (icp_batch_handle b, uint32_t iterations, uin
     const size_t n = b->slots.size ();
     size_t active = 0;
     for (size_t s = 0; s < n; ++s) active += b->count[s] ? 1u : 0u;
+    // the barrier in front of the timed region lives in the slot threads themselves: the last one to arrive takes t0 and opens it
+    // (no gate thread that could be left spinning if a slot's thread cannot be started: `short_` releases the waiters then)
     std::atomic<size_t> arrived { 0 };
-    std::atomic<int> go { 0 };
-    std::chrono::steady_clock::time_point t0;
+    std::atomic<int> go { 0 }, short_ { 0 };
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now ();
     std::vector<float> ms (n, 0.f);
-    std::thread gate ([&] {
-        while (arrived.load (std::memory_order_acquire) < active) std::this_thread::yield ();
-        t0 = std::chrono::steady_clock::now ();
-        go.store (1, std::memory_order_release);
-    });
     int rc = for_each_slot (b, [&] (size_t s) {
         int r = ICP_OK;
         for (uint32_t w = 0; w < warmup && r == ICP_OK; ++w) r = icp_run_fixed_fresh (b->slots[s], iterations);
         if (r == ICP_OK) r = icp_sync (b->slots[s]);
-        arrived.fetch_add (1, std::memory_order_acq_rel);            // (also on failure: the gate must open for the others)
-        while (!go.load (std::memory_order_acquire)) std::this_thread::yield ();
+        if (arrived.fetch_add (1, std::memory_order_acq_rel) + 1 == active) {      // (also on failure: the barrier must open for the others)
+            t0 = std::chrono::steady_clock::now ();
+            go.store (1, std::memory_order_release);
+        }
+        while (!go.load (std::memory_order_acquire) && !short_.load (std::memory_order_acquire)) std::this_thread::yield ();
         if (r != ICP_OK) return r;
+        if (!go.load (std::memory_order_acquire)) return (int) ICP_ENOMEM;
         uint32_t timed = 0;                                           // (events behind the first pass: see icp_time_run_fixed_tail)
         r = icp_time_run_fixed_tail (b->slots[s], iterations, reps, 1, &ms[s], &timed);
         if (r == ICP_OK && timed) ms[s] = ms[s] * (float) reps / (float) timed;      // per-slot figure over all `reps` passes at the timed passes' rate
         return r ? r : icp_sync (b->slots[s]);
-    });
-    gate.join ();
+    }, &short_);
     *seconds = std::chrono::duration<double> (std::chrono::steady_clock::now () - t0).count ();
     if (slot_ms) for (size_t s = 0; s < n; ++s) slot_ms[s] = ms[s];
     return rc;

@@ -731,3 +731,155 @@ def test_resident_kernel_objects_wired_by_device_buffers(engine, oracle, n):
     assert np.array_equal(lm.read(1).view(np.uint32), lo.reshape(-1).view(np.uint32))
     assert np.array_equal(reps.read(1).view(np.uint32), oracle.get_reps(lo, 256)[0].reshape(-1).view(np.uint32))
     reps.close(); lm.close()
+
+
+def test_checked_run_costs_k_launches_and_equals_the_one_graph_form(engine, oracle):
+    """ICP::run as a host-driven checked run (src/ICP/algorithms.cpp:4806-4834 is a host loop that stops at check ()): the launches
+    enqueued are k + the one that finds out + at most `depth` behind it — not max_iterations —, and k, T, every correspondence and the
+    public state are the same bits as rounds 1 - 3's single graph of max_iterations launches and as the oracle.  A x 1 (chained form),
+    a small dense batch (separate launches, registrations stopping at different k) and the reference-order mode."""
+    for side, nr, batch, ref_order in ((64, 64, 1, False), (128, 256, 1, False), (64, 64, 3, False), (64, 64, 1, True)):
+        m = side * side
+        g = engine.ICP(0)
+        g.init(m, nr, 2e2, 1e-6, batch=batch)
+        if ref_order:
+            g.setReduceMode(engine.ReduceMode.REFERENCE_ORDER); g.setPowerMode(engine.PowerMode.LITERAL)
+        pairs = []
+        for b in range(batch):
+            F, M = engine.synth_pair(side, seed=77 + b, rot_deg=2.0 + b)
+            g.write(engine.Memory.F, F, batch_index=b); g.write(engine.Memory.M, M, batch_index=b)
+            pairs.append((F, M))
+        got = {}
+        for adaptive in (True, False):
+            g.set_run_depth(3, adaptive)
+            g.reset_transform(); g.buildRBC()
+            k = g.run()
+            n, kk, dead = g.run_stats()
+            states = [g.state(b) for b in range(batch)]
+            kmax = max(s.k for s in states)
+            if adaptive:
+                assert n <= min(40, kmax + 1 + 3), (n, kmax)
+                assert dead <= 3 and kk == kmax
+            else:
+                assert n == 40
+            got[adaptive] = (k, [g.read(engine.Memory.T, b).tobytes() for b in range(batch)], [g.read(engine.Memory.NN_ID, b).tobytes() for b in range(batch)],
+                             [(s.k, s.converged, bytes(s.R), bytes(s.Rk)) for s in states])
+        assert got[True] == got[False]
+        for b in range(batch):
+            o = oracle.OracleICP(m, nr, 2e2, 1e-6, threads=4, power_fast=not ref_order, fused=not ref_order)
+            o.write_f(pairs[b][0]); o.write_m(pairs[b][1]); o.build_rbc()
+            ko = o.run()
+            assert got[True][3][b][0] == ko and got[True][1][b] == o.T.tobytes()
+        g.close()
+
+
+def test_lazy_per_query_outputs(engine, oracle):
+    """Checked runs store no per-query outputs on the way (ICP_OUTPUTS_LAZY): the first read re-runs the search of the last executed
+    iteration with the transform it used — the same bits as storing them every iteration, as the oracle's, for NN_ID, W, the matched and
+    the transformed points; once the inputs have changed the read says so instead of returning something else."""
+    side, nr = 64, 64
+    F, M = engine.synth_pair(side, seed=5)
+    res = []
+    for every in (False, True):
+        g = engine.ICP(0)
+        g.init(side * side, nr, 2e2, 1e-6)
+        g.set_output_mode(every)
+        g.write(engine.Memory.F, F); g.write(engine.Memory.M, M); g.buildRBC()
+        k = g.run()
+        res.append((k, g.read(engine.Memory.NN_ID).tobytes(), g.read(engine.Memory.W).tobytes(), g.read(engine.Memory.NN).tobytes(),
+                    g.read(engine.Memory.QT).tobytes(), g.read(engine.Memory.RID).tobytes(), g.read(engine.Memory.T).tobytes()))
+        if not every:
+            g.write(engine.Memory.T, [0, 0, 0, 1, 0, 0, 0, 1])                  # T written: the outputs are still those of the run
+            assert g.read(engine.Memory.NN_ID).tobytes() == res[0][1]
+            g.reset_transform(); g.buildRBC(); g.run()
+            g.write(engine.Memory.M, M)                                          # an input changes before anybody has asked
+            with pytest.raises(engine.ICPError) as e:
+                g.read(engine.Memory.NN_ID)
+            assert e.value.code == 4 and "lazy" in str(e.value)                  # ICP_ESTATE
+            g.read(engine.Memory.T)                                              # (the state is there as ever)
+            g.buildRBC(); g.step()
+            g.read(engine.Memory.NN_ID)                                          # a step stores them itself
+        g.close()
+    assert res[0] == res[1]
+    o = oracle.OracleICP(side * side, nr, 2e2, 1e-6, threads=4, power_fast=True, fused=True)
+    o.write_f(F); o.write_m(M); o.build_rbc()
+    assert o.run() == res[0][0]
+    assert o.nn_id.tobytes() == res[0][1] and o.W.tobytes() == res[0][2]
+
+
+def test_setters_leave_the_graphs_standing(engine, oracle):
+    """setAlpha / setScaling / the thresholds between two runs change a number and nothing else: no graph is dropped (a checked run is plain
+    launches; a cached fixed-length graph is updated in place on its next use) — the call costs microseconds, and both kinds of run see
+    the new value (same bits as a handle created with it).  More cached graph lengths than the cache holds still give the right answers."""
+    import time
+    side, nr = 64, 64
+    F, M = engine.synth_pair(side, seed=9)
+    def fresh(alpha):
+        h = engine.ICP(0); h.init(side * side, nr, alpha, 1e-6)
+        h.write(engine.Memory.F, F); h.write(engine.Memory.M, M); h.buildRBC()
+        return h
+    g = fresh(2e2)
+    g.run_fixed_fresh(6); g.sync()
+    k1 = g.run()
+    t0 = time.perf_counter()
+    g.setAlpha(5.0)
+    dt = time.perf_counter() - t0
+    assert dt < 50e-6 * 20, dt                                     # (the bar is 50 us; a 20 x margin for a loaded test host)
+    g.buildRBC()                                                   # (alpha is part of the lists: rebuilt by the caller, as in the reference)
+    g.run_fixed_fresh(6)                                           # the cached graph of 6 iterations, updated in place
+    Tg = g.read(engine.Memory.T).tobytes()
+    r = fresh(5.0)
+    r.run_fixed_fresh(6)
+    assert Tg == r.read(engine.Memory.T).tobytes()
+    g.reset_transform(); g.buildRBC(); r.reset_transform(); r.buildRBC()
+    assert g.run() == r.run() and g.read(engine.Memory.T).tobytes() == r.read(engine.Memory.T).tobytes()
+    want = {}
+    for n in list(range(1, 13)) + [1, 2, 3]:                       # 12 lengths through a cache of 8, then the evicted ones again
+        g.run_fixed_fresh(n)
+        T = g.read(engine.Memory.T).tobytes()
+        assert want.setdefault(n, T) == T
+    r.run_fixed_fresh(3)
+    assert want[3] == r.read(engine.Memory.T).tobytes()
+    g.close(); r.close()
+
+
+def test_warm_sequence_after_a_reset_starts_from_the_identity(engine, oracle):
+    """Advisor, round 3: warm start = the previous hop's transform — the first registration of a sequence has no previous hop.  A warm
+    sequence, icp_track_reset (the state still holds the old sequence's last T), an icp_run on the handle, then another warm sequence:
+    its first registration equals the oracle's from the identity, the following ones from their predecessors — blocking and pipelined."""
+    clouds = [engine.synth_cloud_vga(moved=f) for f in range(3)]
+    lms = [oracle.get_lms(c) for c in clouds]
+    g = engine.ICP(0)
+    g.init(16384, 256, 2e2, 1e-6)
+    for c in clouds:
+        g.track_next(c, True)
+    for pipelined in (False, True):
+        g.track_reset()
+        order = [2, 1, 0]
+        if pipelined:
+            res = g.track_pipelined([clouds[i] for i in order], warm_start=True, depth=2)
+        else:
+            res = [(lambda k: None if k is None else (k, g.read(engine.Memory.T)))(g.track_next(clouds[i], True)) for i in order]
+        o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+        for i in range(1, 3):
+            o.write_f(lms[order[i - 1]]); o.write_m(lms[order[i]])
+            o.write_t(o.T if i > 1 else [0, 0, 0, 1, 0, 0, 0, 1])
+            o.build_rbc()
+            ko = o.run()
+            assert res[i][0] == ko and np.array_equal(res[i][1].view(np.uint32), o.T.view(np.uint32)), (pipelined, i)
+    g.close()
+
+
+def test_pinned_frame_buffers_with_four_frames_in_flight(engine, oracle):
+    """Advisor, round 3: a pinned frame buffer is handed out again only after the band of the frame it last held has left it
+    (icp_track_staging waits for that upload) — with three and four frames in flight the results are those of two."""
+    clouds = [engine.synth_cloud_vga(moved=f) for f in range(4)]
+    order = [0, 1, 2, 3, 2, 1, 0, 1, 2]
+    g = engine.ICP(0)
+    g.init(16384, 256, 2e2, 1e-6)
+    ref = g.track_pipelined([clouds[i] for i in order], warm_start=False, depth=2, pinned=True)
+    for depth in (3, 4):
+        g.track_reset()
+        got = g.track_pipelined([clouds[i] for i in order], warm_start=False, depth=depth, pinned=True)
+        assert got[0] is None and all(a[0] == b[0] and a[1].tobytes() == b[1].tobytes() for a, b in zip(got[1:], ref[1:])), depth
+    g.close()

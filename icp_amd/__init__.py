@@ -85,7 +85,11 @@ def lib():
     vp, u32, i32, f32, f64 = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_double
 
     def sig(name, res, *args):
-        f = getattr(L, name)
+        f = getattr(L, name, None)
+        if f is None:
+            if "ICP_AMD_LIB" in os.environ:          # an A/B build of an older ABI (tests/diag_ab.sh): entry points it lacks stay unbound
+                return
+            raise AttributeError("%s does not export %s" % (_SO, name))
         f.restype = res
         f.argtypes = list(args)
 

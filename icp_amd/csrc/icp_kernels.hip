@@ -494,7 +494,11 @@ static __device__ __forceinline__ void fin_result_to_state (const icp_fin_result
 // TILE = representatives per LDS tile: 1024, or 256 for the dense variant at |R| <= 256 (batches of config 4): 22 KB instead of
 // 47 KB of LDS per block and a register budget for 8 waves per SIMD — four blocks per CU instead of three.
 // SINGLE: the launcher guarantees |R| <= TILE (the tile loop and everything multi-tile fold away).
-template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER = false, int ROT = 1, int TILE = 1024, bool SINGLE = false, bool S2W = false>
+// HOSTRUN (CHAIN only): the launch belongs to a host-driven checked run (run_ctl in icp_capi.hip) — progress words, the final state of a
+// converged registration to the user-visible state and to host memory, the transform each search used (p.st_prev).  Fixed-length graphs
+// (the metric's path) instantiate the kernel without any of it: what the publishing lane of block 0 carries in its prologue is on the
+// path the whole grid waits for (measured with everything decided at run time: 8.58 -> 8.73 us per dispatch).
+template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER = false, int ROT = 1, int TILE = 1024, bool SINGLE = false, bool S2W = false, bool HOSTRUN = false>
 __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (const float *gM, const float *gR, icp_reg_state *gst, const double *gmom,
                                                               uint32_t m, uint32_t nr, uint32_t side, uint32_t tpr_magic,
                                                               uint32_t nb, uint32_t check_flags, icp_params p)
@@ -721,8 +725,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             };
             fused_finalize_block<32, 64 * LPQ, ROT, true> (p, gmom + (size_t) b * 2 * ICP_NMOM * nb, nb, 0u, sv, ma0, &s_fin, s_l1, s_t, nullptr,
                                                            blockIdx.x == 0 ? sout : nullptr, hand_over, 1u,
-                                                           (blockIdx.x == 0 && p.hmirror) ? p.hmirror + b : nullptr, true, p.st + b,
-                                                           p.hstate ? p.hstate + b : nullptr, p.st_prev ? p.st_prev + b : nullptr);
+                                                           (HOSTRUN && blockIdx.x == 0 && p.hmirror) ? p.hmirror + b : nullptr, HOSTRUN, HOSTRUN ? p.st + b : nullptr,
+                                                           (HOSTRUN && p.hstate) ? p.hstate + b : nullptr, (HOSTRUN && p.st_prev) ? p.st_prev + b : nullptr);
             handed = true;
             KS_STAMP (9)
             if (s_fin.done) return;
@@ -1754,15 +1758,17 @@ void icp_launch_chain_one (const icp_params &p0, hipStream_t s, uint32_t j, bool
     p.slot = j & 1u;
     p.emit = emit ? 1 : 0;
     const uint32_t first_flags = 2u | (fresh ? 16u : 0u);             // (fresh: the run starts from the identity, see k_search)
-    if (p.rot == 1) {
-        if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 1>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, (const double *) p.mom,
-                                        p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | first_flags, p);
-        else hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 1>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
-    } else {
-        if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 0>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st, (const double *) p.mom,
-                                        p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | first_flags, p);
-        else hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, 0>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);
-    }
+    // (host-driven checked runs — p.hmirror set — take the HOSTRUN instantiation, fixed-length graphs the plain one)
+#define KS_CHAIN_LAUNCH(ROT_, HR_)                                                                                                              \
+    do {                                                                                                                                        \
+        if (j == 0) hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, ROT_, 1024, false, false, HR_>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, p.M, p.R, p.st,   \
+                                        (const double *) p.mom, p.m, p.nr, p.side, icp_tpr_magic (p.side), p.nb, KS_FLAGS (p) | first_flags, p);     \
+        else hipLaunchKernelGGL ((k_search<true, true, 2, 16, false, ROT_, 1024, false, false, HR_>), dim3 (p.nb, p.batch), dim3 (1024), 0, s, KS_CHAIN_ARGS);          \
+    } while (0)
+    const bool hostrun = p.hmirror != nullptr;
+    if (p.rot == 1) { if (hostrun) KS_CHAIN_LAUNCH (1, true); else KS_CHAIN_LAUNCH (1, false); }
+    else            { if (hostrun) KS_CHAIN_LAUNCH (0, true); else KS_CHAIN_LAUNCH (0, false); }
+#undef KS_CHAIN_LAUNCH
 }
 
 void icp_launch_chain_end (const icp_params &p0, hipStream_t s, uint32_t launches)

@@ -136,6 +136,7 @@ def lib():
     sig("icp_transform_cloud_ex", i32, vp, i32, vp, vp, vp, u32)
     sig("icp_track_next", i32, vp, vp, i32, C.POINTER(u32), C.POINTER(i32))
     sig("icp_track_reset", i32, vp)
+    sig("icp_track_form", i32, vp, C.POINTER(i32))
     sig("icp_track_submit", i32, vp, vp, i32)
     sig("icp_track_collect", i32, vp, C.POINTER(u32), vp, C.POINTER(i32))
     sig("icp_track_staging", i32, vp, u32, C.POINTER(vp))
@@ -570,6 +571,12 @@ class ICPStep:
         k, reg = C.c_uint32(), C.c_int()
         self._chk(self._L.icp_track_next(self._h, _p(cloud), int(warm_start), C.byref(k), C.byref(reg)))
         return k.value if reg.value else None
+
+    def track_form(self):
+        """1: tracked frames alternate between two streams behind device-side gates; 0: one stream, host-ordered (icp_track_form)."""
+        g = C.c_int()
+        self._chk(self._L.icp_track_form(self._h, C.byref(g)))
+        return g.value
 
     def track_reset(self):
         self._chk(self._L.icp_track_reset(self._h))

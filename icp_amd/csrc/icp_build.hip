@@ -26,9 +26,10 @@ __global__ void k_reset_state (icp_params p, int reset_T)
 }
 
 // write (D_IO_T): T is replaced and the cumulative rotation re-derived from it
-__global__ void k_set_T (icp_reg_state *st, const float *T8)
+__global__ void k_set_T (icp_reg_state *st, const float *T8, int reset_k)
 {
     if (threadIdx.x != 0) return;
+    if (reset_k) { st->k = 0; st->done = 0; st->pm_iters = 0; }      // (tracking: what buildRBC would have reset, see icp_params::no_state_reset)
     float T[8]; for (int i = 0; i < 8; ++i) T[i] = T8[i];
     for (int i = 0; i < 8; ++i) st->T[i] = T[i];
     float R[9]; icp_quat_to_rot (T, R);
@@ -315,7 +316,7 @@ __global__ __launch_bounds__ (1024) void k_place (icp_params p)
             rank += (v.x == own) ? v.y : 0u;
         }
     }
-    if (chunk == 0u && t == 0u) { icp_reg_state *st = p.st + b; st->k = 0; st->done = 0; st->pm_iters = 0; }     // ICP::buildRBC (:4796)
+    if (chunk == 0u && t == 0u && !p.no_state_reset) { icp_reg_state *st = p.st + b; st->k = 0; st->done = 0; st->pm_iters = 0; }     // ICP::buildRBC (:4796)
     if (valid) {
         const uint32_t pos = base + rank;
         const float4 *F4 = reinterpret_cast<const float4 *> (p.F + (size_t) b * p.m * 8);
@@ -416,7 +417,7 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
         s_before[r] += run;                          // position of the chunk's first point of list r
         run += n;
     }
-    if (c == 0u && t == 0u) { icp_reg_state *st = p.st + b; st->k = 0; st->done = 0; st->pm_iters = 0; }
+    if (c == 0u && t == 0u && !p.no_state_reset) { icp_reg_state *st = p.st + b; st->k = 0; st->done = 0; st->pm_iters = 0; }
     __syncthreads ();
     if (valid) {
         uint32_t pos = s_before[own] + rk;
@@ -472,10 +473,33 @@ void icp_launch_reset_state (const icp_params &p, hipStream_t s, int reset_T)
     hipLaunchKernelGGL (k_reset_state, dim3 ((p.batch + 63) / 64), dim3 (64), 0, s, p, reset_T);
 }
 
-void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStream_t s)
+void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStream_t s, int reset_k)
 {
-    hipLaunchKernelGGL (k_set_T, dim3 (1), dim3 (64), 0, s, p.st + b, dT8);
+    hipLaunchKernelGGL (k_set_T, dim3 (1), dim3 (64), 0, s, p.st + b, dT8, reset_k);
 }
+
+// Gate of a tracked frame: one wave that holds its stream until registration `want` of the sequence has finished (*seq >= want, written
+// by the launch that found the previous frame converged, or by its end kernel) — the previous frame runs on the OTHER stream, and the
+// launches behind this kernel were enqueued while it was still running.  Every wave reaches the exit: the wait is bounded (~0.5 s of
+// s_sleep rounds, far beyond any registration); a timeout raises *flag (host memory) and lets the stream go on.
+__global__ __launch_bounds__ (64) void k_gate (const uint32_t *seq, uint32_t want, uint32_t *flag, uint32_t max_spins)
+{
+    if (threadIdx.x != 0) return;
+    for (uint32_t spin = 0; spin < max_spins; ++spin) {
+        const uint32_t v = __hip_atomic_load (seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int32_t) (v - want) >= 0) return;
+        __builtin_amdgcn_s_sleep (8);
+    }
+    if (flag) __hip_atomic_store (flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void icp_launch_gate (const uint32_t *seq, uint32_t want, uint32_t *host_timeout_flag, hipStream_t s, uint32_t max_spins)
+{
+    hipLaunchKernelGGL (k_gate, dim3 (1), dim3 (64), 0, s, seq, want, host_timeout_flag, max_spins);
+}
+
+__global__ void k_seq_set (uint32_t *seq, uint32_t v) { if (threadIdx.x == 0) __hip_atomic_store (seq, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+void icp_launch_seq_set (uint32_t *seq, uint32_t v, hipStream_t s) { hipLaunchKernelGGL (k_seq_set, dim3 (1), dim3 (64), 0, s, seq, v); }
 
 void icp_launch_get_lms (const float *cloud, float *lms, hipStream_t s)
 {

@@ -42,7 +42,8 @@ struct run_ctl {
     int done_seen = 0;
     bool final_seen = false;                            // every registration's final state has arrived with its converged flag: no end kernel
     volatile unsigned long long *mirror = nullptr;      // host view of p.hmirror
-    int track_slot = -1;                                // tracking: the ring slot whose evDone follows the end kernel
+    int track_slot = -1;                                // tracking: the ring slot of the frame this run registers
+    hipStream_t stream = nullptr;                       // the stream the run's launches go to (tracking alternates between two)
     // host timeline of the run (icp_run_timeline), seconds on the steady clock: begin, blind launches enqueued, first progress word seen,
     // decided, end kernel enqueued
     double t[5] = { 0, 0, 0, 0, 0 };
@@ -73,7 +74,8 @@ struct icp_context {
     uint32_t epoch = 0;                          // tag of the last checked run
     uint32_t run_depth = 3;                      // launches kept queued behind the one in flight (ICP_AMD_RUN_DEPTH)
     int run_adaptive = 1;                        // 0 (ICP_AMD_RUN_ADAPTIVE=0): checked runs as one graph of max_iterations launches (rounds 1 - 3)
-    run_ctl run;
+    run_ctl run;                                 // the open checked run (tracking: of the frames on the handle's own stream)
+    run_ctl run2;                                // tracking with device-side gates: the open run of the frames on stream2
     // Per-query outputs (NN_ID, W, NN, QT, RID) of checked runs: fused kernels consume none of them, and a checked run cannot know which
     // iteration is its last — storing them every iteration costs 0.4 us of every 9 at |F| = 16384.  lazy: the run stores none; every finalize
     // leaves the transform its search used in p.st_prev, and the first read of such an output re-runs that one search (same T, same
@@ -97,6 +99,18 @@ struct icp_context {
     uint32_t track_epoch[4] = { 0, 0, 0, 0 };                // epoch of the run in each ring slot
     uint32_t track_k_hist[2] = { 0, 0 };                     // k of the last two registrations of the sequence (0: none yet): the next frame's blind launches
     hipStream_t copy_stream = nullptr;
+    // Tracking with frames gated on the device (track_gate; ICP_AMD_TRACK_GATE=0 switches it off): registration f runs on stream f & 1 (the
+    // handle's own stream / stream2) behind k_gate, which waits for registration f - 1's release of *dSeq — so frame f's RBC construction
+    // and all its predicted launches are enqueued while frame f - 1 is still running, and the host is nowhere on the path between two
+    // frames.  The RBC of two consecutive frames lives in two sets of buffers (rbc2 = the second set; swapped into h->p by frame parity).
+    hipStream_t stream2 = nullptr;
+    int track_gate = 1;
+    uint32_t *dSeq = nullptr, *dRunFlag = nullptr, *hGateFlag = nullptr;
+    bool stream2_dirty = false;                  // stream2 holds work the handle's own stream must not overtake
+    struct rbc_set { float *R = nullptr; float4 *GB = nullptr; float *XP = nullptr, *XQ = nullptr; uint32_t *rep_src = nullptr, *owner = nullptr, *N = nullptr, *O = nullptr,
+                     *perm = nullptr, *chunk_hist = nullptr; uint2 *blist = nullptr; uint32_t *bn = nullptr; uint8_t *brank = nullptr; } rbc[2];
+    bool rbc2_ready = false;
+    bool track_last_gated = false;                // the form of the last submitted frame
     hipEvent_t evUp[2] = { nullptr, nullptr }, evDone[4] = { nullptr, nullptr, nullptr, nullptr };
     hipEvent_t evStage[3] = { nullptr, nullptr, nullptr };   // the last asynchronous copy out of the pinned staging of F / M / T (icp_write)
     uint64_t track_submitted = 0, track_collected = 0;       // frames fed / frames whose result has been handed out since init / icp_track_reset
@@ -154,6 +168,16 @@ void free_all (icp_context *h)
     h->lm[0] = h->lm[1] = h->lm[2] = nullptr;
     if (h->hTrack) (void) hipHostFree (h->hTrack);
     h->hTrack = nullptr;
+    if (h->rbc2_ready) {
+        icp_context::rbc_set &q = h->rbc[1];
+        void *ptrs[] = { q.R, q.GB, q.XP, q.XQ, q.rep_src, q.owner, q.N, q.O, q.perm, q.chunk_hist, q.blist, q.bn, q.brank };
+        for (void *x : ptrs) if (x) (void) hipFree (x);
+    }
+    h->rbc[0] = h->rbc[1] = icp_context::rbc_set {}; h->rbc2_ready = false;
+    if (h->dSeq) (void) hipFree (h->dSeq);
+    if (h->dRunFlag) (void) hipFree (h->dRunFlag);
+    if (h->hGateFlag) (void) hipHostFree (h->hGateFlag);
+    h->dSeq = h->dRunFlag = h->hGateFlag = nullptr; h->run2 = run_ctl {}; h->stream2_dirty = false; h->track_last_gated = false;
     h->inited = h->built = false; h->parity = 0; h->track_submitted = h->track_collected = 0;
 }
 
@@ -188,6 +212,7 @@ bool reps_grid (uint32_t m, uint32_t nr, uint32_t *nrx, uint32_t *nry, uint32_t 
 }
 
 int run_finish (icp_context *h, bool defer_event = false);
+int run_close_all (icp_context *h);
 void note_outputs_stored (icp_context *h);
 
 // keep_run: the caller is one of the tracking entries, which carry an open checked run (run_ctl) across calls themselves; everything
@@ -197,9 +222,9 @@ int need (icp_context *h, bool built, bool keep_run = false)
     if (!h) return ICP_EINVAL;
     if (!h->inited) return fail (h, ICP_ESTATE, "icp_init has not been called");
     if (built && !h->built) return fail (h, ICP_ESTATE, "icp_build_rbc has not been called");
-    if (!keep_run && h->run.active) {
+    if (!keep_run && (h->run.active || h->run2.active || h->stream2_dirty)) {
         if (hipSetDevice (h->device) != hipSuccess) return fail (h, ICP_EHIP, "hipSetDevice");
-        int rc = run_finish (h); if (rc) return rc;
+        int rc = run_close_all (h); if (rc) return rc;
     }
     return ICP_OK;
 }
@@ -302,12 +327,12 @@ int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *o
 
 // ---- host-driven checked runs (run_ctl) ------------------------------------------------------------------------------------------
 
-void run_launch_one (icp_context *h)
+void run_launch_one (icp_context *h, run_ctl &r)
 {
-    run_ctl &r = h->run;
+    (void) h;
     const double t0 = now_s ();
-    if (r.chained) icp_launch_chain_one (r.p, h->stream, r.enq, r.fresh, r.p.emit != 0);
-    else icp_launch_iteration (r.p, h->stream);
+    if (r.chained) icp_launch_chain_one (r.p, r.stream, r.enq, r.fresh, r.p.emit != 0);
+    else icp_launch_iteration (r.p, r.stream);
     const double us = (now_s () - t0) * 1e6;
     if (us > r.launch_max_us) r.launch_max_us = us;
     if (us > 10.0) ++r.launch_slow;
@@ -319,12 +344,15 @@ void run_launch_one (icp_context *h)
 // between (): enqueued after the RBC construction and in front of the first iteration (tracking: the waits and records that need not
 // hold the construction back).
 struct run_no_hook { int operator() () const { return ICP_OK; } };
+bool run_pump (icp_context *h, run_ctl &r);
+// r: the slot the run lives in (h->run; tracking with gates: h->run / h->run2 by frame parity), stream: where its launches go;
+// other: another open run that is looked after while this one's launches are being enqueued (a tracked frame's predecessor).
 template <typename BETWEEN = run_no_hook>
-int run_begin (icp_context *h, const icp_params &p, bool fresh, bool with_build, uint32_t blind,
-               unsigned long long *mirror, icp_reg_state *hstate, int track_slot, BETWEEN between = BETWEEN ())
+int run_begin (icp_context *h, run_ctl &r, hipStream_t stream, const icp_params &p, bool fresh, bool with_build, uint32_t blind,
+               unsigned long long *mirror, icp_reg_state *hstate, int track_slot, BETWEEN between = BETWEEN (), run_ctl *other = nullptr)
 {
-    run_ctl &r = h->run;
     r = run_ctl {};
+    r.stream = stream;
     r.t[0] = now_s ();
     r.p = p; r.p.check = 1;
     r.p.emit = (h->outputs_lazy && p.fused) ? 0 : 1;                    // (reference-order kernels read the outputs themselves: always stored)
@@ -336,12 +364,15 @@ int run_begin (icp_context *h, const icp_params &p, bool fresh, bool with_build,
     std::atomic_thread_fence (std::memory_order_seq_cst);
     r.chained = icp_chain_supported (r.p); r.fresh = fresh;
     r.maxit = h->max_iterations; r.depth = h->run_depth ? h->run_depth : 1u;
-    if (with_build) icp_launch_build_rbc (r.p, h->stream);
+    if (with_build) icp_launch_build_rbc (r.p, r.stream);
     { int rc = between (); if (rc) return rc; }
-    if (fresh && !r.chained) icp_launch_reset_state (r.p, h->stream, 1);
+    if (fresh && !r.chained) icp_launch_reset_state (r.p, r.stream, 1);
     r.active = true;
     const uint32_t n = std::min (std::max (blind, 1u), r.maxit);
-    while (r.enq < n) run_launch_one (h);
+    while (r.enq < n) {
+        run_launch_one (h, r);
+        if (other && other->active && (r.enq & 3u) == 0u) (void) run_pump (h, *other);
+    }
     if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit; }
     HIPCHK (h, hipGetLastError ());
     h->hstate_fresh = false; h->hstate_here = false;
@@ -351,9 +382,8 @@ int run_begin (icp_context *h, const icp_params &p, bool fresh, bool with_build,
 
 // One look at the run's words, then the queue topped up to `depth` launches behind the one in flight.  Returns true once the run is
 // decided: every registration has converged, or max_iterations launches are enqueued (nothing more will be).
-bool run_pump (icp_context *h)
+bool run_pump (icp_context *h, run_ctl &r)
 {
-    run_ctl &r = h->run;
     if (r.decided) return true;
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u; bool all_done = true, all_final = true;
     for (uint32_t b = 0; b < r.p.batch; ++b) {
@@ -370,20 +400,21 @@ bool run_pump (icp_context *h)
     r.k_seen = kmin;
     // launch (chained) / search (separate launches) j publishes k = j in its prologue: k_seen = the iteration in flight, `depth`
     // iterations are kept queued behind it
-    while (r.enq < r.maxit && r.enq < r.k_seen + 1u + r.depth) run_launch_one (h);
+    while (r.enq < r.maxit && r.enq < r.k_seen + 1u + r.depth) run_launch_one (h, r);
     if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit; }
     return r.decided;
 }
 
 // Drives the open run to its decision (the calling thread polls; bounded wait on a device that has stopped answering), then
 // enqueues its end kernel — final state -> p.st and -> host memory, FINAL bit — and closes it.
-int run_finish (icp_context *h, bool defer_event)
+// other: a run this one may be waiting for on the device (a gated frame's predecessor): it is topped up in the same loop.
+int run_finish (icp_context *h, run_ctl &r, run_ctl *other)
 {
-    run_ctl &r = h->run;
     if (!r.active) return ICP_OK;
     uint32_t spins = 0, k_last = 0xFFFFFFFFu;
     auto t_last = std::chrono::steady_clock::now ();
-    while (!run_pump (h)) {
+    while (!run_pump (h, r)) {
+        if (other && other->active) { const uint32_t ko = other->k_seen; (void) run_pump (h, *other); if (other->k_seen != ko || other->decided) t_last = std::chrono::steady_clock::now (); }
         _mm_pause ();
         if ((++spins & 0x3FFu) == 0u) {
             const auto now = std::chrono::steady_clock::now ();
@@ -397,8 +428,8 @@ int run_finish (icp_context *h, bool defer_event)
     r.t[3] = now_s ();
     // (converged in the fused forms: the finalize that set the flag has left the final state in p.st and in host memory already)
     if (!r.final_seen) {
-        if (r.chained) icp_launch_chain_end (r.p, h->stream, r.enq);
-        else icp_launch_publish_state (r.p, h->stream);
+        if (r.chained) icp_launch_chain_end (r.p, r.stream, r.enq);
+        else icp_launch_publish_state (r.p, r.stream);
     }
     r.t[4] = now_s ();
     for (int i = 0; i < 5; ++i) h->stat_t[i] = r.t[i];
@@ -409,9 +440,9 @@ int run_finish (icp_context *h, bool defer_event)
     // is the one that sets it —, the rest leave at their first load)
     h->stat_dead = r.done_seen ? r.enq - std::min (r.enq, r.k_final + 1u) : 0u;
     HIPCHK (h, hipGetLastError ());
-    (void) defer_event;                                                 // (host-driven tracked frames carry no event: see track_submit)
     return ICP_OK;
 }
+int run_finish (icp_context *h, bool) { return run_finish (h, h->run, h->run2.active ? &h->run2 : nullptr); }
 
 // Waits for the FINAL bit of `n` words of epoch `epoch` (the end kernel's last store: the final states are in host memory).
 int run_wait_final (icp_context *h, volatile unsigned long long *mirror, uint32_t n, uint32_t epoch)
@@ -432,6 +463,19 @@ int run_wait_final (icp_context *h, volatile unsigned long long *mirror, uint32_
         }
     }
     std::atomic_thread_fence (std::memory_order_acquire);
+    return ICP_OK;
+}
+
+// Brings every open run to its end (older frame first) and, after gated tracking, drains stream2: whatever is enqueued on the handle's own
+// stream next must not overtake it.
+int run_close_all (icp_context *h)
+{
+    run_ctl *a = &h->run, *b = &h->run2;
+    if (a->active && b->active && b->p.seq_value < a->p.seq_value) std::swap (a, b);      // a = the older frame
+    int rc;
+    if (a->active && (rc = run_finish (h, *a, b->active ? b : nullptr))) return rc;
+    if (b->active && (rc = run_finish (h, *b, nullptr))) return rc;
+    if (h->stream2_dirty && h->stream2) { HIPCHK (h, hipStreamSynchronize (h->stream2)); h->stream2_dirty = false; }
     return ICP_OK;
 }
 
@@ -540,6 +584,7 @@ int icp_create (icp_handle *out, int device, int rot, int weighted)
     { const char *e = std::getenv ("ICP_AMD_MODE"); if (e && (e[0] == 'r' || e[0] == 'R')) { h->p.power_mode = ICP_POWER_LITERAL; h->p.fused = ICP_REDUCE_REFERENCE_ORDER; } }
     { const char *e = std::getenv ("ICP_AMD_CHAIN"); h->p.chain = !e ? 1 : (e[0] == '1') ? 2 : (e[0] == '0') ? 0 : 1; }   // see icp_chain_supported
     { const char *e = std::getenv ("ICP_AMD_RUN_ADAPTIVE"); if (e && e[0] == '0') h->run_adaptive = 0; }                  // see run_ctl
+    { const char *e = std::getenv ("ICP_AMD_TRACK_GATE"); if (e && e[0] == '0') h->track_gate = 0; }
     { const char *e = std::getenv ("ICP_AMD_OUTPUTS"); if (e && (e[0] == 'e' || e[0] == 'E')) h->outputs_lazy = 0; }
     { const char *e = std::getenv ("ICP_AMD_RUN_DEPTH"); if (e) { const int d = std::atoi (e); if (d >= 1 && d <= 64) h->run_depth = (uint32_t) d; } }
     e = hipSetDevice (device);
@@ -559,7 +604,8 @@ int icp_destroy (icp_handle h)
 {
     if (!h) return ICP_EINVAL;
     (void) hipSetDevice (h->device);
-    if (h->run.active) (void) run_finish (h);
+    if (h->run.active || h->run2.active) (void) run_close_all (h);
+    if (h->stream2) (void) hipStreamSynchronize (h->stream2);
     if (h->copy_stream) (void) hipStreamSynchronize (h->copy_stream);
     if (h->stream) (void) hipStreamSynchronize (h->stream);
     free_all (h);
@@ -570,6 +616,7 @@ int icp_destroy (icp_handle h)
     for (int k = 0; k < 4; ++k) if (h->evDone[k]) (void) hipEventDestroy (h->evDone[k]);
     for (int k = 0; k < 3; ++k) if (h->evStage[k]) (void) hipEventDestroy (h->evStage[k]);
     if (h->copy_stream) (void) hipStreamDestroy (h->copy_stream);
+    if (h->stream2) (void) hipStreamDestroy (h->stream2);
     if (h->stream) (void) hipStreamDestroy (h->stream);
     delete h;
     return ICP_OK;
@@ -592,8 +639,9 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if (nr > 32768u) return fail (h, ICP_EINVAL, "nr must be <= 32768");
     if (m > (1u << 20)) return fail (h, ICP_EINVAL, "m must be <= 2^20");
     int rc = set_device (h); if (rc) return rc;
-    if (h->run.active && (rc = run_finish (h))) return rc;
+    if ((rc = run_close_all (h))) return rc;
     if (h->copy_stream) HIPCHK (h, hipStreamSynchronize (h->copy_stream));
+    if (h->stream2) HIPCHK (h, hipStreamSynchronize (h->stream2));
     if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
     int rot = h->p.rot, weighted = h->p.weighted, pmode = h->p.power_mode, fused = h->p.fused, chain = h->p.chain;
     const float dist_scale = h->p.dist_scale;
@@ -889,7 +937,7 @@ int icp_run (icp_handle h, uint32_t *k)
     } else {
         // the host loop of the reference (:4806-4814: run one step, check (), stop), with the check on the device and the host `run_depth`
         // launches ahead of it: the calling thread polls the registration's progress word and tops the queue up
-        if ((rc = run_begin (h, h->p, false, false, h->run_depth + 1u, h->hMirror, h->hState, -1))) return rc;
+        if ((rc = run_begin (h, h->run, h->stream, h->p, false, false, h->run_depth + 1u, h->hMirror, h->hState, -1))) return rc;
         if ((rc = run_finish (h))) return rc;
         if ((rc = run_wait_final (h, h->hMirror, h->p.batch, h->run.p.epoch))) return rc;      // (the end kernel is the last thing on the stream: queue.finish ())
         h->stat_t[5] = now_s ();
@@ -944,7 +992,7 @@ int icp_set_run_depth (icp_handle h, uint32_t depth, int adaptive)
 {
     if (!h) return ICP_EINVAL;
     if (depth == 0 || depth > 64u) return fail (h, ICP_EINVAL, "icp_set_run_depth: depth must be in [1, 64]");
-    if (h->run.active) { int rc = set_device (h); if (rc) return rc; if ((rc = run_finish (h))) return rc; }
+    { int rc = set_device (h); if (rc) return rc; if ((rc = run_close_all (h))) return rc; }
     h->run_depth = depth; h->run_adaptive = adaptive ? 1 : 0;
     return ICP_OK;
 }
@@ -1098,18 +1146,70 @@ static int track_prepare (icp_context *h)
         HIPCHK (h, hipHostMalloc ((void **) &h->hTrackMirror, ICP_TRACK_RING * sizeof (unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset (h->hTrackMirror, 0, ICP_TRACK_RING * sizeof (unsigned long long));
     }
+    if (h->run_adaptive && h->track_gate && !h->rbc2_ready) {
+        // frames gated on the device: a second stream, the sequence word and the run flags, a second set of RBC buffers (frame f builds its
+        // RBC while frame f - 1 is still searching its own)
+        const icp_params &p = h->p;
+        if (!h->stream2) HIPCHK (h, hipStreamCreateWithFlags (&h->stream2, hipStreamNonBlocking));
+        if (!h->dSeq) { HIPCHK (h, hipMalloc ((void **) &h->dSeq, sizeof (uint32_t))); HIPCHK (h, hipMemset (h->dSeq, 0, sizeof (uint32_t))); }
+        if (!h->dRunFlag) { HIPCHK (h, hipMalloc ((void **) &h->dRunFlag, sizeof (uint32_t))); HIPCHK (h, hipMemset (h->dRunFlag, 0, sizeof (uint32_t))); }
+        if (!h->hGateFlag) { HIPCHK (h, hipHostMalloc ((void **) &h->hGateFlag, sizeof (uint32_t), hipHostMallocMapped | hipHostMallocCoherent)); *h->hGateFlag = 0u; }
+        icp_context::rbc_set &a = h->rbc[0], &b = h->rbc[1];
+        a.R = p.R; a.GB = p.GB; a.XP = p.XP; a.XQ = p.XQ; a.rep_src = p.rep_src; a.owner = p.owner; a.N = p.N; a.O = p.O; a.perm = p.perm;
+        a.chunk_hist = p.chunk_hist; a.blist = p.blist; a.bn = p.bn; a.brank = p.brank;
+        auto al = [&] (void **q, size_t bytes) -> int {
+            hipError_t e = hipMalloc (q, bytes ? bytes : 1);
+            if (e == hipSuccess) e = hipMemset (*q, 0, bytes ? bytes : 1);
+            return e == hipSuccess ? ICP_OK : fail (h, ICP_ENOMEM, std::string ("tracking (second RBC set): ") + hipGetErrorString (e));
+        };
+        int rc;
+        if ((rc = al ((void **) &b.R, (size_t) p.nr * 32)) || (rc = al ((void **) &b.GB, (size_t) 2 * (p.n16 + p.n1k) * 16)) || (rc = al ((void **) &b.XP, (size_t) p.m * 32)) ||
+            (rc = al ((void **) &b.XQ, (size_t) p.m * 32)) || (rc = al ((void **) &b.rep_src, (size_t) p.nr * 4)) || (rc = al ((void **) &b.owner, (size_t) p.m * 4)) ||
+            (rc = al ((void **) &b.N, (size_t) p.nr * 4)) || (rc = al ((void **) &b.O, (size_t) p.nr * 4)) || (rc = al ((void **) &b.perm, (size_t) p.m * 4)) ||
+            (rc = al ((void **) &b.chunk_hist, (size_t) p.nchunk * p.nr * 4)) || (rc = al ((void **) &b.blist, (size_t) p.nb * 64 * 8)) ||
+            (rc = al ((void **) &b.bn, (size_t) p.nb * 4)) || (rc = al ((void **) &b.brank, (size_t) p.m))) {
+            void *ptrs[] = { b.R, b.GB, b.XP, b.XQ, b.rep_src, b.owner, b.N, b.O, b.perm, b.chunk_hist, b.blist, b.bn, b.brank };
+            for (void *x : ptrs) if (x) (void) hipFree (x);
+            b = icp_context::rbc_set {};
+            return rc;
+        }
+        // Do the two streams really run side by side?  HIP spreads streams over a few hardware queues; two streams that share one are served in
+        // order, and a gate would then hold back the very launches it is waiting for.  One probe at set-up: a short-lived gate on stream2
+        // waits for a word that a kernel on the handle's own stream sets.  If the gate gives up (2 ms), gating stays off for this handle.
+        *h->hGateFlag = 0u;
+        icp_launch_gate (h->dSeq, 1u, h->hGateFlag, h->stream2, 1u << 13);
+        icp_launch_seq_set (h->dSeq, 1u, h->stream);
+        HIPCHK (h, hipGetLastError ());
+        HIPCHK (h, hipStreamSynchronize (h->stream2));
+        HIPCHK (h, hipStreamSynchronize (h->stream));
+        if (*h->hGateFlag) { h->track_gate = 0; *h->hGateFlag = 0u; }
+        HIPCHK (h, hipMemset (h->dSeq, 0, sizeof (uint32_t)));
+        h->rbc2_ready = true;
+    }
     return ICP_OK;
 }
+
+static void rbc_into (icp_params &p, const icp_context::rbc_set &q)
+{
+    p.R = q.R; p.GB = q.GB; p.XP = q.XP; p.XQ = q.XQ; p.rep_src = q.rep_src; p.owner = q.owner; p.N = q.N; p.O = q.O; p.perm = q.perm;
+    p.chunk_hist = q.chunk_hist; p.blist = q.blist; p.bn = q.bn; p.brank = q.brank;
+}
+
+static void track_note_k (icp_context *h, const run_ctl &r) { h->track_k_hist[1] = h->track_k_hist[0]; h->track_k_hist[0] = r.k_final; }
 
 int icp_track_reset (icp_handle h)
 {
     if (!h) return ICP_EINVAL;
     int rc = set_device (h); if (rc) return rc;
-    if (h->run.active && (rc = run_finish (h))) return rc;
+    if ((rc = run_close_all (h))) return rc;
     if (h->copy_stream) HIPCHK (h, hipStreamSynchronize (h->copy_stream));
+    if (h->stream2) HIPCHK (h, hipStreamSynchronize (h->stream2));
     if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
+    if (h->dSeq) HIPCHK (h, hipMemset (h->dSeq, 0, sizeof (uint32_t)));
+    if (h->hGateFlag) *h->hGateFlag = 0u;
     h->track_submitted = h->track_collected = 0;
     h->track_k_hist[0] = h->track_k_hist[1] = 0;
+    h->track_last_gated = false;
     return ICP_OK;
 }
 
@@ -1148,14 +1248,33 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     const uint32_t s = (uint32_t) (f & 1u), buf = (uint32_t) (f % 3u), ring = (uint32_t) (f % ICP_TRACK_RING);
     const char *src = static_cast<const char *> (cloud) + ((size_t) ICP_BAND_ROW0 * 640u + ICP_BAND_COL0) * 32u;
     const size_t spitch = (size_t) ICP_BAND_ROW_STEP * 640u * 32u;
+    // gated: registration f lives in run slot f & 1 on stream f & 1; its predecessor (f - 1) in the other slot, possibly still open
+    // (the release of the sequence word lives in the chained kernel: other forms — reference-order reductions, |R| > 1024 — stay host-ordered)
+    const bool gated = h->run_adaptive && h->track_gate && h->rbc2_ready && icp_chain_supported (h->p);
+    if (gated != h->track_last_gated) {                                 // the form changes in mid-sequence (a mode was switched): start from a drained device
+        if ((rc = run_close_all (h))) return rc;
+        if (h->stream2) HIPCHK (h, hipStreamSynchronize (h->stream2));
+        HIPCHK (h, hipStreamSynchronize (h->stream));
+        if (gated && f > 0u) { icp_launch_seq_set (h->dSeq, (uint32_t) (f - 1u), h->stream); HIPCHK (h, hipGetLastError ()); HIPCHK (h, hipStreamSynchronize (h->stream)); }
+        h->track_last_gated = gated;
+    }
+    run_ctl &R = (gated && (f & 1u)) ? h->run2 : h->run;
+    run_ctl *P = gated ? ((f & 1u) ? &h->run : &h->run2) : &h->run;     // the run to look after meanwhile (ungated: the one and only)
+    hipStream_t st = (gated && (f & 1u)) ? h->stream2 : h->stream;
+    if (gated && R.active) {                                            // the slot still holds registration f - 2: decided long ago, or nearly
+        if ((rc = run_finish (h, R, P->active ? P : nullptr))) return rc;
+        track_note_k (h, R);
+    }
     // the copy stream: not before registration f - 2 (the last reader of lm[buf], as its fixed set) is done.  Host-driven runs: the host
-    // knows — the FINAL bit of that frame's word (it is there long before: that registration was decided before frame f - 1 was even
-    // begun) —, and neither stream carries an event for it (a record + a cross-stream wait cost the main stream ~10 us per frame between
-    // the RBC construction and the first iteration, profiles/r04_track_trace.txt)
+    // knows — the FINAL bit of that frame's word —, and neither stream carries an event for it (a record + a cross-stream wait cost the
+    // main stream ~10 us per frame between the RBC construction and the first iteration, profiles/r04_track_trace.txt)
     if (f >= 2u) {
         const uint32_t r2 = (uint32_t) ((f - 2u) % ICP_TRACK_RING);
-        if (h->track_epoch[r2]) { if ((rc = run_wait_final (h, h->hTrackMirror + r2, 1u, h->track_epoch[r2]))) return rc; }
-        else HIPCHK (h, hipStreamWaitEvent (h->copy_stream, h->evDone[r2], 0));
+        if (h->track_epoch[r2]) {
+            // (its end kernel, if it needs one, is enqueued: run_finish above / at the previous submit)
+            if (!gated && h->run.active && h->run.track_slot == (int) r2) { if ((rc = run_finish (h))) return rc; track_note_k (h, h->run); }
+            if ((rc = run_wait_final (h, h->hTrackMirror + r2, 1u, h->track_epoch[r2]))) return rc;
+        } else HIPCHK (h, hipStreamWaitEvent (h->copy_stream, h->evDone[r2], 0));
     }
     const bool pinned = cloud == h->hFrame[0] || cloud == h->hFrame[1];
     if (pinned) {
@@ -1167,46 +1286,52 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
         for (uint32_t j = 0; j < ICP_BAND_ROWS; ++j) {
             std::memcpy (reinterpret_cast<char *> (h->hBand[s]) + (size_t) j * ICP_BAND_ROW_BYTES, src + (size_t) j * spitch, ICP_BAND_ROW_BYTES);
             // (the copy takes ~60 us: the previous frame's open registration is looked after on the way — a word read, a launch if it needs one)
-            if ((j & 7u) == 7u && h->run.active) (void) run_pump (h);
+            if ((j & 7u) == 7u && P->active) (void) run_pump (h, *P);
         }
         HIPCHK (h, hipMemcpyAsync (h->dBand[s], h->hBand[s], ICP_BAND_BYTES, hipMemcpyHostToDevice, h->copy_stream));
     }
     icp_launch_get_lms_band (h->dBand[s], h->lm[buf], h->copy_stream);
     HIPCHK (h, hipGetLastError ());
     HIPCHK (h, hipEventRecord (h->evUp[s], h->copy_stream));
-    // the main stream.  The previous frame's registration may still be open (its blind launches enqueued, the rest not): bring it to
-    // its end first.  Its evDone — "the landmark buffers it read are free" — is recorded behind this frame's RBC construction: the device
-    // has run dry by the time the host sees the converged flag, and the first kernel of this frame is what it is waiting for
+    // ungated: one stream, in order — the previous frame's registration is brought to its end before this frame's work goes behind it
     int prev_slot = -1;
-    if (h->run.active) {
+    if (!gated && h->run.active) {
         prev_slot = h->run.track_slot;
-        if ((rc = run_finish (h, true))) return rc;
-        h->track_k_hist[1] = h->track_k_hist[0]; h->track_k_hist[0] = h->run.k_final;
+        if ((rc = run_finish (h))) return rc;
+        track_note_k (h, h->run);
     }
     // (rounds 1 - 3's form only: host-driven runs order the streams from the host, see above)
     auto record_prev = [&] () -> int { if (prev_slot >= 0 && !h->track_epoch[prev_slot]) { HIPCHK (h, hipEventRecord (h->evDone[prev_slot], h->stream)); } prev_slot = -1; return ICP_OK; };
-    // this frame's upload: waited for on the stream only if it is not through yet (it is, whenever a registration takes longer than an upload)
-    auto wait_upload = [&] () -> int { if (hipEventQuery (h->evUp[s]) != hipSuccess) { (void) hipGetLastError (); HIPCHK (h, hipStreamWaitEvent (h->stream, h->evUp[s], 0)); } return ICP_OK; };
+    // an upload is waited for on the stream only if it is not through yet (it is, whenever a registration takes longer than an upload)
+    auto wait_upload = [&] (uint32_t slot) -> int { if (hipEventQuery (h->evUp[slot]) != hipSuccess) { (void) hipGetLastError (); HIPCHK (h, hipStreamWaitEvent (st, h->evUp[slot], 0)); } return ICP_OK; };
     note_inputs_change (h);
     float *newM = h->lm[buf], *newF = h->lm[(f + 2u) % 3u];             // (f - 1) mod 3: the previous frame's landmarks (first frame: a buffer that is not M)
+    icp_params p = h->p; p.M = newM; p.F = newF;
+    if (gated) rbc_into (p, h->rbc[f & 1u]);
     if (f > 0u) {
-        icp_params p = h->p; p.M = newM; p.F = newF;
         note_enqueue (h);
         // warm start: from the previous hop's transform, as by write (D_IO_T) — the first registration of a sequence has no previous hop
         // and starts from the identity whatever the state holds (an earlier sequence's last transform, an icp_run before the reset)
         const bool warm = warm_start && f > 1u;
         if (h->run_adaptive) {
             const uint32_t blind = blocking ? h->run_depth + 1u : track_blind (h);
-            // buildRBC reads the fixed set only — the previous frame's landmarks, resident since that frame's own registration —: this frame's
-            // upload is waited for behind it
+            if (gated) {
+                // buildRBC runs AHEAD of the previous frame's end (its own RBC set, the fixed landmarks resident since that frame's upload)
+                // and must not touch the registration state; behind it the gate: registration f - 1 has released the sequence word
+                p.no_state_reset = 1u; p.run_flag = h->dRunFlag; p.track_seq = h->dSeq; p.seq_value = (uint32_t) f;
+                if ((rc = wait_upload ((uint32_t) ((f - 1u) & 1u)))) return rc;          // (the fixed set: frame f - 1's landmarks)
+            }
+            // buildRBC reads the fixed set only — the previous frame's landmarks —: this frame's upload is waited for behind it
             auto between = [&] () -> int {
                 int rc2 = record_prev (); if (rc2) return rc2;
-                if ((rc2 = wait_upload ())) return rc2;
-                if (warm) { icp_launch_set_T (p, 0, p.st->T, h->stream); HIPCHK (h, hipGetLastError ()); }
+                if ((rc2 = wait_upload (s))) return rc2;
+                if (gated && f >= 2u) { icp_launch_gate (h->dSeq, (uint32_t) (f - 1u), h->hGateFlag, st); HIPCHK (h, hipGetLastError ()); }
+                if (warm) { icp_launch_set_T (p, 0, p.st->T, st, gated ? 1 : 0); HIPCHK (h, hipGetLastError ()); }
                 return ICP_OK;
             };
-            if ((rc = run_begin (h, p, !warm, true, blind, h->hTrackMirror + ring, h->hTrack + ring, (int) ring, between))) return rc;
-            h->track_epoch[ring] = h->run.p.epoch;
+            if ((rc = run_begin (h, R, st, p, !warm, true, blind, h->hTrackMirror + ring, h->hTrack + ring, (int) ring, between, (gated && P->active) ? P : nullptr))) return rc;
+            h->track_epoch[ring] = R.p.epoch;
+            if (gated && (f & 1u)) h->stream2_dirty = true;
         } else {
             // rounds 1 - 3: buildRBC + a checked run of max_iterations launches as one cached graph (the graphs hold the buffer pointers)
             if ((rc = record_prev ())) return rc;
@@ -1228,6 +1353,7 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     }
     // everything that can fail is behind us: the handle now points at this frame's buffers
     h->dM = newM; h->p.M = newM; h->dF = newF; h->p.F = newF;
+    if (gated && f > 0u) rbc_into (h->p, h->rbc[f & 1u]);
     h->parity = 1u + buf;                                               // graphs hold the pointers: one cached set per rotation step (0: the buffers of icp_init)
     h->built = f > 0u;
     h->track_submitted = f + 1u;
@@ -1236,6 +1362,16 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
 
 int icp_track_submit (icp_handle h, const void *cloud, int warm_start) { return track_submit (h, cloud, warm_start, false); }
 
+int icp_track_form (icp_handle h, int *gated)
+{
+    int rc = need (h, false, true); if (rc) return rc;
+    if (!gated) return fail (h, ICP_EINVAL, "null output");
+    if ((rc = set_device (h))) return rc;
+    if (h->run_adaptive && h->track_gate && h->p.m == 16384u && h->p.batch == 1u && h->ownF && h->ownM && (rc = track_prepare (h))) return rc;   // (runs the probe)
+    *gated = (h->run_adaptive && h->track_gate && h->rbc2_ready && icp_chain_supported (h->p)) ? 1 : 0;
+    return ICP_OK;
+}
+
 int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered)
 {
     int rc = need (h, false, true); if (rc) return rc;
@@ -1243,12 +1379,17 @@ int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered)
     if ((rc = set_device (h))) return rc;
     const uint64_t f = h->track_collected;
     const uint32_t ring = (uint32_t) (f % ICP_TRACK_RING);
-    if (h->run.active && h->run.track_slot == (int) ring) {             // the frame's registration is still open: top it up to its end
-        if ((rc = run_finish (h))) return rc;
-        h->track_k_hist[1] = h->track_k_hist[0]; h->track_k_hist[0] = h->run.k_final;
+    for (int i = 0; i < 2; ++i) {                                       // the frame's registration is still open: top it up to its end
+        run_ctl &R = i ? h->run2 : h->run;
+        run_ctl &O = i ? h->run : h->run2;
+        if (R.active && R.track_slot == (int) ring && R.p.epoch == h->track_epoch[ring]) {
+            if ((rc = run_finish (h, R, O.active ? &O : nullptr))) return rc;
+            track_note_k (h, R);
+        }
     }
     if (f > 0u && h->track_epoch[ring]) { if ((rc = run_wait_final (h, h->hTrackMirror + ring, 1u, h->track_epoch[ring]))) return rc; }
     else HIPCHK (h, hipEventSynchronize (h->evDone[ring]));
+    if (h->hGateFlag && *h->hGateFlag) return fail (h, ICP_EHIP, "tracking: a frame's gate gave up waiting for its predecessor (device-side wait of ~0.5 s exceeded)");
     h->track_collected = f + 1u;
     if (f + 1u == h->track_submitted && f > 0u && h->track_epoch[ring]) {
         // nothing behind this frame: the handle's state is this registration's final state, and the host holds it

@@ -80,6 +80,12 @@ struct icp_params {
     unsigned long long *hmirror; // [batch]  ICP_MIRROR_WORD (epoch, done, k) stored by the lane that publishes a registration's state
     icp_reg_state *hstate;       // [batch]  the final state of a run, stored by its end kernel in front of the word's FINAL bit
     uint32_t epoch;              // tag of the run the words belong to (a word of another epoch is stale)
+    // tracking with frames gated on the device (icp_capi.hip: track_submit): consecutive frames alternate between two streams, so the
+    // launches of a frame that has converged and the next frame's run concurrently
+    uint32_t *run_flag;          // [batch]  epoch of the run that has converged: its remaining launches leave at once and WRITE NOTHING
+    uint32_t *track_seq;         // number of the last registration of a tracked sequence that has finished (k_gate waits on it)
+    uint32_t seq_value;          // this registration's number
+    uint32_t no_state_reset;     // buildRBC leaves k / done alone (it runs ahead of the previous frame's end; the run's first launch resets them)
 };
 
 // progress word of a checked run: bits 0..23 k (iterations whose transform has been published), bit 30 FINAL (the end kernel has
@@ -121,7 +127,10 @@ uint32_t icp_tbox_of (const icp_params &p);
 uint32_t icp_s2_wave_of (const icp_params &p);
 void icp_search_layout_of (const icp_params &p, int *dense, int *tile, int *stage2);   // what icp_launch_search selects          // 1: the dense search scans the lists with lanes = candidates (long lists)
 void icp_launch_reset_state (const icp_params &p, hipStream_t s, int reset_T);
-void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStream_t s);
+void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStream_t s, int reset_k = 0);
+// holds the stream until *seq >= want; bounded: max_spins rounds of ~0.25 us, then *host_timeout_flag = 1 and the stream goes on
+void icp_launch_gate (const uint32_t *seq, uint32_t want, uint32_t *host_timeout_flag, hipStream_t s, uint32_t max_spins = 1u << 22);
+void icp_launch_seq_set (uint32_t *seq, uint32_t v, hipStream_t s);
 void icp_launch_rotation_solver (int rot, int power_mode, const float *din19, float *dout18, hipStream_t s);   // [S 11 | means 8] -> [Tk 8 | Rk 9 | trips]
 void icp_launch_get_lms (const float *cloud, float *lms, hipStream_t s);
 void icp_launch_get_lms_band (const float *band, float *lms, hipStream_t s);

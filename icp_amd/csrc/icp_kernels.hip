@@ -443,6 +443,12 @@ static __device__ bool fused_finalize_block (const icp_params &p, const double *
                             if (final_dst) store_image (final_dst);
                             if (host_dst) { store_image (host_dst); __threadfence_system (); }
                             icp_mirror_store (mirror, ICP_MIRROR_WORD (p.epoch, kprev + 1u, 1u) | (host_dst ? ICP_MIRROR_FINAL : 0ull));
+                            if (progress && p.run_flag) {
+                                // the run is over: its later launches see the flag; a tracked sequence's next frame (held by k_gate on
+                                // the other stream) may start — behind the user-visible state above (release at agent scope)
+                                p.run_flag[blockIdx.y] = p.epoch;
+                                if (p.track_seq) __hip_atomic_store (p.track_seq, p.seq_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                         } else if (progress) icp_mirror_store (mirror, ICP_MIRROR_WORD (p.epoch, kprev + 1u, 0u));
                     }
                 }
@@ -581,6 +587,10 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // lane j = dword j: scalar loads of T would queue behind the waits of the vector loads), the first tile of
     // representatives (+ list offsets / sizes), the query point (clamped address, selected afterwards)
     uint32_t sv = OWNER ? 0u : state_load_lanes (st);
+    // HOSTRUN: the run this launch belongs to may have converged already (its flag holds the run's epoch): such a launch leaves below
+    // without a single store — the next tracked frame may be running on the other stream, in the same state slots and moment buffers
+    uint32_t run_over = 0u;
+    if constexpr (CHAIN && HOSTRUN) { if (p.run_flag) run_over = (p.run_flag[b] == p.epoch) ? 1u : 0u; }
     if constexpr (CHAIN) {
         // bit 4 of check_flags (first launch of a chain): the run starts from the identity transform — what k_reset_state
         // would have left in the state (T = Tk = (0,0,0,1 | 0,0,0,1), R = Rk = I, S = means = sum_w = 0, k = done = 0),
@@ -676,6 +686,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             icp_mirror_store (p.hmirror + b, ICP_MIRROR_WORD (p.epoch, (uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (k)),
                                                               __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))));
     }
+    if constexpr (CHAIN && HOSTRUN) { if (run_over) return; }
     if (!OWNER && check && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))) {    // converged earlier
         if constexpr (CHAIN) {                       // carry the state forward
             if (blockIdx.x == 0 && tid < sizeof (icp_reg_state) / 4) reinterpret_cast<uint32_t *> (sout)[tid] = sv;
@@ -1580,6 +1591,14 @@ static __device__ __forceinline__ void state_to_host (const icp_params &p, uint3
     if (t == 0 && p.hmirror) icp_mirror_store (p.hmirror + b, ICP_MIRROR_WORD (p.epoch, k, done) | ICP_MIRROR_FINAL);
 }
 
+// (tracked sequences: the end kernel of a registration that did not converge releases the next frame's gate — behind the state it has written)
+static __device__ __forceinline__ void seq_release (const icp_params &p, uint32_t t)
+{
+    if (!p.track_seq) return;
+    __threadfence ();
+    if (t == 0) __hip_atomic_store (p.track_seq, p.seq_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int ROT>
 __global__ __launch_bounds__ (320) void k_chain_end (icp_params p)
 {
@@ -1596,6 +1615,7 @@ __global__ __launch_bounds__ (320) void k_chain_end (icp_params p)
             if (t == offsetof (icp_reg_state, pending) / 4) v = 0u;
             if (t < sizeof (icp_reg_state) / 4) reinterpret_cast<uint32_t *> (st)[t] = v;
             state_to_host (p, b, t, v, sin->k, sin->done);
+            seq_release (p, t);
         }
         return;
     }
@@ -1610,6 +1630,7 @@ __global__ __launch_bounds__ (320) void k_chain_end (icp_params p)
         uint32_t v = reinterpret_cast<const uint32_t *> (&s_fin)[min (t, (uint32_t) sizeof (icp_reg_state) / 4u - 1u)];
         if (t == offsetof (icp_reg_state, pending) / 4) v = 0u;
         state_to_host (p, b, t, v, s_fin.k, s_fin.done);
+        seq_release (p, t);
     }
 }
 

@@ -270,6 +270,12 @@ int icp_track_submit (icp_handle h, const void *host_cloud_640x480x8, int warm_s
 int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered);
 int icp_track_staging (icp_handle h, uint32_t slot /* 0 | 1 */, void **pinned_host_frame);
 int icp_track_reset (icp_handle h);
+/* How tracked frames follow each other on the device: *gated = 1 — consecutive registrations alternate between two streams, each held by a
+ * device-side gate (a one-wave kernel, bounded wait) until its predecessor has released the sequence word: a frame's RBC construction and
+ * its predicted launches are enqueued while the previous frame is still running, and the host is not on the path between two frames;
+ * 0 — one stream, a frame's work enqueued when the host has seen the previous one decided (ICP_AMD_TRACK_GATE=0, checked runs as graphs, or
+ * a runtime that serves the two streams from one hardware queue: probed once per handle).  Same results either way. */
+int icp_track_form (icp_handle h, int *gated);
 
 /* ICPTransform<QUATERNION> / ICPTransform<MATRIX> with an explicit transformation — include/ICP/algorithms.hpp:1189-1211,
  * 1240, 1348; src/ICP/algorithms.cpp:2554-2753 (quaternion), :2760-2960 (matrix); kernels/icp_kernels.cl:772-802

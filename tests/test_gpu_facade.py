@@ -603,17 +603,25 @@ def test_resident_reduce_scan_objects_and_timing(engine, oracle):
         engine.ReduceScan(engine.ReduceConfig.SUM, 6, 2)
 
 
-@pytest.mark.parametrize("warm,pinned", [(False, False), (True, False), (True, True)])
-def test_tracking_pipelined_equals_oracle(engine, oracle, warm, pinned):
+@pytest.mark.parametrize("warm,pinned,form", [(False, False, "gated"), (True, False, "gated"), (True, True, "gated"), (False, False, "host-ordered"),
+                                              (True, True, "host-ordered"), (True, False, "graph")])
+def test_tracking_pipelined_equals_oracle(engine, oracle, warm, pinned, form, monkeypatch):
     """icp_track_submit / icp_track_collect with two frames in flight (frame f + 1 is uploaded and its landmarks extracted on the
     copy stream while frame f registers; three landmark buffers in rotation; only the band of a frame that getLMs reads is
     uploaded): every hop's k and T equal the oracle's bit for bit over a 7-frame sequence that revisits frames — pageable
-    sources and the engine's pinned frame buffers —, and equal what the blocking icp_track_next gives."""
+    sources and the engine's pinned frame buffers —, and equal what the blocking icp_track_next gives.  In all three forms a frame
+    can follow its predecessor: behind a device-side gate on the other stream (default), on one stream ordered by the host
+    (ICP_AMD_TRACK_GATE=0), and rounds 1 - 3's one graph per frame (ICP_AMD_RUN_ADAPTIVE=0)."""
+    if form == "host-ordered":
+        monkeypatch.setenv("ICP_AMD_TRACK_GATE", "0")
+    if form == "graph":
+        monkeypatch.setenv("ICP_AMD_RUN_ADAPTIVE", "0")
     clouds = [engine.synth_cloud_vga(moved=f) for f in range(4)]
     order = [0, 1, 2, 3, 2, 1, 0]
     lms = [oracle.get_lms(c) for c in clouds]
     g = engine.ICP(0)
     g.init(16384, 256, 2e2, 1e-6)
+    assert g.track_form() == (1 if form == "gated" else 0)
     res = g.track_pipelined([clouds[i] for i in order], warm_start=warm, depth=2, pinned=pinned)
     assert res[0] is None and len(res) == len(order)
     o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
@@ -882,4 +890,33 @@ def test_pinned_frame_buffers_with_four_frames_in_flight(engine, oracle):
         g.track_reset()
         got = g.track_pipelined([clouds[i] for i in order], warm_start=False, depth=depth, pinned=True)
         assert got[0] is None and all(a[0] == b[0] and a[1].tobytes() == b[1].tobytes() for a, b in zip(got[1:], ref[1:])), depth
+    g.close()
+
+
+def test_tracking_survives_a_mode_switch_in_mid_sequence(engine, oracle):
+    """A tracked sequence whose frames change form on the way: gated (default modes) -> host-ordered (reference-order modes: separate
+    launches carry no gate) -> gated again, two frames in flight throughout; every hop equals the oracle in the modes it ran in."""
+    clouds = [engine.synth_cloud_vga(moved=f) for f in range(4)]
+    lms = [oracle.get_lms(c) for c in clouds]
+    order = [0, 1, 2, 3, 2, 1, 0]
+    ref_hops = (3, 4)
+    g = engine.ICP(0)
+    g.init(16384, 256, 2e2, 1e-6)
+    res, forms = [], []
+    for i, fi in enumerate(order):
+        ref = i in ref_hops
+        g.setReduceMode(engine.ReduceMode.REFERENCE_ORDER if ref else engine.ReduceMode.FUSED)
+        g.setPowerMode(engine.PowerMode.LITERAL if ref else engine.PowerMode.SQUARED)
+        forms.append(g.track_form())
+        g.track_submit(clouds[fi], False)
+        if i >= 1:
+            res.append(g.track_collect())
+    res.append(g.track_collect())
+    assert forms == [0 if i in ref_hops else 1 for i in range(len(order))]
+    for i in range(1, len(order)):
+        ref = i in ref_hops
+        o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=not ref, fused=not ref)
+        o.write_f(lms[order[i - 1]]); o.write_m(lms[order[i]]); o.build_rbc()
+        ko = o.run()
+        assert res[i][0] == ko and np.array_equal(res[i][1].view(np.uint32), o.T.view(np.uint32)), (i, ref)
     g.close()

@@ -1250,7 +1250,8 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     const size_t spitch = (size_t) ICP_BAND_ROW_STEP * 640u * 32u;
     // gated: registration f lives in run slot f & 1 on stream f & 1; its predecessor (f - 1) in the other slot, possibly still open
     // (the release of the sequence word lives in the chained kernel: other forms — reference-order reductions, |R| > 1024 — stay host-ordered)
-    const bool gated = h->run_adaptive && h->track_gate && h->rbc2_ready && icp_chain_supported (h->p);
+    // (and the blocking icp_track_next has nothing to overlap: it stays on one stream and spares itself the gate)
+    const bool gated = !blocking && h->run_adaptive && h->track_gate && h->rbc2_ready && icp_chain_supported (h->p);
     if (gated != h->track_last_gated) {                                 // the form changes in mid-sequence (a mode was switched): start from a drained device
         if ((rc = run_close_all (h))) return rc;
         if (h->stream2) HIPCHK (h, hipStreamSynchronize (h->stream2));

@@ -245,13 +245,14 @@ int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint
  * fixed set by a rotation of three landmark buffers (no copy, no host trip).  Only the band of a frame that getLMs reads
  * (128 rows x 509 pixels = 2.08 MB of the 9.83 MB) is uploaded; the landmarks are extracted on the device (kernels/icp_kernels.cl:63-76).
  *
- * icp_track_submit   upload + getLMs on a copy stream, then buildRBC + ICP::run on the handle's stream; up to four frames may be
- *                    in flight, so frame f + 1 is uploaded while frame f registers.  The registration is a host-driven checked
- *                    run (icp_run): the call first brings the PREVIOUS frame's run to its end (polling its progress word,
- *                    topping up its launches: it returns once that frame is decided), then enqueues this frame's buildRBC and
- *                    as many iterations as the last two registrations suggest it needs (the smaller k, + 1) and returns; the
- *                    next icp_track_* call tops it up.  No launch is spent on iterations past the convergence of a frame
- *                    beyond that prediction / the run depth.
+ * icp_track_submit   upload + getLMs on a copy stream, then buildRBC + ICP::run; up to four frames may be in flight, so frame f + 1 is
+ *                    uploaded while frame f registers.  The registration is a host-driven checked run (icp_run) that gets as many
+ *                    iterations up front as the last two registrations suggest it needs (the smaller k, + 1); later icp_track_* calls
+ *                    top it up.  No launch is spent on iterations past the convergence of a frame beyond that prediction / the run depth.
+ *                    Consecutive registrations alternate between two streams (icp_track_form: gated): this frame's RBC construction
+ *                    (into its own set of RBC buffers) and its launches are enqueued at once, behind a one-wave gate kernel that holds
+ *                    its stream until the previous registration has released the sequence word — the device goes from one frame to
+ *                    the next without the host.  (Host-ordered form: the call first brings the previous frame's run to its end.)
  *                    warm_start != 0: the registration starts from the previous hop's transform (written back as by
  *                    icp_write (ICP_MEM_T): the rotation state is re-derived from it) instead of the identity; the first
  *                    registration of a sequence (after icp_init / icp_track_reset) has no previous hop and starts from the

@@ -3,14 +3,20 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 # -ffp-contract=off: the canonical arithmetic has no fused multiply-add
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -pthread -mllvm -amdgpu-kernarg-preload-count=14
-SRC      := icp_amd/csrc/icp_kernels.hip icp_amd/csrc/icp_build.hip icp_amd/csrc/icp_capi.hip icp_amd/csrc/icp_reduce_scan.hip icp_amd/csrc/icp_standalone.hip icp_amd/csrc/icp_synth.cpp icp_amd/csrc/icp_batch.cpp
-HDR      := icp_amd/csrc/icp_device.h icp_amd/csrc/icp_kernels.h include/icp_amd.h
+SRC      := icp_amd/csrc/icp_kernels.hip icp_amd/csrc/icp_search_dense.hip icp_amd/csrc/icp_build.hip icp_amd/csrc/icp_capi.hip icp_amd/csrc/icp_reduce_scan.hip icp_amd/csrc/icp_standalone.hip icp_amd/csrc/icp_synth.cpp icp_amd/csrc/icp_batch.cpp
+HDR      := icp_amd/csrc/icp_device.h icp_amd/csrc/icp_kernels.h icp_amd/csrc/icp_search.h include/icp_amd.h
 LIB      := icp_amd/libicp_amd.so
+OBJ      := $(patsubst icp_amd/csrc/%,build/%.o,$(SRC))
 
 all: $(LIB) oracle
 
-$(LIB): $(SRC) $(HDR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRC)
+# one object per source (the two k_search translation units are the long ones: `make` builds them side by side)
+build/%.o: icp_amd/csrc/% $(HDR)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(OBJ)
+	$(HIPCC) -fPIC --offload-arch=$(ARCH) -pthread -shared -o $@ $(OBJ)
 
 oracle:
 	$(MAKE) -C oracle
@@ -41,7 +47,7 @@ asan: tests/cpp/asan_host
 	ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 tests/cpp/asan_host
 
 clean:
-	rm -f $(LIB) examples/registration examples/step_by_step tests/cpp/facade_test tests/cpp/capi_example tests/cpp/icpreg_test tests/cpp/asan_host tests/cpp/asan_oracle.o
+	rm -rf build; rm -f $(LIB) examples/registration examples/step_by_step tests/cpp/facade_test tests/cpp/capi_example tests/cpp/icpreg_test tests/cpp/asan_host tests/cpp/asan_oracle.o
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean asan examples

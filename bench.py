@@ -609,6 +609,17 @@ def main():
             if torch is not None and torch.cuda.is_available():
                 torch.cuda.synchronize()
 
+        # what a freshly started process sees (reported beside the metric, never as it): the same W warm-up + K timed steps BEFORE the
+        # device has been kept busy for SETUP_MS — an MI355X that was idle runs its first ~10 ms of work below its steady clocks
+        unsettled = None
+        if dist is None:
+            for _ in range(warmup):
+                g.run_fixed_fresh(iters)
+            g.sync()
+            t0u = time.perf_counter()
+            g.time_run_fixed_tail(iters, steps, from_identity=True)
+            g.sync()
+            unsettled = steps * iters * batch / (time.perf_counter() - t0u)
         setup_passes = settle(g, iters)
         for _ in range(warmup):
             g.run_fixed_fresh(iters)                     # a fresh registration: from the identity transform, one graph
@@ -694,6 +705,11 @@ def main():
                        "reduce_mode": args.reduce_mode, "launches_per_iteration": launches},
             "roofline": roofline,
         }
+        if launch == "single":
+            line["value_right_after_start"] = {"iterations_per_s": unsettled,
+                                               "note": "the same %d warm-up + %d timed steps measured BEFORE the %.0f ms of untimed set-up work (a device that has just been "
+                                                       "idle, below its steady clocks): what the first registrations of a freshly started process run at; `value` is "
+                                                       "the steady state" % (warmup, steps, SETUP_MS)}
         line["per_gpu_iterations_per_s"] = per_gpu
         if devices_used is not None:
             line["config"]["devices"] = devices_used
@@ -714,7 +730,7 @@ def main():
             oc = {"A_x64": measure_config(icp_amd, device, "A", 64, 20, 3, ITERS_PER_STEP, args.power_mode, args.reduce_mode, warm_seed=not args.no_other_configs)}
             line["config4_per_gpu_value"] = oc["A_x64"]["iterations_per_s"]
             if not args.no_other_configs:
-                for key, cfg, b, st, wu, it in (("B", "B", 1, 40, 5, ITERS_PER_STEP), ("C", "C", 1, 3, 1, 10)):
+                for key, cfg, b, st, wu, it in (("B", "B", 1, 40, 5, ITERS_PER_STEP), ("C", "C", 1, 10, 2, 10)):
                     oc[key] = measure_config(icp_amd, device, cfg, b, st, wu, it, args.power_mode, args.reduce_mode)
                 oc["track"] = measure_tracking(icp_amd, device)
             line["other_configs"] = oc

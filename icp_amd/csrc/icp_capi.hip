@@ -1284,12 +1284,21 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     } else {
         // pageable source: the band's 128 row segments into the slot's pinned staging (free once the upload of frame f - 2 is through)
         if (f >= 2u) HIPCHK (h, hipEventSynchronize (h->evUp[s]));
+        // in two pieces, each uploaded as soon as it is staged: the DMA of the first runs under the host copy of the second (a blocking
+        // icp_track_next waits for 60 us of copy + 45 us of upload otherwise; every copy command costs ~12 us by itself, so more pieces
+        // give the gain back: 1 / 2 / 4 pieces = 393 / 371 / 393 us per blocking cold frame; ICP_AMD_BAND_PIECES for the comparison)
+        static const uint32_t npieces = [] { const char *e = std::getenv ("ICP_AMD_BAND_PIECES"); const int v = e ? std::atoi (e) : 2; return (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t) v : 2u; } ();
+        const uint32_t piece = ICP_BAND_ROWS / npieces;
         for (uint32_t j = 0; j < ICP_BAND_ROWS; ++j) {
             std::memcpy (reinterpret_cast<char *> (h->hBand[s]) + (size_t) j * ICP_BAND_ROW_BYTES, src + (size_t) j * spitch, ICP_BAND_ROW_BYTES);
             // (the copy takes ~60 us: the previous frame's open registration is looked after on the way — a word read, a launch if it needs one)
             if ((j & 7u) == 7u && P->active) (void) run_pump (h, *P);
+            if ((j + 1u) % piece == 0u) {
+                const size_t off = (size_t) (j + 1u - piece) * ICP_BAND_ROW_BYTES;
+                HIPCHK (h, hipMemcpyAsync (reinterpret_cast<char *> (h->dBand[s]) + off, reinterpret_cast<char *> (h->hBand[s]) + off, (size_t) piece * ICP_BAND_ROW_BYTES,
+                                           hipMemcpyHostToDevice, h->copy_stream));
+            }
         }
-        HIPCHK (h, hipMemcpyAsync (h->dBand[s], h->hBand[s], ICP_BAND_BYTES, hipMemcpyHostToDevice, h->copy_stream));
     }
     icp_launch_get_lms_band (h->dBand[s], h->lm[buf], h->copy_stream);
     HIPCHK (h, hipGetLastError ());

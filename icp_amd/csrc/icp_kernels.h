@@ -123,6 +123,8 @@ bool icp_build_lists (const icp_params &p);      // buildRBC = owner search + k_
 bool icp_dense (const icp_params &p);            // the dense search variant (several blocks per CU, stage-1 pruning)
 uint32_t icp_dense_tile (const icp_params &p);   // its LDS tile: 256 or 1024 representatives
 void icp_launch_owner_search (const icp_params &p, hipStream_t s);   // RBC construct, step 1 (k_search<.., OWNER>)
+void icp_launch_search_dense (const icp_params &p, hipStream_t s);          // icp_search_dense.hip: the dense variants (icp_dense (p))
+void icp_launch_owner_search_dense (const icp_params &p, hipStream_t s);
 uint32_t icp_tbox_of (const icp_params &p);
 uint32_t icp_s2_wave_of (const icp_params &p);
 void icp_search_layout_of (const icp_params &p, int *dense, int *tile, int *stage2);   // what icp_launch_search selects          // 1: the dense search scans the lists with lanes = candidates (long lists)

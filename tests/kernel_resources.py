@@ -47,7 +47,7 @@ def kernel_resources(source="icp_amd/csrc/icp_kernels.hip", extra_flags=()):
 
 
 if __name__ == "__main__":
-    srcs = sys.argv[1:] or ["icp_amd/csrc/icp_kernels.hip", "icp_amd/csrc/icp_build.hip", "icp_amd/csrc/icp_reduce_scan.hip"]
+    srcs = sys.argv[1:] or ["icp_amd/csrc/icp_kernels.hip", "icp_amd/csrc/icp_search_dense.hip", "icp_amd/csrc/icp_build.hip", "icp_amd/csrc/icp_reduce_scan.hip"]
     for s in srcs:
         for n, r in kernel_resources(s).items():
             print("%-60s vgpr %3d sgpr %3d scratch %4d occupancy %d lds %6d" % (n[:60], r.get("vgprs", -1), r.get("sgprs", -1),

@@ -920,3 +920,29 @@ def test_tracking_survives_a_mode_switch_in_mid_sequence(engine, oracle):
         ko = o.run()
         assert res[i][0] == ko and np.array_equal(res[i][1].view(np.uint32), o.T.view(np.uint32)), (i, ref)
     g.close()
+
+
+@pytest.mark.parametrize("warm", [False, True])
+def test_tracked_frames_that_run_out_of_iterations(engine, oracle, warm):
+    """max_iterations = 5: no registration of the sequence converges — every frame ends in its end kernel, which is what releases the next
+    frame's gate then (and what leaves the final state in host memory); two and three frames in flight, every hop equal to the oracle's
+    five iterations bit for bit."""
+    clouds = [engine.synth_cloud_vga(moved=f) for f in range(4)]
+    lms = [oracle.get_lms(c) for c in clouds]
+    order = [0, 1, 2, 3, 2, 1, 0, 1]
+    g = engine.ICP(0)
+    g.init(16384, 256, 2e2, 1e-6, max_iterations=5)
+    assert g.track_form() == 1
+    for depth in (2, 3):
+        g.track_reset()
+        res = g.track_pipelined([clouds[i] for i in order], warm_start=warm, depth=depth)
+        o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True, max_iterations=5)
+        for i in range(1, len(order)):
+            o.write_f(lms[order[i - 1]]); o.write_m(lms[order[i]])
+            o.write_t(o.T if (warm and i > 1) else [0, 0, 0, 1, 0, 0, 0, 1])
+            o.build_rbc()
+            ko = o.run()
+            assert ko == 5 and res[i][0] == 5, (i, res[i][0])
+            assert np.array_equal(res[i][1].view(np.uint32), o.T.view(np.uint32)), (depth, i)
+        assert g.state().converged == 0 and np.array_equal(g.read(engine.Memory.NN_ID)["id"], o.nn_id["id"])
+    g.close()

@@ -14,6 +14,7 @@ from kernel_resources import FLAGS, ROOT, kernel_resources
 @pytest.fixture(scope="module")
 def res():
     r = dict(kernel_resources("icp_amd/csrc/icp_kernels.hip"))
+    r.update(kernel_resources("icp_amd/csrc/icp_search_dense.hip"))   # the dense variants of the search
     r.update(kernel_resources("icp_amd/csrc/icp_build.hip"))        # state, getLMs, transforms, the RBC construction, the rotation solver
     return r
 

@@ -590,9 +590,11 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     if constexpr (!OWNER && !CHAIN) {
         // host-driven checked runs (icp_run; see run_ctl in icp_capi.hip), separate launches: the search of iteration j tells the host that j
         // iterations are through and whether the last one converged — one 8-byte store into host memory that nothing here waits for
-        if (p.hmirror && blockIdx.x == 0 && tid == 0)
-            icp_mirror_store (p.hmirror + b, ICP_MIRROR_WORD (p.epoch, (uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (k)),
-                                                              __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))));
+        // (fused mode: the finalize that found a registration converged has published DONE | FINAL with the final state itself — a search
+        // behind it must not overwrite that word; reference order: the search is the only one that tells)
+        const uint32_t done_ = (uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done));
+        if (p.hmirror && blockIdx.x == 0 && tid == 0 && !(FUSED && done_))
+            icp_mirror_store (p.hmirror + b, ICP_MIRROR_WORD (p.epoch, (uint32_t) __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (k)), done_));
     }
     if constexpr (CHAIN && HOSTRUN) { if (run_over) return; }
     if (!OWNER && check && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (done))) {    // converged earlier

@@ -668,8 +668,12 @@ def main():
     roofline = roofline_of(g, m, nr, batch, iters, ev_steps, ev_ms, fused, tkey) if rank == 0 else None
     launches = g.launches_per_iteration()
     headline = launch == "single" and args.config == "A" and batch == 1
-    modes = measure_modes(icp_amd, device, g, args.power_mode, args.reduce_mode) if (rank == 0 and headline and fused and args.power_mode == "squared"
-                                                                                     and not args.no_other_configs) else None
+    modes = None
+    if rank == 0 and headline and fused and args.power_mode == "squared" and not args.no_other_configs:
+        try:
+            modes = measure_modes(icp_amd, device, g, args.power_mode, args.reduce_mode)
+        except Exception as e:                       # noqa: BLE001 — beside the metric: reported, never fatal
+            modes = {"mode_note": {"error": "%s: %s" % (type(e).__name__, e)}}
     g.close()
 
     if rank == 0:
@@ -727,12 +731,19 @@ def main():
         if headline:
             # config 4's per-GPU share on this GPU (always: the field every line carries), then the other BASELINE configs, same step
             # definition, fewer steps (C: 3 steps of 10 iterations), tracking, and what the benchmarked mode is against the other one
-            oc = {"A_x64": measure_config(icp_amd, device, "A", 64, 20, 3, ITERS_PER_STEP, args.power_mode, args.reduce_mode, warm_seed=not args.no_other_configs)}
-            line["config4_per_gpu_value"] = oc["A_x64"]["iterations_per_s"]
+            # (everything beside the metric is guarded: a failure there is reported in its place and never costs the line its `value`)
+            def guarded(fn, *a, **kw):
+                try:
+                    return fn(*a, **kw)
+                except Exception as e:               # noqa: BLE001
+                    return {"error": "%s: %s" % (type(e).__name__, e)}
+
+            oc = {"A_x64": guarded(measure_config, icp_amd, device, "A", 64, 20, 3, ITERS_PER_STEP, args.power_mode, args.reduce_mode, warm_seed=not args.no_other_configs)}
+            line["config4_per_gpu_value"] = oc["A_x64"].get("iterations_per_s")
             if not args.no_other_configs:
                 for key, cfg, b, st, wu, it in (("B", "B", 1, 40, 5, ITERS_PER_STEP), ("C", "C", 1, 10, 2, 10)):
-                    oc[key] = measure_config(icp_amd, device, cfg, b, st, wu, it, args.power_mode, args.reduce_mode)
-                oc["track"] = measure_tracking(icp_amd, device)
+                    oc[key] = guarded(measure_config, icp_amd, device, cfg, b, st, wu, it, args.power_mode, args.reduce_mode)
+                oc["track"] = guarded(measure_tracking, icp_amd, device)
             line["other_configs"] = oc
             if modes is not None:
                 line.update(modes)

@@ -480,8 +480,8 @@ void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStr
 
 // Gate of a tracked frame: one wave that holds its stream until registration `want` of the sequence has finished (*seq >= want, written
 // by the launch that found the previous frame converged, or by its end kernel) — the previous frame runs on the OTHER stream, and the
-// launches behind this kernel were enqueued while it was still running.  Every wave reaches the exit: the wait is bounded (~0.5 s of
-// s_sleep rounds, far beyond any registration); a timeout raises *flag (host memory) and lets the stream go on.
+// launches behind this kernel were enqueued while it was still running.  Every wave reaches the exit: the wait is bounded (max_spins
+// s_sleep rounds: ~0.5 s by default, far beyond any registration); a timeout raises *flag (host memory) and lets the stream go on.
 __global__ __launch_bounds__ (64) void k_gate (const uint32_t *seq, uint32_t want, uint32_t *flag, uint32_t max_spins)
 {
     if (threadIdx.x != 0) return;

@@ -98,6 +98,7 @@ struct icp_context {
     unsigned long long *hTrackMirror = nullptr;              // pinned: their progress words
     uint32_t track_epoch[4] = { 0, 0, 0, 0 };                // epoch of the run in each ring slot
     uint32_t track_k_hist[2] = { 0, 0 };                     // k of the last two registrations of the sequence (0: none yet): the next frame's blind launches
+    uint64_t track_hist_frame = 0;                           // 1 + the latest frame whose k is in that history
     hipStream_t copy_stream = nullptr;
     // Tracking with frames gated on the device (track_gate; ICP_AMD_TRACK_GATE=0 switches it off): registration f runs on stream f & 1 (the
     // handle's own stream / stream2) behind k_gate, which waits for registration f - 1's release of *dSeq — so frame f's RBC construction
@@ -153,7 +154,7 @@ void free_all (icp_context *h)
     if (h->hMirror) (void) hipHostFree (h->hMirror);
     if (h->hTrackMirror) (void) hipHostFree (h->hTrackMirror);
     h->hState = nullptr; h->hMirror = h->hTrackMirror = nullptr; h->hstate_fresh = false;
-    h->run = run_ctl {}; h->track_k_hist[0] = h->track_k_hist[1] = 0;
+    h->run = run_ctl {}; h->track_k_hist[0] = h->track_k_hist[1] = 0; h->track_hist_frame = 0;
     if (h->dCloud) (void) hipFree (h->dCloud);
     if (h->dCloudOut) (void) hipFree (h->dCloudOut);
     h->hF = h->hM = h->hT = nullptr; h->dCloud = h->dCloudOut = nullptr; h->cloud_cap = 0;
@@ -1152,7 +1153,9 @@ static int track_prepare (icp_context *h)
         const icp_params &p = h->p;
         if (!h->stream2) HIPCHK (h, hipStreamCreateWithFlags (&h->stream2, hipStreamNonBlocking));
         if (!h->dSeq) { HIPCHK (h, hipMalloc ((void **) &h->dSeq, sizeof (uint32_t))); HIPCHK (h, hipMemset (h->dSeq, 0, sizeof (uint32_t))); }
-        if (!h->dRunFlag) { HIPCHK (h, hipMalloc ((void **) &h->dRunFlag, sizeof (uint32_t))); HIPCHK (h, hipMemset (h->dRunFlag, 0, sizeof (uint32_t))); }
+        // (one flag per stream: a run's flag must stay what it is until the last of that run's launches has gone through — the NEXT frame, on
+        // the other stream, may converge while launches of this one are still queued; the frame after that is behind them on this stream)
+        if (!h->dRunFlag) { HIPCHK (h, hipMalloc ((void **) &h->dRunFlag, 2 * sizeof (uint32_t))); HIPCHK (h, hipMemset (h->dRunFlag, 0, 2 * sizeof (uint32_t))); }
         if (!h->hGateFlag) { HIPCHK (h, hipHostMalloc ((void **) &h->hGateFlag, sizeof (uint32_t), hipHostMallocMapped | hipHostMallocCoherent)); *h->hGateFlag = 0u; }
         icp_context::rbc_set &a = h->rbc[0], &b = h->rbc[1];
         a.R = p.R; a.GB = p.GB; a.XP = p.XP; a.XQ = p.XQ; a.rep_src = p.rep_src; a.owner = p.owner; a.N = p.N; a.O = p.O; a.perm = p.perm;
@@ -1195,7 +1198,15 @@ static void rbc_into (icp_params &p, const icp_context::rbc_set &q)
     p.chunk_hist = q.chunk_hist; p.blist = q.blist; p.bn = q.bn; p.brank = q.brank;
 }
 
-static void track_note_k (icp_context *h, const run_ctl &r) { h->track_k_hist[1] = h->track_k_hist[0]; h->track_k_hist[0] = r.k_final; }
+// the iteration counts of the last two registrations the host knows the outcome of (a run that was decided because all max_iterations
+// launches were out tells nothing yet: its real k comes with its final state, at icp_track_collect)
+static void track_note_k (icp_context *h, uint64_t frame, uint32_t k)
+{
+    if (frame + 1u <= h->track_hist_frame) return;                       // (this frame, or a later one, is in the history already)
+    h->track_hist_frame = frame + 1u;
+    h->track_k_hist[1] = h->track_k_hist[0]; h->track_k_hist[0] = k;
+}
+static void track_note_k (icp_context *h, const run_ctl &r) { if (r.done_seen) track_note_k (h, r.p.seq_value, r.k_final); }
 
 int icp_track_reset (icp_handle h)
 {
@@ -1208,7 +1219,7 @@ int icp_track_reset (icp_handle h)
     if (h->dSeq) HIPCHK (h, hipMemset (h->dSeq, 0, sizeof (uint32_t)));
     if (h->hGateFlag) *h->hGateFlag = 0u;
     h->track_submitted = h->track_collected = 0;
-    h->track_k_hist[0] = h->track_k_hist[1] = 0;
+    h->track_k_hist[0] = h->track_k_hist[1] = 0; h->track_hist_frame = 0;
     h->track_last_gated = false;
     return ICP_OK;
 }
@@ -1231,6 +1242,7 @@ int icp_track_staging (icp_handle h, uint32_t slot, void **host_ptr)
 // registration of a sequence gets depth + 1 and is topped up by the next call.
 static uint32_t track_blind (const icp_context *h)
 {
+    { const char *e = std::getenv ("ICP_AMD_TRACK_BLIND"); if (e) return (uint32_t) std::max (1, std::atoi (e)); }     // diagnostics / tests: a fixed number
     const uint32_t a = h->track_k_hist[0], b = h->track_k_hist[1];
     const uint32_t k = a && b ? std::min (a, b) : (a ? a : b);
     return k ? k + 1u : h->run_depth + 1u;
@@ -1316,7 +1328,7 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     auto wait_upload = [&] (uint32_t slot) -> int { if (hipEventQuery (h->evUp[slot]) != hipSuccess) { (void) hipGetLastError (); HIPCHK (h, hipStreamWaitEvent (st, h->evUp[slot], 0)); } return ICP_OK; };
     note_inputs_change (h);
     float *newM = h->lm[buf], *newF = h->lm[(f + 2u) % 3u];             // (f - 1) mod 3: the previous frame's landmarks (first frame: a buffer that is not M)
-    icp_params p = h->p; p.M = newM; p.F = newF;
+    icp_params p = h->p; p.M = newM; p.F = newF; p.seq_value = (uint32_t) f;
     if (gated) rbc_into (p, h->rbc[f & 1u]);
     if (f > 0u) {
         note_enqueue (h);
@@ -1328,7 +1340,7 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
             if (gated) {
                 // buildRBC runs AHEAD of the previous frame's end (its own RBC set, the fixed landmarks resident since that frame's upload)
                 // and must not touch the registration state; behind it the gate: registration f - 1 has released the sequence word
-                p.no_state_reset = 1u; p.run_flag = h->dRunFlag; p.track_seq = h->dSeq; p.seq_value = (uint32_t) f;
+                p.no_state_reset = 1u; p.run_flag = h->dRunFlag + (f & 1u); p.track_seq = h->dSeq; p.seq_value = (uint32_t) f;
                 if ((rc = wait_upload ((uint32_t) ((f - 1u) & 1u)))) return rc;          // (the fixed set: frame f - 1's landmarks)
             }
             // buildRBC reads the fixed set only — the previous frame's landmarks —: this frame's upload is waited for behind it
@@ -1409,6 +1421,7 @@ int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered)
     if (registered) *registered = f > 0u ? 1 : 0;
     if (f > 0u) {
         const icp_reg_state &st = h->hTrack[ring];
+        track_note_k (h, f, st.k);
         if (k) *k = st.k;
         if (T8) std::memcpy (T8, st.T, 8 * sizeof (float));
     } else if (T8) { const float T0[8] = { 0, 0, 0, 1, 0, 0, 0, 1 }; std::memcpy (T8, T0, sizeof T0); }

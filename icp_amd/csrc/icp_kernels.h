@@ -82,7 +82,8 @@ struct icp_params {
     uint32_t epoch;              // tag of the run the words belong to (a word of another epoch is stale)
     // tracking with frames gated on the device (icp_capi.hip: track_submit): consecutive frames alternate between two streams, so the
     // launches of a frame that has converged and the next frame's run concurrently
-    uint32_t *run_flag;          // [batch]  epoch of the run that has converged: its remaining launches leave at once and WRITE NOTHING
+    uint32_t *run_flag;          // [batch]  epoch of the run that has converged: its remaining launches leave at once and WRITE NOTHING (one flag per
+                                 // stream: it has to outlive the run's last queued launch, and the next frame on the other stream may converge before that)
     uint32_t *track_seq;         // number of the last registration of a tracked sequence that has finished (k_gate waits on it)
     uint32_t seq_value;          // this registration's number
     uint32_t no_state_reset;     // buildRBC leaves k / done alone (it runs ahead of the previous frame's end; the run's first launch resets them)

@@ -417,6 +417,10 @@ __global__ __launch_bounds__ (320) void k_chain_end (icp_params p)
     __shared__ icp_fin_result s_fin;
     __shared__ double s_l1[ICP_NMOM][32];
     __shared__ double s_t[ICP_NMOM];
+    // a run whose flag is up has converged: the launch that found out has stored the final state (user-visible and host) and released the
+    // sequence word itself, and the launches behind it carried nothing forward — the state slot this kernel would read is stale.  (The host
+    // enqueues this kernel without knowing when all max_iterations launches went out at once.)
+    if (p.run_flag && p.run_flag[b] == p.epoch) return;
     if ((p.check && sin->done) || !sin->pending) {
         if (threadIdx.x < 64) {
             const uint32_t t = threadIdx.x;

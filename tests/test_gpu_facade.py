@@ -946,3 +946,49 @@ def test_tracked_frames_that_run_out_of_iterations(engine, oracle, warm):
             assert np.array_equal(res[i][1].view(np.uint32), o.T.view(np.uint32)), (depth, i)
         assert g.state().converged == 0 and np.array_equal(g.read(engine.Memory.NN_ID)["id"], o.nn_id["id"])
     g.close()
+
+
+@pytest.mark.parametrize("warm,seed,blind", [(False, 1, None), (True, 2, None), (False, 1, "40"), (True, 3, "40"), (False, 4, "2")])
+def test_tracking_stress_random_sequence(engine, oracle, warm, seed, blind, monkeypatch):
+    """Forty-eight hops through five frames in random order (also the same frame twice in a row: a registration that converges at once), the
+    number of frames in flight changing on the way (1 .. 4), pageable and pinned sources mixed — frames gated on the device —: every hop's k
+    and T equal the oracle's bit for bit.  Also with every frame's launches all enqueued up front (ICP_AMD_TRACK_BLIND=40: a frame that
+    converges early leaves dozens of launches behind it that run beside the next frame, and an end kernel the host enqueued blindly) and
+    with next to none (2: everything topped up).  (This test found both: a converged run's flag overwritten by the next frame's while its
+    own launches were still queued, and the blind end kernel finalizing a stale state slot.)"""
+    if blind:
+        monkeypatch.setenv("ICP_AMD_TRACK_BLIND", blind)
+    rng = np.random.default_rng(seed)
+    clouds = [engine.synth_cloud_vga(moved=f) for f in range(5)]
+    lms = [oracle.get_lms(c) for c in clouds]
+    order = [int(x) for x in rng.integers(0, 5, 49)]
+    g = engine.ICP(0)
+    g.init(16384, 256, 2e2, 1e-6)
+    assert g.track_form() == 1
+    res, inflight = [], 0
+    for i, fi in enumerate(order):
+        depth = int(rng.integers(1, 5))
+        while inflight >= depth:
+            res.append(g.track_collect()); inflight -= 1
+        if rng.random() < 0.4:
+            slot = i & 1
+            g.track_staging(slot)[...] = clouds[fi]
+            g.track_submit(slot, warm)
+        else:
+            g.track_submit(clouds[fi], warm)
+        inflight += 1
+    while inflight:
+        res.append(g.track_collect()); inflight -= 1
+    assert res[0] is None and len(res) == len(order)
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+    ks = []
+    for i in range(1, len(order)):
+        o.write_f(lms[order[i - 1]]); o.write_m(lms[order[i]])
+        o.write_t(o.T if (warm and i > 1) else [0, 0, 0, 1, 0, 0, 0, 1])
+        o.build_rbc()
+        ko = o.run()
+        ks.append(ko)
+        assert res[i][0] == ko, (i, res[i][0], ko)
+        assert np.array_equal(res[i][1].view(np.uint32), o.T.view(np.uint32)), i
+    assert min(ks) <= 3 and max(ks) >= 25                     # from "already there" to a long registration
+    g.close()

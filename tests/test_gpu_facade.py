@@ -992,3 +992,43 @@ def test_tracking_stress_random_sequence(engine, oracle, warm, seed, blind, monk
         assert np.array_equal(res[i][1].view(np.uint32), o.T.view(np.uint32)), i
     assert min(ks) <= 3 and max(ks) >= 25                     # from "already there" to a long registration
     g.close()
+
+
+def test_tracking_interrupted_by_other_calls_and_resets(engine, oracle):
+    """Frames in flight on two streams, and the caller does something else: a read of T with three frames uncollected (every open run is
+    brought to its end, the second stream drained: T is the last submitted hop's), the frames are collected afterwards and the sequence goes
+    on; then icp_track_reset with frames in flight and a new sequence; then a plain icp_run on the same handle."""
+    clouds = [engine.synth_cloud_vga(moved=f) for f in range(4)]
+    lms = [oracle.get_lms(c) for c in clouds]
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+    def hop(a, b):
+        o.write_f(lms[a]); o.write_m(lms[b]); o.write_t([0, 0, 0, 1, 0, 0, 0, 1]); o.build_rbc()
+        return o.run(), o.T.copy()
+    g = engine.ICP(0)
+    g.init(16384, 256, 2e2, 1e-6)
+    for i in (0, 1, 2, 3):
+        g.track_submit(clouds[i], False)
+    k23, T23 = hop(2, 3)
+    assert np.array_equal(g.read(engine.Memory.T).view(np.uint32), T23.view(np.uint32))      # three registrations in flight: all ended here
+    got = [g.track_collect() for _ in range(4)]
+    assert got[0] is None
+    for i in (1, 2, 3):
+        k, T = hop(i - 1, i)
+        assert got[i][0] == k and np.array_equal(got[i][1].view(np.uint32), T.view(np.uint32)), i
+    g.track_submit(clouds[1], False)                                                         # the sequence goes on: 3 -> 1
+    k, T = hop(3, 1)
+    r = g.track_collect()
+    assert r[0] == k and np.array_equal(r[1].view(np.uint32), T.view(np.uint32))
+    g.track_submit(clouds[0], False); g.track_submit(clouds[2], False)                       # two in flight ...
+    g.track_reset()                                                                          # ... and gone
+    res = g.track_pipelined([clouds[2], clouds[0], clouds[3]], warm_start=False, depth=3)
+    assert res[0] is None
+    for (a, b), r in zip(((2, 0), (0, 3)), res[1:]):
+        k, T = hop(a, b)
+        assert r[0] == k and np.array_equal(r[1].view(np.uint32), T.view(np.uint32)), (a, b)
+    # a plain registration on the same handle afterwards: F / M are the last hop's sets, the RBC is rebuilt by the caller
+    g.reset_transform(); g.buildRBC()
+    k, T = hop(0, 3)
+    assert g.run() == k and np.array_equal(g.read(engine.Memory.T).view(np.uint32), T.view(np.uint32))
+    assert np.array_equal(g.read(engine.Memory.NN_ID)["id"], o.nn_id["id"])
+    g.close()

@@ -38,7 +38,7 @@ struct graph_entry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; 
 struct run_ctl {
     bool active = false, decided = false, chained = false, fresh = false;
     icp_params p {};
-    uint32_t enq = 0, maxit = 0, depth = 0, k_seen = 0, k_final = 0;
+    uint32_t enq = 0, maxit = 0, depth = 0, k_seen = 0, k_final = 0, k0 = 0;     // k0: the device's k when the run began (k_seen is relative to it)
     int done_seen = 0;
     bool final_seen = false;                            // every registration's final state has arrived with its converged flag: no end kernel
     volatile unsigned long long *mirror = nullptr;      // host view of p.hmirror
@@ -72,6 +72,10 @@ struct icp_context {
     bool hstate_here = false;                    // ... and it has arrived (host-driven run: its FINAL bit was seen); else: once the stream has drained
     unsigned long long *hMirror = nullptr;       // pinned (fine-grained): progress words of the checked run in flight, [batch] (run_ctl)
     uint32_t epoch = 0;                          // tag of the last checked run
+    // what the host knows about the device's iteration counter k (all registrations alike): a checked run's progress words carry k itself,
+    // and a run that does not start at 0 (a second icp_run without buildRBC) paces itself against k - k_base.  -1: unknown (paced as from 0:
+    // a few launches more queued than `depth`, nothing else)
+    long long k_base = 0;
     uint32_t run_depth = 3;                      // launches kept queued behind the one in flight (ICP_AMD_RUN_DEPTH)
     int run_adaptive = 1;                        // 0 (ICP_AMD_RUN_ADAPTIVE=0): checked runs as one graph of max_iterations launches (rounds 1 - 3)
     run_ctl run;                                 // the open checked run (tracking: of the frames on the handle's own stream)
@@ -364,6 +368,7 @@ int run_begin (icp_context *h, run_ctl &r, hipStream_t stream, const icp_params 
     for (uint32_t b = 0; b < p.batch; ++b) mirror[b] = 0ull;
     std::atomic_thread_fence (std::memory_order_seq_cst);
     r.chained = icp_chain_supported (r.p); r.fresh = fresh;
+    r.k0 = (fresh || with_build || h->k_base < 0) ? 0u : (uint32_t) h->k_base;      // (a fresh run and a rebuilt RBC start the count at 0)
     r.maxit = h->max_iterations; r.depth = h->run_depth ? h->run_depth : 1u;
     if (with_build) icp_launch_build_rbc (r.p, r.stream);
     { int rc = between (); if (rc) return rc; }
@@ -374,9 +379,9 @@ int run_begin (icp_context *h, run_ctl &r, hipStream_t stream, const icp_params 
         run_launch_one (h, r);
         if (other && other->active && (r.enq & 3u) == 0u) (void) run_pump (h, *other);
     }
-    if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit; }
+    if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit + r.k0; }
     HIPCHK (h, hipGetLastError ());
-    h->hstate_fresh = false; h->hstate_here = false;
+    h->hstate_fresh = false; h->hstate_here = false; h->k_base = -1;
     r.t[1] = now_s ();
     return ICP_OK;
 }
@@ -390,19 +395,19 @@ bool run_pump (icp_context *h, run_ctl &r)
     for (uint32_t b = 0; b < r.p.batch; ++b) {
         const unsigned long long w = r.mirror[b];
         const bool mine = (uint32_t) (w >> 32) == r.p.epoch;
-        const uint32_t k = mine ? (uint32_t) (w & 0xFFFFFFull) : 0u;
+        const uint32_t kabs = mine ? (uint32_t) (w & 0xFFFFFFull) : 0u, k = kabs > r.k0 ? kabs - r.k0 : 0u;
         const bool done = mine && (w & ICP_MIRROR_DONE);
         kmax = std::max (kmax, k);
         if (!done) { all_done = false; kmin = std::min (kmin, k); }
         if (!(mine && (w & ICP_MIRROR_FINAL))) all_final = false;
     }
-    if (all_done) { r.decided = true; r.done_seen = 1; r.final_seen = all_final; r.k_seen = kmax; r.k_final = kmax; return true; }
+    if (all_done) { r.decided = true; r.done_seen = 1; r.final_seen = all_final; r.k_seen = kmax; r.k_final = kmax + r.k0; return true; }
     if (kmin && !r.k_seen) r.t[2] = now_s ();
     r.k_seen = kmin;
     // launch (chained) / search (separate launches) j publishes k = j in its prologue: k_seen = the iteration in flight, `depth`
     // iterations are kept queued behind it
     while (r.enq < r.maxit && r.enq < r.k_seen + 1u + r.depth) run_launch_one (h, r);
-    if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit; }
+    if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit + r.k0; }
     return r.decided;
 }
 
@@ -420,6 +425,7 @@ int run_finish (icp_context *h, run_ctl &r, run_ctl *other)
         if ((++spins & 0x3FFu) == 0u) {
             const auto now = std::chrono::steady_clock::now ();
             if (r.k_seen != k_last) { k_last = r.k_seen; t_last = now; }
+            else if (r.k0 && std::chrono::duration<double> (now - t_last).count () > 0.05) { r.k0 = 0u; t_last = now; }      // (a stale idea of where the count began: pace on k itself)
             else if (std::chrono::duration<double> (now - t_last).count () > 20.0) {
                 r.active = false;
                 return fail (h, ICP_EHIP, "checked run: the device has published no progress for 20 s");
@@ -439,7 +445,7 @@ int run_finish (icp_context *h, run_ctl &r, run_ctl *other)
     h->stat_launches = r.enq; h->stat_k = r.k_final;
     // iterations enqueued past the one that found out (converged at k: iterations 0 .. k - 1 ran, launch k saw the flag — in the chained form it
     // is the one that sets it —, the rest leave at their first load)
-    h->stat_dead = r.done_seen ? r.enq - std::min (r.enq, r.k_final + 1u) : 0u;
+    h->stat_dead = r.done_seen ? r.enq - std::min (r.enq, r.k_final - r.k0 + 1u) : 0u;
     HIPCHK (h, hipGetLastError ());
     return ICP_OK;
 }
@@ -494,6 +500,7 @@ int launch_run (icp_context *h, uint32_t iterations, int check, bool fresh = fal
             if (check) HIPCHK (h, hipMemcpyAsync (h->hState, p.st, sizeof (icp_reg_state) * p.batch, hipMemcpyDeviceToHost, h->stream));
             HIPCHK (h, hipGetLastError ());
             h->hstate_fresh = check != 0; h->hstate_here = false;
+            h->k_base = check ? -1 : (fresh || with_build) ? (long long) iterations : (h->k_base >= 0 ? h->k_base + iterations : -1);
             note_outputs_stored (h);
             return ICP_OK;
         }
@@ -503,6 +510,7 @@ int launch_run (icp_context *h, uint32_t iterations, int check, bool fresh = fal
     if (rc) return rc;
     HIPCHK (h, hipGraphLaunch (exec, h->stream));
     h->hstate_fresh = check != 0; h->hstate_here = false;
+    h->k_base = check ? -1 : (fresh || with_build) ? (long long) iterations : (h->k_base >= 0 ? h->k_base + iterations : -1);
     note_outputs_stored (h);
     return ICP_OK;
 }
@@ -515,7 +523,7 @@ int settle (icp_context *h)
 }
 
 // every state-changing enqueue that is not a checked run graph: the pinned mirror of the states is stale from here on
-void note_enqueue (icp_context *h) { h->hstate_fresh = false; h->hstate_here = false; }
+void note_enqueue (icp_context *h) { h->hstate_fresh = false; h->hstate_here = false; h->k_base = -1; }
 
 // the inputs of the last checked run are about to change (F / M / the RBC): per-query outputs it did not store can no longer be reproduced
 void note_inputs_change (icp_context *h) { if (h->outputs_stale) { h->outputs_stale = false; h->outputs_lost = true; } }
@@ -755,7 +763,7 @@ int icp_write_b (icp_handle h, uint32_t b, int mem, const void *host_ptr, int bl
             if (host_ptr) std::memcpy (h->hT, host_ptr, 8 * sizeof (float));   // :4613-4617
             HIPCHK (h, hipMemcpyAsync (h->dTin, h->hT, 8 * sizeof (float), hipMemcpyHostToDevice, h->stream));
             HIPCHK (h, hipEventRecord (h->evStage[2], h->stream));
-            note_enqueue (h);
+            { const long long kb = h->k_base; note_enqueue (h); h->k_base = kb; }       // (T changes, the iteration count does not)
             icp_launch_set_T (h->p, b, h->dTin, h->stream);
             HIPCHK (h, hipGetLastError ());
             break;
@@ -880,7 +888,7 @@ int icp_build_rbc (icp_handle h)
             note_enqueue (h);
             icp_launch_build_rbc (h->p, h->stream);
             HIPCHK (h, hipGetLastError ());
-            h->built = true;
+            h->built = true; h->k_base = 0;                                 // (ICP::buildRBC resets k, :4796)
             return ICP_OK;
         }
     }
@@ -895,7 +903,7 @@ int icp_build_rbc (icp_handle h)
     }
     note_enqueue (h);
     HIPCHK (h, hipGraphLaunch (it->second.exec, h->stream));
-    h->built = true;
+    h->built = true; h->k_base = 0;
     return ICP_OK;
 }
 
@@ -905,7 +913,8 @@ int icp_step (icp_handle h, int config)
     int rc = need (h, true); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
     icp_params p = h->p; p.check = 0; p.hmirror = nullptr; p.hstate = nullptr;
-    note_enqueue (h); note_outputs_stored (h);
+    { const long long kb = h->k_base; note_enqueue (h); if (kb >= 0) h->k_base = kb + 1; }
+    note_outputs_stored (h);
     icp_launch_iteration (p, h->stream);
     HIPCHK (h, hipGetLastError ());
     return ICP_OK;
@@ -943,6 +952,14 @@ int icp_run (icp_handle h, uint32_t *k)
         if ((rc = run_wait_final (h, h->hMirror, h->p.batch, h->run.p.epoch))) return rc;      // (the end kernel is the last thing on the stream: queue.finish ())
         h->stat_t[5] = now_s ();
         h->hstate_fresh = true; h->hstate_here = true;
+        if (h->p.batch == 1u) h->k_base = h->hState[0].k;
+        {   // the statistics of the run, now that its outcome is known (a run whose launches all went out at once was "decided" before it ran)
+            uint32_t kmax = 0u, all_done = 1u;
+            for (uint32_t b = 0; b < h->p.batch; ++b) { kmax = std::max (kmax, h->hState[b].k); all_done &= h->hState[b].done ? 1u : 0u; }
+            h->stat_k = kmax;
+            const uint32_t ran = kmax > h->run.k0 ? kmax - h->run.k0 : 0u;
+            h->stat_dead = all_done ? h->run.enq - std::min (h->run.enq, ran + 1u) : 0u;
+        }
     }
     if (k) {
         if (h->hstate_fresh) *k = h->hState[0].k;                        // (the run left the states in the pinned mirror)
@@ -1500,6 +1517,7 @@ int icp_reset_transform (icp_handle h)
     note_enqueue (h);
     icp_launch_reset_state (h->p, h->stream, 1);
     HIPCHK (h, hipGetLastError ());
+    h->k_base = 0;
     return ICP_OK;
 }
 
@@ -1512,7 +1530,7 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int fr
     if ((rc = get_graph (h, iterations, 0, &exec, from_identity != 0))) return rc;     // from_identity: every pass is a fresh registration
     HIPCHK (h, hipEventRecord (h->ev0, h->stream));
     for (uint32_t r = 0; r < reps; ++r) HIPCHK (h, hipGraphLaunch (exec, h->stream));
-    h->hstate_fresh = false; note_outputs_stored (h);
+    h->hstate_fresh = false; h->k_base = -1; note_outputs_stored (h);
     HIPCHK (h, hipEventRecord (h->ev1, h->stream));
     HIPCHK (h, hipStreamSynchronize (h->stream));                       // (not hipEventSynchronize: its wake-up now and then takes 0.5 ms, tests/diag_overhead.py)
     HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));
@@ -1533,7 +1551,7 @@ int icp_time_run_fixed_tail (icp_handle h, uint32_t iterations, uint32_t reps, i
     if (lead) HIPCHK (h, hipGraphLaunch (exec, h->stream));
     HIPCHK (h, hipEventRecord (h->ev0, h->stream));
     for (uint32_t r = lead; r < reps; ++r) HIPCHK (h, hipGraphLaunch (exec, h->stream));
-    h->hstate_fresh = false; note_outputs_stored (h);
+    h->hstate_fresh = false; h->k_base = -1; note_outputs_stored (h);
     HIPCHK (h, hipEventRecord (h->ev1, h->stream));
     HIPCHK (h, hipStreamSynchronize (h->stream));                       // (not hipEventSynchronize: its wake-up now and then takes 0.5 ms, tests/diag_overhead.py)
     HIPCHK (h, hipEventElapsedTime (ms_timed, h->ev0, h->ev1));

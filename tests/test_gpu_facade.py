@@ -1032,3 +1032,38 @@ def test_tracking_interrupted_by_other_calls_and_resets(engine, oracle):
     assert g.run() == k and np.array_equal(g.read(engine.Memory.T).view(np.uint32), T.view(np.uint32))
     assert np.array_equal(g.read(engine.Memory.NN_ID)["id"], o.nn_id["id"])
     g.close()
+
+
+def test_a_second_run_without_build_continues_the_count(engine, oracle):
+    """ICP::run twice without buildRBC in between: k keeps counting (src/ICP/algorithms.cpp:4786-4797), the second run still paces itself by
+    its own progress — no more launches than it needs + the run depth — also after single steps and a fixed-length run, and after a reset
+    the host did not see coming (icp_run_fixed_fresh) the pacing recovers."""
+    side, nr = 64, 64
+    F, M = engine.synth_pair(side, seed=3, rot_deg=6.0)
+    g = engine.ICP(0)
+    g.init(side * side, nr, 2e2, 1e-6, max_iterations=6)              # six iterations at a time: the registration needs several runs
+    g.write(engine.Memory.F, F); g.write(engine.Memory.M, M); g.buildRBC()
+    o = oracle.OracleICP(side * side, nr, 2e2, 1e-6, threads=4, power_fast=True, fused=True, max_iterations=400)
+    o.write_f(F); o.write_m(M); o.build_rbc()
+    ko = o.run()
+    assert ko > 12
+    total = 0
+    for rep in range(8):
+        k = g.run()
+        n, kk, dead = g.run_stats()
+        assert n <= 6 and k == kk
+        total = k
+        if g.state().converged:
+            assert n <= (k - (rep * 6)) + 1 + 3, (rep, n, k)           # the last run: what was left + the launch that finds out + the depth
+            break
+        assert k == 6 * (rep + 1) and n == 6
+    assert total == ko and np.array_equal(g.read(engine.Memory.T).view(np.uint32), o.T.view(np.uint32))
+    # steps and a fixed-length run move the count too; then a fresh fixed run resets it behind the host's back
+    g.reset_transform(); g.buildRBC(); g.step(); g.step(); g.run_fixed(3)
+    assert g.run() in (11, ko) and g.run_stats()[0] <= 6
+    g.run_fixed_fresh(2)
+    g.setMaxIterations(60)
+    k = g.run()
+    assert k == ko and g.run_stats()[0] <= (ko - 2) + 1 + 3
+    assert np.array_equal(g.read(engine.Memory.T).view(np.uint32), o.T.view(np.uint32))
+    g.close()

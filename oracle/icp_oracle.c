@@ -1024,6 +1024,7 @@ uint32_t orc_icp_run (orc_icp *h)
 }
 
 void               orc_icp_set_dist_scale (orc_icp *h, float f_g) { h->dist_scale = f_g; }
+void               orc_icp_set_alpha (orc_icp *h, float a) { h->a = a; }     /* setAlpha, src/ICP/algorithms.cpp:4712-4717 (the lists are rebuilt by the caller) */
 int                orc_icp_converged (const orc_icp *h) { return h->converged; }
 const float       *orc_icp_T (const orc_icp *h) { return h->T; }
 const float       *orc_icp_Tk (const orc_icp *h) { return h->Tk; }

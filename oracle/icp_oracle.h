@@ -89,6 +89,7 @@ void     orc_icp_set_power_fast (orc_icp *h, int fast);
 void     orc_icp_set_fused (orc_icp *h, int fused);
 void     orc_icp_set_threads (orc_icp *h, int threads);
 void     orc_icp_set_dist_scale (orc_icp *h, float f_g);   /* reported dist = f_g (geo + a pho); default 1 */
+void     orc_icp_set_alpha (orc_icp *h, float a);
 void     orc_icp_write_f (orc_icp *h, const float *F);
 void     orc_icp_write_m (orc_icp *h, const float *M);
 void     orc_icp_write_t (orc_icp *h, const float *T8);

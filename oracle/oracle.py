@@ -75,6 +75,7 @@ def lib():
     sig("orc_moments_fused", None, vp, vp, vp, u32, u32, C.c_float, C.POINTER(C.c_double), vp, vp)
     sig("orc_icp_set_threads", None, vp, C.c_int)
     sig("orc_icp_set_dist_scale", None, vp, C.c_float)
+    sig("orc_icp_set_alpha", None, vp, C.c_float)
     sig("orc_icp_write_f", None, vp, vp)
     sig("orc_icp_write_m", None, vp, vp)
     sig("orc_icp_write_t", None, vp, vp)

@@ -1067,3 +1067,80 @@ def test_a_second_run_without_build_continues_the_count(engine, oracle):
     assert k == ko and g.run_stats()[0] <= (ko - 2) + 1 + 3
     assert np.array_equal(g.read(engine.Memory.T).view(np.uint32), o.T.view(np.uint32))
     g.close()
+
+
+@pytest.mark.parametrize("side,nr,ref_order,seed", [(32, 16, False, 11), (32, 16, True, 12), (64, 1024, False, 13), (48, 64, False, 14)])
+def test_random_api_sequences_against_the_oracle(engine, oracle, side, nr, ref_order, seed):
+    """Seventy random calls — buildRBC, single steps, checked runs, fixed-length runs (continuing and fresh: cached graphs of several
+    lengths), write (T), reset, setAlpha, reads of T and of the per-query outputs in between — applied to the engine and to the oracle:
+    after every read the transform and the correspondences are the same bits, and the engine's k is what the calls add up to.  What this
+    exercises is the host's bookkeeping: where the state lives (device, pinned mirror), lazy per-query outputs and when they are lost,
+    graphs updated in place after a setter, the pacing of a checked run that continues a count.  Chained form (32 x 32 / 16, 48 x 48 / 64),
+    reference-order modes, and separate launches with the dense search (64 x 64 / 1024)."""
+    rng = np.random.default_rng(seed)
+    m = side * side
+    F, M = engine.synth_pair(side, seed=seed, rot_deg=2.5)
+    MAXIT = 12
+    g = engine.ICP(0)
+    g.init(m, nr, 2e2, 1e-6, max_iterations=MAXIT)
+    if ref_order:
+        g.setReduceMode(engine.ReduceMode.REFERENCE_ORDER); g.setPowerMode(engine.PowerMode.LITERAL)
+    o = oracle.OracleICP(m, nr, 2e2, 1e-6, threads=8, power_fast=not ref_order, fused=not ref_order, max_iterations=100000)
+    g.write(engine.Memory.F, F); g.write(engine.Memory.M, M); o.write_f(F); o.write_m(M)
+    g.buildRBC(); o.build_rbc()
+    k_model, done_model, iters_since_build, alpha = 0, False, 0, 2e2
+    ident = [0, 0, 0, 1, 0, 0, 0, 1]
+    log = []
+    for step in range(70):
+        op = rng.choice(["build", "step", "run", "fixed", "fresh", "write_t", "reset", "alpha", "read", "read", "read_out"])
+        log.append(op)
+        if op == "build":
+            g.buildRBC(); o.build_rbc(); k_model, done_model, iters_since_build = 0, False, 0
+        elif op == "step":
+            g.step(); o.step(); k_model += 1; iters_since_build += 1
+        elif op == "run":
+            if done_model:
+                continue                                   # (a converged registration is left alone until the next buildRBC / reset)
+            kg = g.run()
+            n = 0
+            while n < MAXIT:
+                o.step(); n += 1; k_model += 1; iters_since_build += 1
+                if o.converged:
+                    done_model = True
+                    break
+            assert kg == k_model, (step, log[-8:], kg, k_model)
+            st = g.state()
+            assert st.k == k_model and bool(st.converged) == done_model, (step, log[-8:])
+            assert g.run_stats()[0] <= MAXIT
+        elif op == "fixed":
+            n = int(rng.integers(1, 6))
+            g.run_fixed(n)
+            for _ in range(n):
+                o.step()
+            k_model += n; iters_since_build += n
+        elif op == "fresh":
+            n = int(rng.integers(1, 6))
+            g.run_fixed_fresh(n)
+            o.write_t(ident)
+            for _ in range(n):
+                o.step()
+            k_model, done_model = n, False; iters_since_build += n
+        elif op == "write_t":
+            q = rng.normal(0, 0.01, 3); T = np.array([q[0], q[1], q[2], 0.0, *rng.normal(0, 3.0, 3), 1.0], np.float32)
+            T[3] = np.sqrt(1 - (T[:3] ** 2).sum())
+            g.write(engine.Memory.T, T); o.write_t(T)
+        elif op == "reset":
+            g.reset_transform(); o.write_t(ident); k_model, done_model = 0, False
+        elif op == "alpha":
+            alpha = float(rng.choice([0.5, 2e2, 1e3]))
+            g.setAlpha(alpha); o.L.orc_icp_set_alpha(o.h, alpha)
+            g.buildRBC(); o.build_rbc(); k_model, done_model, iters_since_build = 0, False, 0
+        elif op == "read":
+            assert np.array_equal(g.read(engine.Memory.T).view(np.uint32), o.T.view(np.uint32)), (step, log[-10:])
+            assert g.state().k == k_model, (step, log[-10:], g.state().k, k_model)
+        elif op == "read_out" and iters_since_build > 0:
+            nn = g.read(engine.Memory.NN_ID)
+            assert np.array_equal(nn["id"], o.nn_id["id"]) and np.array_equal(nn["dist"].view(np.uint32), o.nn_id["dist"].view(np.uint32)), (step, log[-10:])
+            assert np.array_equal(g.read(engine.Memory.W).view(np.uint32), o.W.view(np.uint32)), (step, log[-10:])
+    assert np.array_equal(g.read(engine.Memory.T).view(np.uint32), o.T.view(np.uint32))
+    g.close()

@@ -370,14 +370,16 @@ int run_begin (icp_context *h, run_ctl &r, hipStream_t stream, const icp_params 
     r.chained = icp_chain_supported (r.p); r.fresh = fresh;
     r.k0 = (fresh || with_build || h->k_base < 0) ? 0u : (uint32_t) h->k_base;      // (a fresh run and a rebuilt RBC start the count at 0)
     r.maxit = h->max_iterations; r.depth = h->run_depth ? h->run_depth : 1u;
+    if (other && other->active) (void) run_pump (h, *other);
     if (with_build) icp_launch_build_rbc (r.p, r.stream);
+    if (other && other->active) (void) run_pump (h, *other);
     { int rc = between (); if (rc) return rc; }
     if (fresh && !r.chained) icp_launch_reset_state (r.p, r.stream, 1);
     r.active = true;
     const uint32_t n = std::min (std::max (blind, 1u), r.maxit);
     while (r.enq < n) {
         run_launch_one (h, r);
-        if (other && other->active && (r.enq & 3u) == 0u) (void) run_pump (h, *other);
+        if (other && other->active && (r.enq & 1u) == 0u) (void) run_pump (h, *other);
     }
     if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit + r.k0; }
     HIPCHK (h, hipGetLastError ());
@@ -1291,6 +1293,9 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     run_ctl &R = (gated && (f & 1u)) ? h->run2 : h->run;
     run_ctl *P = gated ? ((f & 1u) ? &h->run : &h->run2) : &h->run;     // the run to look after meanwhile (ungated: the one and only)
     hipStream_t st = (gated && (f & 1u)) ? h->stream2 : h->stream;
+    // the previous frame's registration may still need launches while this call does its own work: it is looked after between the steps
+    // (a word read; a launch if its queue has run down)
+    auto tend = [&] () { if (P->active) (void) run_pump (h, *P); };
     if (gated && R.active) {                                            // the slot still holds registration f - 2: decided long ago, or nearly
         if ((rc = run_finish (h, R, P->active ? P : nullptr))) return rc;
         track_note_k (h, R);
@@ -1306,10 +1311,12 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
             if ((rc = run_wait_final (h, h->hTrackMirror + r2, 1u, h->track_epoch[r2]))) return rc;
         } else HIPCHK (h, hipStreamWaitEvent (h->copy_stream, h->evDone[r2], 0));
     }
+    tend ();
     const bool pinned = cloud == h->hFrame[0] || cloud == h->hFrame[1];
     if (pinned) {
         // the caller filled one of the engine's pinned frame buffers (icp_track_staging): the band goes by DMA straight from there
         HIPCHK (h, hipMemcpy2DAsync (h->dBand[s], ICP_BAND_ROW_BYTES, src, spitch, ICP_BAND_ROW_BYTES, ICP_BAND_ROWS, hipMemcpyHostToDevice, h->copy_stream));
+        tend ();
     } else {
         // pageable source: the band's 128 row segments into the slot's pinned staging (free once the upload of frame f - 2 is through)
         if (f >= 2u) HIPCHK (h, hipEventSynchronize (h->evUp[s]));
@@ -1326,12 +1333,15 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
                 const size_t off = (size_t) (j + 1u - piece) * ICP_BAND_ROW_BYTES;
                 HIPCHK (h, hipMemcpyAsync (reinterpret_cast<char *> (h->dBand[s]) + off, reinterpret_cast<char *> (h->hBand[s]) + off, (size_t) piece * ICP_BAND_ROW_BYTES,
                                            hipMemcpyHostToDevice, h->copy_stream));
+                tend ();
             }
         }
     }
     icp_launch_get_lms_band (h->dBand[s], h->lm[buf], h->copy_stream);
     HIPCHK (h, hipGetLastError ());
+    tend ();
     HIPCHK (h, hipEventRecord (h->evUp[s], h->copy_stream));
+    tend ();
     // ungated: one stream, in order — the previous frame's registration is brought to its end before this frame's work goes behind it
     int prev_slot = -1;
     if (!gated && h->run.active) {
@@ -1370,6 +1380,9 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
             };
             if ((rc = run_begin (h, R, st, p, !warm, true, blind, h->hTrackMirror + ring, h->hTrack + ring, (int) ring, between, (gated && P->active) ? P : nullptr))) return rc;
             h->track_epoch[ring] = R.p.epoch;
+            // (gated: a launch past the convergence of a frame runs beside the next frame and costs ~0.6 - 0.9 us, a queue that runs dry while
+            // the host is busy with the next frame costs what the host is late by: the queue is kept twice as deep)
+            if (gated) R.depth = std::max (R.depth, 2u * h->run_depth);
             if (gated && (f & 1u)) h->stream2_dirty = true;
         } else {
             // rounds 1 - 3: buildRBC + a checked run of max_iterations launches as one cached graph (the graphs hold the buffer pointers)

@@ -108,6 +108,25 @@ def git_head():
         return None
 
 
+def cpu_share():
+    """The cores this process may actually use: the scheduler affinity and the cgroup's CPU quota (a one-GPU box of the pool has a share of
+    16 of its host's 256 cores — thread counts above the share time-slice, which is what the tail of the sweep shows)."""
+    share = float(len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else float(os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                share = min(share, float(quota) / period)
+            break
+        except Exception:
+            continue
+    return share
+
+
 def cpu_baseline(F, M, m, nr, fused, budget_s=15.0):
     """The oracle (CPU port of the same iteration) on this host's cores: a thread sweep {1, 8, 16, 64, all host cores}, each count timed on
     a bounded sample of the same workload (fresh 40-iteration passes of the benchmark pair), the best one reported as `value` with the
@@ -116,7 +135,8 @@ def cpu_baseline(F, M, m, nr, fused, budget_s=15.0):
     from oracle import oracle as O
     host = os.cpu_count() or 1
     env = os.environ.get("ICP_BASELINE_THREADS")
-    counts = [int(env)] if env else sorted({t for t in (1, 8, 16, 64, host) if t <= host})
+    share = cpu_share()
+    counts = [int(env)] if env else sorted({t for t in (1, 8, 16, 64, int(round(share)), host) if 1 <= t <= host})
     o = O.OracleICP(m, nr, ALPHA, SCALING, threads=counts[0], power_fast=True, fused=fused)
     o.write_f(F)
     o.write_m(M)
@@ -140,10 +160,10 @@ def cpu_baseline(F, M, m, nr, fused, budget_s=15.0):
         total_t += el
     best = max(sweep, key=lambda x: x["iterations_per_s"])
     return {"value": best["iterations_per_s"], "unit": "iterations/s", "cores": best["threads"], "threads": best["threads"], "host_cores": host,
-            "kind": "port", "sweep": sweep,
-            "sample": "%d iterations of the same pair (|F|=|M|=%d, |R|=%d) in %.1f s over a sweep of %s threads of the host's %d cores "
+            "cpu_share": share, "kind": "port", "sweep": sweep,
+            "sample": "%d iterations of the same pair (|F|=|M|=%d, |R|=%d) in %.1f s over a sweep of %s threads of the host's %d cores (this process's share: %.4g) "
                       "(~%.0f s each); `value` = the best count; search, transform, weights and the block partials of the moment "
-                      "reduction in OpenMP, deterministic per-thread partials" % (total_n, m, nr, total_t, [x["threads"] for x in sweep], host, per)}
+                      "reduction in OpenMP, deterministic per-thread partials" % (total_n, m, nr, total_t, [x["threads"] for x in sweep], host, share, per)}
 
 
 def setup(icp_amd, device, cfg, batch, seed_index0, power_mode, reduce_mode):

@@ -1,150 +1,19 @@
-// icp_capi.hip — C-ABI (include/icp_amd.h) over the HIP kernels: handle, buffers, stream, hipGraphs.
+// icp_capi.hip — C-ABI (include/icp_amd.h) over the HIP kernels: life cycle of a handle, its buffers, reads and writes, single steps and
+// runs, setters, diagnostics.
 //
 // Host-side counterpart of ICPStep<CR,CW> / ICP<CR,CW> (include/ICP/algorithms.hpp:2234-2496,
 // src/ICP/algorithms.cpp:4348-4903).  The reference wires ten kernel-wrapper objects by sharing
 // cl::Buffer handles (:4499-4581) and syncs with the host every iteration (:4681-4697); here one
-// handle owns one stream, all device buffers of a batch of registrations and the device-resident
-// registration state, and an ICP run is a single hipGraph launch.
+// handle owns its streams, all device buffers of a batch of registrations and the device-resident
+// registration state; a fixed-length run is one hipGraph launch, a checked run is driven launch by launch
+// from the host (icp_run.hip), frame-to-frame tracking lives in icp_track.hip.
 //
 // There is NO CPU fallback: without a gfx950 device icp_create fails with ICP_ENODEVICE.
-#include "../../include/icp_amd.h"
-#include "icp_kernels.h"
+#include "icp_host.h"
 
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-#include <immintrin.h>
+using namespace icp_host;
 
 namespace {
-
-thread_local std::string g_create_error;
-
-struct graph_entry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t used = 0, gen = 0; };
-
-// A checked run (ICP::run — src/ICP/algorithms.cpp:4806-4834: iterate until check () says stop) that the HOST drives, launch by launch.
-// The device publishes every new transform's (k, done) as one 8-byte store into fine-grained host memory (icp_params::hmirror); the
-// host keeps `depth` launches queued behind the one in flight and stops enqueueing the moment `done` shows: a run costs k launches
-// (+ at most `depth` that leave at their first load), not max_iterations.  Plain launches, not graphs: back to back they run at the
-// graph's rate (8.77 against 8.73 us per iteration at |F| = 16384) and every graph boundary costs 4 - 8 us (profiles/r04_segments.txt).
-// The end kernel leaves the final state in host memory too (icp_params::hstate) and sets the word's FINAL bit: the caller polls that
-// instead of synchronising the stream.  At most one run per handle is open; tracking keeps it open across calls (icp_track_submit
-// returns with a frame's predicted launches enqueued, the next call tops it up).
-struct run_ctl {
-    bool active = false, decided = false, chained = false, fresh = false;
-    icp_params p {};
-    uint32_t enq = 0, maxit = 0, depth = 0, k_seen = 0, k_final = 0, k0 = 0;     // k0: the device's k when the run began (k_seen is relative to it)
-    int done_seen = 0;
-    bool final_seen = false;                            // every registration's final state has arrived with its converged flag: no end kernel
-    volatile unsigned long long *mirror = nullptr;      // host view of p.hmirror
-    int track_slot = -1;                                // tracking: the ring slot of the frame this run registers
-    hipStream_t stream = nullptr;                       // the stream the run's launches go to (tracking alternates between two)
-    // host timeline of the run (icp_run_timeline), seconds on the steady clock: begin, blind launches enqueued, first progress word seen,
-    // decided, end kernel enqueued
-    double t[5] = { 0, 0, 0, 0, 0 };
-    double launch_max_us = 0.0; uint32_t launch_slow = 0;   // the host's own launch calls: the longest, and how many took more than 10 us
-};
-
-inline double now_s () { return std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count (); }
-
-}  // namespace
-
-struct icp_context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool inited = false, built = false;
-    icp_params p {};
-    uint32_t max_iterations = 40;
-    double angle_threshold = 0.001, translation_threshold = 0.01;
-    std::string err;
-    // owned allocations
-    std::vector<void *> dev_allocs;
-    float *dF = nullptr, *dM = nullptr;          // may be adopted
-    bool ownF = true, ownM = true;
-    float *hF = nullptr, *hM = nullptr, *hT = nullptr;   // pinned staging (H_IN_F / H_IN_M / H_IO_T)
-    icp_reg_state *hState = nullptr;             // pinned (fine-grained) mirror of the registration states: the end kernel of a checked run stores into it
-    bool hstate_fresh = false;                   // the mirror is what the device holds (a checked run was the last state-changing thing on the stream)
-    bool hstate_here = false;                    // ... and it has arrived (host-driven run: its FINAL bit was seen); else: once the stream has drained
-    unsigned long long *hMirror = nullptr;       // pinned (fine-grained): progress words of the checked run in flight, [batch] (run_ctl)
-    uint32_t epoch = 0;                          // tag of the last checked run
-    // what the host knows about the device's iteration counter k (all registrations alike): a checked run's progress words carry k itself,
-    // and a run that does not start at 0 (a second icp_run without buildRBC) paces itself against k - k_base.  -1: unknown (paced as from 0:
-    // a few launches more queued than `depth`, nothing else)
-    long long k_base = 0;
-    uint32_t run_depth = 3;                      // launches kept queued behind the one in flight (ICP_AMD_RUN_DEPTH)
-    int run_adaptive = 1;                        // 0 (ICP_AMD_RUN_ADAPTIVE=0): checked runs as one graph of max_iterations launches (rounds 1 - 3)
-    run_ctl run;                                 // the open checked run (tracking: of the frames on the handle's own stream)
-    run_ctl run2;                                // tracking with device-side gates: the open run of the frames on stream2
-    // Per-query outputs (NN_ID, W, NN, QT, RID) of checked runs: fused kernels consume none of them, and a checked run cannot know which
-    // iteration is its last — storing them every iteration costs 0.4 us of every 9 at |F| = 16384.  lazy: the run stores none; every finalize
-    // leaves the transform its search used in p.st_prev, and the first read of such an output re-runs that one search (same T, same
-    // lists: same bits).  Inputs changed in between (F / M written, RBC rebuilt, tracking moved on): the outputs are gone, reads say so.
-    int outputs_lazy = 1;                        // ICP_AMD_OUTPUTS=eager / icp_set_output_mode
-    bool outputs_stale = false, outputs_lost = false;
-    uint32_t stat_launches = 0, stat_k = 0, stat_dead = 0;   // last finished checked run: iteration launches enqueued, final k, launches past the last live one
-    double stat_t[6] = { 0, 0, 0, 0, 0, 0 };     // its host timeline (run_ctl::t) + the moment its FINAL bit was seen
-    double stat_launch_max_us = 0.0; uint64_t stat_launch_slow = 0, stat_launch_total = 0;   // launch calls of all checked runs since icp_init
-    uint64_t graph_clock = 0, param_gen = 0;     // LRU stamp of the graph cache; generation of the parameters the cached graphs were captured with
-    float *dTin = nullptr;                       // device scratch for write(T)
-    float *dCloud = nullptr, *dCloudOut = nullptr; uint32_t cloud_cap = 0;
-    std::map<uint64_t, graph_entry> graphs;      // key: iterations << 3 | check << 2 | parity (+ fresh, + kind: see get_graph)
-    uint32_t parity = 0;                         // tracking: which landmark buffers are the fixed / moving set (graphs hold pointers): frame f -> f mod 3
-    // frame-to-frame tracking (icp_track_*): three landmark buffers in rotation, band staging, a copy stream
-    float *lm[3] = { nullptr, nullptr, nullptr };            // landmarks of frame f live in lm[f mod 3] (lm[0] / lm[1] = the handle's F / M buffers)
-    float *hBand[2] = { nullptr, nullptr }, *dBand[2] = { nullptr, nullptr };     // the part of a frame getLMs reads (ICP_BAND_*), pinned / device
-    float *hFrame[2] = { nullptr, nullptr };                 // whole-frame pinned staging handed to the caller (icp_track_staging)
-    icp_reg_state *hTrack = nullptr;                         // pinned: final state of the frames in flight (ICP_TRACK_RING slots)
-    unsigned long long *hTrackMirror = nullptr;              // pinned: their progress words
-    uint32_t track_epoch[4] = { 0, 0, 0, 0 };                // epoch of the run in each ring slot
-    uint32_t track_k_hist[2] = { 0, 0 };                     // k of the last two registrations of the sequence (0: none yet): the next frame's blind launches
-    uint64_t track_hist_frame = 0;                           // 1 + the latest frame whose k is in that history
-    hipStream_t copy_stream = nullptr;
-    // Tracking with frames gated on the device (track_gate; ICP_AMD_TRACK_GATE=0 switches it off): registration f runs on stream f & 1 (the
-    // handle's own stream / stream2) behind k_gate, which waits for registration f - 1's release of *dSeq — so frame f's RBC construction
-    // and all its predicted launches are enqueued while frame f - 1 is still running, and the host is nowhere on the path between two
-    // frames.  The RBC of two consecutive frames lives in two sets of buffers (rbc2 = the second set; swapped into h->p by frame parity).
-    hipStream_t stream2 = nullptr;
-    int track_gate = 1;
-    uint32_t *dSeq = nullptr, *dRunFlag = nullptr, *hGateFlag = nullptr;
-    bool stream2_dirty = false;                  // stream2 holds work the handle's own stream must not overtake
-    struct rbc_set { float *R = nullptr; float4 *GB = nullptr; float *XP = nullptr, *XQ = nullptr; uint32_t *rep_src = nullptr, *owner = nullptr, *N = nullptr, *O = nullptr,
-                     *perm = nullptr, *chunk_hist = nullptr; uint2 *blist = nullptr; uint32_t *bn = nullptr; uint8_t *brank = nullptr; } rbc[2];
-    bool rbc2_ready = false;
-    bool track_last_gated = false;                // the form of the last submitted frame
-    hipEvent_t evUp[2] = { nullptr, nullptr }, evDone[4] = { nullptr, nullptr, nullptr, nullptr };
-    hipEvent_t evStage[3] = { nullptr, nullptr, nullptr };   // the last asynchronous copy out of the pinned staging of F / M / T (icp_write)
-    uint64_t track_submitted = 0, track_collected = 0;       // frames fed / frames whose result has been handed out since init / icp_track_reset
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-};
-
-namespace {
-
-int fail (icp_context *h, int code, const std::string &msg)
-{
-    if (h) h->err = msg; else g_create_error = msg;
-    return code;
-}
-
-#define HIPCHK(h, expr)                                                                         \
-    do {                                                                                        \
-        hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess)                                                                   \
-            return fail ((h), ICP_EHIP, std::string (#expr) + ": " + hipGetErrorString (e_));   \
-    } while (0)
-
-void drop_graphs (icp_context *h)
-{
-    for (auto &kv : h->graphs) {
-        if (kv.second.exec) (void) hipGraphExecDestroy (kv.second.exec);
-        if (kv.second.graph) (void) hipGraphDestroy (kv.second.graph);
-    }
-    h->graphs.clear ();
-}
 
 void free_all (icp_context *h)
 {
@@ -186,22 +55,6 @@ void free_all (icp_context *h)
     h->inited = h->built = false; h->parity = 0; h->track_submitted = h->track_collected = 0;
 }
 
-template <typename T>
-int dalloc (icp_context *h, T **ptr, size_t count, bool zero = true)
-{
-    void *q = nullptr;
-    size_t bytes = (count ? count : 1) * sizeof (T);
-    hipError_t e = hipMalloc (&q, bytes);
-    if (e != hipSuccess) return fail (h, ICP_ENOMEM, std::string ("hipMalloc: ") + hipGetErrorString (e));
-    h->dev_allocs.push_back (q);
-    if (zero) {
-        e = hipMemsetAsync (q, 0, bytes, h->stream);
-        if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("hipMemsetAsync: ") + hipGetErrorString (e));
-    }
-    *ptr = static_cast<T *> (q);
-    return ICP_OK;
-}
-
 // landmark-grid / representative-grid validation — src/ICP/algorithms.cpp:842-854 generalised (oracle: orc_reps_grid)
 bool reps_grid (uint32_t m, uint32_t nr, uint32_t *nrx, uint32_t *nry, uint32_t *side)
 {
@@ -214,341 +67,6 @@ bool reps_grid (uint32_t m, uint32_t nr, uint32_t *nrx, uint32_t *nry, uint32_t 
     if (g % x || g % y) return false;
     *nrx = x; *nry = y; *side = g;
     return true;
-}
-
-int run_finish (icp_context *h, bool defer_event = false);
-int run_close_all (icp_context *h);
-void note_outputs_stored (icp_context *h);
-
-// keep_run: the caller is one of the tracking entries, which carry an open checked run (run_ctl) across calls themselves; everything
-// else that touches the handle's stream first brings an open run to its end (its remaining launches must not interleave with others)
-int need (icp_context *h, bool built, bool keep_run = false)
-{
-    if (!h) return ICP_EINVAL;
-    if (!h->inited) return fail (h, ICP_ESTATE, "icp_init has not been called");
-    if (built && !h->built) return fail (h, ICP_ESTATE, "icp_build_rbc has not been called");
-    if (!keep_run && (h->run.active || h->run2.active || h->stream2_dirty)) {
-        if (hipSetDevice (h->device) != hipSuccess) return fail (h, ICP_EHIP, "hipSetDevice");
-        int rc = run_close_all (h); if (rc) return rc;
-    }
-    return ICP_OK;
-}
-
-int set_device (icp_context *h)
-{
-    HIPCHK (h, hipSetDevice (h->device));
-    return ICP_OK;
-}
-
-// Captures the launches `launches ()` enqueues on the handle's stream into a graph (instantiate: also into an executable one).
-// Whatever fails, the stream has left capture mode and nothing is leaked when this returns.
-template <typename Fn>
-int capture_graph (icp_context *h, Fn &&launches, graph_entry *out, bool instantiate = true)
-{
-    graph_entry ge;
-    HIPCHK (h, hipStreamBeginCapture (h->stream, hipStreamCaptureModeThreadLocal));
-    launches ();
-    const hipError_t le = hipGetLastError ();                        // launch-configuration errors of the captured kernels
-    hipError_t e = hipStreamEndCapture (h->stream, &ge.graph);      // always: ends the capture also on the error path
-    if (e == hipSuccess && le != hipSuccess) e = le;
-    if (e != hipSuccess) {
-        if (ge.graph) (void) hipGraphDestroy (ge.graph);
-        return fail (h, ICP_EHIP, std::string ("graph capture: ") + hipGetErrorString (e));
-    }
-    if (instantiate) {
-        e = hipGraphInstantiate (&ge.exec, ge.graph, nullptr, nullptr, 0);
-        if (e != hipSuccess) {
-            (void) hipGraphDestroy (ge.graph);
-            return fail (h, ICP_EHIP, std::string ("hipGraphInstantiate: ") + hipGetErrorString (e));
-        }
-    }
-    *out = ge;
-    return ICP_OK;
-}
-
-#define ICP_GRAPH_CACHE 8u       // cached run graphs per handle (least recently used goes first)
-
-// Graph of `iterations` iterations, cached (fixed-length runs: icp_run_fixed*, the timing entries; checked runs only with
-// ICP_AMD_RUN_ADAPTIVE=0).  A parameter change (setAlpha, setScaling, thresholds, modes) does not throw the executable graphs away: an
-// entry of an older parameter generation is re-captured and its executable graph UPDATED in place (hipGraphExecUpdate: the kernel
-// nodes' arguments; instantiating anew costs milliseconds) — same topology by construction, re-instantiated only if the update is refused.
-// fresh: the graph starts the registration from the identity transform (icp_reset_transform + the run as one graph; the
-// chained form folds the reset into its first launch).  with_build: buildRBC in front of the run.
-int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *out, bool fresh = false, bool with_build = false)
-{
-    uint64_t key = ((uint64_t) iterations << 3) | (uint64_t) (check ? 4 : 0) | (uint64_t) h->parity | ((uint64_t) (fresh ? 1 : 0) << 62) | ((uint64_t) (with_build ? 1 : 0) << 61);
-    auto it = h->graphs.find (key);
-    if (it != h->graphs.end () && it->second.gen == h->param_gen) { it->second.used = ++h->graph_clock; *out = it->second.exec; return ICP_OK; }
-    icp_params p = h->p;
-    p.check = check; p.hmirror = nullptr; p.hstate = nullptr;
-    auto launches = [&] {
-        if (with_build) icp_launch_build_rbc (p, h->stream);
-        if (fresh && !icp_chain_supported (p)) icp_launch_reset_state (p, h->stream, 1);
-        if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations, fresh);   // one launch per iteration
-        else for (uint32_t k = 0; k < iterations; ++k) {
-            p.emit = (check || k + 1 == iterations) ? 1 : 0;            // (with checks on, any iteration may be the last executed)
-            icp_launch_iteration (p, h->stream);
-        }
-        // checked graphs: the states travel to the pinned mirror as the last node of the graph
-        if (check) (void) hipMemcpyAsync (h->hState, p.st, sizeof (icp_reg_state) * p.batch, hipMemcpyDeviceToHost, h->stream);
-    };
-    if (it != h->graphs.end ()) {                                       // stale parameters: update the executable graph in place
-        graph_entry ng;
-        int rc = capture_graph (h, launches, &ng, false);
-        if (rc) return rc;
-        hipGraphNode_t bad = nullptr; hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
-        hipError_t e = hipGraphExecUpdate (it->second.exec, ng.graph, &bad, &res);
-        if (e != hipSuccess || res != hipGraphExecUpdateSuccess) {
-            (void) hipGetLastError ();
-            (void) hipGraphExecDestroy (it->second.exec); it->second.exec = nullptr;
-            e = hipGraphInstantiate (&it->second.exec, ng.graph, nullptr, nullptr, 0);
-            if (e != hipSuccess) {
-                (void) hipGraphDestroy (ng.graph); (void) hipGraphDestroy (it->second.graph);
-                h->graphs.erase (it);
-                return fail (h, ICP_EHIP, std::string ("hipGraphInstantiate: ") + hipGetErrorString (e));
-            }
-        }
-        (void) hipGraphDestroy (it->second.graph);
-        it->second.graph = ng.graph; it->second.gen = h->param_gen; it->second.used = ++h->graph_clock;
-        *out = it->second.exec;
-        return ICP_OK;
-    }
-    graph_entry ge;
-    int rc = capture_graph (h, launches, &ge);
-    if (rc) return rc;
-    ge.gen = h->param_gen; ge.used = ++h->graph_clock;
-    if (h->graphs.size () >= ICP_GRAPH_CACHE) {                          // bounded: the least recently used entry goes
-        auto lru = h->graphs.begin ();
-        for (auto jt = h->graphs.begin (); jt != h->graphs.end (); ++jt) if (jt->second.used < lru->second.used) lru = jt;
-        // (an executable graph may still be queued on the stream: the runtime keeps what a launched graph needs until it has run)
-        if (lru->second.exec) (void) hipGraphExecDestroy (lru->second.exec);
-        if (lru->second.graph) (void) hipGraphDestroy (lru->second.graph);
-        h->graphs.erase (lru);
-    }
-    h->graphs[key] = ge;
-    *out = ge.exec;
-    return ICP_OK;
-}
-
-// ---- host-driven checked runs (run_ctl) ------------------------------------------------------------------------------------------
-
-void run_launch_one (icp_context *h, run_ctl &r)
-{
-    (void) h;
-    const double t0 = now_s ();
-    if (r.chained) icp_launch_chain_one (r.p, r.stream, r.enq, r.fresh, r.p.emit != 0);
-    else icp_launch_iteration (r.p, r.stream);
-    const double us = (now_s () - t0) * 1e6;
-    if (us > r.launch_max_us) r.launch_max_us = us;
-    if (us > 10.0) ++r.launch_slow;
-    ++r.enq;
-}
-
-// Opens a checked run on the handle's stream with `blind` iterations enqueued at once (at least one).  p: the parameters of THIS run
-// (tracking passes the frame's own landmark buffers); mirror / hstate: the host memory its words and final state go to.
-// between (): enqueued after the RBC construction and in front of the first iteration (tracking: the waits and records that need not
-// hold the construction back).
-struct run_no_hook { int operator() () const { return ICP_OK; } };
-bool run_pump (icp_context *h, run_ctl &r);
-// r: the slot the run lives in (h->run; tracking with gates: h->run / h->run2 by frame parity), stream: where its launches go;
-// other: another open run that is looked after while this one's launches are being enqueued (a tracked frame's predecessor).
-template <typename BETWEEN = run_no_hook>
-int run_begin (icp_context *h, run_ctl &r, hipStream_t stream, const icp_params &p, bool fresh, bool with_build, uint32_t blind,
-               unsigned long long *mirror, icp_reg_state *hstate, int track_slot, BETWEEN between = BETWEEN (), run_ctl *other = nullptr)
-{
-    r = run_ctl {};
-    r.stream = stream;
-    r.t[0] = now_s ();
-    r.p = p; r.p.check = 1;
-    r.p.emit = (h->outputs_lazy && p.fused) ? 0 : 1;                    // (reference-order kernels read the outputs themselves: always stored)
-    h->outputs_stale = r.p.emit == 0; h->outputs_lost = false;
-    if (++h->epoch == 0u) h->epoch = 1u;
-    r.p.epoch = h->epoch; r.p.hmirror = mirror; r.p.hstate = hstate;    // (fine-grained host allocations: the host pointer is the device pointer)
-    r.mirror = mirror; r.track_slot = track_slot;
-    for (uint32_t b = 0; b < p.batch; ++b) mirror[b] = 0ull;
-    std::atomic_thread_fence (std::memory_order_seq_cst);
-    r.chained = icp_chain_supported (r.p); r.fresh = fresh;
-    r.k0 = (fresh || with_build || h->k_base < 0) ? 0u : (uint32_t) h->k_base;      // (a fresh run and a rebuilt RBC start the count at 0)
-    r.maxit = h->max_iterations; r.depth = h->run_depth ? h->run_depth : 1u;
-    if (other && other->active) (void) run_pump (h, *other);
-    if (with_build) icp_launch_build_rbc (r.p, r.stream);
-    if (other && other->active) (void) run_pump (h, *other);
-    { int rc = between (); if (rc) return rc; }
-    if (fresh && !r.chained) icp_launch_reset_state (r.p, r.stream, 1);
-    r.active = true;
-    const uint32_t n = std::min (std::max (blind, 1u), r.maxit);
-    while (r.enq < n) {
-        run_launch_one (h, r);
-        if (other && other->active && (r.enq & 1u) == 0u) (void) run_pump (h, *other);
-    }
-    if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit + r.k0; }
-    HIPCHK (h, hipGetLastError ());
-    h->hstate_fresh = false; h->hstate_here = false; h->k_base = -1;
-    r.t[1] = now_s ();
-    return ICP_OK;
-}
-
-// One look at the run's words, then the queue topped up to `depth` launches behind the one in flight.  Returns true once the run is
-// decided: every registration has converged, or max_iterations launches are enqueued (nothing more will be).
-bool run_pump (icp_context *h, run_ctl &r)
-{
-    if (r.decided) return true;
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u; bool all_done = true, all_final = true;
-    for (uint32_t b = 0; b < r.p.batch; ++b) {
-        const unsigned long long w = r.mirror[b];
-        const bool mine = (uint32_t) (w >> 32) == r.p.epoch;
-        const uint32_t kabs = mine ? (uint32_t) (w & 0xFFFFFFull) : 0u, k = kabs > r.k0 ? kabs - r.k0 : 0u;
-        const bool done = mine && (w & ICP_MIRROR_DONE);
-        kmax = std::max (kmax, k);
-        if (!done) { all_done = false; kmin = std::min (kmin, k); }
-        if (!(mine && (w & ICP_MIRROR_FINAL))) all_final = false;
-    }
-    if (all_done) { r.decided = true; r.done_seen = 1; r.final_seen = all_final; r.k_seen = kmax; r.k_final = kmax + r.k0; return true; }
-    if (kmin && !r.k_seen) r.t[2] = now_s ();
-    r.k_seen = kmin;
-    // launch (chained) / search (separate launches) j publishes k = j in its prologue: k_seen = the iteration in flight, `depth`
-    // iterations are kept queued behind it
-    while (r.enq < r.maxit && r.enq < r.k_seen + 1u + r.depth) run_launch_one (h, r);
-    if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit + r.k0; }
-    return r.decided;
-}
-
-// Drives the open run to its decision (the calling thread polls; bounded wait on a device that has stopped answering), then
-// enqueues its end kernel — final state -> p.st and -> host memory, FINAL bit — and closes it.
-// other: a run this one may be waiting for on the device (a gated frame's predecessor): it is topped up in the same loop.
-int run_finish (icp_context *h, run_ctl &r, run_ctl *other)
-{
-    if (!r.active) return ICP_OK;
-    uint32_t spins = 0, k_last = 0xFFFFFFFFu;
-    auto t_last = std::chrono::steady_clock::now ();
-    while (!run_pump (h, r)) {
-        if (other && other->active) { const uint32_t ko = other->k_seen; (void) run_pump (h, *other); if (other->k_seen != ko || other->decided) t_last = std::chrono::steady_clock::now (); }
-        _mm_pause ();
-        if ((++spins & 0x3FFu) == 0u) {
-            const auto now = std::chrono::steady_clock::now ();
-            if (r.k_seen != k_last) { k_last = r.k_seen; t_last = now; }
-            else if (r.k0 && std::chrono::duration<double> (now - t_last).count () > 0.05) { r.k0 = 0u; t_last = now; }      // (a stale idea of where the count began: pace on k itself)
-            else if (std::chrono::duration<double> (now - t_last).count () > 20.0) {
-                r.active = false;
-                return fail (h, ICP_EHIP, "checked run: the device has published no progress for 20 s");
-            }
-        }
-    }
-    r.t[3] = now_s ();
-    // (converged in the fused forms: the finalize that set the flag has left the final state in p.st and in host memory already)
-    if (!r.final_seen) {
-        if (r.chained) icp_launch_chain_end (r.p, r.stream, r.enq);
-        else icp_launch_publish_state (r.p, r.stream);
-    }
-    r.t[4] = now_s ();
-    for (int i = 0; i < 5; ++i) h->stat_t[i] = r.t[i];
-    h->stat_launch_max_us = std::max (h->stat_launch_max_us, r.launch_max_us); h->stat_launch_slow += r.launch_slow; h->stat_launch_total += r.enq;
-    r.active = false;
-    h->stat_launches = r.enq; h->stat_k = r.k_final;
-    // iterations enqueued past the one that found out (converged at k: iterations 0 .. k - 1 ran, launch k saw the flag — in the chained form it
-    // is the one that sets it —, the rest leave at their first load)
-    h->stat_dead = r.done_seen ? r.enq - std::min (r.enq, r.k_final - r.k0 + 1u) : 0u;
-    HIPCHK (h, hipGetLastError ());
-    return ICP_OK;
-}
-int run_finish (icp_context *h, bool) { return run_finish (h, h->run, h->run2.active ? &h->run2 : nullptr); }
-
-// Waits for the FINAL bit of `n` words of epoch `epoch` (the end kernel's last store: the final states are in host memory).
-int run_wait_final (icp_context *h, volatile unsigned long long *mirror, uint32_t n, uint32_t epoch)
-{
-    uint32_t spins = 0;
-    const auto t0 = std::chrono::steady_clock::now ();
-    for (uint32_t b = 0; b < n; ++b) {
-        for (;;) {
-            const unsigned long long w = mirror[b];
-            if ((uint32_t) (w >> 32) == epoch && (w & ICP_MIRROR_FINAL)) break;
-            _mm_pause ();
-            if ((++spins & 0x3FFFu) == 0u && std::chrono::duration<double> (std::chrono::steady_clock::now () - t0).count () > 60.0) {
-                // (is the stream in error?  hipStreamQuery reports a faulted queue)
-                const hipError_t e = hipStreamQuery (h->stream);
-                if (e != hipSuccess && e != hipErrorNotReady) return fail (h, ICP_EHIP, std::string ("checked run: ") + hipGetErrorString (e));
-                return fail (h, ICP_EHIP, "checked run: the final state has not arrived after 60 s");
-            }
-        }
-    }
-    std::atomic_thread_fence (std::memory_order_acquire);
-    return ICP_OK;
-}
-
-// Brings every open run to its end (older frame first) and, after gated tracking, drains stream2: whatever is enqueued on the handle's own
-// stream next must not overtake it.
-int run_close_all (icp_context *h)
-{
-    run_ctl *a = &h->run, *b = &h->run2;
-    if (a->active && b->active && b->p.seq_value < a->p.seq_value) std::swap (a, b);      // a = the older frame
-    int rc;
-    if (a->active && (rc = run_finish (h, *a, b->active ? b : nullptr))) return rc;
-    if (b->active && (rc = run_finish (h, *b, nullptr))) return rc;
-    if (h->stream2_dirty && h->stream2) { HIPCHK (h, hipStreamSynchronize (h->stream2)); h->stream2_dirty = false; }
-    return ICP_OK;
-}
-
-// Launches the graph of a run.
-int launch_run (icp_context *h, uint32_t iterations, int check, bool fresh = false, bool with_build = false)
-{
-    {   // diagnostic (ICP_AMD_RUN_GRAPH=0): the same launches enqueued one by one instead of as a cached graph
-        static const char *e = std::getenv ("ICP_AMD_RUN_GRAPH");
-        if (e && e[0] == '0') {
-            icp_params p = h->p; p.check = check; p.hmirror = nullptr; p.hstate = nullptr;
-            if (with_build) icp_launch_build_rbc (p, h->stream);
-            if (fresh && !icp_chain_supported (p)) icp_launch_reset_state (p, h->stream, 1);
-            if (icp_chain_supported (p)) icp_launch_chain (p, h->stream, iterations, fresh);
-            else for (uint32_t k = 0; k < iterations; ++k) { p.emit = (check || k + 1 == iterations) ? 1 : 0; icp_launch_iteration (p, h->stream); }
-            if (check) HIPCHK (h, hipMemcpyAsync (h->hState, p.st, sizeof (icp_reg_state) * p.batch, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK (h, hipGetLastError ());
-            h->hstate_fresh = check != 0; h->hstate_here = false;
-            h->k_base = check ? -1 : (fresh || with_build) ? (long long) iterations : (h->k_base >= 0 ? h->k_base + iterations : -1);
-            note_outputs_stored (h);
-            return ICP_OK;
-        }
-    }
-    hipGraphExec_t exec;
-    int rc = get_graph (h, iterations, check, &exec, fresh, with_build);
-    if (rc) return rc;
-    HIPCHK (h, hipGraphLaunch (exec, h->stream));
-    h->hstate_fresh = check != 0; h->hstate_here = false;
-    h->k_base = check ? -1 : (fresh || with_build) ? (long long) iterations : (h->k_base >= 0 ? h->k_base + iterations : -1);
-    note_outputs_stored (h);
-    return ICP_OK;
-}
-
-// Waits for everything enqueued on the handle's stream.
-int settle (icp_context *h)
-{
-    HIPCHK (h, hipStreamSynchronize (h->stream));
-    return ICP_OK;
-}
-
-// every state-changing enqueue that is not a checked run graph: the pinned mirror of the states is stale from here on
-void note_enqueue (icp_context *h) { h->hstate_fresh = false; h->hstate_here = false; h->k_base = -1; }
-
-// the inputs of the last checked run are about to change (F / M / the RBC): per-query outputs it did not store can no longer be reproduced
-void note_inputs_change (icp_context *h) { if (h->outputs_stale) { h->outputs_stale = false; h->outputs_lost = true; } }
-// an enqueue that stores the per-query outputs itself (single steps, fixed-length runs: their last iteration)
-void note_outputs_stored (icp_context *h) { h->outputs_stale = false; h->outputs_lost = false; }
-
-bool is_query_output (int mem) { return mem == ICP_MEM_NN_ID || mem == ICP_MEM_W || mem == ICP_MEM_NN || mem == ICP_MEM_QT || mem == ICP_MEM_RID; }
-
-// Per-query outputs of a checked run that stored none: the search of its last executed iteration again — p.st_prev holds the transform it
-// used — with the stores on.  The moments it leaves are nobody's (the run is over); the state is not touched.
-int materialize_outputs (icp_context *h, int mem)
-{
-    if (!is_query_output (mem)) return ICP_OK;
-    if (h->outputs_lost)
-        return fail (h, ICP_ESTATE, "the per-query outputs of the last checked run were not stored (lazy outputs) and its inputs have changed since: "
-                                    "read them before F / M / the RBC change, or switch to icp_set_output_mode (h, ICP_OUTPUTS_EVERY_ITERATION)");
-    if (!h->outputs_stale) return ICP_OK;
-    icp_params q = h->p;
-    q.st = q.st_prev; q.check = 0; q.emit = 1; q.hmirror = nullptr; q.hstate = nullptr;
-    icp_launch_search (q, h->stream);
-    HIPCHK (h, hipGetLastError ());
-    h->outputs_stale = false;
-    return ICP_OK;
 }
 
 }  // namespace
@@ -1144,332 +662,6 @@ int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint
     return ICP_OK;
 }
 
-// ---- frame-to-frame tracking ---------------------------------------------------------------------------------------------------
-// Frame f's landmarks live in lm[f mod 3]; registration f (frame f onto frame f - 1) reads lm[f mod 3] as the moving and
-// lm[(f - 1) mod 3] as the fixed set, so frame f + 1 can be uploaded and its landmarks extracted (copy stream) while registration f
-// runs (main stream): the buffer it goes to was last read by registration f - 1.  Two staging slots (f mod 2) hold the band of
-// a frame (the 2.08 MB of its 9.83 MB that getLMs reads) in pinned memory; per frame the main stream gets ONE graph — buildRBC +
-// the checked run — and a 248-byte copy of the final state into the frame's slot of a pinned ring.
-#define ICP_TRACK_RING 4u
-
-static int track_prepare (icp_context *h)
-{
-    if (h->p.m != 16384u || h->p.batch != 1u) return fail (h, ICP_EINVAL, "tracking needs m == 16384 (getLMs) and a single registration");
-    if (!h->ownF || !h->ownM) return fail (h, ICP_ESTATE, "tracking rotates the handle's own landmark buffers: not available with adopted F / M buffers");
-    if (!h->lm[2]) HIPCHK (h, hipMalloc ((void **) &h->lm[2], (size_t) h->p.m * 8 * sizeof (float)));
-    for (int k = 0; k < 2; ++k) {
-        if (!h->hBand[k]) HIPCHK (h, hipHostMalloc ((void **) &h->hBand[k], ICP_BAND_BYTES, hipHostMallocDefault));
-        if (!h->dBand[k]) HIPCHK (h, hipMalloc ((void **) &h->dBand[k], ICP_BAND_BYTES));
-    }
-    if (!h->hTrack) HIPCHK (h, hipHostMalloc ((void **) &h->hTrack, ICP_TRACK_RING * sizeof (icp_reg_state), hipHostMallocMapped | hipHostMallocCoherent));
-    if (!h->hTrackMirror) {
-        HIPCHK (h, hipHostMalloc ((void **) &h->hTrackMirror, ICP_TRACK_RING * sizeof (unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset (h->hTrackMirror, 0, ICP_TRACK_RING * sizeof (unsigned long long));
-    }
-    if (h->run_adaptive && h->track_gate && !h->rbc2_ready) {
-        // frames gated on the device: a second stream, the sequence word and the run flags, a second set of RBC buffers (frame f builds its
-        // RBC while frame f - 1 is still searching its own)
-        const icp_params &p = h->p;
-        if (!h->stream2) HIPCHK (h, hipStreamCreateWithFlags (&h->stream2, hipStreamNonBlocking));
-        if (!h->dSeq) { HIPCHK (h, hipMalloc ((void **) &h->dSeq, sizeof (uint32_t))); HIPCHK (h, hipMemset (h->dSeq, 0, sizeof (uint32_t))); }
-        // (one flag per stream: a run's flag must stay what it is until the last of that run's launches has gone through — the NEXT frame, on
-        // the other stream, may converge while launches of this one are still queued; the frame after that is behind them on this stream)
-        if (!h->dRunFlag) { HIPCHK (h, hipMalloc ((void **) &h->dRunFlag, 2 * sizeof (uint32_t))); HIPCHK (h, hipMemset (h->dRunFlag, 0, 2 * sizeof (uint32_t))); }
-        if (!h->hGateFlag) { HIPCHK (h, hipHostMalloc ((void **) &h->hGateFlag, sizeof (uint32_t), hipHostMallocMapped | hipHostMallocCoherent)); *h->hGateFlag = 0u; }
-        icp_context::rbc_set &a = h->rbc[0], &b = h->rbc[1];
-        a.R = p.R; a.GB = p.GB; a.XP = p.XP; a.XQ = p.XQ; a.rep_src = p.rep_src; a.owner = p.owner; a.N = p.N; a.O = p.O; a.perm = p.perm;
-        a.chunk_hist = p.chunk_hist; a.blist = p.blist; a.bn = p.bn; a.brank = p.brank;
-        auto al = [&] (void **q, size_t bytes) -> int {
-            hipError_t e = hipMalloc (q, bytes ? bytes : 1);
-            if (e == hipSuccess) e = hipMemset (*q, 0, bytes ? bytes : 1);
-            return e == hipSuccess ? ICP_OK : fail (h, ICP_ENOMEM, std::string ("tracking (second RBC set): ") + hipGetErrorString (e));
-        };
-        int rc;
-        if ((rc = al ((void **) &b.R, (size_t) p.nr * 32)) || (rc = al ((void **) &b.GB, (size_t) 2 * (p.n16 + p.n1k) * 16)) || (rc = al ((void **) &b.XP, (size_t) p.m * 32)) ||
-            (rc = al ((void **) &b.XQ, (size_t) p.m * 32)) || (rc = al ((void **) &b.rep_src, (size_t) p.nr * 4)) || (rc = al ((void **) &b.owner, (size_t) p.m * 4)) ||
-            (rc = al ((void **) &b.N, (size_t) p.nr * 4)) || (rc = al ((void **) &b.O, (size_t) p.nr * 4)) || (rc = al ((void **) &b.perm, (size_t) p.m * 4)) ||
-            (rc = al ((void **) &b.chunk_hist, (size_t) p.nchunk * p.nr * 4)) || (rc = al ((void **) &b.blist, (size_t) p.nb * 64 * 8)) ||
-            (rc = al ((void **) &b.bn, (size_t) p.nb * 4)) || (rc = al ((void **) &b.brank, (size_t) p.m))) {
-            void *ptrs[] = { b.R, b.GB, b.XP, b.XQ, b.rep_src, b.owner, b.N, b.O, b.perm, b.chunk_hist, b.blist, b.bn, b.brank };
-            for (void *x : ptrs) if (x) (void) hipFree (x);
-            b = icp_context::rbc_set {};
-            return rc;
-        }
-        // Do the two streams really run side by side?  HIP spreads streams over a few hardware queues; two streams that share one are served in
-        // order, and a gate would then hold back the very launches it is waiting for.  One probe at set-up: a short-lived gate on stream2
-        // waits for a word that a kernel on the handle's own stream sets.  If the gate gives up (2 ms), gating stays off for this handle.
-        *h->hGateFlag = 0u;
-        icp_launch_gate (h->dSeq, 1u, h->hGateFlag, h->stream2, 1u << 13);
-        icp_launch_seq_set (h->dSeq, 1u, h->stream);
-        HIPCHK (h, hipGetLastError ());
-        HIPCHK (h, hipStreamSynchronize (h->stream2));
-        HIPCHK (h, hipStreamSynchronize (h->stream));
-        if (*h->hGateFlag) { h->track_gate = 0; *h->hGateFlag = 0u; }
-        HIPCHK (h, hipMemset (h->dSeq, 0, sizeof (uint32_t)));
-        h->rbc2_ready = true;
-    }
-    return ICP_OK;
-}
-
-static void rbc_into (icp_params &p, const icp_context::rbc_set &q)
-{
-    p.R = q.R; p.GB = q.GB; p.XP = q.XP; p.XQ = q.XQ; p.rep_src = q.rep_src; p.owner = q.owner; p.N = q.N; p.O = q.O; p.perm = q.perm;
-    p.chunk_hist = q.chunk_hist; p.blist = q.blist; p.bn = q.bn; p.brank = q.brank;
-}
-
-// the iteration counts of the last two registrations the host knows the outcome of (a run that was decided because all max_iterations
-// launches were out tells nothing yet: its real k comes with its final state, at icp_track_collect)
-static void track_note_k (icp_context *h, uint64_t frame, uint32_t k)
-{
-    if (frame + 1u <= h->track_hist_frame) return;                       // (this frame, or a later one, is in the history already)
-    h->track_hist_frame = frame + 1u;
-    h->track_k_hist[1] = h->track_k_hist[0]; h->track_k_hist[0] = k;
-}
-static void track_note_k (icp_context *h, const run_ctl &r) { if (r.done_seen) track_note_k (h, r.p.seq_value, r.k_final); }
-
-int icp_track_reset (icp_handle h)
-{
-    if (!h) return ICP_EINVAL;
-    int rc = set_device (h); if (rc) return rc;
-    if ((rc = run_close_all (h))) return rc;
-    if (h->copy_stream) HIPCHK (h, hipStreamSynchronize (h->copy_stream));
-    if (h->stream2) HIPCHK (h, hipStreamSynchronize (h->stream2));
-    if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
-    if (h->dSeq) HIPCHK (h, hipMemset (h->dSeq, 0, sizeof (uint32_t)));
-    if (h->hGateFlag) *h->hGateFlag = 0u;
-    h->track_submitted = h->track_collected = 0;
-    h->track_k_hist[0] = h->track_k_hist[1] = 0; h->track_hist_frame = 0;
-    h->track_last_gated = false;
-    return ICP_OK;
-}
-
-int icp_track_staging (icp_handle h, uint32_t slot, void **host_ptr)
-{
-    int rc = need (h, false, true); if (rc) return rc;
-    if (slot > 1u || !host_ptr) return fail (h, ICP_EINVAL, "icp_track_staging: slot must be 0 or 1");
-    if ((rc = set_device (h))) return rc;
-    if (!h->hFrame[slot]) HIPCHK (h, hipHostMalloc ((void **) &h->hFrame[slot], (size_t) 640 * 480 * 32, hipHostMallocDefault));
-    // the buffer is handed out once the band of the frame it last held has left it (its upload may still be queued on the copy stream
-    // when more than two frames are in flight; an event that was never recorded returns at once)
-    HIPCHK (h, hipEventSynchronize (h->evUp[slot]));
-    *host_ptr = h->hFrame[slot];
-    return ICP_OK;
-}
-
-// Tracking: blind launches of a frame's registration — what is enqueued before icp_track_submit returns (the caller is away until its
-// next call: copying the next frame, typically).  The smaller of the last two registrations' k + the launch that finds out; a first
-// registration of a sequence gets depth + 1 and is topped up by the next call.
-static uint32_t track_blind (const icp_context *h)
-{
-    { const char *e = std::getenv ("ICP_AMD_TRACK_BLIND"); if (e) return (uint32_t) std::max (1, std::atoi (e)); }     // diagnostics / tests: a fixed number
-    const uint32_t a = h->track_k_hist[0], b = h->track_k_hist[1];
-    const uint32_t k = a && b ? std::min (a, b) : (a ? a : b);
-    return k ? k + 1u : h->run_depth + 1u;
-}
-
-static int track_submit (icp_context *h, const void *cloud, int warm_start, bool blocking)
-{
-    int rc = need (h, false, true); if (rc) return rc;
-    if (!cloud) return fail (h, ICP_EINVAL, "null pointer");
-    if ((rc = set_device (h))) return rc;
-    if ((rc = track_prepare (h))) return rc;                            // (everything that can fail for lack of memory comes first)
-    if (h->track_submitted - h->track_collected >= ICP_TRACK_RING)
-        return fail (h, ICP_ESTATE, "icp_track_submit: four frames are in flight: collect a result first (icp_track_collect)");
-    const uint64_t f = h->track_submitted;
-    const uint32_t s = (uint32_t) (f & 1u), buf = (uint32_t) (f % 3u), ring = (uint32_t) (f % ICP_TRACK_RING);
-    const char *src = static_cast<const char *> (cloud) + ((size_t) ICP_BAND_ROW0 * 640u + ICP_BAND_COL0) * 32u;
-    const size_t spitch = (size_t) ICP_BAND_ROW_STEP * 640u * 32u;
-    // gated: registration f lives in run slot f & 1 on stream f & 1; its predecessor (f - 1) in the other slot, possibly still open
-    // (the release of the sequence word lives in the chained kernel: other forms — reference-order reductions, |R| > 1024 — stay host-ordered)
-    // (and the blocking icp_track_next has nothing to overlap: it stays on one stream and spares itself the gate)
-    const bool gated = !blocking && h->run_adaptive && h->track_gate && h->rbc2_ready && icp_chain_supported (h->p);
-    if (gated != h->track_last_gated) {                                 // the form changes in mid-sequence (a mode was switched): start from a drained device
-        if ((rc = run_close_all (h))) return rc;
-        if (h->stream2) HIPCHK (h, hipStreamSynchronize (h->stream2));
-        HIPCHK (h, hipStreamSynchronize (h->stream));
-        if (gated && f > 0u) { icp_launch_seq_set (h->dSeq, (uint32_t) (f - 1u), h->stream); HIPCHK (h, hipGetLastError ()); HIPCHK (h, hipStreamSynchronize (h->stream)); }
-        h->track_last_gated = gated;
-    }
-    run_ctl &R = (gated && (f & 1u)) ? h->run2 : h->run;
-    run_ctl *P = gated ? ((f & 1u) ? &h->run : &h->run2) : &h->run;     // the run to look after meanwhile (ungated: the one and only)
-    hipStream_t st = (gated && (f & 1u)) ? h->stream2 : h->stream;
-    // the previous frame's registration may still need launches while this call does its own work: it is looked after between the steps
-    // (a word read; a launch if its queue has run down)
-    auto tend = [&] () { if (P->active) (void) run_pump (h, *P); };
-    if (gated && R.active) {                                            // the slot still holds registration f - 2: decided long ago, or nearly
-        if ((rc = run_finish (h, R, P->active ? P : nullptr))) return rc;
-        track_note_k (h, R);
-    }
-    // the copy stream: not before registration f - 2 (the last reader of lm[buf], as its fixed set) is done.  Host-driven runs: the host
-    // knows — the FINAL bit of that frame's word —, and neither stream carries an event for it (a record + a cross-stream wait cost the
-    // main stream ~10 us per frame between the RBC construction and the first iteration, profiles/r04_track_trace.txt)
-    if (f >= 2u) {
-        const uint32_t r2 = (uint32_t) ((f - 2u) % ICP_TRACK_RING);
-        if (h->track_epoch[r2]) {
-            // (its end kernel, if it needs one, is enqueued: run_finish above / at the previous submit)
-            if (!gated && h->run.active && h->run.track_slot == (int) r2) { if ((rc = run_finish (h))) return rc; track_note_k (h, h->run); }
-            if ((rc = run_wait_final (h, h->hTrackMirror + r2, 1u, h->track_epoch[r2]))) return rc;
-        } else HIPCHK (h, hipStreamWaitEvent (h->copy_stream, h->evDone[r2], 0));
-    }
-    tend ();
-    const bool pinned = cloud == h->hFrame[0] || cloud == h->hFrame[1];
-    if (pinned) {
-        // the caller filled one of the engine's pinned frame buffers (icp_track_staging): the band goes by DMA straight from there
-        HIPCHK (h, hipMemcpy2DAsync (h->dBand[s], ICP_BAND_ROW_BYTES, src, spitch, ICP_BAND_ROW_BYTES, ICP_BAND_ROWS, hipMemcpyHostToDevice, h->copy_stream));
-        tend ();
-    } else {
-        // pageable source: the band's 128 row segments into the slot's pinned staging (free once the upload of frame f - 2 is through)
-        if (f >= 2u) HIPCHK (h, hipEventSynchronize (h->evUp[s]));
-        // in two pieces, each uploaded as soon as it is staged: the DMA of the first runs under the host copy of the second (a blocking
-        // icp_track_next waits for 60 us of copy + 45 us of upload otherwise; every copy command costs ~12 us by itself, so more pieces
-        // give the gain back: 1 / 2 / 4 pieces = 393 / 371 / 393 us per blocking cold frame; ICP_AMD_BAND_PIECES for the comparison)
-        static const uint32_t npieces = [] { const char *e = std::getenv ("ICP_AMD_BAND_PIECES"); const int v = e ? std::atoi (e) : 2; return (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t) v : 2u; } ();
-        const uint32_t piece = ICP_BAND_ROWS / npieces;
-        for (uint32_t j = 0; j < ICP_BAND_ROWS; ++j) {
-            std::memcpy (reinterpret_cast<char *> (h->hBand[s]) + (size_t) j * ICP_BAND_ROW_BYTES, src + (size_t) j * spitch, ICP_BAND_ROW_BYTES);
-            // (the copy takes ~60 us: the previous frame's open registration is looked after on the way — a word read, a launch if it needs one)
-            if ((j & 7u) == 7u && P->active) (void) run_pump (h, *P);
-            if ((j + 1u) % piece == 0u) {
-                const size_t off = (size_t) (j + 1u - piece) * ICP_BAND_ROW_BYTES;
-                HIPCHK (h, hipMemcpyAsync (reinterpret_cast<char *> (h->dBand[s]) + off, reinterpret_cast<char *> (h->hBand[s]) + off, (size_t) piece * ICP_BAND_ROW_BYTES,
-                                           hipMemcpyHostToDevice, h->copy_stream));
-                tend ();
-            }
-        }
-    }
-    icp_launch_get_lms_band (h->dBand[s], h->lm[buf], h->copy_stream);
-    HIPCHK (h, hipGetLastError ());
-    tend ();
-    HIPCHK (h, hipEventRecord (h->evUp[s], h->copy_stream));
-    tend ();
-    // ungated: one stream, in order — the previous frame's registration is brought to its end before this frame's work goes behind it
-    int prev_slot = -1;
-    if (!gated && h->run.active) {
-        prev_slot = h->run.track_slot;
-        if ((rc = run_finish (h))) return rc;
-        track_note_k (h, h->run);
-    }
-    // (rounds 1 - 3's form only: host-driven runs order the streams from the host, see above)
-    auto record_prev = [&] () -> int { if (prev_slot >= 0 && !h->track_epoch[prev_slot]) { HIPCHK (h, hipEventRecord (h->evDone[prev_slot], h->stream)); } prev_slot = -1; return ICP_OK; };
-    // an upload is waited for on the stream only if it is not through yet (it is, whenever a registration takes longer than an upload)
-    auto wait_upload = [&] (uint32_t slot) -> int { if (hipEventQuery (h->evUp[slot]) != hipSuccess) { (void) hipGetLastError (); HIPCHK (h, hipStreamWaitEvent (st, h->evUp[slot], 0)); } return ICP_OK; };
-    note_inputs_change (h);
-    float *newM = h->lm[buf], *newF = h->lm[(f + 2u) % 3u];             // (f - 1) mod 3: the previous frame's landmarks (first frame: a buffer that is not M)
-    icp_params p = h->p; p.M = newM; p.F = newF; p.seq_value = (uint32_t) f;
-    if (gated) rbc_into (p, h->rbc[f & 1u]);
-    if (f > 0u) {
-        note_enqueue (h);
-        // warm start: from the previous hop's transform, as by write (D_IO_T) — the first registration of a sequence has no previous hop
-        // and starts from the identity whatever the state holds (an earlier sequence's last transform, an icp_run before the reset)
-        const bool warm = warm_start && f > 1u;
-        if (h->run_adaptive) {
-            const uint32_t blind = blocking ? h->run_depth + 1u : track_blind (h);
-            if (gated) {
-                // buildRBC runs AHEAD of the previous frame's end (its own RBC set, the fixed landmarks resident since that frame's upload)
-                // and must not touch the registration state; behind it the gate: registration f - 1 has released the sequence word
-                p.no_state_reset = 1u; p.run_flag = h->dRunFlag + (f & 1u); p.track_seq = h->dSeq; p.seq_value = (uint32_t) f;
-                if ((rc = wait_upload ((uint32_t) ((f - 1u) & 1u)))) return rc;          // (the fixed set: frame f - 1's landmarks)
-            }
-            // buildRBC reads the fixed set only — the previous frame's landmarks —: this frame's upload is waited for behind it
-            auto between = [&] () -> int {
-                int rc2 = record_prev (); if (rc2) return rc2;
-                if ((rc2 = wait_upload (s))) return rc2;
-                if (gated && f >= 2u) { icp_launch_gate (h->dSeq, (uint32_t) (f - 1u), h->hGateFlag, st); HIPCHK (h, hipGetLastError ()); }
-                if (warm) { icp_launch_set_T (p, 0, p.st->T, st, gated ? 1 : 0); HIPCHK (h, hipGetLastError ()); }
-                return ICP_OK;
-            };
-            if ((rc = run_begin (h, R, st, p, !warm, true, blind, h->hTrackMirror + ring, h->hTrack + ring, (int) ring, between, (gated && P->active) ? P : nullptr))) return rc;
-            h->track_epoch[ring] = R.p.epoch;
-            // (gated: a launch past the convergence of a frame runs beside the next frame and costs ~0.6 - 0.9 us, a queue that runs dry while
-            // the host is busy with the next frame costs what the host is late by: the queue is kept twice as deep)
-            if (gated) R.depth = std::max (R.depth, 2u * h->run_depth);
-            if (gated && (f & 1u)) h->stream2_dirty = true;
-        } else {
-            // rounds 1 - 3: buildRBC + a checked run of max_iterations launches as one cached graph (the graphs hold the buffer pointers)
-            if ((rc = record_prev ())) return rc;
-            HIPCHK (h, hipStreamWaitEvent (h->stream, h->evUp[s], 0));
-            if (warm) { icp_launch_set_T (p, 0, p.st->T, h->stream); HIPCHK (h, hipGetLastError ()); }
-            float *oF = h->dF, *oM = h->dM; const float *opF = h->p.F, *opM = h->p.M; const uint32_t opar = h->parity;
-            h->dM = newM; h->p.M = newM; h->dF = newF; h->p.F = newF; h->parity = 1u + buf;
-            rc = launch_run (h, h->max_iterations, 1, !warm, true);
-            if (rc) { h->dF = oF; h->dM = oM; h->p.F = opF; h->p.M = opM; h->parity = opar; return rc; }
-            HIPCHK (h, hipMemcpyAsync (&h->hTrack[ring], h->p.st, sizeof (icp_reg_state), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK (h, hipEventRecord (h->evDone[ring], h->stream));
-            h->track_epoch[ring] = 0u;
-        }
-    } else {
-        if ((rc = record_prev ())) return rc;
-        HIPCHK (h, hipStreamWaitEvent (h->stream, h->evUp[s], 0));      // this frame's landmarks (nothing to register against yet)
-        HIPCHK (h, hipEventRecord (h->evDone[ring], h->stream));
-        h->track_epoch[ring] = 0u;
-    }
-    // everything that can fail is behind us: the handle now points at this frame's buffers
-    h->dM = newM; h->p.M = newM; h->dF = newF; h->p.F = newF;
-    if (gated && f > 0u) rbc_into (h->p, h->rbc[f & 1u]);
-    h->parity = 1u + buf;                                               // graphs hold the pointers: one cached set per rotation step (0: the buffers of icp_init)
-    h->built = f > 0u;
-    h->track_submitted = f + 1u;
-    return ICP_OK;
-}
-
-int icp_track_submit (icp_handle h, const void *cloud, int warm_start) { return track_submit (h, cloud, warm_start, false); }
-
-int icp_track_form (icp_handle h, int *gated)
-{
-    int rc = need (h, false, true); if (rc) return rc;
-    if (!gated) return fail (h, ICP_EINVAL, "null output");
-    if ((rc = set_device (h))) return rc;
-    if (h->run_adaptive && h->track_gate && h->p.m == 16384u && h->p.batch == 1u && h->ownF && h->ownM && (rc = track_prepare (h))) return rc;   // (runs the probe)
-    *gated = (h->run_adaptive && h->track_gate && h->rbc2_ready && icp_chain_supported (h->p)) ? 1 : 0;
-    return ICP_OK;
-}
-
-int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered)
-{
-    int rc = need (h, false, true); if (rc) return rc;
-    if (h->track_collected >= h->track_submitted) return fail (h, ICP_ESTATE, "icp_track_collect: no frame in flight");
-    if ((rc = set_device (h))) return rc;
-    const uint64_t f = h->track_collected;
-    const uint32_t ring = (uint32_t) (f % ICP_TRACK_RING);
-    for (int i = 0; i < 2; ++i) {                                       // the frame's registration is still open: top it up to its end
-        run_ctl &R = i ? h->run2 : h->run;
-        run_ctl &O = i ? h->run : h->run2;
-        if (R.active && R.track_slot == (int) ring && R.p.epoch == h->track_epoch[ring]) {
-            if ((rc = run_finish (h, R, O.active ? &O : nullptr))) return rc;
-            track_note_k (h, R);
-        }
-    }
-    if (f > 0u && h->track_epoch[ring]) { if ((rc = run_wait_final (h, h->hTrackMirror + ring, 1u, h->track_epoch[ring]))) return rc; }
-    else HIPCHK (h, hipEventSynchronize (h->evDone[ring]));
-    if (h->hGateFlag && *h->hGateFlag) return fail (h, ICP_EHIP, "tracking: a frame's gate gave up waiting for its predecessor (device-side wait of ~0.5 s exceeded)");
-    h->track_collected = f + 1u;
-    if (f + 1u == h->track_submitted && f > 0u && h->track_epoch[ring]) {
-        // nothing behind this frame: the handle's state is this registration's final state, and the host holds it
-        h->hState[0] = h->hTrack[ring]; h->hstate_fresh = true; h->hstate_here = true;
-    }
-    if (k) *k = 0;
-    if (registered) *registered = f > 0u ? 1 : 0;
-    if (f > 0u) {
-        const icp_reg_state &st = h->hTrack[ring];
-        track_note_k (h, f, st.k);
-        if (k) *k = st.k;
-        if (T8) std::memcpy (T8, st.T, 8 * sizeof (float));
-    } else if (T8) { const float T0[8] = { 0, 0, 0, 1, 0, 0, 0, 1 }; std::memcpy (T8, T0, sizeof T0); }
-    return ICP_OK;
-}
-
-int icp_track_next (icp_handle h, const void *cloud, int warm_start, uint32_t *k, int *registered)
-{
-    if (k) *k = 0;
-    if (registered) *registered = 0;
-    int rc = need (h, false, true); if (rc) return rc;
-    while (h->track_collected < h->track_submitted)                     // (results of an earlier pipelined use nobody collected)
-        if ((rc = icp_track_collect (h, nullptr, nullptr, nullptr))) return rc;
-    if ((rc = track_submit (h, cloud, warm_start, true))) return rc;
-    if ((rc = icp_track_collect (h, k, nullptr, registered))) return rc;
-    if (!h->run_adaptive) return settle (h);
-    return ICP_OK;
-}
 
 int icp_transform_cloud_ex (icp_handle h, int kind, const float *T, const void *host_in, void *host_out, uint32_t n)
 {

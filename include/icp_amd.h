@@ -25,6 +25,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with hidden visibility; what this header declares is what it exports. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct icp_context *icp_handle;
 
@@ -462,6 +466,9 @@ int icp_synth_pair (uint64_t seed, uint32_t side, float rot_deg, const float *ax
  * rigidly by f steps of 3 degrees / (25, -10, 15) mm, with noise). */
 int icp_synth_cloud_vga (uint64_t seed, int moved, float *cloud);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

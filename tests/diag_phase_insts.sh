@@ -2,7 +2,7 @@
 # Diagnostic (not a test): executed VALU / SALU / LDS / vector-memory instructions of the dense search kernel PER PHASE — builds of the
 # engine whose k_search returns behind phase k (-DICP_DBG_EXIT_AFTER=k, KS_STAMP points), one PMC run each; the differences between
 # consecutive builds are the phases.  usage: tests/diag_phase_insts.sh build|run [TAG]   (build here, run on the GPU box)
-SRC="icp_amd/csrc/icp_kernels.hip icp_amd/csrc/icp_build.hip icp_amd/csrc/icp_capi.hip icp_amd/csrc/icp_reduce_scan.hip icp_amd/csrc/icp_standalone.hip icp_amd/csrc/icp_synth.cpp icp_amd/csrc/icp_batch.cpp"
+SRC="$(echo icp_amd/csrc/*.hip icp_amd/csrc/*.cpp)"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-result -pthread -mllvm -amdgpu-kernarg-preload-count=14 -Iinclude -shared"
 PH="0 10 2 3 5 6 99"
 if [ "$1" = build ]; then

@@ -38,6 +38,15 @@ def test_library_exports_every_declared_symbol(engine):
     assert L.icp_version().startswith(b"icp_amd")
 
 
+def test_library_exports_nothing_else():
+    """Hidden visibility: the functions the library exports are exactly the header's (a host program's own `fail` or `settle` must not
+    be interposed by the engine's internals); what else is visible are the kernels' handles and a few weak template instances."""
+    lib = os.path.join(ROOT, "icp_amd", "libicp_amd.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    funcs = sorted(l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T")
+    assert funcs == declared_symbols(), sorted(set(funcs) ^ set(declared_symbols()))
+
+
 def test_no_cpu_fallback(engine):
     """Without a device icp_create must fail with ICP_ENODEVICE and a message; with one it must succeed."""
     L = engine.lib()

@@ -38,6 +38,7 @@ struct run_ctl {
     uint32_t enq = 0, maxit = 0, depth = 0, k_seen = 0, k_final = 0, k0 = 0;     // k0: the device's k when the run began (k_seen is relative to it)
     int done_seen = 0;
     bool final_seen = false;                            // every registration's final state has arrived with its converged flag: no end kernel
+    bool end_enqueued = false;                          // the end kernel is on the stream already (a run whose queue reached max_iterations: nothing waits for the host)
     volatile unsigned long long *mirror = nullptr;      // host view of p.hmirror
     int track_slot = -1;                                // tracking: the ring slot of the frame this run registers
     hipStream_t stream = nullptr;                       // the stream the run's launches go to (tracking alternates between two)
@@ -156,6 +157,7 @@ int need (icp_context *h, bool built, bool keep_run = false);
 int set_device (icp_context *h);
 int get_graph (icp_context *h, uint32_t iterations, int check, hipGraphExec_t *out, bool fresh = false, bool with_build = false);
 void run_launch_one (icp_context *h, run_ctl &r);
+void run_enqueue_end (icp_context *h, run_ctl &r);
 bool run_pump (icp_context *h, run_ctl &r);
 int run_finish (icp_context *h, run_ctl &r, run_ctl *other);
 inline int run_finish (icp_context *h) { return run_finish (h, h->run, h->run2.active ? &h->run2 : nullptr); }   // the run on the handle's own stream
@@ -230,7 +232,7 @@ int run_begin (icp_context *h, run_ctl &r, hipStream_t stream, const icp_params 
         run_launch_one (h, r);
         if (other && other->active && (r.enq & 1u) == 0u) (void) run_pump (h, *other);
     }
-    if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit + r.k0; }
+    if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit + r.k0; run_enqueue_end (h, r); }
     HIPCHK (h, hipGetLastError ());
     h->hstate_fresh = false; h->hstate_here = false; h->k_base = -1;
     r.t[1] = now_s ();

@@ -113,6 +113,19 @@ void run_launch_one (icp_context *h, run_ctl &r)
     ++r.enq;
 }
 
+// The end kernel of a run that did not (or may not) end by itself: final state -> p.st and -> host memory, FINAL bit, the release of the
+// tracking sequence word.  It goes behind the last iteration launch the moment the queue has reached max_iterations — nothing more will be
+// enqueued, and a tracked frame's successor (gated on the device) must not wait for the host's next visit —; a run that converged earlier
+// has left its final state already and the kernel returns at its first load (k_chain_end: run_flag).
+void run_enqueue_end (icp_context *h, run_ctl &r)
+{
+    (void) h;
+    if (r.end_enqueued || r.final_seen) return;
+    if (r.chained) icp_launch_chain_end (r.p, r.stream, r.enq);
+    else icp_launch_publish_state (r.p, r.stream);
+    r.end_enqueued = true;
+}
+
 // One look at the run's words, then the queue topped up to `depth` launches behind the one in flight.  Returns true once the run is
 // decided: every registration has converged, or max_iterations launches are enqueued (nothing more will be).
 bool run_pump (icp_context *h, run_ctl &r)
@@ -134,7 +147,7 @@ bool run_pump (icp_context *h, run_ctl &r)
     // launch (chained) / search (separate launches) j publishes k = j in its prologue: k_seen = the iteration in flight, `depth`
     // iterations are kept queued behind it
     while (r.enq < r.maxit && r.enq < r.k_seen + 1u + r.depth) run_launch_one (h, r);
-    if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit + r.k0; }
+    if (r.enq >= r.maxit) { r.decided = true; r.k_final = r.maxit + r.k0; run_enqueue_end (h, r); }
     return r.decided;
 }
 
@@ -161,10 +174,7 @@ int run_finish (icp_context *h, run_ctl &r, run_ctl *other)
     }
     r.t[3] = now_s ();
     // (converged in the fused forms: the finalize that set the flag has left the final state in p.st and in host memory already)
-    if (!r.final_seen) {
-        if (r.chained) icp_launch_chain_end (r.p, r.stream, r.enq);
-        else icp_launch_publish_state (r.p, r.stream);
-    }
+    run_enqueue_end (h, r);
     r.t[4] = now_s ();
     for (int i = 0; i < 5; ++i) h->stat_t[i] = r.t[i];
     h->stat_launch_max_us = std::max (h->stat_launch_max_us, r.launch_max_us); h->stat_launch_slow += r.launch_slow; h->stat_launch_total += r.enq;

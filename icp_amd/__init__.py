@@ -582,7 +582,8 @@ class ICPStep:
         self._chk(self._L.icp_track_reset(self._h))
 
     def track_submit(self, cloud, warm_start=False):
-        """Enqueues a frame (upload of its band + getLMs on the copy stream, buildRBC + run as one graph): returns at once.
+        """Enqueues a frame (upload of its band + getLMs on the copy stream, buildRBC + as many iterations of a host-driven checked run as the
+        last two registrations suggest; later track_* calls top it up): returns at once.
         `cloud`: a 640x480 float8 array, or the index (0 / 1) of one of the engine's pinned frame buffers (track_staging)."""
         if isinstance(cloud, int):
             ptr = C.c_void_p(self.track_staging(cloud).ctypes.data)

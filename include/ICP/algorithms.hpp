@@ -706,7 +706,8 @@ namespace ICP
     /*! \brief Frame-to-frame registration of a sequence of 640 x 480 clouds ("real-time frame-to-frame registration",
      *         reference README.md:4; per pair the demo's flow src/ocl_icp_reg.cpp:128-172): every frame is registered against the
      *         previous one, whose landmarks stay on the device.  `submit` only enqueues (the band of the frame that `getLMs`
-     *         reads is uploaded and the landmarks extracted on a copy stream; buildRBC + run are one graph), `collect` blocks for
+     *         reads is uploaded and the landmarks extracted on a copy stream; buildRBC + a host-driven checked run, consecutive frames on
+     *         two streams gated on the device: see icp_track_submit in icp_amd.h), `collect` blocks for
      *         the oldest frame in flight and updates `k q t s`; up to four frames may be in flight, so the next frame's upload
      *         overlaps the current registration.  `staging (slot)` hands out the engine's two pinned frame buffers (the
      *         reference's mapped `hPtrInF` / `hPtrInM`): a capture loop that writes there and calls `submit (staging (slot))`

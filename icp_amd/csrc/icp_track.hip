@@ -11,8 +11,10 @@ extern "C" {
 // Frame f's landmarks live in lm[f mod 3]; registration f (frame f onto frame f - 1) reads lm[f mod 3] as the moving and
 // lm[(f - 1) mod 3] as the fixed set, so frame f + 1 can be uploaded and its landmarks extracted (copy stream) while registration f
 // runs (main stream): the buffer it goes to was last read by registration f - 1.  Two staging slots (f mod 2) hold the band of
-// a frame (the 2.08 MB of its 9.83 MB that getLMs reads) in pinned memory; per frame the main stream gets ONE graph — buildRBC +
-// the checked run — and a 248-byte copy of the final state into the frame's slot of a pinned ring.
+// a frame (the 2.08 MB of its 9.83 MB that getLMs reads) in pinned memory.  A frame's registration is buildRBC + a host-driven checked
+// run (icp_run.hip) whose final state the device stores into the frame's slot of a pinned ring (hTrack, words in hTrackMirror);
+// consecutive registrations alternate between two streams, each behind a one-wave gate kernel that waits for its predecessor's release
+// of the sequence word (track_submit).  ICP_AMD_RUN_ADAPTIVE=0 keeps rounds 1 - 3's form: one graph per frame on one stream.
 #define ICP_TRACK_RING 4u
 
 static int track_prepare (icp_context *h)

@@ -19,7 +19,7 @@ print("plain=%s" % os.environ.get("ICP_AMD_RUN_GRAPH", "1"))
 print("fixed run of %d                 : %.3f us per iteration" % (N, timed(lambda: g.run_fixed(N))))
 for every in (False, True):
     g.set_output_mode(every)
-    for depth in (2, 3, 6):
+    for depth in (2, 3, 6, 24):
         g.set_run_depth(depth, True)
         print("checked, host-driven, depth %d, outputs %s: %.3f us per iteration" % (depth, "every iteration" if every else "lazy", timed(lambda: g.run())))
     g.set_run_depth(3, False)

@@ -483,7 +483,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // is a piece of exactly that count —, the representatives gathered straight from F (getReps' sampling rule: the launch does
     // not wait for a kernel that writes R; block 0 writes R and rep_src on the side).
     constexpr bool OWNER_LISTS = OWNER && MINW == 2;
-    const uint32_t tile_id = OWNER_LISTS ? blockIdx.x : (FUSED && (MINW == 2 || (check_flags & 64u))) ? ks_tile_of_block (blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t tile_id = OWNER_LISTS ? blockIdx.x : (FUSED && (MINW == 2 || (check_flags & 64u))) ? ks_tile_of_block (blockIdx.x, nb) : blockIdx.x;     // (fused grids are (nb, batch); gridDim is a hidden kernel argument: a scalar load + wait in front of the first vector load)
     const uint32_t iq = OWNER_LISTS ? blockIdx.x * 64u + lane :
                         FUSED ? fused_query_index (m, side, tpr_magic, tile_id, lane)
                               : (blockIdx.x >> 1) * 128u + 2u * lane + (blockIdx.x & 1u);
@@ -498,7 +498,6 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // HOSTRUN: the run this launch belongs to may have converged already (its flag holds the run's epoch): such a launch leaves below
     // without a single store — the next tracked frame may be running on the other stream, in the same state slots and moment buffers
     uint32_t run_over = 0u;
-    if constexpr (CHAIN && HOSTRUN) { if (p.run_flag) run_over = (p.run_flag[b] == p.epoch) ? 1u : 0u; }
     if constexpr (CHAIN) {
         // bit 4 of check_flags (first launch of a chain): the run starts from the identity transform — what k_reset_state
         // would have left in the state (T = Tk = (0,0,0,1 | 0,0,0,1), R = Rk = I, S = means = sum_w = 0, k = done = 0),
@@ -553,6 +552,9 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         if (!OWNER && !MASKED && k < tn0) ron[u] = make_uint2 (gO[k], gN[k]);
         if (!OWNER && MASKED && u == 0 && tid < tnH) ron[0] = make_uint2 (gO[ht * KT + tid], gN[ht * KT + tid]);
     }
+    // (HOSTRUN: the flag is read HERE, behind the prologue's vector loads — a scalar load of the flag's address, a second one of the flag and a
+    // wait for both: in front of them it would hold every load of the prologue back by two scalar round trips)
+    if constexpr (CHAIN && HOSTRUN) { if (p.run_flag) run_over = (p.run_flag[b] == p.epoch) ? 1u : 0u; }
     // seed of the stage-1 pruning bound: this query's nearest representative of the previous search (any index < nr
     // is a valid seed; the buffer starts zeroed)
     // Pruning pays where stage 1 is throughput-bound: the dense variant (MINW == 4: several blocks per CU, or a

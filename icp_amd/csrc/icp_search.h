@@ -1155,8 +1155,20 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             w = p.weighted ? 100.f / (100.f + d) : 1.f;                // icp_kernels.cl:232
             // per-query outputs: uniform bases + 32-bit byte offsets (i < 2^20)
             icp_dist_id di; di.dist = d; di.id = id;
-            char *o_nn = reinterpret_cast<char *> (p.nn_id + (size_t) b * m), *o_pf = reinterpret_cast<char *> (p.PF + (size_t) b * m);
-            char *o_pm = reinterpret_cast<char *> (p.PM + (size_t) b * m), *o_rid = reinterpret_cast<char *> (p.rid + (size_t) b * m);
+            // One-block-per-CU variants: the four output pointers are fetched from the kernel arguments HERE — an opaque copy of the
+            // argument pointer keeps the compiler from hoisting their scalar loads to the top of the kernel with all the others, where
+            // eight more live SGPRs make it spill freshly loaded arguments to VGPR lanes, i.e. wait for the argument block in front of
+            // the prologue's first vector loads (the chained kernel of a host-driven run: 9.26 -> 9.2 us per iteration); a run that
+            // stores no per-query outputs on the way never loads them at all.
+            const icp_params *pe = &p;
+            if constexpr (MINW == 2 && !OWNER) {
+                unsigned long long la_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);   // (icp_params follows four pointers and six dwords)
+                asm volatile ("" : "+s"(la_));
+                pe = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) la_;
+            }
+            typedef char __attribute__ ((address_space (1))) *gchar;           // (pointers read through `pe` are generic to the compiler: say that they are global)
+            char *o_nn = (char *) (gchar) reinterpret_cast<char *> (pe->nn_id + (size_t) b * m), *o_pf = (char *) (gchar) reinterpret_cast<char *> (pe->PF + (size_t) b * m);
+            char *o_pm = (char *) (gchar) reinterpret_cast<char *> (pe->PM + (size_t) b * m), *o_rid = (char *) (gchar) reinterpret_cast<char *> (pe->rid + (size_t) b * m);
             // (fused mode consumes none of these itself: inside a graph of a fixed length only the last iteration
             // stores them — except the nearest representative where the next search seeds its pruning with it)
             const bool emit = !FUSED || (check_flags & 8u);

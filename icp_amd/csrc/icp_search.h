@@ -198,11 +198,18 @@ static __device__ __forceinline__ void fused_moment_loads (const double *mom, ui
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[q] = 0.0;
     if (live) {
+        if (nb & 127u) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {                // clamped address + select: eight loads back to back
-            const uint32_t i = g * 128u + l + 16u * q;
-            const double t = src[min (i, nb - 1u)];
-            a[q] = (i < nb) ? t : 0.0;
+            for (int q = 0; q < 8; ++q) {            // clamped address + select: eight loads back to back
+                const uint32_t i = g * 128u + l + 16u * q;
+                const double t = src[min (i, nb - 1u)];
+                a[q] = (i < nb) ? t : 0.0;
+            }
+        } else {
+            // whole groups of 128 block moments (|F| a multiple of 8192, e.g. the 16384 of the reference): no position is past the end —
+            // the selects (two v_cndmask + a compare per load, executed as the loads arrive) sit on the path from the moments to T
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = src[g * 128u + l + 16u * q];
         }
     }
 }

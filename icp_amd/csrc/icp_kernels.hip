@@ -370,10 +370,9 @@ __global__ __launch_bounds__ (1024) void k_finalize_fused (const double *gmom, i
 // First tree level of the moments for large sets (|F| / 64 blocks > 128 * ICP_L1_MIN_GROUPS): one 16-lane row per
 // (moment k, group g) task, 16 tasks per block, spread over the chip — k_finalize_fused alone would walk the
 // 18 x ceil (nb / 128) tasks 64 at a time (config C: 36 dependent passes, 39 us).  Same tree, same bits.
-__global__ __launch_bounds__ (256) void k_moment_level1 (const double *gmom, const icp_reg_state *gst, uint32_t nb, uint32_t check, uint32_t ng_magic, icp_params p)
+__global__ __launch_bounds__ (256) void k_moment_level1 (const double *gmom, const icp_reg_state *gst, double *gl1, uint32_t nb, uint32_t check, uint32_t ng_magic)
 {
     const uint32_t b = blockIdx.y, l = threadIdx.x & 15u, row = threadIdx.x >> 4;
-    if (check && gst[b].done) return;
     const uint32_t ng = (nb + 127u) / 128u, ntask = ICP_NMOM * ng;
     const uint32_t task = min (blockIdx.x * 16u + row, ntask - 1u), k = ng_magic ? __umulhi (task, ng_magic) : task, g = task - k * ng;   // (ng_magic = floor (2^32 / ng) + 1, a preloaded scalar: no runtime division in front of the loads)
     const double *src = gmom + (size_t) b * 2 * ICP_NMOM * nb + (size_t) k * nb;
@@ -384,8 +383,11 @@ __global__ __launch_bounds__ (256) void k_moment_level1 (const double *gmom, con
         const double t = src[min (i, nb - 1u)];
         a[q] = (i < nb) ? t : 0.0;
     }
+    // (a converged registration: asked behind the loads — in front of them the flag's round trip would come first, every iteration of a checked run)
+    if (check && gst[b].done) return;
     const double v = row_tree8_d (a);
-    if (l == 0 && blockIdx.x * 16u + row < ntask) p.ml1[(size_t) b * ntask + task] = v;
+    // (nine dwords of arguments, all preloaded: the whole parameter block would put a scalar load of the output pointer in front of the kernel's only store)
+    if (l == 0 && blockIdx.x * 16u + row < ntask) gl1[(size_t) b * ntask + task] = v;
 }
 
 // chain end: finalize the last iteration's moments (slot given by p.slot) into the user-visible state.  (There is no
@@ -528,7 +530,7 @@ void icp_launch_finalize (const icp_params &p, hipStream_t s)
     if (p.fused) {
         const uint32_t ng = (p.nb + 127u) / 128u;
         if (ng > ICP_L1_MIN_GROUPS && p.ml1)
-            hipLaunchKernelGGL (k_moment_level1, dim3 ((ICP_NMOM * ng + 15u) / 16u, p.batch), dim3 (256), 0, s, (const double *) p.mom, (const icp_reg_state *) p.st, p.nb, (uint32_t) p.check, p.ng_magic, p);
+            hipLaunchKernelGGL (k_moment_level1, dim3 ((ICP_NMOM * ng + 15u) / 16u, p.batch), dim3 (256), 0, s, (const double *) p.mom, (const icp_reg_state *) p.st, p.ml1, p.nb, (uint32_t) p.check, p.ng_magic);
         if (p.rot == 1) hipLaunchKernelGGL (k_finalize_fused<1>, dim3 (p.batch), dim3 (1024), 0, s, (const double *) p.mom, p.st, p.nb, (uint32_t) p.check, p);
         else hipLaunchKernelGGL (k_finalize_fused<0>, dim3 (p.batch), dim3 (1024), 0, s, (const double *) p.mom, p.st, p.nb, (uint32_t) p.check, p);
     } else {

@@ -542,8 +542,9 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         } else if (!MASKED && k < tn0) { rg[u] = R4[2 * (size_t) k]; rc[u] = R4[2 * (size_t) k + 1]; }
     }
     const uint32_t ic = min (iq, m - 1u);
-    float4 mg = make_float4 (0.f, 0.f, 0.f, 1.f), mc = mg;
-    if (qwave) { mg = M4[2 * (size_t) ic]; mc = M4[2 * (size_t) ic + 1]; }
+    typedef float ks_f4 __attribute__ ((ext_vector_type (4)));
+    ks_f4 mgv = { 0.f, 0.f, 0.f, 1.f }, mcv = mgv;    // (whole 128-bit values until the opaque use below: see there)
+    if (qwave) { mgv = *reinterpret_cast<const ks_f4 *> (M4 + 2 * (size_t) ic); mcv = *reinterpret_cast<const ks_f4 *> (M4 + 2 * (size_t) ic + 1); }
     if constexpr (MASKED) {                          // the home tile: of the cell of the block's first query (block-uniform; no division)
         const uint32_t i0 = (uint32_t) __builtin_amdgcn_readfirstlane ((int) min (FUSED ? fused_query_index (m, side, tpr_magic, tile_id, 0u) : (blockIdx.x >> 1) * 128u + (blockIdx.x & 1u), m - 1u));
         const uint32_t cell = p.side_magic ? cell_rep_of (p, i0) : 0u;
@@ -612,6 +613,12 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         }
         return;
     }
+    // The query point is used as (x, y), (y, z) pairs (packed math): left alone, the compiler loads those pairs with overlapping narrow
+    // loads and assembles them with moves INSIDE the conditional block of the load — i.e. the query wave waits there for every load it has
+    // issued and sends its share of the list headers a memory round trip late, in front of a barrier the whole block stands at.  An opaque
+    // use HERE (everything is issued and waited for by now) keeps the loads whole and the block free of anything that touches their result.
+    if constexpr (MINW == 2) asm volatile ("" : "+v"(mgv), "+v"(mcv));
+    float4 mg = make_float4 (mgv.x, mgv.y, mgv.z, mgv.w), mc = make_float4 (mcv.x, mcv.y, mcv.z, mcv.w);
     if (iq >= m) { mg = make_float4 (0.f, 0.f, 0.f, 1.f); mc = mg; }
     const float4 *XQ4 = reinterpret_cast<const float4 *> (p.XQ + (size_t) b * m * 8);
     const char *XQb = reinterpret_cast<const char *> (XQ4);

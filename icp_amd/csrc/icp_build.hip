@@ -482,20 +482,30 @@ void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStr
 // by the launch that found the previous frame converged, or by its end kernel) — the previous frame runs on the OTHER stream, and the
 // launches behind this kernel were enqueued while it was still running.  Every wave reaches the exit: the wait is bounded (max_spins
 // s_sleep rounds: ~0.5 s by default, far beyond any registration); a timeout raises *flag (host memory) and lets the stream go on.
-__global__ __launch_bounds__ (64) void k_gate (const uint32_t *seq, uint32_t want, uint32_t *flag, uint32_t max_spins)
+// warm != nullptr: a warm-started frame — once the gate is open (the acquire stands behind the previous registration's final state) the same
+// lane does what k_set_T would do in a launch of its own (T stays, the cumulative rotation is re-derived from its quaternion, k = done = 0):
+// one kernel and one launch boundary fewer between two frames.
+__global__ __launch_bounds__ (64) void k_gate (const uint32_t *seq, uint32_t want, uint32_t *flag, uint32_t max_spins, icp_reg_state *warm)
 {
     if (threadIdx.x != 0) return;
-    for (uint32_t spin = 0; spin < max_spins; ++spin) {
+    bool open = false;
+    for (uint32_t spin = 0; spin < max_spins && !open; ++spin) {
         const uint32_t v = __hip_atomic_load (seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int32_t) (v - want) >= 0) return;
-        __builtin_amdgcn_s_sleep (8);
+        open = (int32_t) (v - want) >= 0;
+        if (!open) __builtin_amdgcn_s_sleep (8);
     }
-    if (flag) __hip_atomic_store (flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!open && flag) __hip_atomic_store (flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (warm) {
+        warm->k = 0; warm->done = 0; warm->pm_iters = 0;
+        float T[4]; for (int i = 0; i < 4; ++i) T[i] = warm->T[i];
+        float R[9]; icp_quat_to_rot (T, R);
+        for (int i = 0; i < 9; ++i) warm->R[i] = R[i];
+    }
 }
 
-void icp_launch_gate (const uint32_t *seq, uint32_t want, uint32_t *host_timeout_flag, hipStream_t s, uint32_t max_spins)
+void icp_launch_gate (const uint32_t *seq, uint32_t want, uint32_t *host_timeout_flag, hipStream_t s, uint32_t max_spins, icp_reg_state *warm)
 {
-    hipLaunchKernelGGL (k_gate, dim3 (1), dim3 (64), 0, s, seq, want, host_timeout_flag, max_spins);
+    hipLaunchKernelGGL (k_gate, dim3 (1), dim3 (64), 0, s, seq, want, host_timeout_flag, max_spins, warm);
 }
 
 __global__ void k_seq_set (uint32_t *seq, uint32_t v) { if (threadIdx.x == 0) __hip_atomic_store (seq, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }

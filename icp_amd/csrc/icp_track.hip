@@ -239,8 +239,10 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
             auto between = [&] () -> int {
                 int rc2 = record_prev (); if (rc2) return rc2;
                 if ((rc2 = wait_upload (s))) return rc2;
-                if (gated && f >= 2u) { icp_launch_gate (h->dSeq, (uint32_t) (f - 1u), h->hGateFlag, st); HIPCHK (h, hipGetLastError ()); }
-                if (warm) { icp_launch_set_T (p, 0, p.st->T, st, gated ? 1 : 0); HIPCHK (h, hipGetLastError ()); }
+                // (a warm-started frame behind a gate: the gate kernel writes the state as k_set_T would, once it is open)
+                const bool in_gate = gated && f >= 2u && warm;
+                if (gated && f >= 2u) { icp_launch_gate (h->dSeq, (uint32_t) (f - 1u), h->hGateFlag, st, 1u << 21, in_gate ? p.st : nullptr); HIPCHK (h, hipGetLastError ()); }
+                if (warm && !in_gate) { icp_launch_set_T (p, 0, p.st->T, st, gated ? 1 : 0); HIPCHK (h, hipGetLastError ()); }
                 return ICP_OK;
             };
             if ((rc = run_begin (h, R, st, p, !warm, true, blind, h->hTrackMirror + ring, h->hTrack + ring, (int) ring, between, (gated && P->active) ? P : nullptr))) return rc;

@@ -1176,7 +1176,10 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             // stores no per-query outputs on the way never loads them at all.
             const icp_params *pe = &p;
             if constexpr (MINW == 2 && !OWNER) {
-                unsigned long long la_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);   // (icp_params follows four pointers and six dwords)
+                // (the kernel's explicit arguments: four pointers, six dwords, then icp_params — no padding in between; a change of the
+                // signature has to move this offset with it: every test that reads per-query outputs at a latency-bound size would show it)
+                static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
+                unsigned long long la_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
                 asm volatile ("" : "+s"(la_));
                 pe = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) la_;
             }

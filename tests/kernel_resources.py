@@ -46,6 +46,26 @@ def kernel_resources(source="icp_amd/csrc/icp_kernels.hip", extra_flags=()):
     return {re.sub(r"\(.*$", "", n.replace("(anonymous namespace)::", "")).replace("void ", ""): r for n, r in zip(names, recs)}
 
 
+def kernel_isa(source="icp_amd/csrc/icp_kernels.hip", extra_flags=()):
+    """{mangled kernel name: [instruction lines]} of one translation unit's device code (hipcc -S --cuda-device-only)."""
+    p = subprocess.run([HIPCC] + FLAGS + list(extra_flags) + ["-S", "--cuda-device-only", "-o", "-", os.path.join(ROOT, source)],
+                       capture_output=True, text=True, cwd=ROOT)
+    if p.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + p.stderr[-4000:])
+    out, cur = {}, None
+    for line in p.stdout.splitlines():
+        t = line.strip()
+        m = re.match(r"^(_Z\w+):", line)
+        if m and ".type" not in line:
+            cur = out.setdefault(m.group(1), [])
+            continue
+        if t.startswith(".Lfunc_end"):
+            cur = None
+        elif cur is not None and t and not t.startswith((";", ".")) and not t.endswith(":"):
+            cur.append(t.split(";")[0].strip())
+    return out
+
+
 if __name__ == "__main__":
     srcs = sys.argv[1:] or ["icp_amd/csrc/icp_kernels.hip", "icp_amd/csrc/icp_search_dense.hip", "icp_amd/csrc/icp_build.hip", "icp_amd/csrc/icp_reduce_scan.hip"]
     for s in srcs:

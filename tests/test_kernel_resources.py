@@ -8,7 +8,7 @@ import re
 
 import pytest
 
-from kernel_resources import FLAGS, ROOT, kernel_resources
+from kernel_resources import FLAGS, ROOT, kernel_isa, kernel_resources
 
 
 @pytest.fixture(scope="module")
@@ -49,3 +49,22 @@ def test_launch_bounds_hold(res):
             assert r["occupancy"] >= 4, (n, r)
         if n.startswith("k_search"):
             assert r["lds"] <= 80 * 1024, (n, r)           # two blocks per CU must fit the 160 KiB
+
+
+def test_chained_search_issues_its_first_loads_before_it_waits_for_its_arguments():
+    """The chained k_search (one launch per iteration at the reference's size) gets the 14 dwords its first loads need preloaded in SGPRs;
+    the rest of its arguments arrives by scalar loads, and the only wait for those is `s_waitcnt lgkmcnt (0)` — for all of them.  Such a
+    wait (or a spill of freshly loaded arguments: v_writelane) in front of the state load and the eight block-moment loads starts every
+    wave's first memory round trip an argument fetch late: a scalar-cache miss in a graph replay, a trip to memory in a plain launch
+    ("Where the kernel arguments are waited for": 0.3 - 0.5 us of 9).  Both instantiations, power-method rotation."""
+    isa = kernel_isa("icp_amd/csrc/icp_kernels.hip")
+    names = [n for n in isa if n.startswith("_Z8k_searchILb1ELb1ELi2ELi16ELb0ELi1ELi1024ELb0ELb0E")]
+    assert len(names) == 2, names                                     # HOSTRUN = false (fixed-length graphs) and true (host-driven runs)
+    for n in names:
+        ins = isa[n]
+        entry = next(i for i, t in enumerate(ins) if t.startswith("s_branch"))      # (in front of it: the loads of a loader without preload support)
+        loads = [i for i, t in enumerate(ins) if i > entry and t.startswith("global_load")]
+        assert len(loads) >= 9
+        head = ins[entry:loads[8] + 1]                                 # up to the state load + the eight moment loads
+        bad = [t for t in head if (t.startswith("s_waitcnt") and "lgkmcnt" in t) or t.startswith("v_writelane")]
+        assert not bad, (n, bad)

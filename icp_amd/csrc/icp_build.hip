@@ -359,14 +359,19 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
     if (valid) { own = p.owner[(size_t) b * p.m + i]; rk = p.brank[(size_t) b * p.m + i]; g = F4[2 * (size_t) i]; cc = F4[2 * (size_t) i + 1]; }
     const uint2 *BL = p.blist + (size_t) b * nb * 64u;
     const uint32_t *BN = p.bn + (size_t) b * nb;
-    // the list of owner block t (thread t; further ones in the loop below): its length and, without waiting for it, its first 8
-    // entries (64 neighbouring points share a handful of owners) — one memory round trip for everything above and this
-    uint32_t n0 = 0u; uint4 e0[4] = { make_uint4 (0u, 0u, 0u, 0u), make_uint4 (0u, 0u, 0u, 0u), make_uint4 (0u, 0u, 0u, 0u), make_uint4 (0u, 0u, 0u, 0u) };
+    // the list of owner block t (thread t; further ones in the loop below): its length and, without waiting for it, its first 16
+    // entries — one memory round trip for everything above and this.  (64 neighbouring points share a dozen owners: 12 at the median,
+    // 16 at the 90th percentile, 20 at most on the benchmark pair and on a tracked frame; with 8 entries up front nearly every thread
+    // walked four more, one dependent load each: buildRBC at |F| = 16384 13.85 -> 13.5 us.)
+    constexpr int KP_UP = 8;                          // uint4 = pairs of entries fetched up front
+    uint32_t n0 = 0u; uint4 e0[KP_UP];
+#pragma unroll
+    for (int k = 0; k < KP_UP; ++k) e0[k] = make_uint4 (0u, 0u, 0u, 0u);
     if (t < nb) {
         n0 = BN[t];
         const uint4 *q = reinterpret_cast<const uint4 *> (BL + (size_t) t * 64u);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) e0[k] = q[k];
+        for (int k = 0; k < KP_UP; ++k) e0[k] = q[k];
     }
     uint32_t nown = 0u; uint2 lown = make_uint2 (0u, 0u);
     if (ob0 + wave < nb) {                           // this chunk's own lists
@@ -379,12 +384,12 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
     __syncthreads ();
     {
         const bool earlier = t < ob0;
-        const uint32_t ev[8][2] = { { e0[0].x, e0[0].y }, { e0[0].z, e0[0].w }, { e0[1].x, e0[1].y }, { e0[1].z, e0[1].w },
-                                    { e0[2].x, e0[2].y }, { e0[2].z, e0[2].w }, { e0[3].x, e0[3].y }, { e0[3].z, e0[3].w } };
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if ((uint32_t) e < n0) { atomicAdd (&s_total[ev[e][0]], ev[e][1]); if (earlier) atomicAdd (&s_before[ev[e][0]], ev[e][1]); }
-        for (uint32_t e = 8u; e < n0; ++e) {
+        for (int e = 0; e < 2 * KP_UP; ++e) {
+            const uint32_t o_ = (e & 1) ? e0[e >> 1].z : e0[e >> 1].x, n_ = (e & 1) ? e0[e >> 1].w : e0[e >> 1].y;
+            if ((uint32_t) e < n0) { atomicAdd (&s_total[o_], n_); if (earlier) atomicAdd (&s_before[o_], n_); }
+        }
+        for (uint32_t e = 2u * KP_UP; e < n0; ++e) {
             const uint2 v = BL[(size_t) t * 64u + e];
             atomicAdd (&s_total[v.x], v.y);
             if (earlier) atomicAdd (&s_before[v.x], v.y);

@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             // One-block-per-CU variants: the four output pointers are fetched from the kernel arguments HERE — an opaque copy of the
             // argument pointer keeps the compiler from hoisting their scalar loads to the top of the kernel with all the others, where
             // eight more live SGPRs make it spill freshly loaded arguments to VGPR lanes, i.e. wait for the argument block in front of
-            // the prologue's first vector loads (the chained kernel of a host-driven run: 9.26 -> 9.2 us per iteration); a run that
+            // the prologue's first vector loads (the chained kernel of a host-driven run: 9.29 -> 8.97 us per iteration); a run that
             // stores no per-query outputs on the way never loads them at all.
             const icp_params *pe = &p;
             if constexpr (MINW == 2 && !OWNER) {

@@ -407,11 +407,14 @@ def _dist(a):
             "mean": float(a.mean())}
 
 
-def _track_report(hops, elapsed, gaps_us, lat_us, ks, launches=None):
+def _track_report(hops, elapsed, gaps_us, lat_us, ks, launches=None, period=0):
     """One tracking variant: frames/s and the distributions of the SAME pass.  `gap` = time between two results reaching the host,
     `latency` = submit call -> result on the host.  A frame's time follows its iteration count k (a warm start on a sequence that
     reverses direction needs more iterations at the turning points): `gap_over_same_k` is every frame's gap over the median gap of the
-    frames with the same k — what is left is jitter, not workload."""
+    frames with the same k — what is left is jitter, not workload.  With frames in flight a frame's gap also depends on its
+    neighbours (a 3-iteration frame behind a 40-iteration one is done the moment that one is; behind another 3-iteration frame it waits
+    for the host's next submit): `gap_over_same_hop` compares every frame with the frames at the same position of the sequence's period
+    (same k, same neighbours) — the jitter figure for the warm-start passes."""
     import numpy as np
     gaps, ks = np.asarray(gaps_us, float), np.asarray(ks)
     ratio = []
@@ -419,10 +422,18 @@ def _track_report(hops, elapsed, gaps_us, lat_us, ks, launches=None):
         sel = gaps[ks == k]
         if len(sel) >= 4:
             ratio.extend(sel / np.median(sel))
+    hop_ratio = []
+    if period:
+        for j in range(period):
+            sel = gaps[j::period]
+            if len(sel) >= 4:
+                hop_ratio.extend(sel / np.median(sel))
     out = {"frames": hops, "frames_per_s": hops / elapsed, "ms_per_frame": elapsed / hops * 1e3,
            "completion_gap_us": _dist(gaps), "latency_us": _dist(lat_us),
            "iterations": {"mean": float(ks.mean()), "p50": float(np.percentile(ks, 50)), "max": int(ks.max())},
            "gap_over_same_k": ({"p99": float(np.percentile(ratio, 99)), "max": float(np.max(ratio)), "frames_compared": len(ratio)} if ratio else None),
+           "gap_over_same_hop": ({"p99": float(np.percentile(hop_ratio, 99)), "max": float(np.max(hop_ratio)), "period": period,
+                                  "frames_above_1.25x": int((np.asarray(hop_ratio) > 1.25).sum())} if hop_ratio else None),
            "frames_above_1.25x_median_gap": int((gaps > 1.25 * np.median(gaps)).sum()),
            "first_8_gaps_us": [float(x) for x in gaps[:8]]}
     if launches is not None:
@@ -470,7 +481,7 @@ def measure_tracking(icp_amd, device, hops=256):
             stamps.append(te); lat.append((te - ts) * 1e6); st.append(g.run_stats())
         el = pc() - t0
         gc.enable()
-        res["blocking"] = _track_report(hops, el, np.diff(np.array([t0] + stamps)) * 1e6, lat, ks, st)
+        res["blocking"] = _track_report(hops, el, np.diff(np.array([t0] + stamps)) * 1e6, lat, ks, st, period=len(order))
         res["blocking"]["host_launch_calls"] = dict(zip(("longest_us", "slower_than_10us", "calls"), g.launch_stats(reset=True)))
 
         def pipelined(submit_of, n):
@@ -495,7 +506,7 @@ def measure_tracking(icp_amd, device, hops=256):
         # the warm-up's last frame is frame 7 of the sequence: the pass continues it
         tail = seq[8:]
         el, gaps, lats, ks = pipelined(lambda i: g.track_submit(tail[i], warm), hops)
-        res["pipelined_pageable"] = _track_report(hops, el, gaps, lats, ks)
+        res["pipelined_pageable"] = _track_report(hops, el, gaps, lats, ks, period=len(order))
         res["pipelined_pageable"]["host_launch_calls"] = dict(zip(("longest_us", "slower_than_10us", "calls"), g.launch_stats(reset=True)))
         if not warm:                                  # (two alternating frames make every warm start the inverse of what is needed: cold only)
             g.track_reset()
@@ -506,7 +517,7 @@ def measure_tracking(icp_amd, device, hops=256):
                 g.track_collect()
             g.sync()
             el, gaps, lats, ks = pipelined(lambda i: g.track_submit(i & 1, warm), hops)
-            res["pipelined_pinned"] = _track_report(hops, el, gaps, lats, ks)
+            res["pipelined_pinned"] = _track_report(hops, el, gaps, lats, ks, period=2)
             res["pipelined_pinned"]["host_launch_calls"] = dict(zip(("longest_us", "slower_than_10us", "calls"), g.launch_stats(reset=True)))
             res["pipelined_pinned"]["note"] = ("two frames one step apart alternate in the engine's pinned frame buffers (icp_track_staging): what a capture "
                                                "loop that writes its frames there would see")

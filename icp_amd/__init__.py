@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["ICP", "ICPStep", "ICPError", "Memory", "ICPStepConfigT", "ICPStepConfigW",
-           "PowerMode", "ReduceMode", "TransformKind", "ICPBatch", "batch_partition", "power_method", "KernelObject", "kernel_lms", "kernel_reps", "kernel_weights", "kernel_mean", "kernel_devs", "kernel_s", "ReduceScan", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "device_count", "DIST_ID"]
+           "PowerMode", "ReduceMode", "TransformKind", "ICPBatch", "batch_partition", "power_method", "KernelObject", "kernel_lms", "kernel_reps", "kernel_weights", "kernel_mean", "kernel_devs", "kernel_s", "ReduceScan", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "punch_holes", "HOLES_SCATTERED", "HOLES_CONTIGUOUS", "device_count", "DIST_ID"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("ICP_AMD_LIB", os.path.join(_HERE, "libicp_amd.so"))   # override: A/B builds of the same ABI
@@ -196,6 +196,7 @@ def lib():
     sig("icp_device_count", i32, C.POINTER(i32))
     sig("icp_synth_pair", i32, C.c_uint64, u32, f32, vp, vp, f32, f32, f32, vp, vp)
     sig("icp_synth_cloud_vga", i32, C.c_uint64, i32, vp)
+    sig("icp_synth_punch_holes", i32, C.c_uint64, u32, u32, i32, f32, i32, vp)
     _lib = L
     return L
 
@@ -430,6 +431,20 @@ def synth_cloud_vga(seed=0x1C9D5EED, moved=False):
     if rc:
         raise ICPError(rc, "icp_synth_cloud_vga")
     return cloud
+
+
+HOLES_SCATTERED, HOLES_CONTIGUOUS = 0, 1
+
+
+def punch_holes(cloud, width, height, pattern=HOLES_SCATTERED, fraction=0.1, keep_rgb=True, seed=0x1C9D5EED):
+    """A copy of `cloud` (width x height float8 points) with a Kinect frame's invalid pixels: xyz = 0, the colour kept
+    (reference src/kinect_frame_grabber.cpp:246-262) unless keep_rgb is False (all holes identical). Host only."""
+    out = np.ascontiguousarray(cloud, np.float32).copy()
+    assert out.size == width * height * 8
+    rc = lib().icp_synth_punch_holes(seed, width, height, pattern, fraction, int(bool(keep_rgb)), _p(out))
+    if rc:
+        raise ICPError(rc, "icp_synth_punch_holes")
+    return out
 
 
 _MEM_DTYPE = {

@@ -126,6 +126,9 @@ __global__ __launch_bounds__ (256) void k_transform_cloud_ex (const float4 *in, 
 //                              bound instead of 3.3 - 8.8 with 16 x 1 strips), else 16 consecutive representatives
 //   blocks [nbr + nbg, ..)     the box of every LDS tile of the dense k_search for multi-tile sets (p.tbox consecutive
 //                              representatives: 256, or 1024 for the largest sets), one wave per box
+//   the last block             the representatives at the origin (a frame's invalid points), colour + index, ascending: they stay out
+//                              of every box above (one such member would stretch a box from the scene to the origin) and are scanned
+//                              as a list of their own by the queries that are near the origin (k_search: ks_origin_list)
 // The boxes read the representatives' points from F at src (r): they do not wait for R.  fminf / fmaxf skip NaN
 // coordinates: a representative with a NaN coordinate never wins a '<' anyway; min / max are exact in any order.
 __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t nbr, uint32_t nbg)
@@ -151,16 +154,33 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
             const uint32_t r = tiled ? (4u * ty + (e >> 2)) * p.nrx + 4u * tx + (e & 3u) : g * 16u + e;
             if (r >= p.nr) continue;
             const float4 v = F4[2 * (size_t) rep_src_index (p, r)];
+            if (v.x == 0.f && v.y == 0.f && v.z == 0.f) continue;     // an invalid point (at the origin): kept out of the box, listed in p.OL (k_search: ks_origin_list)
             lo.x = fminf (lo.x, v.x); lo.y = fminf (lo.y, v.y); lo.z = fminf (lo.z, v.z);
             hi.x = fmaxf (hi.x, v.x); hi.y = fmaxf (hi.y, v.y); hi.z = fmaxf (hi.z, v.z);
         }
         float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n1k);
         GB[2 * g] = lo; GB[2 * g + 1] = hi;
+    } else if (blockIdx.x == gridDim.x - 1u) {
+        // the representatives at the origin, ascending: (r, g, b, index) each behind their number (one wave: a ballot and a running offset
+        // per 64 representatives)
+        float4 *OL = p.OL + (size_t) b * (p.nr + 1u);
+        uint32_t run = 0u;
+        for (uint32_t r0 = 0; r0 < p.nr; r0 += 64u) {
+            const uint32_t r = r0 + lane;
+            float4 v = make_float4 (1.f, 1.f, 1.f, 0.f), c = v;
+            if (r < p.nr) { const uint32_t src = rep_src_index (p, r); v = F4[2 * (size_t) src]; c = F4[2 * (size_t) src + 1]; }
+            const bool at0 = r < p.nr && v.x == 0.f && v.y == 0.f && v.z == 0.f;
+            const unsigned long long bal = __ballot (at0);
+            if (at0) OL[1u + run + (uint32_t) __builtin_popcountll (bal & ((1ull << lane) - 1ull))] = make_float4 (c.x, c.y, c.z, __uint_as_float (r));
+            run += (uint32_t) __builtin_popcountll (bal);
+        }
+        if (lane == 0) OL[0] = make_float4 (__uint_as_float (run), 0.f, 0.f, 0.f);
     } else {
         const uint32_t tile = blockIdx.x - nbr - nbg;
         float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
         for (uint32_t r = tile * p.tbox + lane; r < min (p.nr, (tile + 1u) * p.tbox); r += 64u) {
             const float4 v = F4[2 * (size_t) rep_src_index (p, r)];
+            if (v.x == 0.f && v.y == 0.f && v.z == 0.f) continue;
             lo[0] = fminf (lo[0], v.x); lo[1] = fminf (lo[1], v.y); lo[2] = fminf (lo[2], v.z);
             hi[0] = fmaxf (hi[0], v.x); hi[1] = fmaxf (hi[1], v.y); hi[2] = fmaxf (hi[2], v.z);
         }
@@ -440,6 +460,44 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
     }
 }
 
+// 6-D bounding boxes of the list chunks (stage-2 pruning of long lists, k_search): chunk c of list r = its positions 16 c .. 16 c + 15.
+// A one-shot search scans the whole list of the query's representative; a list that is much longer than the others — every invalid
+// point of a frame whose colours were zeroed too is ONE point, and one representative owns them all; a cluttered corner of a scene —
+// is scanned 16 (8) positions at a time by every query that lands in it.  With a box per chunk a query tests a chunk before it loads
+// it.  One block per representative, one 16-lane row per chunk; box of chunk c >= 1 at index (O[r] >> 4) + c: unique over all lists
+// (a list's last chunk can share floor (position / 16) only with the NEXT list's chunk 0, which has no box), < m / 16 + 1.
+// Chunk 0 is always scanned.  min / max are exact in any order; fminf / fmaxf skip NaN coordinates (such a point never wins a '<').
+__global__ __launch_bounds__ (256) void k_list_boxes (icp_params p)
+{
+    const uint32_t r = blockIdx.x, b = blockIdx.y, l = threadIdx.x & 15u, row = threadIdx.x >> 4;
+    const uint32_t n = p.N[(size_t) b * p.nr + r];
+    if (n <= 16u) return;
+    const uint32_t o = p.O[(size_t) b * p.nr + r], nch = (n + 15u) >> 4;
+    const float4 *Q4 = reinterpret_cast<const float4 *> (p.XQ + (size_t) b * p.m * 8);
+    float4 *LB = p.LB + (size_t) b * 3 * p.nlb;
+    const float inf = __builtin_inff ();
+    for (uint32_t c = 1u + row; c < nch; c += 16u) {
+        const uint32_t j = 16u * c + l;
+        float lo[6] = { inf, inf, inf, inf, inf, inf }, hi[6] = { -inf, -inf, -inf, -inf, -inf, -inf };
+        if (j < n) {
+            const float4 g = Q4[2 * (size_t) (o + j)], cc = Q4[2 * (size_t) (o + j) + 1];     // [x r y g | z b id 0]
+            lo[0] = hi[0] = g.x; lo[1] = hi[1] = g.z; lo[2] = hi[2] = cc.x; lo[3] = hi[3] = g.y; lo[4] = hi[4] = g.w; lo[5] = hi[5] = cc.y;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (lo[k] != lo[k]) { lo[k] = inf; hi[k] = -inf; }    // NaN: out of the box
+        }
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { lo[k] = fminf (lo[k], __shfl_xor (lo[k], d, 16)); hi[k] = fmaxf (hi[k], __shfl_xor (hi[k], d, 16)); }
+        if (l == 0) {
+            float4 *dst = LB + 3 * (size_t) ((o >> 4) + c);
+            dst[0] = make_float4 (lo[0], lo[1], lo[2], lo[3]);
+            dst[1] = make_float4 (lo[4], lo[5], hi[0], hi[1]);
+            dst[2] = make_float4 (hi[2], hi[3], hi[4], hi[5]);
+        }
+    }
+}
+
 // ICPPowerMethod as a kernel of its own (reference include/ICP/algorithms.hpp:1451-1537, kernels/icp_kernels.cl:977-1054: an
 // enqueueTask of one work-item; here one wave): S[11], means[8] -> Tk[8] with the rotation solvers the iteration uses
 // (icp_power_method_quad literal / squared start, icp_svd_rotation) — the entry the reference's known-answer test drives
@@ -550,11 +608,12 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
     if (icp_build_lists (p)) {                       // two launches: the owner search (gathers the representatives itself, leaves the lists), the placement
         icp_launch_owner_search (p, s);
         hipLaunchKernelGGL (k_place_lists, dim3 ((p.nb + 3u) / 4u, p.batch), dim3 (256), 0, s, p);
+        hipLaunchKernelGGL (k_list_boxes, dim3 (p.nr, p.batch), dim3 (256), 0, s, p);
         return;
     }
     {   // the representatives, the boxes of their pruning groups and (several tiles only) of the LDS tiles: one launch
         const uint32_t nbr = (p.nr + 63u) / 64u, nbg = (p.n16 + 63u) / 64u, nbt = p.nr > p.tbox ? p.n1k : 0u;
-        hipLaunchKernelGGL (k_reps_and_boxes, dim3 (nbr + nbg + nbt, p.batch), dim3 (64), 0, s, p, nbr, nbg);
+        hipLaunchKernelGGL (k_reps_and_boxes, dim3 (nbr + nbg + nbt + 1u, p.batch), dim3 (64), 0, s, p, nbr, nbg);     // (+ 1: the list of the representatives at the origin)
     }
     icp_launch_owner_search (p, s);                  // step 1, owner(x) = nearest representative (icp_kernels.hip)
     hipLaunchKernelGGL (k_chunk_hist, dim3 (p.nchunk, p.batch), dim3 (256), p.nr * sizeof (uint32_t), s, p);
@@ -564,4 +623,5 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
         hipLaunchKernelGGL (k_offsets, dim3 (1, p.batch), dim3 (1024), 0, s, p);
     }
     hipLaunchKernelGGL (k_place, dim3 (p.nchunk, p.batch), dim3 (1024), 0, s, p);
+    hipLaunchKernelGGL (k_list_boxes, dim3 (p.nr, p.batch), dim3 (256), 0, s, p);
 }

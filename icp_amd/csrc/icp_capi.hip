@@ -44,7 +44,7 @@ void free_all (icp_context *h)
     h->hTrack = nullptr;
     if (h->rbc2_ready) {
         icp_context::rbc_set &q = h->rbc[1];
-        void *ptrs[] = { q.R, q.GB, q.XP, q.XQ, q.rep_src, q.owner, q.N, q.O, q.perm, q.chunk_hist, q.blist, q.bn, q.brank };
+        void *ptrs[] = { q.R, q.GB, q.OL, q.LB, q.XP, q.XQ, q.rep_src, q.owner, q.N, q.O, q.perm, q.chunk_hist, q.blist, q.bn, q.brank };
         for (void *x : ptrs) if (x) (void) hipFree (x);
     }
     h->rbc[0] = h->rbc[1] = icp_context::rbc_set {}; h->rbc2_ready = false;
@@ -214,6 +214,9 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &p.GB, B * 2 * (p.n16 + p.n1k)))) return rc;
     if ((rc = dalloc (h, &p.XP, B * m * 8))) return rc;
     if ((rc = dalloc (h, &p.XQ, B * m * 8))) return rc;
+    if ((rc = dalloc (h, &p.OL, B * (nr + 1u)))) return rc;
+    p.nlb = m / 16u + 2u;
+    if ((rc = dalloc (h, &p.LB, B * 3 * p.nlb))) return rc;
     if ((rc = dalloc (h, &p.rep_src, B * nr))) return rc;
     if ((rc = dalloc (h, &p.owner, B * m))) return rc;
     if ((rc = dalloc (h, &p.N, B * nr))) return rc;

@@ -110,7 +110,7 @@ struct icp_context {
     int track_gate = 1;
     uint32_t *dSeq = nullptr, *dRunFlag = nullptr, *hGateFlag = nullptr;
     bool stream2_dirty = false;                  // stream2 holds work the handle's own stream must not overtake
-    struct rbc_set { float *R = nullptr; float4 *GB = nullptr; float *XP = nullptr, *XQ = nullptr; uint32_t *rep_src = nullptr, *owner = nullptr, *N = nullptr, *O = nullptr,
+    struct rbc_set { float *R = nullptr; float4 *GB = nullptr, *OL = nullptr, *LB = nullptr; float *XP = nullptr, *XQ = nullptr; uint32_t *rep_src = nullptr, *owner = nullptr, *N = nullptr, *O = nullptr,
                      *perm = nullptr, *chunk_hist = nullptr; uint2 *blist = nullptr; uint32_t *bn = nullptr; uint8_t *brank = nullptr; } rbc[2];
     bool rbc2_ready = false;
     bool track_last_gated = false;                // the form of the last submitted frame

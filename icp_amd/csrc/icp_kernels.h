@@ -56,6 +56,11 @@ struct icp_params {
     uint32_t s2wave;             // stage 2 of the dense search with lanes = candidates (lists of >= ICP_S2_WAVE_MIN candidates on average: see k_search)
     float *XP;                   // [batch][m][8]  permuted database (RBCConstruct D_OUT_X_P)
     float *XQ;                   // [batch][m][8]  same, lane 3 = original index bits (search copy)
+    float4 *OL;                  // [batch][nr + 1]  the representatives at the origin (invalid points), ascending: [0].x = their number (bits), then
+                                 // (r, g, b, index bits) each — kept out of the pruning boxes, scanned by the queries near the origin (dense search)
+    float4 *LB;                  // [batch][3 * nlb]  6-D bounding boxes of the list chunks (16 consecutive positions of one list, chunk c >= 1 of list r at
+                                 // index (O[r] >> 4) + c: k_list_boxes) as [lo.x lo.y lo.z lo.r | lo.g lo.b hi.x hi.y | hi.z hi.r hi.g hi.b]
+    uint32_t nlb;                // m / 16 + 2 boxes per registration
     uint32_t *rep_src, *owner, *N, *O, *perm, *chunk_hist;   // [batch][...]
     uint2 *blist; uint32_t *bn; uint8_t *brank;   // buildRBC of the latency-bound sizes (k_place_lists): per block of 64 fixed points its (owner, count) list
                                                   // [batch][nb][64] and the list's length [batch][nb]; rank of a point inside its block [batch][m]

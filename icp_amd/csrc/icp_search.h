@@ -28,6 +28,9 @@ static __device__ __forceinline__ float sum4 (float4 v) { return ((v.x + v.y) + 
 #ifndef ICP_S2_DEPTH16
 #define ICP_S2_DEPTH16 8u            // stage 2, 16 lanes per query: candidates in flight per lane (8 x 16 = 128 covers every list at |R| = m/64)
 #endif
+#ifndef ICP_S2_UNCOND
+#define ICP_S2_UNCOND 128u           // stage 2 (a query's lanes scan its list): positions of a list scanned unconditionally; beyond them chunk boxes first
+#endif
 #ifndef ICP_S1_SEED
 #define ICP_S1_SEED 1                // stage 1: prune with the distance to the previous search's nearest representative
 #endif
@@ -88,6 +91,33 @@ template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint
     return v;
 }
 
+// Invalid points (a Kinect frame's pixels without depth: x = y = z = 0, the colour kept — reference src/kinect_frame_grabber.cpp:246-262,
+// kernels/icp_kernels.cl:49-50) among the members of a pruning box would stretch it from the scene to the origin: a box every query is
+// near, i.e. no pruning at all in a frame with holes.  The boxes are therefore built over the representatives that are NOT at the
+// origin (k_reps_and_boxes), and those at the origin come as a compact list of their own (p.OL: colour + index, ascending): their
+// geometric term is the same for all of them — exactly qq = fma (qz, qz, fma (qy, qy, qx qx)), the metric's operations on q - 0 —, so
+// a query either needs none of them (qq above its bound: every valid point of a scene) or scans the list (a query that is itself an
+// invalid point, moved by T: its nearest representative is the invalid one nearest in colour).  Same bits as the exhaustive scan:
+// the list is visited behind the tiles, out of index order, so its updates carry the tie rule explicitly (equal distance: lower index).
+template <int LPQ>
+static __device__ __forceinline__ void ks_origin_list (const float4 *OL, float qx, float qy, float qz, float qr, float qg, float qb, float alpha,
+                                                       float lim, uint32_t ss, float &best, uint32_t &bid)
+{
+    const uint32_t n_o = __float_as_uint (OL[0].x);  // block-uniform
+    if (n_o == 0u) return;
+    const float qq = __builtin_fmaf (qz, qz, __builtin_fmaf (qy, qy, qx * qx));
+    const bool need = qq <= lim;                     // d >= qq for every member: none can win, or tie at a lower index, beyond that
+    if (!__ballot (need)) return;
+    if (need)
+        for (uint32_t e = ss; e < n_o; e += (uint32_t) LPQ) {
+            const float4 v = OL[1u + e];
+            const float dr_ = qr - v.x, dg_ = qg - v.y, db_ = qb - v.z;
+            const float d = __builtin_fmaf (alpha, __builtin_fmaf (db_, db_, __builtin_fmaf (dg_, dg_, dr_ * dr_)), qq);
+            const uint32_t idx = __float_as_uint (v.w);
+            if (d < best || (d == best && idx < bid)) { best = d; bid = idx; }
+        }
+}
+
 // candidate j of a list: XQ = [x r y g | z b id 0].  The geometric and the photometric sum of the metric are
 // evaluated side by side, one packed instruction per step: (dx, dr), (dy, dg), (dz, db) -> (geo, pho) with exactly the
 // operations of icp_metric8 (mul, fma, fma per half), then d = fma (a, pho, geo).  Keeps the best (distance, position).
@@ -98,6 +128,15 @@ template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint
         const float2v gp_ = __builtin_elementwise_fma (d3_, d3_, __builtin_elementwise_fma (d2_, d2_, d1_ * d1_)); \
         const float d_ = __builtin_fmaf (alpha, gp_.y, gp_.x);                                        \
         if (d_ < best2) { best2 = d_; bj = (J); }                                                     \
+    }
+
+#define KS_CAND_IF(G, C, J, LIVE)                                                                     \
+    {                                                                                                 \
+        const float2v d1_ = vq_xr - float2v { (G).x, (G).y }, d2_ = vq_yg - float2v { (G).z, (G).w }, \
+                      d3_ = vq_zb - float2v { (C).x, (C).y };                                         \
+        const float2v gp_ = __builtin_elementwise_fma (d3_, d3_, __builtin_elementwise_fma (d2_, d2_, d1_ * d1_)); \
+        const float d_ = __builtin_fmaf (alpha, gp_.y, gp_.x);                                        \
+        if (d_ < best2 && (LIVE)) { best2 = d_; bj = (J); }                                           \
     }
 
 #define ICP_NMOM 18
@@ -934,6 +973,10 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             }
         }
     }
+    if constexpr (PRUNE) {
+        // the representatives at the origin (invalid points): kept out of the boxes above, scanned here by the queries that are near the origin
+        if (prune) ks_origin_list<KS_SPLIT> (p.OL + (size_t) b * (nr + 1u), qx, qy, qz, qr, qg, qb, alpha, s1_lim, ss, best, bid);
+    }
     KS_KEEP (best, bid)
     KS_STAMP (2)
     const float dr = ks_grp_min_f<KS_SPLIT> (best);           // the query's nearest representative: smallest distance,
@@ -1111,8 +1154,13 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         // position among equals, so there is no tail test.  The lane keeps the TRIP of its best candidate (a scalar + constant per
         // candidate instead of a recomputed position); trips ascend, so a strict '<' keeps the lane's lowest position.
         const uint32_t alast = (max (je, 1u) - 1u) << 5;
-        for (uint32_t tb = 0; tb < ntrips; tb += KS_DEPTH) {
-            const uint32_t a0 = (o + ss + tb * KS_SPLIT) << 5, nt = min (KS_DEPTH, ntrips - tb);
+        // Lists of up to 2 x ICP_S2_UNCOND positions are scanned as they come (a second batch costs less than the test in front of it:
+        // |F| = 16384 with a list of 135, 9.54 against 8.95 us per iteration); of longer lists the first ICP_S2_UNCOND positions, and what lies
+        // beyond chunk by chunk behind a box test (below).  (The wave's longest list decides: scalar control flow.)
+        constexpr uint32_t KS_UNC = ICP_S2_UNCOND / KS_SPLIT;
+        const uint32_t ntr0 = ntrips <= 2u * KS_UNC ? ntrips : KS_UNC;
+        for (uint32_t tb = 0; tb < ntr0; tb += KS_DEPTH) {
+            const uint32_t a0 = (o + ss + tb * KS_SPLIT) << 5, nt = min (KS_DEPTH, ntr0 - tb);
             float4 g[KS_DEPTH], c[KS_DEPTH];
 #pragma unroll
             for (uint32_t t = 0; t < KS_DEPTH; ++t) {
@@ -1124,6 +1172,67 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             for (uint32_t t = 0; t < KS_DEPTH; ++t) {
                 if (t >= nt) break;
                 KS_CAND (g[t], c[t], tb + t);
+            }
+        }
+        if (ntrips > ntr0) {
+            // ---- long lists: exact pruning over chunks of 16 consecutive positions (boxes: k_list_boxes).  A query tests a chunk with the
+            // metric's own operations applied to the per-axis distances to the chunk's 6-D box — every operation is monotone under
+            // round-to-nearest, so bound <= d of every member (a > 0) — against `lim`: the distance to the representative itself, bumped one
+            // ulp (the representative is a member of its own list: a nearer-or-equal identical point with a lower index would have been
+            // the nearest representative instead; so the list's minimum is <= dr, and a chunk whose bound is above dr holds neither the
+            // minimum nor a tie with it), and the query's best so far (a chunk whose bound is not BELOW it cannot replace a candidate at a
+            // lower position: trips ascend, updates need a strict '<' — the tie rule of the serial scan).  Lane ss tests the chunks
+            // cb + ss, cb + ss + LPQ of a round; the answers of a query's lanes come back through a ballot; the chunks that pass are
+            // scanned in ascending order by all lanes of the query, two chunks per memory round trip.  The bits are those of the
+            // exhaustive scan; a list of identical points (invalid pixels with their colour zeroed) costs a box test per chunk behind
+            // its first 128 candidates instead of the candidates themselves.
+            constexpr uint32_t CPT = 16u / KS_SPLIT, BD = 2u;          // trips per chunk; boxes per lane and round
+            const uint32_t nch = (je - o + 15u) >> 4, nchw = (ntrips + CPT - 1u) / CPT;     // chunks of this query's list / of the wave's longest
+            const float4 *LBq = p.LB + (size_t) b * 3u * p.nlb + 3u * (o >> 4);
+            const float inf_ = __builtin_inff ();
+            float lim = (alpha > 0.f && dr >= 0.f && dr < inf_) ? __uint_as_float (__float_as_uint (dr) + 1u) : inf_;
+            const bool bounds = alpha > 0.f;                            // (a <= 0: d >= bound does not hold; everything is scanned)
+            for (uint32_t cb = ICP_S2_UNCOND / 16u; cb < nchw; cb += BD * KS_SPLIT) {
+                lim = fminf (lim, ks_grp_min_f<KS_SPLIT> (best2));
+                float4 bx[BD][3];
+#pragma unroll
+                for (uint32_t j = 0; j < BD; ++j) {
+                    const uint32_t cc = min (cb + ss + KS_SPLIT * j, max (nch, 1u) - 1u);       // (clamped: inside the buffer; masked below)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) bx[j][k] = LBq[3u * cc + (uint32_t) k];
+                }
+                uint32_t cmask = 0u;
+#pragma unroll
+                for (uint32_t j = 0; j < BD; ++j) {
+                    const float4 b0 = bx[j][0], b1 = bx[j][1], b2 = bx[j][2];                   // [lo.x lo.y lo.z lo.r | lo.g lo.b hi.x hi.y | hi.z hi.r hi.g hi.b]
+                    const float ex = fmaxf (fmaxf (b0.x - qx, qx - b1.z), 0.f), ey = fmaxf (fmaxf (b0.y - qy, qy - b1.w), 0.f);
+                    const float ez = fmaxf (fmaxf (b0.z - qz, qz - b2.x), 0.f), er = fmaxf (fmaxf (b0.w - qr, qr - b2.y), 0.f);
+                    const float eg = fmaxf (fmaxf (b1.x - qg, qg - b2.z), 0.f), eb = fmaxf (fmaxf (b1.y - qb, qb - b2.w), 0.f);
+                    const float geo_ = __builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex)), pho_ = __builtin_fmaf (eb, eb, __builtin_fmaf (eg, eg, er * er));
+                    const bool pass = cb + ss + KS_SPLIT * j < nch && (!bounds || __builtin_fmaf (alpha, pho_, geo_) < lim);
+                    const unsigned long long bal = __ballot (pass);
+                    cmask |= ((uint32_t) (bal >> (lane & (64u - KS_SPLIT))) & ((1u << KS_SPLIT) - 1u)) << (KS_SPLIT * j);      // bit k: chunk cb + k of this query's list
+                }
+                while (__ballot (cmask != 0u)) {
+                    const bool live0 = cmask != 0u;
+                    const uint32_t k0 = live0 ? (uint32_t) __builtin_ctz (cmask) : 0u;
+                    cmask &= cmask - 1u;
+                    const bool live1 = cmask != 0u;
+                    const uint32_t k1 = live1 ? (uint32_t) __builtin_ctz (cmask) : k0;
+                    cmask &= cmask - 1u;
+                    const uint32_t t0 = (cb + k0) * CPT, t1 = (cb + k1) * CPT;
+                    float4 g[2 * CPT], c[2 * CPT];
+#pragma unroll
+                    for (uint32_t h = 0; h < CPT; ++h) {
+                        const char *r0 = XQb + min ((o + ss + (t0 + h) * KS_SPLIT) << 5, alast), *r1 = XQb + min ((o + ss + (t1 + h) * KS_SPLIT) << 5, alast);
+                        g[h] = *reinterpret_cast<const float4 *> (r0); c[h] = *reinterpret_cast<const float4 *> (r0 + 16);
+                        g[CPT + h] = *reinterpret_cast<const float4 *> (r1); c[CPT + h] = *reinterpret_cast<const float4 *> (r1 + 16);
+                    }
+#pragma unroll
+                    for (uint32_t h = 0; h < CPT; ++h) KS_CAND_IF (g[h], c[h], t0 + h, live0);
+#pragma unroll
+                    for (uint32_t h = 0; h < CPT; ++h) KS_CAND_IF (g[CPT + h], c[CPT + h], t1 + h, live1);
+                }
             }
         }
         if (bj != 0xFFFFFFFFu) bj = min (o + ss + bj * KS_SPLIT, max (je, 1u) - 1u);     // trip -> list position

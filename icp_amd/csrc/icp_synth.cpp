@@ -10,6 +10,7 @@
 // RNG: splitmix64 -> xoshiro256**.  Deterministic in (seed, side, parameters) on one libm.
 #include "../../include/icp_amd.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -102,6 +103,54 @@ extern "C" int icp_synth_pair (uint64_t seed, uint32_t side, float rot_deg, cons
             if (zf < zero_fraction) { f[0] = f[1] = f[2] = 0.f; f[4] = f[5] = f[6] = 0.f; }
             if (zm < zero_fraction) { mo[0] = mo[1] = mo[2] = 0.f; mo[4] = mo[5] = mo[6] = 0.f; }
         }
+    return ICP_OK;
+}
+
+// Invalid pixels as the Kinect grabber leaves them (src/kinect_frame_grabber.cpp:246-262: depth 0 -> x = y = z = 0, the colour is
+// written regardless) and as getLMs picks them (kernels/icp_kernels.cl:49-50), punched into a width x height float8 grid in place.
+//   pattern 0  scattered: every point on its own with probability `fraction`;
+//   pattern 1  contiguous: a band along the left edge (a quarter of the fraction: the shadow of the projector's baseline) and
+//              random ellipses (depth shadows, absorbing surfaces) until `fraction` of the points is covered;
+//   keep_rgb   != 0: the colour stays (a real frame); 0: zeroed too — all invalid points identical, the degenerate case in which
+//              one representative's list holds every one of them.
+extern "C" int icp_synth_punch_holes (uint64_t seed, uint32_t width, uint32_t height, int pattern, float fraction, int keep_rgb, float *cloud)
+{
+    if (!cloud || width == 0 || height == 0 || !(fraction >= 0.f) || fraction > 1.f || (pattern != 0 && pattern != 1)) return ICP_EINVAL;
+    rng g (seed ^ 0x401E5ull);
+    const size_t n = (size_t) width * height;
+    auto punch = [&] (size_t i) {
+        float *o = cloud + i * 8;
+        o[0] = o[1] = o[2] = 0.f;
+        if (!keep_rgb) o[4] = o[5] = o[6] = 0.f;
+    };
+    if (pattern == 0) {
+        for (size_t i = 0; i < n; ++i)
+            if (g.uniform () < (double) fraction) punch (i);
+        return ICP_OK;
+    }
+    // contiguous: a bitmap first (ellipses overlap), then the punch
+    uint8_t *mask = new uint8_t[n];
+    std::memset (mask, 0, n);
+    size_t covered = 0;
+    const size_t want = (size_t) ((double) fraction * (double) n);
+    const uint32_t band = (uint32_t) std::lround (0.25 * fraction * width);
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < band && x < width; ++x) { mask[(size_t) y * width + x] = 1; ++covered; }
+    for (int tries = 0; covered < want && tries < 100000; ++tries) {
+        const double cx = g.uniform () * width, cy = g.uniform () * height;
+        const double a = (0.03 + 0.09 * g.uniform ()) * width, b = (0.03 + 0.09 * g.uniform ()) * height;
+        const long x0 = std::max (0l, (long) std::floor (cx - a)), x1 = std::min ((long) width - 1, (long) std::ceil (cx + a));
+        const long y0 = std::max (0l, (long) std::floor (cy - b)), y1 = std::min ((long) height - 1, (long) std::ceil (cy + b));
+        for (long y = y0; y <= y1; ++y)
+            for (long x = x0; x <= x1; ++x) {
+                const double ex = ((double) x - cx) / a, ey = ((double) y - cy) / b;
+                uint8_t &mk = mask[(size_t) y * width + (size_t) x];
+                if (ex * ex + ey * ey < 1.0 && !mk) { mk = 1; ++covered; }
+            }
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (mask[i]) punch (i);
+    delete[] mask;
     return ICP_OK;
 }
 

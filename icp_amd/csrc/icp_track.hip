@@ -42,7 +42,7 @@ static int track_prepare (icp_context *h)
         if (!h->dRunFlag) { HIPCHK (h, hipMalloc ((void **) &h->dRunFlag, 2 * sizeof (uint32_t))); HIPCHK (h, hipMemset (h->dRunFlag, 0, 2 * sizeof (uint32_t))); }
         if (!h->hGateFlag) { HIPCHK (h, hipHostMalloc ((void **) &h->hGateFlag, sizeof (uint32_t), hipHostMallocMapped | hipHostMallocCoherent)); *h->hGateFlag = 0u; }
         icp_context::rbc_set &a = h->rbc[0], &b = h->rbc[1];
-        a.R = p.R; a.GB = p.GB; a.XP = p.XP; a.XQ = p.XQ; a.rep_src = p.rep_src; a.owner = p.owner; a.N = p.N; a.O = p.O; a.perm = p.perm;
+        a.R = p.R; a.GB = p.GB; a.OL = p.OL; a.LB = p.LB; a.XP = p.XP; a.XQ = p.XQ; a.rep_src = p.rep_src; a.owner = p.owner; a.N = p.N; a.O = p.O; a.perm = p.perm;
         a.chunk_hist = p.chunk_hist; a.blist = p.blist; a.bn = p.bn; a.brank = p.brank;
         auto al = [&] (void **q, size_t bytes) -> int {
             hipError_t e = hipMalloc (q, bytes ? bytes : 1);
@@ -50,12 +50,12 @@ static int track_prepare (icp_context *h)
             return e == hipSuccess ? ICP_OK : fail (h, ICP_ENOMEM, std::string ("tracking (second RBC set): ") + hipGetErrorString (e));
         };
         int rc;
-        if ((rc = al ((void **) &b.R, (size_t) p.nr * 32)) || (rc = al ((void **) &b.GB, (size_t) 2 * (p.n16 + p.n1k) * 16)) || (rc = al ((void **) &b.XP, (size_t) p.m * 32)) ||
+        if ((rc = al ((void **) &b.R, (size_t) p.nr * 32)) || (rc = al ((void **) &b.GB, (size_t) 2 * (p.n16 + p.n1k) * 16)) || (rc = al ((void **) &b.LB, (size_t) 3 * p.nlb * 16)) || (rc = al ((void **) &b.OL, (size_t) (p.nr + 1u) * 16)) || (rc = al ((void **) &b.XP, (size_t) p.m * 32)) ||
             (rc = al ((void **) &b.XQ, (size_t) p.m * 32)) || (rc = al ((void **) &b.rep_src, (size_t) p.nr * 4)) || (rc = al ((void **) &b.owner, (size_t) p.m * 4)) ||
             (rc = al ((void **) &b.N, (size_t) p.nr * 4)) || (rc = al ((void **) &b.O, (size_t) p.nr * 4)) || (rc = al ((void **) &b.perm, (size_t) p.m * 4)) ||
             (rc = al ((void **) &b.chunk_hist, (size_t) p.nchunk * p.nr * 4)) || (rc = al ((void **) &b.blist, (size_t) p.nb * 64 * 8)) ||
             (rc = al ((void **) &b.bn, (size_t) p.nb * 4)) || (rc = al ((void **) &b.brank, (size_t) p.m))) {
-            void *ptrs[] = { b.R, b.GB, b.XP, b.XQ, b.rep_src, b.owner, b.N, b.O, b.perm, b.chunk_hist, b.blist, b.bn, b.brank };
+            void *ptrs[] = { b.R, b.GB, b.OL, b.LB, b.XP, b.XQ, b.rep_src, b.owner, b.N, b.O, b.perm, b.chunk_hist, b.blist, b.bn, b.brank };
             for (void *x : ptrs) if (x) (void) hipFree (x);
             b = icp_context::rbc_set {};
             return rc;
@@ -78,7 +78,7 @@ static int track_prepare (icp_context *h)
 
 static void rbc_into (icp_params &p, const icp_context::rbc_set &q)
 {
-    p.R = q.R; p.GB = q.GB; p.XP = q.XP; p.XQ = q.XQ; p.rep_src = q.rep_src; p.owner = q.owner; p.N = q.N; p.O = q.O; p.perm = q.perm;
+    p.R = q.R; p.GB = q.GB; p.OL = q.OL; p.LB = q.LB; p.XP = q.XP; p.XQ = q.XQ; p.rep_src = q.rep_src; p.owner = q.owner; p.N = q.N; p.O = q.O; p.perm = q.perm;
     p.chunk_hist = q.chunk_hist; p.blist = q.blist; p.bn = q.bn; p.brank = q.brank;
 }
 

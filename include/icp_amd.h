@@ -465,6 +465,12 @@ int icp_synth_pair (uint64_t seed, uint32_t side, float rot_deg, const float *ax
 /* Synthetic 640x480 float8 cloud for the getLMs path; `moved` = frame number of a sequence (0: the scene, f: moved
  * rigidly by f steps of 3 degrees / (25, -10, 15) mm, with noise). */
 int icp_synth_cloud_vga (uint64_t seed, int moved, float *cloud);
+/* Invalid pixels as a Kinect frame holds them — depth 0: x = y = z = 0, the colour written regardless (reference
+ * src/kinect_frame_grabber.cpp:246-262; getLMs picks such points on purpose, kernels/icp_kernels.cl:49-50) — punched in place into a
+ * width x height grid of float8 points (a landmark set: side x side; a cloud: 640 x 480).  pattern 0: scattered, every point with
+ * probability `fraction`; 1: contiguous — a band along the left edge and random ellipses until `fraction` of the points is covered.
+ * keep_rgb 0 zeroes the colour too: all invalid points identical, one representative's list holds them all (the degenerate case). */
+int icp_synth_punch_holes (uint64_t seed, uint32_t width, uint32_t height, int pattern, float fraction, int keep_rgb, float *cloud);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

@@ -526,6 +526,79 @@ def measure_tracking(icp_amd, device, hops=256):
     return out
 
 
+def measure_holes(icp_amd, device, iters):
+    """`other_configs.A_holes` (+ the dense layouts beside it): the headline workload with the invalid points of a real capture in BOTH
+    frames — a Kinect frame's pixels without depth are points at the origin with their colour kept (reference
+    src/kinect_frame_grabber.cpp:246-262; getLMs picks them on purpose, kernels/icp_kernels.cl:49-50) — scattered and as contiguous
+    regions, 10 % and 30 %; the `_rgb0` cases zero the colour too: every invalid point is then ONE point and one representative's list
+    holds them all (the degenerate list).  Per case: fixed `iters`-iteration fresh passes like the headline, the longest list, the
+    candidates stage 2 would have to evaluate without pruning (sum over the queries of the length of the list they land in, last
+    iteration), and k of a checked run.  Plus one cold tracking pass on frames with contiguous holes."""
+    import numpy as np
+    from icp_amd import workloads as W
+    out = {"invalid_points": "xyz = 0 in both frames (independent patterns), colour kept unless the case says rgb0; icp_synth_punch_holes",
+           "timing": "per case: 25 ms of untimed passes, 3 warm-up + 20 timed fresh passes of %d iterations (HIP events on the engine's stream)" % iters}
+
+    def one(cfg, batch, name, steps):
+        side, nr = W.CONFIGS[cfg]
+        m = side * side
+        g = icp_amd.ICP(device)
+        g.init(m, nr, ALPHA, SCALING, batch=batch)
+        holes = 0.0
+        for b in range(batch):
+            F, M = (icp_amd.synth_pair(side, seed=W.BASE_SEED + b) if name == "clean" else W.holes_pair(icp_amd, name, side, seed=W.BASE_SEED + b))
+            g.write(icp_amd.Memory.F, F, batch_index=b); g.write(icp_amd.Memory.M, M, batch_index=b)
+            holes += float(np.count_nonzero((F[:, 0] == 0) & (F[:, 1] == 0) & (F[:, 2] == 0))) / m / batch
+        g.buildRBC(); g.sync()
+        settle(g, iters)
+        for _ in range(3):
+            g.run_fixed_fresh(iters)
+        g.sync()
+        ms, n = g.time_run_fixed_tail(iters, steps, from_identity=True)
+        N, rid = g.read(icp_amd.Memory.RBC_N), g.read(icp_amd.Memory.RID)
+        r = {"us_per_iteration": ms * 1e3 / (n * iters * batch), "N_max": int(N.max()), "invalid_fraction_fixed": round(holes, 4),
+             "candidates_per_iteration": int(N[rid].astype(np.int64).sum())}
+        if batch == 1:
+            g.reset_transform(); g.buildRBC()
+            r["run_k"] = int(g.run())
+        g.close()
+        return r
+
+    for key, cfg, batch, names, steps in (("A_holes", "A", 1, ["clean"] + list(W.HOLES), 21),
+                                          ("A_x64_holes", "A", 64, ["clean", "scattered10", "blobs10", "blobs30"], 4),
+                                          ("B_holes", "B", 1, ["clean", "scattered10", "blobs10", "blobs30", "blobs30_rgb0"], 11)):
+        out[key] = {}
+        for name in names:
+            try:
+                out[key][name] = one(cfg, batch, name, steps)
+            except Exception as e:                   # noqa: BLE001
+                out[key][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # tracking: 640 x 480 frames with contiguous invalid regions (10 %, another pattern per frame), cold start, two frames in flight
+    try:
+        frames = [icp_amd.punch_holes(icp_amd.synth_cloud_vga(moved=f), 640, 480, icp_amd.HOLES_CONTIGUOUS, 0.1, True, seed=W.BASE_SEED + f) for f in range(5)]
+        order = [0, 1, 2, 3, 4, 3, 2, 1]
+        hops = 128
+        seq = [frames[order[i % len(order)]] for i in range(hops + 8)]
+        g = icp_amd.ICP(device)
+        g.init(16384, 256, ALPHA, SCALING)
+        g.track_pipelined(seq[:8], warm_start=False)
+        g.sync()
+        ks = []
+        t0 = time.perf_counter()
+        for i, f in enumerate(seq[8:]):
+            g.track_submit(f, False)
+            if i >= 1:
+                ks.append(g.track_collect()[0])
+        ks.append(g.track_collect()[0])
+        el = time.perf_counter() - t0
+        g.close()
+        out["track_blobs10"] = {"frames": hops, "frames_per_s": hops / el, "mean_iterations": float(np.mean(ks)),
+                                "form": "cold start, two frames in flight, pageable source (compare other_configs.track.cold_start.pipelined_pageable)"}
+    except Exception as e:                           # noqa: BLE001
+        out["track_blobs10"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
 def run_inprocess(icp_amd, args, n, batch, iters, steps, warmup):
     """--gpus N from a plain `python bench.py`: devices 0..N-1 (or ICP_BENCH_DEVICES, a comma list: self-test on a 1-GPU box)
     driven through icp_batch_*: registration i on slot i mod N, one host thread + stream per slot, no collective."""
@@ -775,6 +848,7 @@ def main():
                 for key, cfg, b, st, wu, it in (("B", "B", 1, 40, 5, ITERS_PER_STEP), ("C", "C", 1, 10, 2, 10)):
                     oc[key] = guarded(measure_config, icp_amd, device, cfg, b, st, wu, it, args.power_mode, args.reduce_mode)
                 oc["track"] = guarded(measure_tracking, icp_amd, device)
+                oc["holes"] = guarded(measure_holes, icp_amd, device, ITERS_PER_STEP)
             line["other_configs"] = oc
             if modes is not None:
                 line.update(modes)

@@ -108,14 +108,19 @@ static __device__ __forceinline__ void ks_origin_list (const float4 *OL, float q
     const float qq = __builtin_fmaf (qz, qz, __builtin_fmaf (qy, qy, qx * qx));
     const bool need = qq <= lim;                     // d >= qq for every member: none can win, or tie at a lower index, beyond that
     if (!__ballot (need)) return;
-    if (need)
-        for (uint32_t e = ss; e < n_o; e += (uint32_t) LPQ) {
-            const float4 v = OL[1u + e];
-            const float dr_ = qr - v.x, dg_ = qg - v.y, db_ = qb - v.z;
+    // four entries per lane and memory round trip (clamped addresses: a duplicate of the last entry changes nothing under the explicit tie rule)
+    for (uint32_t e0 = 0; e0 < n_o; e0 += 4u * (uint32_t) LPQ) {
+        float4 v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) v[k] = OL[1u + min (e0 + ss + k * (uint32_t) LPQ, n_o - 1u)];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const float dr_ = qr - v[k].x, dg_ = qg - v[k].y, db_ = qb - v[k].z;
             const float d = __builtin_fmaf (alpha, __builtin_fmaf (db_, db_, __builtin_fmaf (dg_, dg_, dr_ * dr_)), qq);
-            const uint32_t idx = __float_as_uint (v.w);
-            if (d < best || (d == best && idx < bid)) { best = d; bid = idx; }
+            const uint32_t idx = __float_as_uint (v[k].w);
+            if (need && (d < best || (d == best && idx < bid))) { best = d; bid = idx; }
         }
+    }
 }
 
 // candidate j of a list: XQ = [x r y g | z b id 0].  The geometric and the photometric sum of the metric are

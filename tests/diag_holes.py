@@ -10,6 +10,8 @@ side, nr = W.CONFIGS[os.environ.get("CFG", "A")]
 m = side * side
 batch = int(os.environ.get("BATCH", "1"))
 names = ["clean"] + list(W.HOLES)
+if os.environ.get("CASE"):
+    names = os.environ["CASE"].split(",")
 for name in names:
     g = icp_amd.ICP(0)
     g.init(m, nr, 2e2, 1e-6, batch=batch)

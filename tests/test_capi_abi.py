@@ -94,3 +94,30 @@ def test_synth_generator_is_host_only_and_deterministic(engine):
     assert 0.1 < np.mean(np.all(Fz[:, :3] == 0, axis=1)) < 0.4
     cloud = engine.synth_cloud_vga()
     assert cloud.shape == (640 * 480, 8) and np.isfinite(cloud).all()
+
+
+def test_hole_generator_makes_kinect_like_invalid_points(engine):
+    """icp_synth_punch_holes: xyz = 0 with the colour kept (reference src/kinect_frame_grabber.cpp:246-262) or zeroed, scattered or
+    contiguous, deterministic, about the requested fraction; the workloads' named cases punch both frames with different patterns."""
+    import numpy as np
+    from icp_amd import workloads as W
+    F, M = engine.synth_pair(64)
+    for pattern in (engine.HOLES_SCATTERED, engine.HOLES_CONTIGUOUS):
+        H = engine.punch_holes(F, 64, 64, pattern, 0.2, True, seed=9)
+        H2 = engine.punch_holes(F, 64, 64, pattern, 0.2, True, seed=9)
+        assert np.array_equal(H, H2)
+        hole = (H[:, 0] == 0) & (H[:, 1] == 0) & (H[:, 2] == 0)
+        assert 0.15 < hole.mean() < 0.3
+        assert np.array_equal(H[:, 3:], F[:, 3:])                       # the colour (and both homogeneous lanes) as they were
+        assert np.array_equal(H[~hole], F[~hole])
+        Z = engine.punch_holes(F, 64, 64, pattern, 0.2, False, seed=9)
+        assert np.all(Z[hole, 4:7] == 0) and np.array_equal(Z[:, [3, 7]], F[:, [3, 7]])
+        if pattern == engine.HOLES_CONTIGUOUS:                          # contiguous: most holes have a hole to their right
+            hm = hole.reshape(64, 64)
+            assert (hm[:, :-1] & hm[:, 1:]).sum() > 0.8 * hm[:, :-1].sum()
+    assert not np.array_equal(F, engine.punch_holes(F, 64, 64, 0, 0.2, True, seed=10)[..., :]) 
+    with pytest.raises(engine.ICPError):
+        engine.punch_holes(F, 64, 64, 2, 0.2)
+    Fh, Mh = W.holes_pair(engine, "blobs30", 64)
+    hf, hm_ = (Fh[:, 2] == 0), (Mh[:, 2] == 0)
+    assert 0.25 < hf.mean() < 0.4 and 0.25 < hm_.mean() < 0.4 and not np.array_equal(hf, hm_)

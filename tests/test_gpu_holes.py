@@ -1,0 +1,181 @@
+"""Invalid points of real captures: a Kinect frame's pixels without depth are points at the origin with
+their colour kept (reference src/kinect_frame_grabber.cpp:246-262), getLMs picks them on purpose (kernels/icp_kernels.cl:49-50), and
+the one-shot search then has (a) representatives at the origin, which the stage-1 pruning keeps out of its boxes and scans as a list
+of their own, and (b) — with the colours zeroed too — ONE list that holds every invalid point, which stage 2 scans behind chunk
+boxes.  Both are exact: everything here is compared with the oracle's serial scans bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_gpu_parity import A, C_, assert_bits, check_rbc, check_step, set_modes      # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(engine, name, side, seed=None):
+    from icp_amd import workloads as W
+    return W.holes_pair(engine, name, side, seed=W.BASE_SEED if seed is None else seed)
+
+
+@pytest.mark.parametrize("name", ["scattered10", "blobs10", "blobs30", "scattered10_rgb0", "blobs10_rgb0", "blobs30_rgb0"])
+def test_holes_at_config_A_steps_and_run(engine, oracle, name):
+    """Config A (16384, 256), the benchmarked modes: RBC structure, two free-running steps (every per-query and per-iteration output),
+    then ICP::run — k, T and all 16384 correspondence ids."""
+    side, nr = 128, 256
+    m = side * side
+    F, M = _pair(engine, name, side)
+    holes = int(np.count_nonzero((F[:, 0] == 0) & (F[:, 1] == 0) & (F[:, 2] == 0)))
+    assert holes > 0.08 * m
+    g = engine.ICP(0)
+    g.init(m, nr, A, C_)
+    g.write(engine.Memory.F, F); g.write(engine.Memory.M, M)
+    o = oracle.OracleICP(m, nr, A, C_, threads=8, power_fast=True, fused=True)
+    o.write_f(F); o.write_m(M)
+    g.buildRBC(); o.build_rbc()
+    check_rbc(engine, g, o)
+    if name.endswith("_rgb0"):
+        assert o.rbc_N.max() >= holes - 1           # one list holds every invalid point (an invalid representative owns them all)
+    for it in range(2):
+        g.step(); o.step()
+        check_step(engine, g, o)
+    g.reset_transform(); g.buildRBC()
+    o.write_t([0, 0, 0, 1, 0, 0, 0, 1]); o.build_rbc()
+    k, ko = g.run(), o.run()
+    assert k == ko
+    assert_bits(g.read(engine.Memory.T), o.T, "T")
+    assert np.array_equal(g.read(engine.Memory.NN_ID)["id"], o.nn_id["id"])
+    assert_bits(g.read(engine.Memory.NN_ID)["dist"], o.nn_id["dist"], "distances")
+    g.close()
+
+
+@pytest.mark.parametrize("name", ["blobs10", "blobs30_rgb0"])
+def test_holes_reference_order_mode(engine, oracle, name):
+    side, nr = 128, 256
+    m = side * side
+    F, M = _pair(engine, name, side)
+    g = engine.ICP(0)
+    g.init(m, nr, A, C_)
+    set_modes(engine, g, power_fast=False, fused=False)
+    g.write(engine.Memory.F, F); g.write(engine.Memory.M, M)
+    o = oracle.OracleICP(m, nr, A, C_, threads=8)
+    o.write_f(F); o.write_m(M)
+    g.buildRBC(); o.build_rbc()
+    for it in range(2):
+        g.step(); o.step()
+        check_step(engine, g, o)
+    g.close()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_holes_dense_batched(engine, oracle, fused):
+    """The dense search (several blocks per CU, exact stage-1 pruning): six registrations of config A's shape in one handle, one per
+    hole case — the representatives at the origin are scanned as a list of their own by the queries near the origin."""
+    from icp_amd import workloads as W
+    side, nr = 128, 256
+    m = side * side
+    names = list(W.HOLES)
+    g = engine.ICP(0)
+    g.init(m, nr, A, C_, batch=len(names))
+    set_modes(engine, g, power_fast=fused, fused=fused)
+    assert g.search_layout()[0] == 1
+    pairs = [_pair(engine, n, side, seed=W.BASE_SEED + 3 * b) for b, n in enumerate(names)]
+    for b, (F, M) in enumerate(pairs):
+        g.write(engine.Memory.F, F, batch_index=b); g.write(engine.Memory.M, M, batch_index=b)
+    g.buildRBC()
+    orcs = []
+    for F, M in pairs:
+        o = oracle.OracleICP(m, nr, A, C_, threads=8, power_fast=fused, fused=fused)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        orcs.append(o)
+    for it in range(3):
+        g.step()
+        for b, o in enumerate(orcs):
+            o.step()
+            assert np.array_equal(g.read(engine.Memory.RID, batch_index=b), o.rid), (it, b)
+            gn = g.read(engine.Memory.NN_ID, batch_index=b)
+            assert np.array_equal(gn["id"], o.nn_id["id"]), (it, b, names[b])
+            assert_bits(gn["dist"], o.nn_id["dist"], "distances")
+            assert_bits(g.read(engine.Memory.T, batch_index=b), o.T, "T of %s" % names[b])
+    g.close()
+
+
+@pytest.mark.parametrize("side,nr,name", [(256, 1024, "scattered10"), (256, 1024, "blobs30_rgb0"), (256, 256, "blobs10"), (256, 256, "scattered10_rgb0"),
+                                          (192, 2048, "blobs30")])
+def test_holes_dense_layouts(engine, oracle, side, nr, name):
+    """Config B (several 256-tiles, tile masks), a set with long lists (lanes = candidates in stage 2) and one on the 1024-tile variant."""
+    m = side * side
+    F, M = _pair(engine, name, side)
+    g = engine.ICP(0)
+    g.init(m, nr, A, C_)
+    g.write(engine.Memory.F, F); g.write(engine.Memory.M, M)
+    o = oracle.OracleICP(m, nr, A, C_, threads=16, power_fast=True, fused=True)
+    o.write_f(F); o.write_m(M)
+    g.buildRBC(); o.build_rbc()
+    check_rbc(engine, g, o)
+    for it in range(3):
+        g.step(); o.step()
+        check_step(engine, g, o)
+    g.close()
+
+
+@pytest.mark.parametrize("warm", [False, True])
+def test_holes_tracked_sequence(engine, oracle, warm):
+    """Frame-to-frame tracking on 640 x 480 frames with contiguous invalid regions (10 - 30 %, another pattern in every frame; one frame with
+    the colours zeroed as well): every hop's k and T equal the oracle's."""
+    pats = [(1, 0.1, True), (1, 0.3, True), (0, 0.1, True), (1, 0.2, False)]
+    clouds = [engine.punch_holes(engine.synth_cloud_vga(moved=f), 640, 480, p, fr, keep, seed=77 + f) for f, (p, fr, keep) in enumerate(pats)]
+    order = [0, 1, 2, 3, 2, 1, 0]
+    lms = [oracle.get_lms(c) for c in clouds]
+    assert all(np.count_nonzero(l[:, 2] == 0) > 1000 for l in lms)
+    g = engine.ICP(0)
+    g.init(16384, 256, A, C_)
+    res = g.track_pipelined([clouds[i] for i in order], warm_start=warm, depth=2)
+    o = oracle.OracleICP(16384, 256, A, C_, threads=8, power_fast=True, fused=True)
+    for i in range(1, len(order)):
+        o.write_f(lms[order[i - 1]]); o.write_m(lms[order[i]])
+        o.write_t(o.T if (warm and i > 1) else [0, 0, 0, 1, 0, 0, 0, 1])
+        o.build_rbc()
+        ko = o.run()
+        k, T = res[i]
+        assert k == ko, (i, k, ko)
+        assert np.array_equal(T.view(np.uint32), o.T.view(np.uint32)), i
+    assert np.array_equal(g.read(engine.Memory.NN_ID)["id"], o.nn_id["id"])
+    g.close()
+
+
+@pytest.mark.parametrize("batch", [1, 5])
+def test_long_lists_of_distinct_points(engine, oracle, batch):
+    """Long lists that are NOT piles of identical points: the representatives of one quarter of the fixed frame — all but one — are
+    moved far away (each to a place of its own), so the quarter's points fall to the one that stays and to the representatives
+    around the quarter: lists of up to ~1100 distinct candidates with the scene's geometry and colours, where the chunk boxes have to
+    discriminate (latency variant, and the dense one through a batch).  Everything against the serial scan."""
+    side, nr = 128, 256
+    m = side * side
+    g = engine.ICP(0)
+    g.init(m, nr, A, C_, batch=batch)
+    orcs = []
+    for b in range(batch):
+        F, M = engine.synth_pair(side, seed=0x1C9D5EED + b)
+        R, rep_src = oracle.get_reps(F, nr)
+        yy, xx = np.divmod(rep_src, side)
+        move = rep_src[(yy < 64) & (xx < 64)][1:]
+        F = F.copy()
+        F[move, 2] += 50000 + np.arange(move.size, dtype=np.float32) * 100
+        g.write(engine.Memory.F, F, batch_index=b); g.write(engine.Memory.M, M, batch_index=b)
+        o = oracle.OracleICP(m, nr, A, C_, threads=8, power_fast=True, fused=True)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        assert o.rbc_N.max() > 512
+        orcs.append(o)
+    g.buildRBC()
+    for it in range(3):
+        g.step()
+        for b, o in enumerate(orcs):
+            o.step()
+            gn = g.read(engine.Memory.NN_ID, batch_index=b)
+            assert np.array_equal(gn["id"], o.nn_id["id"]), (it, b)
+            assert_bits(gn["dist"], o.nn_id["dist"], "distances")
+            assert_bits(g.read(engine.Memory.T, batch_index=b), o.T, "T")
+    g.close()

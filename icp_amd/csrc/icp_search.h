@@ -100,10 +100,11 @@ template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint
 // invalid point, moved by T: its nearest representative is the invalid one nearest in colour).  Same bits as the exhaustive scan:
 // the list is visited behind the tiles, out of index order, so its updates carry the tie rule explicitly (equal distance: lower index).
 template <int LPQ>
-static __device__ __forceinline__ void ks_origin_list (const float4 *OL, float qx, float qy, float qz, float qr, float qg, float qb, float alpha,
+static __device__ __forceinline__ void ks_origin_list (const float4 *OL, uint32_t n_o, float qx, float qy, float qz, float qr, float qg, float qb, float alpha,
                                                        float lim, uint32_t ss, float &best, uint32_t &bid)
 {
-    const uint32_t n_o = __float_as_uint (OL[0].x);  // block-uniform
+    // (n_o = OL[0].x, block-uniform: loaded with the prologue's other loads — asked for here it would be a memory round trip of its own
+    // on every block's path, holes or not: |F| = 16384 x 64 registrations 1.845 -> 1.882 us per registration-iteration)
     if (n_o == 0u) return;
     const float qq = __builtin_fmaf (qz, qz, __builtin_fmaf (qy, qy, qx * qx));
     const bool need = qq <= lim;                     // d >= qq for every member: none can win, or tie at a lower index, beyond that
@@ -604,6 +605,9 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         if (!OWNER && !MASKED && k < tn0) ron[u] = make_uint2 (gO[k], gN[k]);
         if (!OWNER && MASKED && u == 0 && tid < tnH) ron[0] = make_uint2 (gO[ht * KT + tid], gN[ht * KT + tid]);
     }
+    // (dense variants: the number of representatives at the origin — a frame's invalid points: ks_origin_list — travels with the prologue's loads)
+    uint32_t n_origin = 0u;
+    if constexpr (ICP_S1_SEED && MINW == 4) n_origin = reinterpret_cast<const uint32_t *> (p.OL + (size_t) b * (nr + 1u))[0];
     // (HOSTRUN: the flag is read HERE, behind the prologue's vector loads — a scalar load of the flag's address, a second one of the flag and a
     // wait for both: in front of them it would hold every load of the prologue back by two scalar round trips)
     if constexpr (CHAIN && HOSTRUN) { if (p.run_flag) run_over = (p.run_flag[b] == p.epoch) ? 1u : 0u; }
@@ -980,7 +984,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     }
     if constexpr (PRUNE) {
         // the representatives at the origin (invalid points): kept out of the boxes above, scanned here by the queries that are near the origin
-        if (prune) ks_origin_list<KS_SPLIT> (p.OL + (size_t) b * (nr + 1u), qx, qy, qz, qr, qg, qb, alpha, s1_lim, ss, best, bid);
+        if (prune) ks_origin_list<KS_SPLIT> (p.OL + (size_t) b * (nr + 1u), (uint32_t) __builtin_amdgcn_readfirstlane ((int) n_origin), qx, qy, qz, qr, qg, qb, alpha, s1_lim, ss, best, bid);
     }
     KS_KEEP (best, bid)
     KS_STAMP (2)
@@ -1162,8 +1166,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         // Lists of up to 2 x ICP_S2_UNCOND positions are scanned as they come (a second batch costs less than the test in front of it:
         // |F| = 16384 with a list of 135, 9.54 against 8.95 us per iteration); of longer lists the first ICP_S2_UNCOND positions, and what lies
         // beyond chunk by chunk behind a box test (below).  (The wave's longest list decides: scalar control flow.)
-        constexpr uint32_t KS_UNC = ICP_S2_UNCOND / KS_SPLIT;
-        const uint32_t ntr0 = ntrips <= 2u * KS_UNC ? ntrips : KS_UNC;
+        constexpr uint32_t KS_UNC = ICP_S2_UNCOND / KS_SPLIT;      // (ICP_S2_UNCOND = 0, A/B builds: no chunk tests, every list scanned as it comes)
+        const uint32_t ntr0 = (ICP_S2_UNCOND == 0u || ntrips <= 2u * KS_UNC) ? ntrips : KS_UNC;
         for (uint32_t tb = 0; tb < ntr0; tb += KS_DEPTH) {
             const uint32_t a0 = (o + ss + tb * KS_SPLIT) << 5, nt = min (KS_DEPTH, ntr0 - tb);
             float4 g[KS_DEPTH], c[KS_DEPTH];
@@ -1193,7 +1197,15 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             // its first 128 candidates instead of the candidates themselves.
             constexpr uint32_t CPT = 16u / KS_SPLIT, BD = 2u;          // trips per chunk; boxes per lane and round
             const uint32_t nch = (je - o + 15u) >> 4, nchw = (ntrips + CPT - 1u) / CPT;     // chunks of this query's list / of the wave's longest
-            const float4 *LBq = p.LB + (size_t) b * 3u * p.nlb + 3u * (o >> 4);
+            // (the boxes' base and stride are fetched from the kernel arguments HERE, through an opaque copy of the argument pointer — see the
+            // per-query output pointers of the epilogue: left to the compiler, their scalar loads join the ones at the top of the kernel, in
+            // front of the prologue's vector loads, for a path hardly any launch takes: 8.66 -> 8.71 us per iteration at |F| = 16384)
+            static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
+            unsigned long long lb_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
+            asm volatile ("" : "+s"(lb_));
+            const icp_params *pl = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) lb_;
+            typedef float4 __attribute__ ((address_space (1))) *gf4;
+            const float4 *LBq = (const float4 *) (gf4) pl->LB + (size_t) b * 3u * pl->nlb + 3u * (o >> 4);
             const float inf_ = __builtin_inff ();
             float lim = (alpha > 0.f && dr >= 0.f && dr < inf_) ? __uint_as_float (__float_as_uint (dr) + 1u) : inf_;
             const bool bounds = alpha > 0.f;                            // (a <= 0: d >= bound does not hold; everything is scanned)

@@ -548,7 +548,11 @@ void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStr
 // warm != nullptr: a warm-started frame — once the gate is open (the acquire stands behind the previous registration's final state) the same
 // lane does what k_set_T would do in a launch of its own (T stays, the cumulative rotation is re-derived from its quaternion, k = done = 0):
 // one kernel and one launch boundary fewer between two frames.
-__global__ __launch_bounds__ (64) void k_gate (const uint32_t *seq, uint32_t want, uint32_t *flag, uint32_t max_spins, icp_reg_state *warm)
+// A gate that gives up (the predecessor is launch-complete or converged before the frame behind it is handed to the device — see track_submit —,
+// so this is a device that has stopped making progress, not a slow caller) turns the frame behind it into no-ops: it raises the frame's own
+// run flag (run_flag = epoch: every launch of the run leaves at its first load and stores nothing, the end kernel too), so nothing runs into
+// the predecessor's state slots and moment buffers; the host finds *flag set and reports the stall.
+__global__ __launch_bounds__ (64) void k_gate (const uint32_t *seq, uint32_t want, uint32_t *flag, uint32_t max_spins, icp_reg_state *warm, uint32_t *run_flag, uint32_t epoch)
 {
     if (threadIdx.x != 0) return;
     bool open = false;
@@ -557,7 +561,11 @@ __global__ __launch_bounds__ (64) void k_gate (const uint32_t *seq, uint32_t wan
         open = (int32_t) (v - want) >= 0;
         if (!open) __builtin_amdgcn_s_sleep (8);
     }
-    if (!open && flag) __hip_atomic_store (flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!open) {
+        if (run_flag) *run_flag = epoch;
+        if (flag) __hip_atomic_store (flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (warm) {
         warm->k = 0; warm->done = 0; warm->pm_iters = 0;
         float T[4]; for (int i = 0; i < 4; ++i) T[i] = warm->T[i];
@@ -566,9 +574,9 @@ __global__ __launch_bounds__ (64) void k_gate (const uint32_t *seq, uint32_t wan
     }
 }
 
-void icp_launch_gate (const uint32_t *seq, uint32_t want, uint32_t *host_timeout_flag, hipStream_t s, uint32_t max_spins, icp_reg_state *warm)
+void icp_launch_gate (const uint32_t *seq, uint32_t want, uint32_t *host_timeout_flag, hipStream_t s, uint32_t max_spins, icp_reg_state *warm, uint32_t *run_flag, uint32_t epoch)
 {
-    hipLaunchKernelGGL (k_gate, dim3 (1), dim3 (64), 0, s, seq, want, host_timeout_flag, max_spins, warm);
+    hipLaunchKernelGGL (k_gate, dim3 (1), dim3 (64), 0, s, seq, want, host_timeout_flag, max_spins, warm, run_flag, epoch);
 }
 
 __global__ void k_seq_set (uint32_t *seq, uint32_t v) { if (threadIdx.x == 0) __hip_atomic_store (seq, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }

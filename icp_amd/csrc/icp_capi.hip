@@ -42,7 +42,7 @@ void free_all (icp_context *h)
     h->lm[0] = h->lm[1] = h->lm[2] = nullptr;
     if (h->hTrack) (void) hipHostFree (h->hTrack);
     h->hTrack = nullptr;
-    if (h->rbc2_ready) {
+    {   // (whatever track_prepare got to: a failed stream probe leaves the buffers allocated and rbc2_ready false)
         icp_context::rbc_set &q = h->rbc[1];
         void *ptrs[] = { q.R, q.GB, q.OL, q.LB, q.XP, q.XQ, q.rep_src, q.owner, q.N, q.O, q.perm, q.chunk_hist, q.blist, q.bn, q.brank };
         for (void *x : ptrs) if (x) (void) hipFree (x);
@@ -53,6 +53,17 @@ void free_all (icp_context *h)
     if (h->hGateFlag) (void) hipHostFree (h->hGateFlag);
     h->dSeq = h->dRunFlag = h->hGateFlag = nullptr; h->run2 = run_ctl {}; h->stream2_dirty = false; h->track_last_gated = false;
     h->inited = h->built = false; h->parity = 0; h->track_submitted = h->track_collected = 0;
+}
+
+// A setter is about to change what a re-run search would produce (alpha, the metric's scale, the reduction mode): per-query outputs a
+// checked run left to be reproduced on demand (lazy outputs: materialize_outputs) are reproduced NOW, with the parameters the run used —
+// icp_read then returns the bits of the last executed iteration, as include/icp_amd.h promises, whatever was set in between.
+int outputs_before_change (icp_context *h)
+{
+    if (!h->inited || !h->outputs_stale) return ICP_OK;
+    int rc = set_device (h); if (rc) return rc;
+    if ((rc = run_close_all (h))) return rc;
+    return materialize_outputs (h, ICP_MEM_NN_ID);
 }
 
 // landmark-grid / representative-grid validation — src/ICP/algorithms.cpp:842-854 generalised (oracle: orc_reps_grid)
@@ -122,6 +133,7 @@ int icp_create (icp_handle *out, int device, int rot, int weighted)
     if (e == hipSuccess) e = hipEventCreate (&h->ev0);
     if (e == hipSuccess) e = hipEventCreate (&h->ev1);
     for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags (&h->evUp[k], hipEventDisableTiming);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags (&h->evFrame[k], hipEventDisableTiming);
     for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreateWithFlags (&h->evDone[k], hipEventDisableTiming);
     for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipEventCreateWithFlags (&h->evStage[k], hipEventDisableTiming);
     if (e != hipSuccess) { std::string m = hipGetErrorString (e); h->inited = false; icp_destroy (h); return fail (nullptr, ICP_EHIP, "icp_create: " + m); }
@@ -142,6 +154,7 @@ int icp_destroy (icp_handle h)
     if (h->ev0) (void) hipEventDestroy (h->ev0);
     if (h->ev1) (void) hipEventDestroy (h->ev1);
     for (int k = 0; k < 2; ++k) if (h->evUp[k]) (void) hipEventDestroy (h->evUp[k]);
+    for (int k = 0; k < 2; ++k) if (h->evFrame[k]) (void) hipEventDestroy (h->evFrame[k]);
     for (int k = 0; k < 4; ++k) if (h->evDone[k]) (void) hipEventDestroy (h->evDone[k]);
     for (int k = 0; k < 3; ++k) if (h->evStage[k]) (void) hipEventDestroy (h->evStage[k]);
     if (h->copy_stream) (void) hipStreamDestroy (h->copy_stream);
@@ -552,12 +565,14 @@ int icp_set_alpha (icp_handle h, float a)
 {   // setAlpha updates construct and search (src/ICP/algorithms.cpp:4712-4717); lists must be rebuilt by the caller
     if (!h) return ICP_EINVAL;
     if (a == 0.f) return fail (h, ICP_EINVAL, "The alpha parameter cannot be equal to zero");
+    { int rc = outputs_before_change (h); if (rc) return rc; }
     h->p.a = a; ++h->param_gen; return ICP_OK;
 }
 int icp_set_metric_scale (icp_handle h, float f_g)
 {
     if (!h) return ICP_EINVAL;
     if (!(f_g > 0.f) || !std::isfinite (f_g)) return fail (h, ICP_EINVAL, "the metric scale must be positive and finite");
+    { int rc = outputs_before_change (h); if (rc) return rc; }
     h->p.dist_scale = f_g; ++h->param_gen; return ICP_OK;
 }
 int icp_get_metric_scale (icp_handle h, float *f_g) { if (!h || !f_g) return ICP_EINVAL; *f_g = h->p.dist_scale; return ICP_OK; }
@@ -593,6 +608,7 @@ int icp_set_reduce_mode (icp_handle h, int mode)
 {
     if (!h) return ICP_EINVAL;
     if (mode != ICP_REDUCE_REFERENCE_ORDER && mode != ICP_REDUCE_FUSED) return fail (h, ICP_EINVAL, "unknown reduce mode");
+    { int rc = outputs_before_change (h); if (rc) return rc; }
     h->p.fused = mode; drop_graphs (h); return ICP_OK;
 }
 

@@ -115,6 +115,7 @@ struct icp_context {
     bool rbc2_ready = false;
     bool track_last_gated = false;                // the form of the last submitted frame
     hipEvent_t evUp[2] = { nullptr, nullptr }, evDone[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t evFrame[2] = { nullptr, nullptr };           // the last upload out of the pinned frame buffer hFrame[k] (whatever frame parity it was submitted under)
     hipEvent_t evStage[3] = { nullptr, nullptr, nullptr };   // the last asynchronous copy out of the pinned staging of F / M / T (icp_write)
     uint64_t track_submitted = 0, track_collected = 0;       // frames fed / frames whose result has been handed out since init / icp_track_reset
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

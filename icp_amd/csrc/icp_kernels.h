@@ -137,7 +137,9 @@ void icp_search_layout_of (const icp_params &p, int *dense, int *tile, int *stag
 void icp_launch_reset_state (const icp_params &p, hipStream_t s, int reset_T);
 void icp_launch_set_T (const icp_params &p, uint32_t b, const float *dT8, hipStream_t s, int reset_k = 0);
 // holds the stream until *seq >= want; bounded: max_spins rounds of ~0.25 us, then *host_timeout_flag = 1 and the stream goes on
-void icp_launch_gate (const uint32_t *seq, uint32_t want, uint32_t *host_timeout_flag, hipStream_t s, uint32_t max_spins = 1u << 21, icp_reg_state *warm = nullptr);
+// (on a timeout also *run_flag = epoch: the launches of the run behind the gate leave without a store)
+void icp_launch_gate (const uint32_t *seq, uint32_t want, uint32_t *host_timeout_flag, hipStream_t s, uint32_t max_spins = 1u << 21, icp_reg_state *warm = nullptr,
+                      uint32_t *run_flag = nullptr, uint32_t epoch = 0u);
 void icp_launch_seq_set (uint32_t *seq, uint32_t v, hipStream_t s);
 void icp_launch_rotation_solver (int rot, int power_mode, const float *din19, float *dout18, hipStream_t s);   // [S 11 | means 8] -> [Tk 8 | Rk 9 | trips]
 void icp_launch_get_lms (const float *cloud, float *lms, hipStream_t s);

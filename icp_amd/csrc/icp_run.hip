@@ -166,6 +166,10 @@ int run_finish (icp_context *h, run_ctl &r, run_ctl *other)
             const auto now = std::chrono::steady_clock::now ();
             if (r.k_seen != k_last) { k_last = r.k_seen; t_last = now; }
             else if (r.k0 && std::chrono::duration<double> (now - t_last).count () > 0.05) { r.k0 = 0u; t_last = now; }      // (a stale idea of where the count began: pace on k itself)
+            else if (h->hGateFlag && *h->hGateFlag) {
+                r.active = false;
+                return fail (h, ICP_EHIP, "tracking: the device made no progress for ~0.5 s (a frame's gate gave up; the frames behind it were skipped): icp_track_reset starts a new sequence");
+            }
             else if (std::chrono::duration<double> (now - t_last).count () > 20.0) {
                 r.active = false;
                 return fail (h, ICP_EHIP, "checked run: the device has published no progress for 20 s");
@@ -197,7 +201,9 @@ int run_wait_final (icp_context *h, volatile unsigned long long *mirror, uint32_
             const unsigned long long w = mirror[b];
             if ((uint32_t) (w >> 32) == epoch && (w & ICP_MIRROR_FINAL)) break;
             _mm_pause ();
-            if ((++spins & 0x3FFFu) == 0u && std::chrono::duration<double> (std::chrono::steady_clock::now () - t0).count () > 60.0) {
+            if ((++spins & 0x3FFFu) == 0u && h->hGateFlag && *h->hGateFlag)
+                return fail (h, ICP_EHIP, "tracking: the device made no progress for ~0.5 s (a frame's gate gave up; the frames behind it were skipped): icp_track_reset starts a new sequence");
+            if ((spins & 0x3FFFu) == 0u && std::chrono::duration<double> (std::chrono::steady_clock::now () - t0).count () > 60.0) {
                 // (is the stream in error?  hipStreamQuery reports a faulted queue)
                 const hipError_t e = hipStreamQuery (h->stream);
                 if (e != hipSuccess && e != hipErrorNotReady) return fail (h, ICP_EHIP, std::string ("checked run: ") + hipGetErrorString (e));

@@ -301,7 +301,7 @@ int icp_ko_destroy (icp_ko_handle k)
 {
     if (!k) return ICP_EINVAL;
     (void) hipSetDevice (k->device);
-    (void) hipDeviceSynchronize ();
+    (void) hipStreamSynchronize (nullptr);           // (the null stream the kernel objects use — not the device: another handle's tracking streams may hold a waiting gate)
     for (int s = 0; s < icp_ko::MAXS; ++s) if (k->owned[s] && k->slot[s]) (void) hipFree (k->slot[s]);
     for (void *q : k->scratch) (void) hipFree (q);
     delete k;
@@ -322,7 +322,7 @@ int icp_ko_adopt (icp_ko_handle k, int s, void *dptr)
 {
     if (!k || !dptr || s < 0 || s >= k->nslots) return sa_fail (ICP_EINVAL, "icp_ko_adopt: bad arguments");
     if (hipSetDevice (k->device) != hipSuccess) return sa_fail (ICP_EHIP, "hipSetDevice failed");
-    if (k->owned[s] && k->slot[s]) { (void) hipDeviceSynchronize (); (void) hipFree (k->slot[s]); }
+    if (k->owned[s] && k->slot[s]) { (void) hipStreamSynchronize (nullptr); (void) hipFree (k->slot[s]); }
     k->slot[s] = dptr; k->owned[s] = false;
     return ICP_OK;
 }

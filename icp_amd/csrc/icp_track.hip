@@ -50,11 +50,11 @@ static int track_prepare (icp_context *h)
             return e == hipSuccess ? ICP_OK : fail (h, ICP_ENOMEM, std::string ("tracking (second RBC set): ") + hipGetErrorString (e));
         };
         int rc;
-        if ((rc = al ((void **) &b.R, (size_t) p.nr * 32)) || (rc = al ((void **) &b.GB, (size_t) 2 * (p.n16 + p.n1k) * 16)) || (rc = al ((void **) &b.LB, (size_t) 3 * p.nlb * 16)) || (rc = al ((void **) &b.OL, (size_t) (p.nr + 1u) * 16)) || (rc = al ((void **) &b.XP, (size_t) p.m * 32)) ||
+        if (!b.R && ((rc = al ((void **) &b.R, (size_t) p.nr * 32)) || (rc = al ((void **) &b.GB, (size_t) 2 * (p.n16 + p.n1k) * 16)) || (rc = al ((void **) &b.LB, (size_t) 3 * p.nlb * 16)) || (rc = al ((void **) &b.OL, (size_t) (p.nr + 1u) * 16)) || (rc = al ((void **) &b.XP, (size_t) p.m * 32)) ||
             (rc = al ((void **) &b.XQ, (size_t) p.m * 32)) || (rc = al ((void **) &b.rep_src, (size_t) p.nr * 4)) || (rc = al ((void **) &b.owner, (size_t) p.m * 4)) ||
             (rc = al ((void **) &b.N, (size_t) p.nr * 4)) || (rc = al ((void **) &b.O, (size_t) p.nr * 4)) || (rc = al ((void **) &b.perm, (size_t) p.m * 4)) ||
             (rc = al ((void **) &b.chunk_hist, (size_t) p.nchunk * p.nr * 4)) || (rc = al ((void **) &b.blist, (size_t) p.nb * 64 * 8)) ||
-            (rc = al ((void **) &b.bn, (size_t) p.nb * 4)) || (rc = al ((void **) &b.brank, (size_t) p.m))) {
+            (rc = al ((void **) &b.bn, (size_t) p.nb * 4)) || (rc = al ((void **) &b.brank, (size_t) p.m)))) {
             void *ptrs[] = { b.R, b.GB, b.OL, b.LB, b.XP, b.XQ, b.rep_src, b.owner, b.N, b.O, b.perm, b.chunk_hist, b.blist, b.bn, b.brank };
             for (void *x : ptrs) if (x) (void) hipFree (x);
             b = icp_context::rbc_set {};
@@ -115,8 +115,9 @@ int icp_track_staging (icp_handle h, uint32_t slot, void **host_ptr)
     if ((rc = set_device (h))) return rc;
     if (!h->hFrame[slot]) HIPCHK (h, hipHostMalloc ((void **) &h->hFrame[slot], (size_t) 640 * 480 * 32, hipHostMallocDefault));
     // the buffer is handed out once the band of the frame it last held has left it (its upload may still be queued on the copy stream
-    // when more than two frames are in flight; an event that was never recorded returns at once)
-    HIPCHK (h, hipEventSynchronize (h->evUp[slot]));
+    // when more than two frames are in flight; an event that was never recorded returns at once).  The event belongs to the BUFFER: the
+    // frames' own upload events go by frame parity, which is the buffer's number only for a caller who alternates the two from frame 0 on
+    HIPCHK (h, hipEventSynchronize (h->evFrame[slot]));
     *host_ptr = h->hFrame[slot];
     return ICP_OK;
 }
@@ -181,6 +182,7 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     if (pinned) {
         // the caller filled one of the engine's pinned frame buffers (icp_track_staging): the band goes by DMA straight from there
         HIPCHK (h, hipMemcpy2DAsync (h->dBand[s], ICP_BAND_ROW_BYTES, src, spitch, ICP_BAND_ROW_BYTES, ICP_BAND_ROWS, hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK (h, hipEventRecord (h->evFrame[cloud == h->hFrame[0] ? 0 : 1], h->copy_stream));
         tend ();
     } else {
         // pageable source: the band's 128 row segments into the slot's pinned staging (free once the upload of frame f - 2 is through)
@@ -241,7 +243,7 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
                 if ((rc2 = wait_upload (s))) return rc2;
                 // (a warm-started frame behind a gate: the gate kernel writes the state as k_set_T would, once it is open)
                 const bool in_gate = gated && f >= 2u && warm;
-                if (gated && f >= 2u) { icp_launch_gate (h->dSeq, (uint32_t) (f - 1u), h->hGateFlag, st, 1u << 21, in_gate ? p.st : nullptr); HIPCHK (h, hipGetLastError ()); }
+                if (gated && f >= 2u) { icp_launch_gate (h->dSeq, (uint32_t) (f - 1u), h->hGateFlag, st, 1u << 21, in_gate ? p.st : nullptr, R.p.run_flag, R.p.epoch); HIPCHK (h, hipGetLastError ()); }
                 if (warm && !in_gate) { icp_launch_set_T (p, 0, p.st->T, st, gated ? 1 : 0); HIPCHK (h, hipGetLastError ()); }
                 return ICP_OK;
             };
@@ -269,6 +271,18 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
         HIPCHK (h, hipStreamWaitEvent (h->stream, h->evUp[s], 0));      // this frame's landmarks (nothing to register against yet)
         HIPCHK (h, hipEventRecord (h->evDone[ring], h->stream));
         h->track_epoch[ring] = 0u;
+    }
+    // Gated form: frame f waits on the DEVICE for its predecessor's release of the sequence word, and an undecided predecessor gets its
+    // launches from this thread — which is about to leave the library for as long as the application likes (a camera's next frame, a
+    // debugger, a garbage collection).  So the predecessor is brought to its decision HERE: converged (its final state stored, the word
+    // released by the launch that found out), or all max_iterations launches and its end kernel enqueued.  From then on the device goes
+    // from frame f - 1 to frame f by itself; what is left open when this returns is frame f, whose queue may run dry while the caller is
+    // away — nothing waits behind it on the device, it is topped up by the next call: a slow caller costs time, never a frame.
+    // (The caller's cadence is unchanged where it matters: icp_track_collect of frame f - 1, the next call of a pipelined loop, would
+    // have waited for the same decision.  Frame f's launches went out above, while the predecessor was still running.)
+    if (gated && P->active) {
+        if ((rc = run_finish (h, *P, R.active ? &R : nullptr))) return rc;
+        track_note_k (h, *P);
     }
     // everything that can fail is behind us: the handle now points at this frame's buffers
     h->dM = newM; h->p.M = newM; h->dF = newF; h->p.F = newF;
@@ -308,7 +322,9 @@ int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered)
     }
     if (f > 0u && h->track_epoch[ring]) { if ((rc = run_wait_final (h, h->hTrackMirror + ring, 1u, h->track_epoch[ring]))) return rc; }
     else HIPCHK (h, hipEventSynchronize (h->evDone[ring]));
-    if (h->hGateFlag && *h->hGateFlag) return fail (h, ICP_EHIP, "tracking: a frame's gate gave up waiting for its predecessor (device-side wait of ~0.5 s exceeded)");
+    if (h->hGateFlag && *h->hGateFlag)
+        return fail (h, ICP_EHIP, "tracking: the device made no progress for ~0.5 s (a frame's gate gave up waiting for its launch-complete predecessor; the frames behind it "
+                                  "were skipped, nothing was overwritten): icp_track_reset starts a new sequence");
     h->track_collected = f + 1u;
     if (f + 1u == h->track_submitted && f > 0u && h->track_epoch[ring]) {
         // nothing behind this frame: the handle's state is this registration's final state, and the host holds it

@@ -257,6 +257,12 @@ int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint
  *                    (into its own set of RBC buffers) and its launches are enqueued at once, behind a one-wave gate kernel that holds
  *                    its stream until the previous registration has released the sequence word — the device goes from one frame to
  *                    the next without the host.  (Host-ordered form: the call first brings the previous frame's run to its end.)
+ *                    No deadline for the caller: in the gated form the call returns once the PREVIOUS frame's registration is decided —
+ *                    converged, or all its max_iterations launches and its end kernel enqueued —, i.e. what this frame's gate waits
+ *                    for never depends on a later call; the frame submitted last may find its queue empty while the caller is away
+ *                    (nothing waits behind it) and is topped up by the next icp_track_* call.  A caller that stays away for a second
+ *                    or an hour loses that time and nothing else.  (The gate's own bound, ~0.5 s, is a guard against a device that
+ *                    has stopped: the frames behind it are then skipped without a store and the next call returns ICP_EHIP.)
  *                    warm_start != 0: the registration starts from the previous hop's transform (written back as by
  *                    icp_write (ICP_MEM_T): the rotation state is re-derived from it) instead of the identity; the first
  *                    registration of a sequence (after icp_init / icp_track_reset) has no previous hop and starts from the
@@ -264,7 +270,8 @@ int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint
  *                    `cloud` may be pageable host memory (the band is copied into pinned staging by the calling thread) or one
  *                    of the engine's two pinned frame buffers (icp_track_staging: the band goes by DMA straight from there —
  *                    the reference's mapped staging buffers hPtrInF / hPtrInM, src/ICP/algorithms.cpp:4438-4475;
- *                    icp_track_staging returns a buffer only after the band of the frame it last held has left it).
+ *                    icp_track_staging returns a buffer only after the band of the frame it last held has left it — whichever
+ *                    of the two buffers a frame came from, in any order, mixed with pageable frames).
  * icp_track_collect  blocks until the oldest frame in flight is done: *registered = 0 for the first frame after icp_init /
  *                    icp_track_reset (nothing to register against; *k = 0, T8 = identity), else 1, *k = iterations executed and
  *                    T8 = [q | t, s] mapping that frame onto the previous one.  Any output pointer may be NULL.

@@ -994,6 +994,107 @@ def test_tracking_stress_random_sequence(engine, oracle, warm, seed, blind, monk
     g.close()
 
 
+@pytest.mark.parametrize("blind", [None, "2"])
+def test_tracking_caller_stays_away(engine, oracle, blind, monkeypatch):
+    """VERDICT round 4, item 2 / the advisor's finding on icp_track.hip: in the gated form a frame waits ON THE DEVICE for its predecessor,
+    and the predecessor used to get its launches from later calls of the application — which stayed away longer than the gate's bounded
+    wait (0.5 s) at the price of ICP_EHIP and a trampled frame.  Now icp_track_submit returns with the predecessor decided, so a caller may
+    sleep anywhere: warm-started frames whose iteration count swings between a handful and max_iterations, a second of sleep between a
+    submit and the next call (and between a collect and the next submit) at random points, 1 .. 3 frames in flight — every hop's k and T
+    equal the oracle's, no error.  Also with next to no launches up front (ICP_AMD_TRACK_BLIND=2: every queue runs dry at once)."""
+    import time
+    if blind:
+        monkeypatch.setenv("ICP_AMD_TRACK_BLIND", blind)
+    rng = np.random.default_rng(11)
+    clouds = [engine.synth_cloud_vga(moved=f) for f in range(5)]
+    lms = [oracle.get_lms(c) for c in clouds]
+    order = [0, 1, 2, 3, 4, 3, 2, 1, 0, 1, 2, 3, 4, 3, 2, 1, 0]
+    sleeps = set(int(x) for x in rng.choice(np.arange(2, len(order)), 5, replace=False))
+    g = engine.ICP(0)
+    g.init(16384, 256, 2e2, 1e-6)
+    assert g.track_form() == 1
+    res, inflight = [], 0
+    for i, fi in enumerate(order):
+        depth = int(rng.integers(1, 4))
+        while inflight >= depth:
+            res.append(g.track_collect()); inflight -= 1
+            if i in sleeps and rng.random() < 0.3:
+                time.sleep(0.7)
+        g.track_submit(clouds[fi], True)
+        inflight += 1
+        if i in sleeps:
+            time.sleep(1.0)                              # the application is away: twice the gate's bound
+    while inflight:
+        res.append(g.track_collect()); inflight -= 1
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+    ks = []
+    for i in range(1, len(order)):
+        o.write_f(lms[order[i - 1]]); o.write_m(lms[order[i]])
+        o.write_t(o.T if i > 1 else [0, 0, 0, 1, 0, 0, 0, 1])
+        o.build_rbc()
+        ko = o.run()
+        ks.append(ko)
+        assert res[i][0] == ko, (i, res[i][0], ko)
+        assert np.array_equal(res[i][1].view(np.uint32), o.T.view(np.uint32)), i
+    assert min(ks) <= 12 and max(ks) >= 35               # the iteration count swings (the sequence reverses direction)
+    g.close()
+
+
+def test_pinned_frame_buffers_in_any_order(engine, oracle):
+    """The advisor's finding on icp_track_staging: the buffer handed out must wait for the upload of the frame IT last held — not for the
+    upload of the frame with the same parity.  Buffer 0 for consecutive frames, a sequence that starts on buffer 1, pageable frames in
+    between, three frames in flight: a buffer refilled right after its icp_track_staging call never reaches the device half-written."""
+    clouds = [engine.synth_cloud_vga(moved=f) for f in range(4)]
+    lms = [oracle.get_lms(c) for c in clouds]
+    order = [1, 0, 2, 3, 1, 2, 0, 3, 2, 1]
+    how = [1, 1, 0, 0, "p", 0, 1, "p", 1, 1]              # pinned buffer number, or a pageable frame
+    g = engine.ICP(0)
+    g.init(16384, 256, 2e2, 1e-6)
+    res, inflight = [], 0
+    for fi, hw in zip(order, how):
+        while inflight >= 3:
+            res.append(g.track_collect()); inflight -= 1
+        if hw == "p":
+            g.track_submit(clouds[fi], False)
+        else:
+            g.track_staging(hw)[...] = clouds[fi]
+            g.track_submit(hw, False)
+        inflight += 1
+    while inflight:
+        res.append(g.track_collect()); inflight -= 1
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+    for i in range(1, len(order)):
+        o.write_f(lms[order[i - 1]]); o.write_m(lms[order[i]]); o.write_t([0, 0, 0, 1, 0, 0, 0, 1]); o.build_rbc()
+        ko = o.run()
+        assert res[i][0] == ko, (i, res[i][0], ko)
+        assert np.array_equal(res[i][1].view(np.uint32), o.T.view(np.uint32)), i
+    g.close()
+
+
+def test_setters_after_a_lazy_run_keep_the_runs_outputs(engine, oracle):
+    """The advisor's finding on materialize_outputs: per-query outputs a checked run leaves to be reproduced on demand are reproduced with
+    the parameters the RUN used, also when alpha, the metric's scale or the reduction mode is changed before the first read."""
+    F, M = engine.synth_pair(128)
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+    o.write_f(F); o.write_m(M); o.build_rbc(); ko = o.run()
+    for setter in ("alpha", "scale", "mode"):
+        g = engine.ICP(0)
+        g.init(16384, 256, 2e2, 1e-6)
+        g.write(engine.Memory.F, F); g.write(engine.Memory.M, M); g.buildRBC()
+        assert g.run() == ko
+        if setter == "alpha":
+            g.setAlpha(5.0)
+        elif setter == "scale":
+            g.setMetricScale(0.25)
+        else:
+            g.setReduceMode(engine.ReduceMode.REFERENCE_ORDER)
+        n = g.read(engine.Memory.NN_ID)
+        assert np.array_equal(n["id"], o.nn_id["id"]), setter
+        assert np.array_equal(n["dist"].view(np.uint32), o.nn_id["dist"].view(np.uint32)), setter
+        assert np.array_equal(g.read(engine.Memory.W).view(np.uint32), o.W.view(np.uint32)), setter
+        g.close()
+
+
 def test_tracking_interrupted_by_other_calls_and_resets(engine, oracle):
     """Frames in flight on two streams, and the caller does something else: a read of T with three frames uncollected (every open run is
     brought to its end, the second stream drained: T is the last submitted hop's), the frames are collected afterwards and the sequence goes

@@ -573,6 +573,29 @@ def measure_holes(icp_amd, device, iters):
                 out[key][name] = one(cfg, batch, name, steps)
             except Exception as e:                   # noqa: BLE001
                 out[key][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # The reference's second example scene (data/kg_pc8d_wall, data/README.md:11-16), stand-in: a textured plane moved in its own plane
+    try:
+        F, M, Tt = W.wall_pair(icp_amd)
+        wall = {"scene": "textured plane at 600 mm, moved %.0f degrees about its normal and %s mm in its plane; |F|=|M|=16384, |R|=256" % (W.WALL_ROT_DEG, (W.WALL_T[:2],))}
+        for tag, a in (("a_2e2", ALPHA), ("a_1e-6", W.WALL_A_SMALL)):
+            g = icp_amd.ICP(device)
+            g.init(16384, 256, a, SCALING, max_iterations=W.WALL_MAX_ITERATIONS)
+            g.write(icp_amd.Memory.F, F); g.write(icp_amd.Memory.M, M)
+            g.buildRBC(); g.sync()
+            settle(g, iters)
+            ms, n = g.time_run_fixed_tail(iters, 21, from_identity=True)
+            g.reset_transform(); g.buildRBC()
+            t0 = time.perf_counter()
+            k = int(g.run())
+            run_ms = (time.perf_counter() - t0) * 1e3
+            st = g.state()
+            wall[tag] = {"us_per_iteration": ms * 1e3 / (n * iters), "N_max": int(g.read(icp_amd.Memory.RBC_N).max()),
+                         "run_k": k, "run_converged": bool(st.converged), "run_ms": run_ms, "max_iterations": W.WALL_MAX_ITERATIONS,
+                         "rotation_error_deg": W.rotation_error_deg(g.read(icp_amd.Memory.T), Tt), "scale": float(g.read(icp_amd.Memory.T)[7])}
+            g.close()
+        out["A_wall"] = wall
+    except Exception as e:                           # noqa: BLE001
+        out["A_wall"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # tracking: 640 x 480 frames with contiguous invalid regions (10 %, another pattern per frame), cold start, two frames in flight
     try:
         frames = [icp_amd.punch_holes(icp_amd.synth_cloud_vga(moved=f), 640, 480, icp_amd.HOLES_CONTIGUOUS, 0.1, True, seed=W.BASE_SEED + f) for f in range(5)]

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["ICP", "ICPStep", "ICPError", "Memory", "ICPStepConfigT", "ICPStepConfigW",
-           "PowerMode", "ReduceMode", "TransformKind", "ICPBatch", "batch_partition", "power_method", "KernelObject", "kernel_lms", "kernel_reps", "kernel_weights", "kernel_mean", "kernel_devs", "kernel_s", "ReduceScan", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "punch_holes", "HOLES_SCATTERED", "HOLES_CONTIGUOUS", "device_count", "DIST_ID"]
+           "PowerMode", "ReduceMode", "TransformKind", "ICPBatch", "batch_partition", "power_method", "KernelObject", "kernel_lms", "kernel_reps", "kernel_weights", "kernel_mean", "kernel_devs", "kernel_s", "ReduceScan", "lib", "lib_path", "reduce", "scan", "ReduceConfig", "synth_pair", "synth_cloud_vga", "punch_holes", "HOLES_SCATTERED", "HOLES_CONTIGUOUS", "synth_pair_scene", "SCENE_CURVED", "SCENE_WALL", "device_count", "DIST_ID"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("ICP_AMD_LIB", os.path.join(_HERE, "libicp_amd.so"))   # override: A/B builds of the same ABI
@@ -196,6 +196,7 @@ def lib():
     sig("icp_device_count", i32, C.POINTER(i32))
     sig("icp_synth_pair", i32, C.c_uint64, u32, f32, vp, vp, f32, f32, f32, vp, vp)
     sig("icp_synth_cloud_vga", i32, C.c_uint64, i32, vp)
+    sig("icp_synth_pair_scene", i32, C.c_uint64, u32, i32, f32, vp, vp, f32, f32, vp, vp, vp)
     sig("icp_synth_punch_holes", i32, C.c_uint64, u32, u32, i32, f32, i32, vp)
     _lib = L
     return L
@@ -434,6 +435,22 @@ def synth_cloud_vga(seed=0x1C9D5EED, moved=False):
 
 
 HOLES_SCATTERED, HOLES_CONTIGUOUS = 0, 1
+SCENE_CURVED, SCENE_WALL = 0, 1
+
+
+def synth_pair_scene(side, scene=SCENE_CURVED, seed=0x1C9D5EED, rot_deg=3.0, axis=(0.3, 0.9, 0.1), t=(25.0, -10.0, 15.0),
+                     noise_mm=1.0, noise_rgb=0.01):
+    """(F, M, T_true): a synthetic pair of the chosen scene and the ground truth [q | t, 1] that maps M onto F.  SCENE_WALL: the
+    reference's kg_pc8d_wall stand-in (data/README.md:11-16) — a textured plane moved in its own plane. Host only."""
+    F = np.empty((side * side, 8), np.float32)
+    M = np.empty((side * side, 8), np.float32)
+    T = np.empty(8, np.float32)
+    ax = np.asarray(axis, np.float32)
+    tt = np.asarray(t, np.float32)
+    rc = lib().icp_synth_pair_scene(seed, side, scene, rot_deg, _p(ax), _p(tt), noise_mm, noise_rgb, _p(F), _p(M), _p(T))
+    if rc:
+        raise ICPError(rc, "icp_synth_pair_scene")
+    return F, M, T
 
 
 def punch_holes(cloud, width, height, pattern=HOLES_SCATTERED, fraction=0.1, keep_rgb=True, seed=0x1C9D5EED):

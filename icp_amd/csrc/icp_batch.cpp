@@ -10,11 +10,25 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <system_error>
 #include <thread>
 #include <vector>
+#include <immintrin.h>
+#include <pthread.h>
+#include <sched.h>
 
+// One host thread per device slot, for the life of the batch object (round 5; rounds 1 - 4 spawned and joined a thread per slot in
+// every icp_batch_* call — eight creations and joins per call are noise beside 64 x 40 iterations and a visible fraction of a converged
+// warm batch, and not what a service loop over eight GPUs wants).  A call publishes a job (a generation number + the function), every
+// worker runs it for its slot, the caller waits for the count of pending slots to reach zero.  Both sides spin briefly before they sleep
+// on a condition variable: back-to-back calls hand over in a microsecond or two, an idle batch object costs no CPU.
+// ICP_AMD_SLOT_CPUS: a comma-separated list of CPU numbers; the worker of slot s is pinned to entry s mod (length) — on a multi-socket
+// host the thread that drives a GPU belongs on that GPU's NUMA node.
 struct icp_batch_context {
     std::vector<int> devices;                    // device ordinal of every slot (ordinals may repeat)
     std::vector<icp_handle> slots;               // one engine handle per slot
@@ -23,6 +37,15 @@ struct icp_batch_context {
     int rot = 1, weighted = 1;
     bool inited = false;
     std::string err;
+    // the slot workers
+    std::vector<std::thread> workers;
+    std::mutex mx;
+    std::condition_variable cv_job, cv_done;
+    std::atomic<uint64_t> generation { 0 };
+    std::atomic<int> pending { 0 };
+    std::atomic<bool> stop { false };
+    std::function<int (size_t)> job;
+    std::vector<int> rc;
 };
 
 namespace {
@@ -35,25 +58,75 @@ int bfail (icp_batch_context *b, int code, const std::string &msg)
     return code;
 }
 
-// runs fn (slot) on one host thread per slot that holds registrations; returns the first failing status
-// started_short (optional): set when not every slot's thread could be started, so that threads waiting for each other give up
-template <typename Fn>
-int for_each_slot (icp_batch_context *b, Fn &&fn, std::atomic<int> *started_short = nullptr)
+constexpr int SPIN = 4000;                       // ~20 - 40 us of _mm_pause before a side goes to sleep
+
+void worker_main (icp_batch_context *b, size_t s)
+{
+    uint64_t seen = 0;
+    for (;;) {
+        int spins = 0;
+        while (b->generation.load (std::memory_order_acquire) == seen && !b->stop.load (std::memory_order_acquire)) {
+            if (++spins < SPIN) { _mm_pause (); continue; }
+            std::unique_lock<std::mutex> lk (b->mx);
+            b->cv_job.wait (lk, [&] { return b->generation.load (std::memory_order_acquire) != seen || b->stop.load (std::memory_order_acquire); });
+        }
+        if (b->stop.load (std::memory_order_acquire)) return;
+        seen = b->generation.load (std::memory_order_acquire);
+        b->rc[s] = b->count[s] ? b->job (s) : (int) ICP_OK;
+        if (b->pending.fetch_sub (1, std::memory_order_acq_rel) == 1) {
+            std::lock_guard<std::mutex> lk (b->mx);       // (the caller may be on its way to sleep: the lock orders this notify behind its wait)
+            b->cv_done.notify_one ();
+        }
+    }
+}
+
+int start_workers (icp_batch_context *b)
 {
     const size_t n = b->slots.size ();
-    std::vector<int> rc (n, ICP_OK);
-    std::vector<std::thread> th;
-    bool spawn_failed = false;
-    for (size_t s = 0; s < n && !spawn_failed; ++s) {
-        if (!b->count[s]) continue;
-        try { th.emplace_back ([&, s] { rc[s] = fn (s); }); }
-        catch (const std::system_error &) { spawn_failed = true; }     // (resource exhaustion: the threads already started are joined, never abandoned)
+    b->rc.assign (n, ICP_OK);
+    std::vector<int> cpus;
+    if (const char *e = std::getenv ("ICP_AMD_SLOT_CPUS")) {
+        const char *q = e;
+        while (*q) { char *end = nullptr; const long v = std::strtol (q, &end, 10); if (end == q) break; if (v >= 0) cpus.push_back ((int) v); q = (*end == ',') ? end + 1 : end; if (*end && *end != ',') break; }
     }
-    if (spawn_failed && started_short) started_short->store (1, std::memory_order_release);
-    for (auto &t : th) t.join ();
-    if (spawn_failed) return bfail (b, ICP_ENOMEM, "a host thread per device slot could not be started");
+    try {
+        for (size_t s = 0; s < n; ++s) {
+            b->workers.emplace_back (worker_main, b, s);
+            if (!cpus.empty ()) {
+                cpu_set_t set; CPU_ZERO (&set); CPU_SET (cpus[s % cpus.size ()], &set);
+                (void) pthread_setaffinity_np (b->workers.back ().native_handle (), sizeof (set), &set);      // (a CPU that is not there: the thread stays where it is)
+            }
+        }
+    } catch (const std::system_error &) { return ICP_ENOMEM; }
+    return ICP_OK;
+}
+
+void stop_workers (icp_batch_context *b)
+{
+    { std::lock_guard<std::mutex> lk (b->mx); b->stop.store (true, std::memory_order_release); }
+    b->cv_job.notify_all ();
+    for (auto &t : b->workers) if (t.joinable ()) t.join ();
+    b->workers.clear ();
+}
+
+// runs fn (slot) on the worker of every slot that holds registrations; returns the first failing status
+template <typename Fn>
+int for_each_slot (icp_batch_context *b, Fn &&fn)
+{
+    const size_t n = b->slots.size ();
+    b->job = std::forward<Fn> (fn);
+    b->pending.store ((int) n, std::memory_order_release);
+    { std::lock_guard<std::mutex> lk (b->mx); b->generation.fetch_add (1, std::memory_order_acq_rel); }
+    b->cv_job.notify_all ();
+    int spins = 0;
+    while (b->pending.load (std::memory_order_acquire) != 0) {
+        if (++spins < SPIN) { _mm_pause (); continue; }
+        std::unique_lock<std::mutex> lk (b->mx);
+        b->cv_done.wait (lk, [&] { return b->pending.load (std::memory_order_acquire) == 0; });
+    }
+    b->job = nullptr;
     for (size_t s = 0; s < n; ++s)
-        if (rc[s] != ICP_OK) return bfail (b, rc[s], "slot " + std::to_string (s) + " (device " + std::to_string (b->devices[s]) + "): " + icp_last_error (b->slots[s]));
+        if (b->rc[s] != ICP_OK) return bfail (b, b->rc[s], "slot " + std::to_string (s) + " (device " + std::to_string (b->devices[s]) + "): " + icp_last_error (b->slots[s]));
     return ICP_OK;
 }
 
@@ -92,6 +165,12 @@ int icp_batch_create (icp_batch_handle *out, const int *devices, int n_devices, 
         b->devices.push_back (devices[d]); b->slots.push_back (h);
     }
     b->count.assign (b->slots.size (), 0u);
+    if (start_workers (b) != ICP_OK) {
+        stop_workers (b);
+        for (icp_handle q : b->slots) icp_destroy (q);
+        delete b;
+        return bfail (nullptr, ICP_ENOMEM, "icp_batch_create: a host thread per device slot could not be started");
+    }
     *out = b;
     return ICP_OK;
 }
@@ -99,6 +178,7 @@ int icp_batch_create (icp_batch_handle *out, const int *devices, int n_devices, 
 int icp_batch_destroy (icp_batch_handle b)
 {
     if (!b) return ICP_EINVAL;
+    stop_workers (b);
     for (icp_handle h : b->slots) icp_destroy (h);
     delete b;
     return ICP_OK;
@@ -203,9 +283,8 @@ int icp_batch_time_run_fixed_slots (icp_batch_handle b, uint32_t iterations, uin
     size_t active = 0;
     for (size_t s = 0; s < n; ++s) active += b->count[s] ? 1u : 0u;
     // the barrier in front of the timed region lives in the slot threads themselves: the last one to arrive takes t0 and opens it
-    // (no gate thread that could be left spinning if a slot's thread cannot be started: `short_` releases the waiters then)
     std::atomic<size_t> arrived { 0 };
-    std::atomic<int> go { 0 }, short_ { 0 };
+    std::atomic<int> go { 0 };
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now ();
     std::vector<float> ms (n, 0.f);
     int rc = for_each_slot (b, [&] (size_t s) {
@@ -216,14 +295,13 @@ int icp_batch_time_run_fixed_slots (icp_batch_handle b, uint32_t iterations, uin
             t0 = std::chrono::steady_clock::now ();
             go.store (1, std::memory_order_release);
         }
-        while (!go.load (std::memory_order_acquire) && !short_.load (std::memory_order_acquire)) std::this_thread::yield ();
+        while (!go.load (std::memory_order_acquire)) std::this_thread::yield ();
         if (r != ICP_OK) return r;
-        if (!go.load (std::memory_order_acquire)) return (int) ICP_ENOMEM;
         uint32_t timed = 0;                                           // (events behind the first pass: see icp_time_run_fixed_tail)
         r = icp_time_run_fixed_tail (b->slots[s], iterations, reps, 1, &ms[s], &timed);
         if (r == ICP_OK && timed) ms[s] = ms[s] * (float) reps / (float) timed;      // per-slot figure over all `reps` passes at the timed passes' rate
         return r ? r : icp_sync (b->slots[s]);
-    }, &short_);
+    });
     *seconds = std::chrono::duration<double> (std::chrono::steady_clock::now () - t0).count ();
     if (slot_ms) for (size_t s = 0; s < n; ++s) slot_ms[s] = ms[s];
     return rc;

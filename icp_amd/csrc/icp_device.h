@@ -230,6 +230,7 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
         Tk[7] = sk;
     };
     PM_STAMP (0)
+    bool shifted = false;
     if (squared_start) {
         // oracle power_fast: B = N^1024, u = B 1, x = normalize (u), xn = normalize (N u) (two independent chains),
         // loop on squared step lengths, division-free sign test, no extra pass after the loop
@@ -272,6 +273,18 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
                     }
                     tk_of (xn);
                     break;
+                }
+                // not converged after 1024 steps: +-lambda pairs of a planar scene (oracle power_fast: the norm shift, once per solve)
+                if (!shifted) {
+                    shifted = true;
+                    float sigma = ((__builtin_fabsf (Nrow[0]) + __builtin_fabsf (Nrow[1])) + __builtin_fabsf (Nrow[2])) + __builtin_fabsf (Nrow[3]);
+                    sigma = fmaxf (sigma, icp_dpp<0xB1> (sigma));           // quad_perm [1,0,3,2]
+                    sigma = fmaxf (sigma, icp_dpp<0x4E> (sigma));           // quad_perm [2,3,0,1]: the largest absolute row sum (max is exact)
+                    if (sigma > 0.f && sigma < __builtin_inff ()) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) Nrow[k] = (i == (uint32_t) k) ? Nrow[k] + sigma : Nrow[k];
+                        continue;
+                    }
                 }
             }
             x = pmq_normalize (u);

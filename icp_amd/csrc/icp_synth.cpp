@@ -60,6 +60,33 @@ void scene (double u, double v, double G, double *xyz, double *rgb)
     rgb[2] = std::fmin (1.0, std::fmax (0.0, b));
 }
 
+// The reference's second example scene, data/kg_pc8d_wall (data/README.md:11-16): "non-salient surface geometry" — a wall.  Here: a plane
+// through (0, 0, 600) mm (a wall at arm's length: landmarks 5 mm apart, so that a patch edge outweighs a few landmark spacings at a = 2e2) with the normal (0.25, 0.10, -1) / |.|, seen by the same pinhole camera, a millimetre of roughness that is part of
+// the SURFACE (both frames see the same bumps), and the procedural texture.  Geometry alone cannot tell where on the wall a point is.
+const double WALL_N[3] = { 0.25 / 1.0356157588603989, 0.10 / 1.0356157588603989, -1.0 / 1.0356157588603989 };
+const double WALL_Z0 = 600.0;
+
+void scene_wall (double u, double v, double G, double *xyz, double *rgb)
+{
+    // the texture: what hangs on a wall — patches of 1/16 of the view with a colour of their own (a hash of the patch), sharp edges, a
+    // little shading across each: an edge between two patches is worth about one landmark spacing in the metric at a = 2e2
+    {
+        const long cu = (long) std::floor (16.0 * u / G), cv = (long) std::floor (16.0 * v / G);
+        uint64_t hsh = (uint64_t) (cu + 1000) * 0x9E3779B97F4A7C15ull ^ (uint64_t) (cv + 1000) * 0xC2B2AE3D27D4EB4Full;
+        for (int k = 0; k < 3; ++k) {
+            hsh = rng::splitmix (hsh);
+            const double base = 0.1 + 0.8 * (double) (hsh >> 11) * (1.0 / 9007199254740992.0);
+            const double fu = 16.0 * u / G - (double) cu, fv = 16.0 * v / G - (double) cv;
+            rgb[k] = std::fmin (1.0, std::fmax (0.0, base + 0.05 * (fu - 0.5) + 0.03 * (fv - 0.5)));
+        }
+    }
+    const double rx = (u * 640.0 / G - 319.5) / 595.0, ry = (v * 480.0 / G - 239.5) / 595.0;
+    const double tau = 2.0 * M_PI;
+    const double bump = 1.0 * std::sin (tau * 11.0 * u / G) * std::sin (tau * 9.0 * v / G);      // +- 1 mm along the viewing ray
+    const double z = WALL_N[2] * WALL_Z0 / (WALL_N[0] * rx + WALL_N[1] * ry + WALL_N[2]) + bump;
+    xyz[0] = rx * z; xyz[1] = ry * z; xyz[2] = z;
+}
+
 void rotation (double deg, const float *axis, double R[9])
 {
     double n = std::sqrt ((double) axis[0] * axis[0] + (double) axis[1] * axis[1] + (double) axis[2] * axis[2]);
@@ -113,6 +140,53 @@ extern "C" int icp_synth_pair (uint64_t seed, uint32_t side, float rot_deg, cons
 //              random ellipses (depth shadows, absorbing surfaces) until `fraction` of the points is covered;
 //   keep_rgb   != 0: the colour stays (a real frame); 0: zeroed too — all invalid points identical, the degenerate case in which
 //              one representative's list holds every one of them.
+// scene 0: the curved scene of icp_synth_pair (rotation about axis3 through the origin, translation t3);
+// scene 1: the wall — the motion is IN the wall's plane: a rotation by rot_deg about the plane's normal through its centre (axis3 is
+//          ignored) and the in-plane part of t3; *T_true (may be NULL) receives the ground truth [q | t, 1] that maps the moving frame
+//          onto the fixed one, in the engine's convention.
+extern "C" int icp_synth_pair_scene (uint64_t seed, uint32_t side, int scene_kind, float rot_deg, const float *axis3, const float *t3,
+                                     float noise_mm, float noise_rgb, float *F, float *M, float *T_true)
+{
+    if (!F || !M || side == 0 || !t3 || (scene_kind == 0 && !axis3) || (scene_kind != 0 && scene_kind != 1)) return ICP_EINVAL;
+    rng g (seed);
+    const float wall_axis[3] = { (float) WALL_N[0], (float) WALL_N[1], (float) WALL_N[2] };
+    const float *axis = scene_kind == 1 ? wall_axis : axis3;
+    double R[9]; rotation (rot_deg, axis, R);
+    double t[3] = { t3[0], t3[1], t3[2] };
+    if (scene_kind == 1) {
+        // in-plane translation, rotation about the normal through the plane's centre c0: q = R (p - c0) + c0 + t_in
+        const double tn = t[0] * WALL_N[0] + t[1] * WALL_N[1] + t[2] * WALL_N[2];
+        const double c0[3] = { 0.0, 0.0, WALL_Z0 };
+        for (int k = 0; k < 3; ++k) t[k] = t[k] - tn * WALL_N[k] + c0[k] - (R[k * 3] * c0[0] + R[k * 3 + 1] * c0[1] + R[k * 3 + 2] * c0[2]);
+    }
+    const double G = (double) side;
+    for (uint32_t v = 0; v < side; ++v)
+        for (uint32_t u = 0; u < side; ++u) {
+            size_t i = (size_t) v * side + u;
+            double p[3], c[3];
+            (scene_kind == 1 ? scene_wall : scene) ((double) u, (double) v, G, p, c);
+            float *f = F + i * 8;
+            f[0] = (float) p[0]; f[1] = (float) p[1]; f[2] = (float) p[2]; f[3] = 1.f;
+            f[4] = (float) c[0]; f[5] = (float) c[1]; f[6] = (float) c[2]; f[7] = 1.f;
+            (scene_kind == 1 ? scene_wall : scene) ((double) u + 0.5, (double) v + 0.5, G, p, c);
+            float *mo = M + i * 8;
+            for (int k = 0; k < 3; ++k)
+                mo[k] = (float) (R[k * 3] * p[0] + R[k * 3 + 1] * p[1] + R[k * 3 + 2] * p[2] + t[k] + noise_mm * g.normal ());
+            mo[3] = 1.f;
+            for (int k = 0; k < 3; ++k) mo[4 + k] = (float) std::fmin (1.0, std::fmax (0.0, c[k] + noise_rgb * g.normal ()));
+            mo[7] = 1.f;
+        }
+    if (T_true) {
+        // M = R P + t  =>  P = R^T (M - t): q = quaternion of R^T (axis, -angle), translation -R^T t
+        const double n = std::sqrt ((double) axis[0] * axis[0] + (double) axis[1] * axis[1] + (double) axis[2] * axis[2]);
+        const double th = -rot_deg * M_PI / 180.0, s = std::sin (th / 2.0);
+        T_true[0] = (float) (axis[0] / n * s); T_true[1] = (float) (axis[1] / n * s); T_true[2] = (float) (axis[2] / n * s); T_true[3] = (float) std::cos (th / 2.0);
+        for (int k = 0; k < 3; ++k) T_true[4 + k] = (float) -(R[k] * t[0] + R[3 + k] * t[1] + R[6 + k] * t[2]);
+        T_true[7] = 1.f;
+    }
+    return ICP_OK;
+}
+
 extern "C" int icp_synth_punch_holes (uint64_t seed, uint32_t width, uint32_t height, int pattern, float fraction, int keep_rgb, float *cloud)
 {
     if (!cloud || width == 0 || height == 0 || !(fraction >= 0.f) || fraction > 1.f || (pattern != 0 && pattern != 1)) return ICP_EINVAL;

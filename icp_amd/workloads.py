@@ -61,3 +61,21 @@ def holes_pair(engine, name, side=SIDE, seed=BASE_SEED):
     F = engine.punch_holes(F, side, side, pattern, fraction, keep, seed=seed + 101)
     M = engine.punch_holes(M, side, side, pattern, fraction, keep, seed=seed + 202)
     return F, M
+
+
+# The reference's second example pair, data/kg_pc8d_wall (data/README.md:11-16): "non-salient surface geometry ... highlights the benefit
+# of utilizing the photometric information ... change the a parameter to a really small strictly positive number" to see what happens
+# without colour.  Stand-in: a textured plane at 600 mm moved in its own plane (2 degrees about its normal, (8, -4) mm).
+WALL_ROT_DEG, WALL_T, WALL_MAX_ITERATIONS, WALL_A_SMALL = 2.0, (8.0, -4.0, 0.0), 300, 1e-6
+
+
+def wall_pair(engine, side=SIDE, seed=BASE_SEED):
+    """(F, M, T_true) of the wall scene."""
+    return engine.synth_pair_scene(side, engine.SCENE_WALL, seed=seed, rot_deg=WALL_ROT_DEG, t=WALL_T)
+
+
+def rotation_error_deg(T, T_true):
+    """Angle of the rotation that separates two transforms' quaternions [x y z w ...], degrees."""
+    a, b = np.asarray(T[:4], np.float64), np.asarray(T_true[:4], np.float64)
+    c = abs(float(np.dot(a, b))) / (np.linalg.norm(a) * np.linalg.norm(b))
+    return float(np.degrees(2.0 * np.arccos(min(1.0, c))))

@@ -469,6 +469,13 @@ int icp_device_count (int *n);
 int icp_synth_pair (uint64_t seed, uint32_t side, float rot_deg, const float *axis3,
                     const float *t3, float noise_mm, float noise_rgb, float zero_fraction,
                     float *F, float *M);
+/* The same with a choice of scene.  scene 0: the curved scene of icp_synth_pair.  scene 1: a WALL — the reference's second example pair,
+ * data/kg_pc8d_wall ("non-salient surface geometry ... highlights the benefit of utilizing the photometric information",
+ * data/README.md:11-16): a tilted plane with a millimetre of surface roughness and the procedural texture, moved IN its own plane (a
+ * rotation by rot_deg about the plane's normal through its centre — axis3 is ignored — and the in-plane part of t3): geometry alone
+ * cannot see that motion.  T_true8 (may be NULL): the ground truth [q | t, 1] mapping the moving frame onto the fixed one. */
+int icp_synth_pair_scene (uint64_t seed, uint32_t side, int scene, float rot_deg, const float *axis3, const float *t3,
+                          float noise_mm, float noise_rgb, float *F, float *M, float *T_true8);
 /* Synthetic 640x480 float8 cloud for the getLMs path; `moved` = frame number of a sequence (0: the scene, f: moved
  * rigidly by f steps of 3 degrees / (25, -10, 15) mm, with noise). */
 int icp_synth_cloud_vga (uint64_t seed, int moved, float *cloud);

@@ -578,7 +578,7 @@ static int power_fast (const float *S, const float *means, float *Tk)
     float N[16]; build_N (S, N);
     float x[4], xn[4], u[4];
     const float ones[4] = { 1.f, 1.f, 1.f, 1.f };
-    int iters = 0;
+    int iters = 0, shifted = 0;
     for (;;) {
         float B[16], C[16]; memcpy (B, N, sizeof B); rescale16 (B);
         for (int s = 0; s < PM_SQUARINGS; ++s) {
@@ -616,6 +616,24 @@ static int power_fast (const float *S, const float *means, float *Tk)
                 }
                 memcpy (xn, v, sizeof xn); normalize4 (xn);
                 break;
+            }
+            /* Not converged after 1024 steps: two eigenvalues of (nearly) the same magnitude.  The case that occurs is a PLANAR scene (the
+             * reference's kg_pc8d_wall, data/README.md:11-16): S has rank 2, and N's eigenvalues come in pairs +-lambda — the power method,
+             * squared or not, cannot separate +lambda_max from -lambda_max (an even power least of all), and the literal loop spends its
+             * 1000 trips on a mixture of the two eigenvectors.  N is symmetric with trace 0: N + sigma I with sigma = the largest absolute
+             * row sum (>= every |eigenvalue|) has the same eigenvectors, every eigenvalue >= 0 and lambda_max + sigma on top alone.  Once per
+             * solve; the squaring starts over on the shifted matrix (rows summed left to right, the maximum is exact in any order). */
+            if (!shifted) {
+                float sigma = 0.f;
+                for (int i = 0; i < 4; ++i) {
+                    const float rs = ((fabsf (N[4 * i]) + fabsf (N[4 * i + 1])) + fabsf (N[4 * i + 2])) + fabsf (N[4 * i + 3]);
+                    if (rs > sigma) sigma = rs;
+                }
+                shifted = 1;
+                if (sigma > 0.f && sigma < INFINITY) {
+                    N[0] += sigma; N[5] += sigma; N[10] += sigma; N[15] += sigma;
+                    continue;
+                }
             }
         }
         memcpy (x, u, sizeof x); normalize4 (x);

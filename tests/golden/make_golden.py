@@ -71,6 +71,39 @@ def main():
     print("wrote", os.path.join(HERE, "oracle_vectors.npz"), {k: np.asarray(v).shape for k, v in out.items()})
     config4()
     bench_configs()
+    round5()
+
+
+def round5():
+    """Round 5's workloads (icp_amd/workloads.py), default modes, oracle (power_fast=True, fused=True):
+    holes — the benchmark pair with a Kinect frame's invalid points in both frames (six cases): N.max, run () (k, converged, T, digest of all
+            16384 ids), and the 40-iteration fixed pass from the identity (T, ids digest);
+    wall  — the textured plane moved in its own plane (the reference's kg_pc8d_wall stand-in): run () with max_iterations = 300 at a = 2e2
+            and at a = 1e-6 (k, converged, T, ids digest), the ground truth beside them."""
+    from icp_amd import workloads as W
+    out = {}
+    for name in W.HOLES:
+        F, M = W.holes_pair(icp_amd, name)
+        o = O.OracleICP(W.M_POINTS, W.NR, W.A, W.C_, power_fast=True, fused=True, threads=8)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        out[name + "_N_max"] = np.array([int(o.rbc_N.max())])
+        k = o.run()
+        out[name + "_run"] = np.array([k, int(o.converged)])
+        out[name + "_run_T"], out[name + "_run_ids_digest"] = o.T, W.ids_digest(o.nn_id["id"])
+        o.write_t([0, 0, 0, 1, 0, 0, 0, 1])
+        for _ in range(40):
+            o.step()
+        out[name + "_fixed40_T"], out[name + "_fixed40_ids_digest"] = o.T, W.ids_digest(o.nn_id["id"])
+    F, M, Tt = W.wall_pair(icp_amd)
+    out["wall_T_true"] = Tt
+    for tag, a in (("wall_a2e2", W.A), ("wall_asmall", W.WALL_A_SMALL)):
+        o = O.OracleICP(W.M_POINTS, W.NR, a, W.C_, power_fast=True, fused=True, threads=8, max_iterations=W.WALL_MAX_ITERATIONS)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        k = o.run()
+        out[tag + "_run"] = np.array([k, int(o.converged)])
+        out[tag + "_run_T"], out[tag + "_run_ids_digest"] = o.T, W.ids_digest(o.nn_id["id"])
+    np.savez_compressed(os.path.join(HERE, "round5_vectors.npz"), **out)
+    print("wrote round5_vectors.npz:", {k: (v.tolist() if v.size <= 2 else v.shape) for k, v in out.items() if k.endswith("_run") or k.endswith("N_max")})
 
 
 def config4():

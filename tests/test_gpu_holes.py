@@ -179,3 +179,53 @@ def test_long_lists_of_distinct_points(engine, oracle, batch):
             assert_bits(gn["dist"], o.nn_id["dist"], "distances")
             assert_bits(g.read(engine.Memory.T, batch_index=b), o.T, "T")
     g.close()
+
+
+@pytest.mark.parametrize("name", ["scattered10", "blobs10", "blobs30", "scattered10_rgb0", "blobs10_rgb0", "blobs30_rgb0"])
+def test_holes_engine_against_the_committed_fixture(engine, name):
+    """tests/golden/round5_vectors.npz (oracle outputs, make_golden.py): ICP::run and the bench's 40-iteration fixed pass on the six hole
+    cases at config A — k, convergence, T bit for bit, a digest of all 16384 correspondence ids — without the oracle in the loop."""
+    from icp_amd import workloads as W
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "round5_vectors.npz"))
+    F, M = W.holes_pair(engine, name)
+    g = engine.ICP(0)
+    g.init(W.M_POINTS, W.NR, W.A, W.C_)
+    g.write(engine.Memory.F, F); g.write(engine.Memory.M, M)
+    g.buildRBC()
+    assert int(g.read(engine.Memory.RBC_N).max()) == int(gold[name + "_N_max"][0])
+    k = g.run()
+    assert (k, int(g.state().converged)) == tuple(int(v) for v in gold[name + "_run"])
+    assert_bits(g.read(engine.Memory.T), gold[name + "_run_T"], "T")
+    assert np.array_equal(W.ids_digest(g.read(engine.Memory.NN_ID)["id"]), gold[name + "_run_ids_digest"])
+    g.run_fixed_fresh(40)
+    assert_bits(g.read(engine.Memory.T), gold[name + "_fixed40_T"], "T after 40 fixed iterations")
+    assert np.array_equal(W.ids_digest(g.read(engine.Memory.NN_ID)["id"]), gold[name + "_fixed40_ids_digest"])
+    g.close()
+
+
+@pytest.mark.parametrize("tag", ["wall_a2e2", "wall_asmall"])
+def test_wall_scene_engine_equals_oracle_and_fixture(engine, oracle, tag):
+    """The reference's second example pair (data/kg_pc8d_wall: geometry that does not constrain the motion, data/README.md:11-16), stand-in:
+    the engine's run with max_iterations = 300 equals the oracle's bit for bit — k, convergence, T, every correspondence id — with the
+    photometric term (a = 2e2: converges, finds the in-plane rotation) and without it (a = 1e-6: 300 iterations, neither)."""
+    from icp_amd import workloads as W
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "round5_vectors.npz"))
+    a = W.A if tag == "wall_a2e2" else W.WALL_A_SMALL
+    F, M, Tt = W.wall_pair(engine)
+    g = engine.ICP(0)
+    g.init(W.M_POINTS, W.NR, a, W.C_, max_iterations=W.WALL_MAX_ITERATIONS)
+    g.write(engine.Memory.F, F); g.write(engine.Memory.M, M)
+    g.buildRBC()
+    k = g.run()
+    o = oracle.OracleICP(W.M_POINTS, W.NR, a, W.C_, threads=8, power_fast=True, fused=True, max_iterations=W.WALL_MAX_ITERATIONS)
+    o.write_f(F); o.write_m(M); o.build_rbc()
+    assert k == o.run() and bool(g.state().converged) == bool(o.converged)
+    assert (k, int(o.converged)) == tuple(int(v) for v in gold[tag + "_run"])
+    assert_bits(g.read(engine.Memory.T), o.T, "T")
+    assert_bits(g.read(engine.Memory.T), gold[tag + "_run_T"], "T (fixture)")
+    n = g.read(engine.Memory.NN_ID)
+    assert np.array_equal(n["id"], o.nn_id["id"])
+    assert_bits(n["dist"], o.nn_id["dist"], "distances")
+    err = W.rotation_error_deg(g.read(engine.Memory.T), Tt)
+    assert (err < 0.1) if tag == "wall_a2e2" else (err > 0.1)
+    g.close()

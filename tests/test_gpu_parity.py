@@ -1020,6 +1020,22 @@ def test_reference_kat_through_the_hip_rotation_solvers(engine, oracle):
         engine.power_method(S, means, rot=7)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_planar_scene_through_the_hip_rotation_solvers(engine, oracle, seed):
+    """Coplanar points (the reference's wall scene at the solver, tests/test_oracle_golden.py::test_squared_power_method_on_a_planar_scene):
+    the device's squared start takes the norm shift exactly as the oracle does — same bits, two passes — and the literal loop its 1000 trips."""
+    from test_oracle_golden import _planar_case
+    S, means, Rt = _planar_case(seed)
+    Tq, Rq, itq = engine.power_method(S, means, mode=engine.PowerMode.SQUARED)
+    Tl, Rl, itl = engine.power_method(S, means, mode=engine.PowerMode.LITERAL)
+    oq, oq_it = oracle.power_method(S, means, fast=True)
+    ol, ol_it = oracle.power_method(S, means)
+    assert_bits(Tq, oq, "squared start, planar scene")
+    assert_bits(Tl, ol, "literal loop, planar scene")
+    assert (itq, itl) == (oq_it, ol_it) and itq == 2
+    assert np.abs(Rq.reshape(3, 3) - Rt).max() < 1e-6
+
+
 def test_first_search_seed_policy_does_not_change_a_bit(engine, oracle, monkeypatch):
     """A registration's first search (k = 0) is seeded from the queries' own grid cells; ICP_AMD_WARM_SEED=1 (diagnostics: what
     bench.py's `warm_seed_us_per_iteration` measures) keeps whatever the previous registration left in `rid`.  Any valid index is

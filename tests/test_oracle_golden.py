@@ -380,6 +380,101 @@ def test_config4_fixture_pins_the_oracle(oracle, engine, i):
     assert np.array_equal(C4.ids_digest(ids), gold["r%d_run_ids_digest" % i])
 
 
+def _round5():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "round5_vectors.npz"))
+
+
+@pytest.mark.parametrize("name", ["blobs10", "scattered10_rgb0"])
+def test_holes_fixture_pins_the_oracle(oracle, engine, name):
+    """tests/golden/round5_vectors.npz (make_golden.py: round5): the benchmark pair with a Kinect frame's invalid points — colour kept
+    (reference src/kinect_frame_grabber.cpp:246-262) and, the degenerate case, zeroed — : the oracle reproduces the fixture (two of the
+    six cases here; the GPU test checks the engine against all of them)."""
+    from icp_amd import workloads as W
+    gold = _round5()
+    F, M = W.holes_pair(engine, name)
+    o = oracle.OracleICP(W.M_POINTS, W.NR, W.A, W.C_, power_fast=True, fused=True, threads=8)
+    o.write_f(F); o.write_m(M); o.build_rbc()
+    assert int(o.rbc_N.max()) == int(gold[name + "_N_max"][0])
+    k = o.run()
+    assert (k, int(o.converged)) == tuple(int(v) for v in gold[name + "_run"])
+    assert np.array_equal(o.T.view(np.uint32), gold[name + "_run_T"].view(np.uint32))
+    assert np.array_equal(W.ids_digest(o.nn_id["id"]), gold[name + "_run_ids_digest"])
+
+
+def test_wall_scene_needs_the_photometric_term(oracle, engine):
+    """The reference's second example pair (data/kg_pc8d_wall, data/README.md:11-16): "non-salient surface geometry. It highlights the
+    benefit of utilizing the photometric information. To see what happens in the absence of color, change the a parameter ... to a really
+    small strictly positive number."  Stand-in: a textured plane moved IN its plane (2 degrees about its normal).  With a = 2e2 the
+    registration converges and finds the rotation; with a = 1e-6 it slides: after 300 iterations it has neither converged nor found
+    it, and the reference's scale estimate has collapsed.  Both runs are in the fixture."""
+    from icp_amd import workloads as W
+    gold = _round5()
+    F, M, Tt = W.wall_pair(engine)
+    assert np.array_equal(Tt, gold["wall_T_true"])
+    res = {}
+    for tag, a in (("wall_a2e2", W.A), ("wall_asmall", W.WALL_A_SMALL)):
+        o = oracle.OracleICP(W.M_POINTS, W.NR, a, W.C_, power_fast=True, fused=True, threads=8, max_iterations=W.WALL_MAX_ITERATIONS)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        k = o.run()
+        assert (k, int(o.converged)) == tuple(int(v) for v in gold[tag + "_run"])
+        assert np.array_equal(o.T.view(np.uint32), gold[tag + "_run_T"].view(np.uint32))
+        assert np.array_equal(W.ids_digest(o.nn_id["id"]), gold[tag + "_run_ids_digest"])
+        res[tag] = (k, o.converged, W.rotation_error_deg(o.T, Tt), float(o.T[7]))
+    k, conv, err, s = res["wall_a2e2"]
+    assert conv and k < 200 and err < 0.1 and s > 0.98            # 2 degrees of in-plane rotation found to 0.1 degree
+    k, conv, err, s = res["wall_asmall"]
+    assert not conv and k == W.WALL_MAX_ITERATIONS and err > 3 * res["wall_a2e2"][2] and s < 0.97
+
+
+def _planar_case(seed, tilt=0.3):
+    """S[11], means[8] of an exactly planar pair: points on a tilted plane, the moving set rotated by 7 degrees about the plane's normal
+    (S of rank 2: Horn's N has the eigenvalue pairs +-(s1 + s2), +-(s1 - s2))."""
+    rng = np.random.default_rng(seed)
+    uv = rng.uniform(-1, 1, (400, 2)) * np.array([300.0, 200.0])
+    e1 = np.array([1.0, 0.0, tilt]); e1 /= np.linalg.norm(e1)
+    e2 = np.cross(np.array([0.2, 1.0, 0.1]), e1); e2 /= np.linalg.norm(e2)
+    n = np.cross(e1, e2)
+    f = uv[:, :1] * e1 + uv[:, 1:] * e2
+    th = np.radians(7.0)
+    K = np.array([[0, -n[2], n[1]], [n[2], 0, -n[0]], [-n[1], n[0], 0]])
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    q = f @ R.T                                            # moving = R fixed: the solver must find R^T
+    c = 1e-3
+    S9 = (c * q).T @ (c * f)                               # S_ab = sum m_a f_b
+    S = np.concatenate([S9.ravel(), [((c * f) ** 2).sum(), ((c * q) ** 2).sum()]]).astype(np.float32)
+    means = np.zeros(8, np.float32)
+    return S, means, R.T
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_squared_power_method_on_a_planar_scene(oracle, seed):
+    """The reference's kg_pc8d_wall case (data/README.md:11-16) at the solver: for coplanar points Horn's matrix has eigenvalues in
+    +- pairs, which no power method separates (the literal loop spends all its 1000 trips: kernels/icp_kernels.cl:1012-1022); the
+    squared start shifts the matrix by its largest absolute row sum once when its first pass does not converge and finds the rotation
+    in two passes.  Ordinary scenes never take that branch (every other fixture is unchanged)."""
+    S, means, Rt = _planar_case(seed)
+    Tq, itq = oracle.power_method(S, means, fast=True)
+    assert itq == 2                                        # the first pass does not converge (+- pairs), the shifted one does
+    assert np.abs(oracle.quat_to_rot(Tq[:4]) - Rt).max() < 1e-6
+
+
+def test_wall_scene_power_method_trip_counts(oracle, engine):
+    """S and the means of the wall pair's first iterations (icp_amd/workloads.py: wall_pair — a plane with a millimetre of roughness
+    and noise): the literal loop runs into its 1000-trip limit every time (its vector is still a mixture of the +lambda and -lambda
+    eigenvectors), the squared start needs its two passes; both are what the engine's modes run per ICP iteration on that scene."""
+    from icp_amd import workloads as W
+    F, M, Tt = W.wall_pair(engine)
+    o = oracle.OracleICP(W.M_POINTS, W.NR, W.A, W.C_, threads=8, power_fast=True, fused=True)
+    o.write_f(F); o.write_m(M); o.build_rbc()
+    for it in range(3):
+        o.step()
+        assert o.power_iters == 2
+        Tl, itl = oracle.power_method(o.S, o.means)
+        assert itl >= 1000
+        Tq, itq = oracle.power_method(o.S, o.means, fast=True)
+        assert itq == 2 and np.array_equal(Tq.view(np.uint32), o.Tk.view(np.uint32))
+
+
 def test_host_sanitizer_build_is_clean():
     """`make asan`: the oracle + the synthetic generator under AddressSanitizer / UBSan over every oracle
     entry point at small, ragged and degenerate sizes; any report aborts the program."""

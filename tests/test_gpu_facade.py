@@ -461,6 +461,7 @@ def test_batch_slot_workers_hand_over_quickly(engine):
     assert t_b8 < t_serial
     ident = np.array([0, 0, 0, 1, 0, 0, 0, 1], np.float32)
     for rep in range(3):
+        b8.buildRBC()                                        # (ICP::buildRBC: k = 0)
         for i in range(8):
             b8.write(i, engine.Memory.T, ident)              # (ICP::run goes on from the transform it finds: start every pass from the identity)
         b8.run()
@@ -469,7 +470,6 @@ def test_batch_slot_workers_hand_over_quickly(engine):
                 h.reset_transform(); h.buildRBC(); h.run()
             assert np.array_equal(b8.read(i, engine.Memory.T).view(np.uint32), h.read(engine.Memory.T).view(np.uint32)), (rep, i)
             assert b8.state(i).k == h.state().k
-        b8.buildRBC()
     for h in hs:
         h.close()
     g.close(); b8.close()

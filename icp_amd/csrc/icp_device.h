@@ -308,16 +308,34 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
         PM_STAMP (4)
         PM_STAMP (5)
     } else {
+        // The reference's loop (icp_kernels.cl:1012-1022), the same operations on the same values, arranged for ONE wave that the whole grid
+        // waits for: a trip is a chain of ~55 dependent instructions (N x, the sum of squares, an IEEE square root, an IEEE division; then
+        // the step length: a difference, a sum of squares, another IEEE square root, a compare), and only the first half is carried from
+        // trip to trip.  So the NEXT trip's vector is computed while this trip's step length is still under way (it depends on x_new only;
+        // if the loop stops here it is exactly the pass the reference makes behind its loop, :1039-1041, so it is never wasted), and the
+        // stop test is a scalar branch (every quad holds the same values; left as a per-lane compare the compiler builds a divergent
+        // loop: ~20 mask instructions per trip).  Round 4: 0.57 us per trip (k_finalize<1> 32.6 us per dispatch).
+        // What it does NOT buy is the factor the loop would need to matter less: a trip is ~75 vector instructions that no re-arrangement
+        // removes (N x: 8, two sums of squares: 12, two IEEE square roots: 34, one IEEE division: 12, the rest moves and compares) plus ~20
+        // hazard no-ops around the quad broadcasts, and ONE wave issues a vector instruction every 4 cycles at best, a dependent one every
+        // ~6.6, a no-op every 4 (MI355X_MICROARCH.md, cycle constants): ~520 cycles = 0.22 us per trip, 118 trips per iteration on the
+        // benchmark pair.  Measured (tests/diag_power_time.py, fused reductions + literal loop): 34.9 -> 33.2 us per iteration with the
+        // look-ahead and the scalar branch; replacing the step length's square root by a comparison of the sums (equal sums have equal
+        // roots, sums more than 8 ulps apart have different ones, both roots only in between) was bit-identical and no faster (34.2 us: the
+        // band test costs what the root's 17 instructions cost less the hazards) and is not kept.  The squared start (the default) is the
+        // way out of this loop, not a faster trip.
+        float xnn = 0.f;
         for (;;) {
-            float error, error_new = __builtin_inff ();
-            for (uint32_t it = 0; it < 1000; ++it) {                  // icp_kernels.cl:1012-1022
-                xn = pmq_normalize (pmq_matvec (Nrow, x));
+            float error = __builtin_inff ();
+            xn = pmq_normalize (pmq_matvec (Nrow, x));                // trip 1
+            ++iters;
+            for (uint32_t it = 1;; ++it) {
+                xnn = pmq_normalize (pmq_matvec (Nrow, xn));          // trip it + 1, ahead of the test (or the pass behind the loop)
+                const float d = x - xn;
+                const float error_new = sqrtf (pmq_seq4 (d * d));
+                if (__ballot (error_new == error) || it >= 1000u) break;      // :1019 (stop when the step length repeats) / :1012 (1000 trips)
+                error = error_new; x = xn; xn = xnn;
                 ++iters;
-                error = error_new;
-                float d = x - xn;
-                error_new = sqrtf (pmq_seq4 (d * d));
-                if (error_new == error) break;
-                x = xn;
             }
             float lam_num = pmq_lane (pmq_matvec (Nrow, xn), 0);
             float lambda = lam_num / pmq_lane (xn, 0);                // :1024
@@ -327,8 +345,7 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
                 x = 1.f;
             } else break;
         }
-        x = xn;                                                       // :1039-1041
-        xn = pmq_normalize (pmq_matvec (Nrow, x));
+        xn = xnn;                                                     // :1039-1041: x = x_new; x_new = normalize (N x)
         tk_of (xn);
     }
     PM_STAMP (6)

@@ -508,6 +508,23 @@ def measure_tracking(icp_amd, device, hops=256):
         el, gaps, lats, ks = pipelined(lambda i: g.track_submit(tail[i], warm), hops)
         res["pipelined_pageable"] = _track_report(hops, el, gaps, lats, ks, period=len(order))
         res["pipelined_pageable"]["host_launch_calls"] = dict(zip(("longest_us", "slower_than_10us", "calls"), g.launch_stats(reset=True)))
+        # the same pass with the sequence's five frame buffers registered as DMA sources (icp_track_register_source: what a capture loop that
+        # reuses its buffers does once): the band goes by DMA from the caller's own memory, the calling thread copies nothing
+        try:
+            for fr in frames:
+                g.track_register(fr)
+            g.track_reset()
+            g.track_pipelined(seq[:8], warm_start=warm)
+            g.sync()
+            g.launch_stats(reset=True)
+            el, gaps, lats, ks = pipelined(lambda i: g.track_submit(tail[i], warm), hops)
+            res["pipelined_registered"] = _track_report(hops, el, gaps, lats, ks, period=len(order))
+            res["pipelined_registered"]["host_launch_calls"] = dict(zip(("longest_us", "slower_than_10us", "calls"), g.launch_stats(reset=True)))
+            res["pipelined_registered"]["note"] = "the caller's own frame buffers, page-locked once (icp_track_register_source): band by 2-D DMA, no host copy"
+            for fr in frames:
+                g.track_unregister(fr)
+        except Exception as e:                       # noqa: BLE001
+            res["pipelined_registered"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not warm:                                  # (two alternating frames make every warm start the inverse of what is needed: cold only)
             g.track_reset()
             g.track_staging(0)[...] = frames[1]

@@ -196,6 +196,8 @@ def lib():
     sig("icp_device_count", i32, C.POINTER(i32))
     sig("icp_synth_pair", i32, C.c_uint64, u32, f32, vp, vp, f32, f32, f32, vp, vp)
     sig("icp_synth_cloud_vga", i32, C.c_uint64, i32, vp)
+    sig("icp_track_register_source", i32, vp, vp, C.c_size_t)
+    sig("icp_track_unregister_source", i32, vp, vp)
     sig("icp_synth_pair_scene", i32, C.c_uint64, u32, i32, f32, vp, vp, f32, f32, vp, vp, vp)
     sig("icp_synth_punch_holes", i32, C.c_uint64, u32, u32, i32, f32, i32, vp)
     _lib = L
@@ -637,6 +639,15 @@ class ICPStep:
         p = C.c_void_p()
         self._chk(self._L.icp_track_staging(self._h, slot, C.byref(p)))
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(640 * 480, 8))
+
+    def track_register(self, frames):
+        """Page-locks the caller's own frame array(s) (C-contiguous float32, one or more 640x480x8 frames) as DMA sources."""
+        a = np.asarray(frames)
+        assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.nbytes >= 640 * 480 * 32
+        self._chk(self._L.icp_track_register_source(self._h, _p(a), a.nbytes))
+
+    def track_unregister(self, frames):
+        self._chk(self._L.icp_track_unregister_source(self._h, _p(np.asarray(frames))))
 
     def track_pipelined(self, frames, warm_start=False, depth=2, pinned=False):
         """Feeds a sequence with `depth` frames in flight; returns [None | (k, T)] per frame.  pinned: every frame is first copied

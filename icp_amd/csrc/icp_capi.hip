@@ -38,6 +38,8 @@ void free_all (icp_context *h)
         if (h->dBand[k]) (void) hipFree (h->dBand[k]);
         h->hBand[k] = h->hFrame[k] = h->dBand[k] = nullptr;
     }
+    for (const auto &r : h->sources) (void) hipHostUnregister (const_cast<char *> (r.base));
+    h->sources.clear ();
     if (h->lm[2]) (void) hipFree (h->lm[2]);
     h->lm[0] = h->lm[1] = h->lm[2] = nullptr;
     if (h->hTrack) (void) hipHostFree (h->hTrack);

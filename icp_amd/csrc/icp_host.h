@@ -96,6 +96,8 @@ struct icp_context {
     float *lm[3] = { nullptr, nullptr, nullptr };            // landmarks of frame f live in lm[f mod 3] (lm[0] / lm[1] = the handle's F / M buffers)
     float *hBand[2] = { nullptr, nullptr }, *dBand[2] = { nullptr, nullptr };     // the part of a frame getLMs reads (ICP_BAND_*), pinned / device
     float *hFrame[2] = { nullptr, nullptr };                 // whole-frame pinned staging handed to the caller (icp_track_staging)
+    struct host_range { const char *base; size_t bytes; };
+    std::vector<host_range> sources;                         // the caller's own frame buffers, page-locked for DMA (icp_track_register_source)
     icp_reg_state *hTrack = nullptr;                         // pinned: final state of the frames in flight (ICP_TRACK_RING slots)
     unsigned long long *hTrackMirror = nullptr;              // pinned: their progress words
     uint32_t track_epoch[4] = { 0, 0, 0, 0 };                // epoch of the run in each ring slot

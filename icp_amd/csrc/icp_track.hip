@@ -108,6 +108,38 @@ int icp_track_reset (icp_handle h)
     return ICP_OK;
 }
 
+// The caller's own frame buffers as DMA sources: a capture loop that fills the same few buffers over and over
+// registers them once (hipHostRegister: the pages are locked, the runtime maps them for the device), and a frame submitted from inside a
+// registered range goes the way of the engine's pinned frame buffers — the band getLMs reads by one 2-D DMA, no host copy: the
+// calling thread's 60 us per frame (the 128 row segments into pinned staging) were the largest fixed part of a warm-started frame's host time.
+int icp_track_register_source (icp_handle h, void *frames, size_t bytes)
+{
+    int rc = need (h, false, true); if (rc) return rc;
+    if (!frames || bytes < (size_t) 640 * 480 * 32) return fail (h, ICP_EINVAL, "icp_track_register_source: a range of at least one 640 x 480 float8 frame");
+    if ((rc = set_device (h))) return rc;
+    for (const auto &r : h->sources)
+        if (static_cast<const char *> (frames) < r.base + r.bytes && r.base < static_cast<const char *> (frames) + bytes)
+            return fail (h, ICP_ESTATE, "icp_track_register_source: the range overlaps one that is registered already");
+    const hipError_t e = hipHostRegister (frames, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void) hipGetLastError (); return fail (h, ICP_EHIP, std::string ("hipHostRegister: ") + hipGetErrorString (e)); }
+    h->sources.push_back ({ static_cast<const char *> (frames), bytes });
+    return ICP_OK;
+}
+
+int icp_track_unregister_source (icp_handle h, void *frames)
+{
+    int rc = need (h, false, true); if (rc) return rc;
+    if ((rc = set_device (h))) return rc;
+    for (size_t i = 0; i < h->sources.size (); ++i)
+        if (h->sources[i].base == static_cast<const char *> (frames)) {
+            if (h->copy_stream) HIPCHK (h, hipStreamSynchronize (h->copy_stream));      // (no upload out of the range is still queued)
+            HIPCHK (h, hipHostUnregister (frames));
+            h->sources.erase (h->sources.begin () + (long) i);
+            return ICP_OK;
+        }
+    return fail (h, ICP_EINVAL, "icp_track_unregister_source: not the start of a registered range");
+}
+
 int icp_track_staging (icp_handle h, uint32_t slot, void **host_ptr)
 {
     int rc = need (h, false, true); if (rc) return rc;
@@ -178,11 +210,14 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
         } else HIPCHK (h, hipStreamWaitEvent (h->copy_stream, h->evDone[r2], 0));
     }
     tend ();
-    const bool pinned = cloud == h->hFrame[0] || cloud == h->hFrame[1];
+    const bool staged = cloud == h->hFrame[0] || cloud == h->hFrame[1];
+    bool pinned = staged;
+    for (const auto &r : h->sources)                                    // a frame in one of the caller's registered (page-locked) buffers
+        if (static_cast<const char *> (cloud) >= r.base && static_cast<const char *> (cloud) + (size_t) 640 * 480 * 32 <= r.base + r.bytes) pinned = true;
     if (pinned) {
         // the caller filled one of the engine's pinned frame buffers (icp_track_staging): the band goes by DMA straight from there
         HIPCHK (h, hipMemcpy2DAsync (h->dBand[s], ICP_BAND_ROW_BYTES, src, spitch, ICP_BAND_ROW_BYTES, ICP_BAND_ROWS, hipMemcpyHostToDevice, h->copy_stream));
-        HIPCHK (h, hipEventRecord (h->evFrame[cloud == h->hFrame[0] ? 0 : 1], h->copy_stream));
+        if (staged) HIPCHK (h, hipEventRecord (h->evFrame[cloud == h->hFrame[0] ? 0 : 1], h->copy_stream));
         tend ();
     } else {
         // pageable source: the band's 128 row segments into the slot's pinned staging (free once the upload of frame f - 2 is through)

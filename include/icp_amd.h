@@ -281,6 +281,13 @@ int icp_track_next (icp_handle h, const void *host_cloud_640x480x8, int warm_sta
 int icp_track_submit (icp_handle h, const void *host_cloud_640x480x8, int warm_start);
 int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered);
 int icp_track_staging (icp_handle h, uint32_t slot /* 0 | 1 */, void **pinned_host_frame);
+/* The caller's own frame buffers as DMA sources: page-locks `bytes` (>= one frame) at `frames` (hipHostRegister, once: a capture loop
+ * reuses its buffers); a frame submitted from inside a registered range is uploaded like one from the engine's pinned frame buffers —
+ * the band by one 2-D DMA, no copy by the calling thread (60 us of a frame's host time).  A frame must stay as it is until it has been
+ * collected (icp_track_collect) — the engine cannot tell when the caller refills its own memory.  icp_track_unregister_source (the
+ * range's start) before the memory is freed; icp_init / icp_destroy unregister what is left. */
+int icp_track_register_source (icp_handle h, void *frames, size_t bytes);
+int icp_track_unregister_source (icp_handle h, void *frames);
 int icp_track_reset (icp_handle h);
 /* How tracked frames follow each other on the device: *gated = 1 — consecutive registrations alternate between two streams, each held by a
  * device-side gate (a one-wave kernel, bounded wait) until its predecessor has released the sequence word: a frame's RBC construction and

@@ -1099,6 +1099,47 @@ def test_tracking_caller_stays_away(engine, oracle, blind, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("warm", [False, True])
+def test_tracking_from_registered_frame_buffers(engine, oracle, warm):
+    """icp_track_register_source: the caller's own frame buffers, page-locked once, are DMA sources — a frame
+    submitted from inside a registered range is uploaded without a copy by the calling thread.  One array holding four frames back to
+    back and a fifth buffer of its own; a frame from pageable memory in between; every hop equals the oracle; overlapping and unknown
+    ranges are refused; after unregistering the same frames go through the pageable path with the same bits."""
+    clouds = [engine.synth_cloud_vga(moved=f) for f in range(5)]
+    lms = [oracle.get_lms(c) for c in clouds]
+    block = np.ascontiguousarray(np.stack(clouds[:4]))       # four frames in one allocation
+    single = clouds[4].copy()
+    pageable = clouds[2].copy()
+    g = engine.ICP(0)
+    g.init(16384, 256, 2e2, 1e-6)
+    g.track_register(block); g.track_register(single)
+    with pytest.raises(engine.ICPError):
+        g.track_register(block[1])                           # overlaps a registered range
+    with pytest.raises(engine.ICPError):
+        g.track_unregister(block[1])                         # not the start of a range
+    order = [0, 1, 2, 3, 4, 3, 2, 1, 0]
+    def frame(i, n):
+        if order[i] == 4:
+            return single
+        if order[i] == 2 and n == 0 and i == 2:
+            return pageable
+        return block[order[i]]
+    for n in range(2):
+        g.track_reset()
+        res = g.track_pipelined([frame(i, n) for i in range(len(order))], warm_start=warm, depth=2)
+        o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+        for i in range(1, len(order)):
+            o.write_f(lms[order[i - 1]]); o.write_m(lms[order[i]])
+            o.write_t(o.T if (warm and i > 1) else [0, 0, 0, 1, 0, 0, 0, 1])
+            o.build_rbc()
+            ko = o.run()
+            assert res[i][0] == ko, (n, i, res[i][0], ko)
+            assert np.array_equal(res[i][1].view(np.uint32), o.T.view(np.uint32)), (n, i)
+        if n == 0:
+            g.track_unregister(block); g.track_unregister(single)      # second pass: the same buffers, pageable now
+    g.close()
+
+
 def test_pinned_frame_buffers_in_any_order(engine, oracle):
     """The advisor's finding on icp_track_staging: the buffer handed out must wait for the upload of the frame IT last held — not for the
     upload of the frame with the same parity.  Buffer 0 for consecutive frames, a sequence that starts on buffer 1, pageable frames in

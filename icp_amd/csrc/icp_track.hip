@@ -92,10 +92,23 @@ static void track_note_k (icp_context *h, uint64_t frame, uint32_t k)
 }
 static void track_note_k (icp_context *h, const run_ctl &r) { if (r.done_seen) track_note_k (h, r.p.seq_value, r.k_final); }
 
+// Diagnostic (ICP_AMD_TRACK_PROF=1): where the calling thread's time goes inside icp_track_submit — accumulated per step, printed to stderr
+// by icp_track_reset.  Steps: 0 bookkeeping + the slot's old run, 1 wait for frame f - 2, 2 band copy / DMA enqueue, 3 getLMs + event,
+// 4 run_begin (RBC construction, gate, blind launches), 5 the predecessor brought to its decision, 6 everything.
+static struct track_prof_t { bool on; double t[8]; uint64_t n; } g_tp = { std::getenv ("ICP_AMD_TRACK_PROF") != nullptr, { 0, 0, 0, 0, 0, 0, 0, 0 }, 0 };
+#define TP(k) do { if (g_tp.on) { const double now_ = now_s (); g_tp.t[k] += now_ - tp_last; tp_last = now_; } } while (0)
+
 int icp_track_reset (icp_handle h)
 {
     if (!h) return ICP_EINVAL;
     int rc = set_device (h); if (rc) return rc;
+    if (g_tp.on && g_tp.n) {
+        std::fprintf (stderr, "icp_track_submit, %llu calls, us per call: bookkeeping %.1f | wait f-2 %.1f | band %.1f | getLMs + event %.1f | run_begin %.1f | predecessor decided %.1f | all %.1f\n",
+                      (unsigned long long) g_tp.n, g_tp.t[0] * 1e6 / g_tp.n, g_tp.t[1] * 1e6 / g_tp.n, g_tp.t[2] * 1e6 / g_tp.n, g_tp.t[3] * 1e6 / g_tp.n, g_tp.t[4] * 1e6 / g_tp.n,
+                      g_tp.t[5] * 1e6 / g_tp.n, g_tp.t[6] * 1e6 / g_tp.n);
+        for (double &v : g_tp.t) v = 0.0;
+        g_tp.n = 0;
+    }
     if ((rc = run_close_all (h))) return rc;
     if (h->copy_stream) HIPCHK (h, hipStreamSynchronize (h->copy_stream));
     if (h->stream2) HIPCHK (h, hipStreamSynchronize (h->stream2));
@@ -167,6 +180,7 @@ static uint32_t track_blind (const icp_context *h)
 
 static int track_submit (icp_context *h, const void *cloud, int warm_start, bool blocking)
 {
+    double tp_last = g_tp.on ? now_s () : 0.0; const double tp_first = tp_last;
     int rc = need (h, false, true); if (rc) return rc;
     if (!cloud) return fail (h, ICP_EINVAL, "null pointer");
     if ((rc = set_device (h))) return rc;
@@ -198,6 +212,7 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
         if ((rc = run_finish (h, R, P->active ? P : nullptr))) return rc;
         track_note_k (h, R);
     }
+    TP (0);
     // the copy stream: not before registration f - 2 (the last reader of lm[buf], as its fixed set) is done.  Host-driven runs: the host
     // knows — the FINAL bit of that frame's word —, and neither stream carries an event for it (a record + a cross-stream wait cost the
     // main stream ~10 us per frame between the RBC construction and the first iteration, profiles/r04_track_trace.txt)
@@ -210,6 +225,7 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
         } else HIPCHK (h, hipStreamWaitEvent (h->copy_stream, h->evDone[r2], 0));
     }
     tend ();
+    TP (1);
     const bool staged = cloud == h->hFrame[0] || cloud == h->hFrame[1];
     bool pinned = staged;
     for (const auto &r : h->sources)                                    // a frame in one of the caller's registered (page-locked) buffers
@@ -239,11 +255,13 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
             }
         }
     }
+    TP (2);
     icp_launch_get_lms_band (h->dBand[s], h->lm[buf], h->copy_stream);
     HIPCHK (h, hipGetLastError ());
     tend ();
     HIPCHK (h, hipEventRecord (h->evUp[s], h->copy_stream));
     tend ();
+    TP (3);
     // ungated: one stream, in order — the previous frame's registration is brought to its end before this frame's work goes behind it
     int prev_slot = -1;
     if (!gated && h->run.active) {
@@ -315,10 +333,13 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     // away — nothing waits behind it on the device, it is topped up by the next call: a slow caller costs time, never a frame.
     // (The caller's cadence is unchanged where it matters: icp_track_collect of frame f - 1, the next call of a pipelined loop, would
     // have waited for the same decision.  Frame f's launches went out above, while the predecessor was still running.)
+    TP (4);
     if (gated && P->active) {
         if ((rc = run_finish (h, *P, R.active ? &R : nullptr))) return rc;
         track_note_k (h, *P);
     }
+    TP (5);
+    if (g_tp.on) { g_tp.t[6] += now_s () - tp_first; ++g_tp.n; }
     // everything that can fail is behind us: the handle now points at this frame's buffers
     h->dM = newM; h->p.M = newM; h->dF = newF; h->p.F = newF;
     if (gated && f > 0u) rbc_into (h->p, h->rbc[f & 1u]);

@@ -1,4 +1,5 @@
-"""Diagnostic (not a test, CPU only, ~15 min): how much exact stage-2 pruning over list chunks could skip in the lanes = candidates form at config C\n(profiles/r05_s2w_pruning_sim.txt)."""
+"""Diagnostic (not a test, CPU only, ~15 min): how much exact stage-2 pruning over list chunks could skip in the lanes = candidates form at config C
+(profiles/r05_s2w_pruning_sim.txt)."""
 import sys, numpy as np, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import icp_amd

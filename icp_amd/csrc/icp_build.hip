@@ -174,7 +174,11 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
             if (at0) OL[1u + run + (uint32_t) __builtin_popcountll (bal & ((1ull << lane) - 1ull))] = make_float4 (c.x, c.y, c.z, __uint_as_float (r));
             run += (uint32_t) __builtin_popcountll (bal);
         }
-        if (lane == 0) OL[0] = make_float4 (__uint_as_float (run), 0.f, 0.f, 0.f);
+        if (lane == 0) {
+            OL[0] = make_float4 (__uint_as_float (run), 0.f, 0.f, 0.f);
+            // the number the search reads: a spare lane of the box array (hi.w of the first tile box: nobody else writes that word)
+            reinterpret_cast<float *> (p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + 1u)[3] = __uint_as_float (run);
+        }
     } else {
         const uint32_t tile = blockIdx.x - nbr - nbg;
         float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
@@ -190,7 +194,9 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
             for (int k = 0; k < 3; ++k) { lo[k] = fminf (lo[k], __shfl_xor (lo[k], d)); hi[k] = fmaxf (hi[k], __shfl_xor (hi[k], d)); }
         if (lane == 0) {
             float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16;
-            GB[2 * tile] = make_float4 (lo[0], lo[1], lo[2], 0.f); GB[2 * tile + 1] = make_float4 (hi[0], hi[1], hi[2], 0.f);
+            GB[2 * tile] = make_float4 (lo[0], lo[1], lo[2], 0.f);
+            float *hi4 = reinterpret_cast<float *> (GB + 2 * tile + 1);       // (hi.w of tile box 0 belongs to the block that lists the representatives at the origin)
+            hi4[0] = hi[0]; hi4[1] = hi[1]; hi4[2] = hi[2];
         }
     }
 }

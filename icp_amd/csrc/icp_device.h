@@ -264,8 +264,10 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
                 c2 = c2 + pmq_q<0> (a1); c2 = c2 + pmq_q<0> (a2); c2 = c2 + pmq_q<3> (a1);
                 c2 = c2 + pmq_q<1> (a1); c2 = c2 + pmq_q<1> (a2); c2 = c2 + pmq_q<2> (a1);
                 const float uu = pmq_seq4 (u * u), vv = pmq_seq4 (v * v), uv = pmq_seq4 (u * v);
-                if (!(c2 > 0x1p-44f * (uu * vv))) {
-                    if (uv < 0.f) {
+                // (scalar branches: every quad holds the same values; as per-lane compares the compiler builds divergent control flow around the
+                // one path every iteration of every ordinary scene takes)
+                if (__builtin_expect (!__ballot (c2 > 0x1p-44f * (uu * vv)), 1)) {
+                    if (__ballot (uv < 0.f)) {
                         const float lambda = uv / uu;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) Nrow[k] = (i == (uint32_t) k) ? Nrow[k] - lambda : Nrow[k];

@@ -5,6 +5,20 @@
 //   icp_search_dense.hip   the dense variants (512-thread blocks, several per CU, exact stage-1 pruning, 256- / 1024-representative tiles,
 //                          both list-scan forms) + the dense owner search
 // so that the two families compile side by side and a change to one family's launch code does not rebuild the other.
+//
+// Map of this file (round 5: k_search split into its phases; what a phase needs from the others is in its parameter list):
+//   helpers                      sums, group minima (DPP), KS_CAND / KS_CAND_IF (one list candidate against the lane's query), ks_tile_of_block,
+//                                fused_query_index, cell_rep_of, ks_origin_list (representatives at the origin: a frame's invalid points)
+//   fused_moment_* / fused_finalize_block / fin_result_to_state      the finalize of a block: 18 double moments -> T (shared with icp_kernels.hip)
+//   ks_stage2_wave               stage 2, lanes = candidates (dense variant, long lists)
+//   ks_stage2_lanes<LPQ>         stage 2, a query's lanes scan its list; exact chunk-box pruning beyond the first 128 positions of long lists
+//   ks_epilogue<...>             hand-off to the finishing wave, winner record, weights, per-query outputs, block moments / weight tree
+//   ks_owner_lists_tail          RBC construct of the latency-bound sizes: what the owner search leaves for k_place_lists
+//   k_search<...>                the kernel: PROLOGUE (every independent load issued before the first wait; chained form: the previous
+//                                iteration's finalize), STAGE 1 (nearest representative: the coarse / fine passes over one LDS tile are the
+//                                lambdas coarse_pass / fine_pass, their drivers — MASKED: tile set decided once; else a tile loop — follow
+//                                them; kept inside the kernel: as free functions the 64-register variants spill, measured), then the calls above
+//   host side                    icp_tpr_magic, KS_FLAGS, KS_ARGS
 #pragma once
 #include "icp_kernels.h"
 
@@ -30,6 +44,9 @@ static __device__ __forceinline__ float sum4 (float4 v) { return ((v.x + v.y) + 
 #endif
 #ifndef ICP_S2_UNCOND
 #define ICP_S2_UNCOND 128u           // stage 2 (a query's lanes scan its list): positions of a list scanned unconditionally; beyond them chunk boxes first
+#endif
+#ifndef ICP_S1_ORIGIN_LIST
+#define ICP_S1_ORIGIN_LIST 1         // dense variants: the representatives at the origin are scanned as a list of their own (0: A/B builds without it — wrong results on frames with invalid points)
 #endif
 #ifndef ICP_S1_SEED
 #define ICP_S1_SEED 1                // stage 1: prune with the distance to the previous search's nearest representative
@@ -105,7 +122,7 @@ static __device__ __forceinline__ void ks_origin_list (const float4 *OL, uint32_
 {
     // (n_o = OL[0].x, block-uniform: loaded with the prologue's other loads — asked for here it would be a memory round trip of its own
     // on every block's path, holes or not: |F| = 16384 x 64 registrations 1.845 -> 1.882 us per registration-iteration)
-    if (n_o == 0u) return;
+    if (__builtin_expect (n_o == 0u, 1)) return;
     const float qq = __builtin_fmaf (qz, qz, __builtin_fmaf (qy, qy, qx * qx));
     const bool need = qq <= lim;                     // d >= qq for every member: none can win, or tie at a lower index, beyond that
     if (!__ballot (need)) return;
@@ -447,6 +464,403 @@ static __device__ __forceinline__ void fin_result_to_state (const icp_fin_result
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// ks_stage2_wave — stage 2, lanes = candidates (dense variant, long lists: icp_s2_wave_of): called by every lane of the wave.
+//   o, n, valid, rstar, q*: the calling lane's query (LPQ = 8: query lane >> 3); dmin / jmin: that query's winner (distance, list
+//   position; 0xFFFFFFFF: no candidate) in all of its lanes.
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void ks_stage2_wave (const char *XQb, uint32_t o, uint32_t n, bool valid, uint32_t rstar, float qx, float qy, float qz,
+                                                       float qr, float qg, float qb, float alpha, uint32_t lane, float &dmin, uint32_t &jmin)
+{
+    // ---- stage 2, long lists (dense variant, icp_s2_wave): lanes = candidates.  The scan above is bound by the vector-memory
+    // path (every query's lanes load their list for themselves: 24 bytes per candidate and query through the L1); the
+    // wave's 8 queries are neighbours and mostly share ONE list, so here the wave loads a list once — lane l takes the
+    // positions l, l + 64, .. — and every lane evaluates its candidate against each query of the wave that has this list,
+    // the query's six coordinates in SGPRs.  Distinct lists of the wave are served one after the other.  Per lane and
+    // query: best (distance, trip); at the end one butterfly over the 64 lanes that halves the number of queries a lane
+    // holds while it doubles the lanes reduced ((distance bits, position) as one 64-bit key: distances are >= +0, so
+    // the unsigned order of the bits is the order of the values; smallest distance, ties -> lowest position).
+    const uint32_t je = valid ? o + n : o;
+    unsigned long long todo = __ballot (je != o);                // lanes of the queries with a list to scan
+    float sx[8], sy[8], sz[8], sr[8], sg[8], sb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        sx[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qx), 8 * q));
+        sy[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qy), 8 * q));
+        sz[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qz), 8 * q));
+        sr[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qr), 8 * q));
+        sg[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qg), 8 * q));
+        sb[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qb), 8 * q));
+    }
+    float bd[8]; uint32_t btr[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bd[q] = __builtin_inff (); btr[q] = 0xFFFFFFFFu; }
+    // (m8: one bit per query of the wave that has the list; made opaque per trip so that the eight tests stay scalar bit
+    // tests inside the loop instead of eight hoisted lane masks)
+#define KS_WCAND(G, C, TRIP)                                                                                  \
+    asm volatile ("" : "+s"(m8));                                                                         \
+    _Pragma ("unroll") for (int q = 0; q < 8; ++q)                                                        \
+        if (m8 & (1u << q)) {                                                                             \
+            const float2v d1_ = float2v { sx[q], sr[q] } - float2v { (G).x, (G).y },                      \
+                          d2_ = float2v { sy[q], sg[q] } - float2v { (G).z, (G).w },                      \
+                          d3_ = float2v { sz[q], sb[q] } - float2v { (C).x, (C).y };                      \
+            const float2v gp_ = __builtin_elementwise_fma (d3_, d3_, __builtin_elementwise_fma (d2_, d2_, d1_ * d1_)); \
+            const float d_ = __builtin_fmaf (alpha, gp_.y, gp_.x);                                        \
+            if (d_ < bd[q]) { bd[q] = d_; btr[q] = (TRIP); }                                              \
+        }
+    while (todo) {
+        const int l0 = (int) __builtin_ctzll (todo);
+        const uint32_t rL = (uint32_t) __builtin_amdgcn_readlane ((int) rstar, l0);
+        const uint32_t oL = (uint32_t) __builtin_amdgcn_readlane ((int) o, l0), nL = (uint32_t) __builtin_amdgcn_readlane ((int) n, l0);
+        const unsigned long long match = __ballot (rstar == rL) & todo;      // same representative = same list
+        todo &= ~match;
+        uint32_t m8 = 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m8 |= (uint32_t) ((match >> (8 * q)) & 1ull) << q;
+        m8 = (uint32_t) __builtin_amdgcn_readfirstlane ((int) m8);
+        const uint32_t vlastL = (oL + nL - 1u) << 5, ntr = (nL + 63u) >> 6;
+        uint32_t voff = (oL + lane) << 5;
+        for (uint32_t t = 0; t < ntr; t += 2u, voff += 2u * 64u * 32u) {
+            const char *rec0 = XQb + min (voff, vlastL), *rec1 = XQb + min (voff + 64u * 32u, vlastL);
+            const float4 g0 = *reinterpret_cast<const float4 *> (rec0); const float2 c0 = *reinterpret_cast<const float2 *> (rec0 + 16);
+            const float4 g1 = *reinterpret_cast<const float4 *> (rec1); const float2 c1 = *reinterpret_cast<const float2 *> (rec1 + 16);
+            KS_WCAND (g0, c0, t)
+            if (t + 1u < ntr) { KS_WCAND (g1, c1, t + 1u) }
+        }
+    }
+#undef KS_WCAND
+    // the wave's winner per query: (distance bits, position) as one 64-bit key (distances are >= +0: the unsigned order of
+    // the bits is the order of the values), and a butterfly over the 64 lanes that halves the queries a lane holds while it
+    // doubles the lanes reduced — after three steps lane l holds query l & 7 over its group of 8 lanes, after six over the wave.
+    // (Measured against it and slower, 283 -> 292 us at C: the distances alone through the butterfly and the winner's
+    // position looked up with ballots / readlanes in scalars.)
+    unsigned long long key[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const uint32_t oq = (uint32_t) __builtin_amdgcn_readlane ((int) o, 8 * q), jeq = (uint32_t) __builtin_amdgcn_readlane ((int) je, 8 * q);
+        const uint32_t pos = (btr[q] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : min (oq + lane + 64u * btr[q], jeq - 1u);
+        key[q] = ((unsigned long long) __float_as_uint (bd[q]) << 32) | pos;
+    }
+    auto xchg_dpp = [] (unsigned long long v, auto ctrl) -> unsigned long long {
+        const uint32_t lo = (uint32_t) __builtin_amdgcn_update_dpp (0, (int) (uint32_t) v, decltype (ctrl)::value, 0xF, 0xF, true);
+        const uint32_t hi = (uint32_t) __builtin_amdgcn_update_dpp (0, (int) (uint32_t) (v >> 32), decltype (ctrl)::value, 0xF, 0xF, true);
+        return ((unsigned long long) hi << 32) | lo;
+    };
+    auto xchg_lane = [] (unsigned long long v, uint32_t src) -> unsigned long long {      // v of lane src
+        const uint32_t lo = (uint32_t) __builtin_amdgcn_ds_bpermute ((int) (src << 2), (int) (uint32_t) v);
+        const uint32_t hi = (uint32_t) __builtin_amdgcn_ds_bpermute ((int) (src << 2), (int) (uint32_t) (v >> 32));
+        return ((unsigned long long) hi << 32) | lo;
+    };
+    auto min64 = [] (unsigned long long a_, unsigned long long b_) { return a_ < b_ ? a_ : b_; };
+    unsigned long long k4[4], k2[2], k1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                // lane bit 0: keeps the queries 2j + (lane & 1)
+        const bool odd = (lane & 1u) != 0u;
+        const unsigned long long keep = odd ? key[2 * j + 1] : key[2 * j], send = odd ? key[2 * j] : key[2 * j + 1];
+        k4[j] = min64 (keep, xchg_dpp (send, std::integral_constant<int, 0xB1> {}));      // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                // lane bit 1
+        const bool odd = (lane & 2u) != 0u;
+        const unsigned long long keep = odd ? k4[2 * j + 1] : k4[2 * j], send = odd ? k4[2 * j] : k4[2 * j + 1];
+        k2[j] = min64 (keep, xchg_dpp (send, std::integral_constant<int, 0x4E> {}));      // quad_perm [2,3,0,1]
+    }
+    {                                            // lane bit 2
+        const bool odd = (lane & 4u) != 0u;
+        const unsigned long long keep = odd ? k2[1] : k2[0], send = odd ? k2[0] : k2[1];
+        k1 = min64 (keep, xchg_lane (send, lane ^ 4u));
+    }
+    k1 = min64 (k1, xchg_lane (k1, lane ^ 8u));  // over the wave's 8 groups of 8 lanes
+    k1 = min64 (k1, xchg_lane (k1, lane ^ 16u));
+    k1 = min64 (k1, xchg_lane (k1, lane ^ 32u));
+    k1 = xchg_lane (k1, (lane & 56u) | (lane >> 3));            // to the lanes of query lane >> 3
+    dmin = __uint_as_float ((uint32_t) (k1 >> 32)); jmin = (uint32_t) k1;
+}
+
+// ------------------------------------------------------------------------------------------
+// ks_stage2_lanes — stage 2, the lanes of a query scan its representative's list (latency variant: LPQ = 16; dense variant, short
+// lists: LPQ = 8): exhaustive over the first positions, behind chunk boxes beyond them (long lists: see inside).  dr = the query's
+// distance to the representative (the bound of the chunk tests); dmin / jmin as in ks_stage2_wave.
+// ------------------------------------------------------------------------------------------
+template <int LPQ>
+static __device__ __forceinline__ void ks_stage2_lanes (const char *XQb, uint32_t o, uint32_t n, bool valid, float qx, float qy, float qz, float qr, float qg, float qb,
+                                                        float alpha, float dr, uint32_t b, uint32_t lane, uint32_t ss, float &dmin, uint32_t &jmin)
+{
+    float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
+    const float2v vq_xr = { qx, qr }, vq_yg = { qy, qg }, vq_zb = { qz, qb };
+    {
+        // a batch = KS_DEPTH candidates per lane, all loads issued before the first distance (clamped addresses, the
+        // tail is masked): one memory round trip per batch, and one batch covers a list of KS_DEPTH * LPQ candidates.
+        // The number of trips the wave needs (its longest list) is a scalar: a trip no lane needs is neither loaded
+        // nor evaluated, at the cost of scalar compares only (the scan is bound by the vector-memory issue rate).
+        constexpr uint32_t KS_DEPTH = (KS_SPLIT == 16) ? ICP_S2_DEPTH16 : 4u;
+        const uint32_t je = valid ? o + n : o;       // (invalid queries: an empty range)
+        // the wave's trip count = its longest list: the lanes of a query hold the same count, so one mirror inside the 16-lane rows
+        // (two queries per row at 8 lanes per query) and the two row broadcasts of a wave reduction leave the maximum in lane 63
+        uint32_t nl = (je - o + KS_SPLIT - 1u) / KS_SPLIT;
+        if (KS_SPLIT == 8) nl = max (nl, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) nl, 0x140, 0xF, 0xF, true));        // row_mirror
+        nl = max (nl, (uint32_t) __builtin_amdgcn_update_dpp ((int) nl, (int) nl, 0x142, 0xA, 0xF, false));                   // row_bcast:15 -> rows 1, 3
+        nl = max (nl, (uint32_t) __builtin_amdgcn_update_dpp ((int) nl, (int) nl, 0x143, 0xC, 0xF, false));                   // row_bcast:31 -> rows 2, 3
+        const uint32_t ntrips = (uint32_t) __builtin_amdgcn_readlane ((int) nl, 63);
+        // byte offsets from the uniform base (m <= 2^20: < 2^25 bytes); a position past the list's end is clamped to its last
+        // element, whose (distance, position) some lane holds anyway — a duplicate changes neither the minimum nor the lowest
+        // position among equals, so there is no tail test.  The lane keeps the TRIP of its best candidate (a scalar + constant per
+        // candidate instead of a recomputed position); trips ascend, so a strict '<' keeps the lane's lowest position.
+        const uint32_t alast = (max (je, 1u) - 1u) << 5;
+        // Lists of up to 2 x ICP_S2_UNCOND positions are scanned as they come (a second batch costs less than the test in front of it:
+        // |F| = 16384 with a list of 135, 9.54 against 8.95 us per iteration); of longer lists the first ICP_S2_UNCOND positions, and what lies
+        // beyond chunk by chunk behind a box test (below).  (The wave's longest list decides: scalar control flow.)
+        constexpr uint32_t KS_UNC = ICP_S2_UNCOND / KS_SPLIT;      // (ICP_S2_UNCOND = 0, A/B builds: no chunk tests, every list scanned as it comes)
+        const uint32_t ntr0 = (ICP_S2_UNCOND == 0u || ntrips <= 2u * KS_UNC) ? ntrips : KS_UNC;
+        for (uint32_t tb = 0; tb < ntr0; tb += KS_DEPTH) {
+            const uint32_t a0 = (o + ss + tb * KS_SPLIT) << 5, nt = min (KS_DEPTH, ntr0 - tb);
+            float4 g[KS_DEPTH], c[KS_DEPTH];
+#pragma unroll
+            for (uint32_t t = 0; t < KS_DEPTH; ++t) {
+                if (t >= nt) break;
+                const char *rec = XQb + min (a0 + t * (KS_SPLIT * 32u), alast);
+                g[t] = *reinterpret_cast<const float4 *> (rec); c[t] = *reinterpret_cast<const float4 *> (rec + 16);
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < KS_DEPTH; ++t) {
+                if (t >= nt) break;
+                KS_CAND (g[t], c[t], tb + t);
+            }
+        }
+        if (__builtin_expect (ntrips > ntr0, 0)) {
+            // ---- long lists: exact pruning over chunks of 16 consecutive positions (boxes: k_list_boxes).  A query tests a chunk with the
+            // metric's own operations applied to the per-axis distances to the chunk's 6-D box — every operation is monotone under
+            // round-to-nearest, so bound <= d of every member (a > 0) — against `lim`: the distance to the representative itself, bumped one
+            // ulp (the representative is a member of its own list: a nearer-or-equal identical point with a lower index would have been
+            // the nearest representative instead; so the list's minimum is <= dr, and a chunk whose bound is above dr holds neither the
+            // minimum nor a tie with it), and the query's best so far (a chunk whose bound is not BELOW it cannot replace a candidate at a
+            // lower position: trips ascend, updates need a strict '<' — the tie rule of the serial scan).  Lane ss tests the chunks
+            // cb + ss, cb + ss + LPQ of a round; the answers of a query's lanes come back through a ballot; the chunks that pass are
+            // scanned in ascending order by all lanes of the query, two chunks per memory round trip.  The bits are those of the
+            // exhaustive scan; a list of identical points (invalid pixels with their colour zeroed) costs a box test per chunk behind
+            // its first 128 candidates instead of the candidates themselves.
+            constexpr uint32_t CPT = 16u / KS_SPLIT, BD = KS_SPLIT == 16 ? 2u : 1u;     // trips per chunk; boxes per lane and round (LPQ = 8: the 64-register variants have room for one)
+            const uint32_t nch = (je - o + 15u) >> 4, nchw = (ntrips + CPT - 1u) / CPT;     // chunks of this query's list / of the wave's longest
+            // (the boxes' base and stride are fetched from the kernel arguments HERE, through an opaque copy of the argument pointer — see the
+            // per-query output pointers of the epilogue: left to the compiler, their scalar loads join the ones at the top of the kernel, in
+            // front of the prologue's vector loads, for a path hardly any launch takes: 8.66 -> 8.71 us per iteration at |F| = 16384)
+            static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
+            unsigned long long lb_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
+            asm volatile ("" : "+s"(lb_));
+            const icp_params *pl = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) lb_;
+            typedef float4 __attribute__ ((address_space (1))) *gf4;
+            const float4 *LBq = (const float4 *) (gf4) pl->LB + (size_t) b * 3u * pl->nlb + 3u * (o >> 4);
+            const float inf_ = __builtin_inff ();
+            float lim = (alpha > 0.f && dr >= 0.f && dr < inf_) ? __uint_as_float (__float_as_uint (dr) + 1u) : inf_;
+            const bool bounds = alpha > 0.f;                            // (a <= 0: d >= bound does not hold; everything is scanned)
+            for (uint32_t cb = ICP_S2_UNCOND / 16u; cb < nchw; cb += BD * KS_SPLIT) {
+                lim = fminf (lim, ks_grp_min_f<KS_SPLIT> (best2));
+                float4 bx[BD][3];
+#pragma unroll
+                for (uint32_t j = 0; j < BD; ++j) {
+                    const uint32_t cc = min (cb + ss + KS_SPLIT * j, max (nch, 1u) - 1u);       // (clamped: inside the buffer; masked below)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) bx[j][k] = LBq[3u * cc + (uint32_t) k];
+                }
+                uint32_t cmask = 0u;
+#pragma unroll
+                for (uint32_t j = 0; j < BD; ++j) {
+                    const float4 b0 = bx[j][0], b1 = bx[j][1], b2 = bx[j][2];                   // [lo.x lo.y lo.z lo.r | lo.g lo.b hi.x hi.y | hi.z hi.r hi.g hi.b]
+                    const float ex = fmaxf (fmaxf (b0.x - qx, qx - b1.z), 0.f), ey = fmaxf (fmaxf (b0.y - qy, qy - b1.w), 0.f);
+                    const float ez = fmaxf (fmaxf (b0.z - qz, qz - b2.x), 0.f), er = fmaxf (fmaxf (b0.w - qr, qr - b2.y), 0.f);
+                    const float eg = fmaxf (fmaxf (b1.x - qg, qg - b2.z), 0.f), eb = fmaxf (fmaxf (b1.y - qb, qb - b2.w), 0.f);
+                    const float geo_ = __builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex)), pho_ = __builtin_fmaf (eb, eb, __builtin_fmaf (eg, eg, er * er));
+                    const bool pass = cb + ss + KS_SPLIT * j < nch && (!bounds || __builtin_fmaf (alpha, pho_, geo_) < lim);
+                    const unsigned long long bal = __ballot (pass);
+                    cmask |= ((uint32_t) (bal >> (lane & (64u - KS_SPLIT))) & ((1u << KS_SPLIT) - 1u)) << (KS_SPLIT * j);      // bit k: chunk cb + k of this query's list
+                }
+                while (__ballot (cmask != 0u)) {
+                    const bool live0 = cmask != 0u;
+                    const uint32_t k0 = live0 ? (uint32_t) __builtin_ctz (cmask) : 0u;
+                    cmask &= cmask - 1u;
+                    const bool live1 = cmask != 0u;
+                    const uint32_t k1 = live1 ? (uint32_t) __builtin_ctz (cmask) : k0;
+                    cmask &= cmask - 1u;
+                    const uint32_t t0 = (cb + k0) * CPT, t1 = (cb + k1) * CPT;
+                    float4 g[2 * CPT], c[2 * CPT];
+#pragma unroll
+                    for (uint32_t h = 0; h < CPT; ++h) {
+                        const char *r0 = XQb + min ((o + ss + (t0 + h) * KS_SPLIT) << 5, alast), *r1 = XQb + min ((o + ss + (t1 + h) * KS_SPLIT) << 5, alast);
+                        g[h] = *reinterpret_cast<const float4 *> (r0); c[h] = *reinterpret_cast<const float4 *> (r0 + 16);
+                        g[CPT + h] = *reinterpret_cast<const float4 *> (r1); c[CPT + h] = *reinterpret_cast<const float4 *> (r1 + 16);
+                    }
+#pragma unroll
+                    for (uint32_t h = 0; h < CPT; ++h) KS_CAND_IF (g[h], c[h], t0 + h, live0);
+#pragma unroll
+                    for (uint32_t h = 0; h < CPT; ++h) KS_CAND_IF (g[CPT + h], c[CPT + h], t1 + h, live1);
+                }
+            }
+        }
+        if (bj != 0xFFFFFFFFu) bj = min (o + ss + bj * KS_SPLIT, max (je, 1u) - 1u);     // trip -> list position
+        if (je == o) { best2 = __builtin_inff (); bj = 0xFFFFFFFFu; }      // empty list / invalid query: nothing above was a candidate
+    }
+    // the query's winner among its lanes: smallest distance, ties -> lowest list position; that lane finishes
+    // the query (lane ss == 0 when the list is empty or no candidate has a finite distance)
+    dmin = ks_grp_min_f<KS_SPLIT> (best2);
+    jmin = ks_grp_min_u<KS_SPLIT> (best2 == dmin ? bj : 0xFFFFFFFFu);
+}
+
+// ------------------------------------------------------------------------------------------
+// ks_epilogue — the per-query hand-off to the finishing wave, the winner's record, weights (a5), per-query outputs, the block's
+// moments (fused) or the first levels of the weight tree (reference order).  The LAST thing k_search does: every thread of the
+// block calls it (two block barriers inside), and its returns end the kernel.
+// ------------------------------------------------------------------------------------------
+template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER, bool PRUNE>
+static __device__ __forceinline__ void ks_epilogue (const icp_params &p, float4 *s_qa, uint4 *s_qb, double (*s_mom)[64], float *s_w, const float4 *R4, const char *XQb,
+                                                    uint32_t b, uint32_t m, uint32_t nr, uint32_t check_flags, uint32_t tid, uint32_t lane, uint32_t slice, uint32_t tile_id,
+                                                    uint32_t qe, uint32_t ss, uint32_t i, bool valid, uint32_t o, uint32_t n, uint32_t rstar, float dr, float dmin, uint32_t jmin,
+                                                    float qx, float qy, float qz)
+{
+    // Hand-off: lane 0 of every query leaves (q, distance, winner position, representative, flags) in LDS, and ONE wave
+    // finishes all 64 queries of the block with every lane active (lane e = query e): the winner's record, the weight,
+    // the per-query outputs and the 18 moment products are then issued once per block instead of once per wave for a
+    // handful of active lanes (an instruction costs the same whatever its lane count).
+    if (ss == 0u) {
+        const bool empty = (n == 0u);
+        s_qa[qe] = make_float4 (qx, qy, qz, empty ? dr : dmin);
+        s_qb[qe] = make_uint4 (empty ? rstar : ((jmin == 0xFFFFFFFFu) ? o : jmin), rstar, (valid ? 1u : 0u) | (empty ? 2u : 0u), i);
+    }
+    __syncthreads ();
+    if (slice == 0u) {
+        const float4 qa = s_qa[lane]; const uint4 qb = s_qb[lane];
+        const bool v = (qb.z & 1u) != 0u, empty = (qb.z & 2u) != 0u;
+        // the search ran on geo + a pho (a positive common factor changes neither the argmin nor the ties, and the pruning
+        // bound d >= geo stays as it is); the distance reported and fed to the weights carries the metric's absolute scale
+        const float ex = qa.x, ey = qa.y, ez = qa.z, d = p.dist_scale * qa.w;
+        const uint32_t ei = qb.w;
+        float w = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f;
+        if (v) {
+            uint32_t id;
+            if (empty) {             // empty list: fall back to the representative itself
+                const float4 nn = R4[2 * (size_t) qb.x];
+                // (dense variants: rep_src — needed for this rare case only — and the moments' base below are fetched where they are used: held
+                // from the top of the kernel they were the scalar registers the compiler spilled in front of the prologue's loads)
+                const uint32_t *rsrc = p.rep_src;
+                if constexpr (MINW == 4) {
+                    unsigned long long lr_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
+                    asm volatile ("" : "+s"(lr_));
+                    typedef uint32_t __attribute__ ((address_space (1))) *gu32;
+                    rsrc = (const uint32_t *) (gu32) ((const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) lr_)->rep_src;
+                }
+                id = rsrc[(size_t) b * nr + qb.x]; f0 = nn.x; f1 = nn.y; f2 = nn.z;
+            } else {                 // the winner's point, or, when every distance is inf / NaN, the first list element as
+                                     // the serial scan would: one reload instead of tracking it per candidate
+                const char *rec = XQb + (qb.x << 5);
+                const float4 wg = *reinterpret_cast<const float4 *> (rec), wc = *reinterpret_cast<const float4 *> (rec + 16);
+                f0 = wg.x; f1 = wg.z; f2 = wc.x; id = __float_as_uint (wc.z);
+            }
+            w = p.weighted ? 100.f / (100.f + d) : 1.f;                // icp_kernels.cl:232
+            // per-query outputs: uniform bases + 32-bit byte offsets (i < 2^20)
+            icp_dist_id di; di.dist = d; di.id = id;
+            // One-block-per-CU variants: the four output pointers are fetched from the kernel arguments HERE — an opaque copy of the
+            // argument pointer keeps the compiler from hoisting their scalar loads to the top of the kernel with all the others, where
+            // eight more live SGPRs make it spill freshly loaded arguments to VGPR lanes, i.e. wait for the argument block in front of
+            // the prologue's first vector loads (the chained kernel of a host-driven run: 9.29 -> 8.97 us per iteration); a run that
+            // stores no per-query outputs on the way never loads them at all.
+            const icp_params *pe = &p;
+            if constexpr (MINW == 2 && !OWNER) {
+                // (the kernel's explicit arguments: four pointers, six dwords, then icp_params — no padding in between; a change of the
+                // signature has to move this offset with it: every test that reads per-query outputs at a latency-bound size would show it)
+                static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
+                unsigned long long la_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
+                asm volatile ("" : "+s"(la_));
+                pe = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) la_;
+            }
+            typedef char __attribute__ ((address_space (1))) *gchar;           // (pointers read through `pe` are generic to the compiler: say that they are global)
+            char *o_nn = (char *) (gchar) reinterpret_cast<char *> (pe->nn_id + (size_t) b * m), *o_pf = (char *) (gchar) reinterpret_cast<char *> (pe->PF + (size_t) b * m);
+            char *o_pm = (char *) (gchar) reinterpret_cast<char *> (pe->PM + (size_t) b * m), *o_rid = (char *) (gchar) reinterpret_cast<char *> (pe->rid + (size_t) b * m);
+            // (fused mode consumes none of these itself: inside a graph of a fixed length only the last iteration
+            // stores them — except the nearest representative where the next search seeds its pruning with it)
+            const bool emit = !FUSED || (check_flags & 8u);
+            if (emit) {
+                *reinterpret_cast<icp_dist_id *> (o_nn + (ei << 3)) = di;
+                *reinterpret_cast<float4 *> (o_pf + (ei << 4)) = make_float4 (f0, f1, f2, w);
+                *reinterpret_cast<float4 *> (o_pm + (ei << 4)) = make_float4 (ex, ey, ez, d);
+            }
+            if (emit || PRUNE) *reinterpret_cast<uint32_t *> (o_rid + (ei << 2)) = qb.y;
+        }
+        if constexpr (FUSED) {
+            // the 18 moments of this pair in double (oracle orc_moments_fused); invalid queries contribute 0
+            double W = (double) w;
+            double g0 = v ? (double) f0 : 0.0, g1 = v ? (double) f1 : 0.0, g2 = v ? (double) f2 : 0.0;
+            double q0 = (double) ex, q1 = (double) ey, q2 = (double) ez;
+            if (!v) { W = 0.0; q0 = q1 = q2 = 0.0; }
+            double wq0 = W * q0, wq1 = W * q1, wq2 = W * q2;
+            s_mom[0][lane] = W;
+            s_mom[1][lane] = W * g0; s_mom[2][lane] = W * g1; s_mom[3][lane] = W * g2;
+            s_mom[4][lane] = wq0; s_mom[5][lane] = wq1; s_mom[6][lane] = wq2;
+            s_mom[7][lane] = wq0 * g0; s_mom[8][lane] = wq0 * g1; s_mom[9][lane] = wq0 * g2;
+            s_mom[10][lane] = wq1 * g0; s_mom[11][lane] = wq1 * g1; s_mom[12][lane] = wq1 * g2;
+            s_mom[13][lane] = wq2 * g0; s_mom[14][lane] = wq2 * g1; s_mom[15][lane] = wq2 * g2;
+            s_mom[16][lane] = W * ((g0 * g0 + g1 * g1) + g2 * g2);
+            s_mom[17][lane] = W * ((q0 * q0 + q1 * q1) + q2 * q2);
+        } else
+            s_w[lane] = w;
+    }
+    KS_STAMP (6)
+    __syncthreads ();
+    if constexpr (FUSED) {
+        // halving tree over the block's 64 pairs, one 16-lane row per moment (rows 0..17 of the 32 rows)
+        if (slice * 4u >= (uint32_t) ICP_NMOM) return;                     // (waves without a row: done)
+        const uint32_t l = lane & 15u, mrow = slice * 4u + (lane >> 4);     // first 18 of the block's 4*KS_SPLIT rows
+        const uint32_t k = min (mrow, (uint32_t) ICP_NMOM - 1u);
+        double c0 = s_mom[k][l] + s_mom[k][l + 32], c1 = s_mom[k][l + 16] + s_mom[k][l + 48];
+        double v = row_tree_tail_d (c0 + c1);
+        const uint32_t obuf = CHAIN ? (p.slot ^ 1u) : 0u;
+        double *momw = p.mom;
+        if constexpr (MINW == 4) {
+            unsigned long long lm_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
+            asm volatile ("" : "+s"(lm_));
+            typedef double __attribute__ ((address_space (1))) *gf64;
+            momw = (double *) (gf64) ((const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) lm_)->mom;
+        }
+        if (l == 0 && mrow < ICP_NMOM) momw[(((size_t) b * 2 + obuf) * ICP_NMOM + mrow) * p.nb + tile_id] = v;
+    } else if (slice == 0 && p.weighted) {
+        // tree levels d = 64 .. 2 restricted to this block's parity class (icp_kernels.cl:244-249):
+        // element e of the class is position 2e + parity; levels pair e with e+32, e+16, .., e+1.
+        const uint32_t l = lane & 15u;
+        float a[4] = { s_w[l], s_w[l + 16], s_w[l + 32], s_w[l + 48] };
+        float v = row_tree4 (a);
+        if (lane == 0) p.wpart[(size_t) b * 2 * p.nwp + blockIdx.x] = v;
+    }
+    KS_STAMP (7)
+}
+
+// ------------------------------------------------------------------------------------------
+// ks_owner_lists_tail — RBC construct of the latency-bound sizes (the owner search with per-block lists, see k_place_lists): what
+// the block leaves behind stage 1.  Every thread of the block calls it; it ends the kernel.
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void ks_owner_lists_tail (const icp_params &p, uint4 *s_qb, uint32_t b, uint32_t m, uint32_t nb, uint32_t lane, uint32_t slice, uint32_t qe,
+                                                            uint32_t ss, bool valid, uint32_t rstar)
+{
+    // the block's 64 owners meet in LDS; wave 0 (lane e = point 64 blockIdx.x + e) stores them in one coalesced row, ranks every
+    // point among the earlier points of the block with the same owner (one ballot per distinct owner: neighbours share a
+    // handful) and leaves the block's (owner, count) list: k_place_lists needs nothing else to place the points
+    if (ss == 0u) s_qb[qe] = make_uint4 (rstar, valid ? 1u : 0u, 0u, 0u);
+    __syncthreads ();
+    if (slice != 0u) return;
+    const uint4 e4 = s_qb[lane];
+    const bool v = e4.y != 0u;
+    const uint32_t own = v ? e4.x : 0xFFFFFFFFu, ip = blockIdx.x * 64u + lane;
+    uint32_t rank = 0u, kk = 0u;
+    uint2 *bl = p.blist + ((size_t) b * nb + blockIdx.x) * 64u;
+    for (unsigned long long rem = __ballot (v); rem; ++kk) {
+        const uint32_t o = (uint32_t) __builtin_amdgcn_readlane ((int) own, (int) __builtin_ctzll (rem));
+        const unsigned long long same = __ballot (own == o);     // (an owner is < nr: never the marker of an invalid lane)
+        if (own == o) rank = (uint32_t) __builtin_popcountll (same & ((1ull << lane) - 1ull));
+        if (lane == 0) bl[kk] = make_uint2 (o, (uint32_t) __builtin_popcountll (same));
+        rem &= ~same;
+    }
+    if (lane == 0) p.bn[(size_t) b * nb + blockIdx.x] = kk;
+    if (v) { p.owner[(size_t) b * m + ip] = own; p.brank[(size_t) b * m + ip] = (uint8_t) rank; }
+    return;
+}
+
 // CHAIN (fused mode only): launch j reads state slot j&1 and the moments buffer j&1, turns the previous
 // iteration's moments into T in its prologue (every block redundantly; block 0 publishes the result in the
 // other slot), searches, and leaves its own moments in the other buffer: ONE launch per ICP iteration.
@@ -476,6 +890,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // check_flags: bit 0 = convergence checks on; bit 1 (CHAIN) = first launch of a chain: gst is the user-visible
     // state array (stride 1) instead of a pair of slots; bit 3 = store the matched / transformed points too (fused
     // mode needs them only after the last iteration of a graph; the reference-order kernels read them every time).
+    // ==================================================== PROLOGUE ====================================================
     constexpr uint32_t KT = (uint32_t) TILE;
     // MASKED (dense variant, several small tiles): the set of tiles a block needs is decided ONCE, before anything is staged —
     // every query tests the boxes of all tiles against its seed bound, the block ORs the answers — and only those tiles
@@ -606,8 +1021,16 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         if (!OWNER && MASKED && u == 0 && tid < tnH) ron[0] = make_uint2 (gO[ht * KT + tid], gN[ht * KT + tid]);
     }
     // (dense variants: the number of representatives at the origin — a frame's invalid points: ks_origin_list — travels with the prologue's loads)
+    // (a SCALAR load — the address is block-uniform, the word was written by an earlier launch (k_reps_and_boxes): through the constant address
+    // space the compiler emits s_load_dword; as a vector load + readfirstlane it cost 0.8 % at |F| = 16384 x 64 and 0.4 % at |F| = 65536)
+    // The number lives in a spare lane of the box array (hi.w of the first tile box: k_reps_and_boxes), i.e. behind a pointer the prologue holds
+    // anyway: the list's own pointer is fetched where the list is scanned — one more pointer held from the top of the kernel made the compiler spill
+    // scalar registers to vector lanes THERE, each spill behind a wait for the argument loads (|F| = 65536: search 11.88 -> 12.22 us).
     uint32_t n_origin = 0u;
-    if constexpr (ICP_S1_SEED && MINW == 4) n_origin = reinterpret_cast<const uint32_t *> (p.OL + (size_t) b * (nr + 1u))[0];
+    if constexpr (ICP_S1_SEED && ICP_S1_ORIGIN_LIST && MINW == 4) {
+        typedef const uint32_t __attribute__ ((address_space (4))) *cu32;
+        n_origin = ((cu32) (unsigned long long) (p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + 1u))[3];
+    }
     // (HOSTRUN: the flag is read HERE, behind the prologue's vector loads — a scalar load of the flag's address, a second one of the flag and a
     // wait for both: in front of them it would hold every load of the prologue back by two scalar round trips)
     if constexpr (CHAIN && HOSTRUN) { if (p.run_flag) run_over = (p.run_flag[b] == p.epoch) ? 1u : 0u; }
@@ -730,6 +1153,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     const float alpha = p.a;
     KS_STAMP (0)
 
+    // ==================================================== STAGE 1 =====================================================
     // ---- stage 1: nearest representative, two representatives per packed instruction ----
     float best = __builtin_inff (), s1_lim = __builtin_inff (); uint32_t bid = 0xFFFFFFFFu;
     // coarse pass of the pruning over the groups of the tile in LDS (s_box): bit t of the result = this lane's t-th
@@ -982,9 +1406,16 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             }
         }
     }
-    if constexpr (PRUNE) {
+    if constexpr (PRUNE && ICP_S1_ORIGIN_LIST) {
         // the representatives at the origin (invalid points): kept out of the boxes above, scanned here by the queries that are near the origin
-        if (prune) ks_origin_list<KS_SPLIT> (p.OL + (size_t) b * (nr + 1u), (uint32_t) __builtin_amdgcn_readfirstlane ((int) n_origin), qx, qy, qz, qr, qg, qb, alpha, s1_lim, ss, best, bid);
+        if (prune && __builtin_expect (n_origin != 0u, 0)) {
+            static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
+            unsigned long long ol_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
+            asm volatile ("" : "+s"(ol_));
+            const icp_params *po = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) ol_;
+            typedef float4 __attribute__ ((address_space (1))) *gf4;
+            ks_origin_list<KS_SPLIT> ((const float4 *) (gf4) po->OL + (size_t) b * (nr + 1u), n_origin, qx, qy, qz, qr, qg, qb, alpha, s1_lim, ss, best, bid);
+        }
     }
     KS_KEEP (best, bid)
     KS_STAMP (2)
@@ -992,26 +1423,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     uint32_t rstar = ks_grp_min_u<KS_SPLIT> (best == dr ? bid : 0xFFFFFFFFu);     // ties -> lowest index
     if (rstar == 0xFFFFFFFFu) rstar = 0u;            // every distance inf / NaN: representative 0, as the serial scan would
     if constexpr (OWNER_LISTS) {
-        // the block's 64 owners meet in LDS; wave 0 (lane e = point 64 blockIdx.x + e) stores them in one coalesced row, ranks every
-        // point among the earlier points of the block with the same owner (one ballot per distinct owner: neighbours share a
-        // handful) and leaves the block's (owner, count) list: k_place_lists needs nothing else to place the points
-        if (ss == 0u) s_qb[qe] = make_uint4 (rstar, valid ? 1u : 0u, 0u, 0u);
-        __syncthreads ();
-        if (slice != 0u) return;
-        const uint4 e4 = s_qb[lane];
-        const bool v = e4.y != 0u;
-        const uint32_t own = v ? e4.x : 0xFFFFFFFFu, ip = blockIdx.x * 64u + lane;
-        uint32_t rank = 0u, kk = 0u;
-        uint2 *bl = p.blist + ((size_t) b * nb + blockIdx.x) * 64u;
-        for (unsigned long long rem = __ballot (v); rem; ++kk) {
-            const uint32_t o = (uint32_t) __builtin_amdgcn_readlane ((int) own, (int) __builtin_ctzll (rem));
-            const unsigned long long same = __ballot (own == o);     // (an owner is < nr: never the marker of an invalid lane)
-            if (own == o) rank = (uint32_t) __builtin_popcountll (same & ((1ull << lane) - 1ull));
-            if (lane == 0) bl[kk] = make_uint2 (o, (uint32_t) __builtin_popcountll (same));
-            rem &= ~same;
-        }
-        if (lane == 0) p.bn[(size_t) b * nb + blockIdx.x] = kk;
-        if (v) { p.owner[(size_t) b * m + ip] = own; p.brank[(size_t) b * m + ip] = (uint8_t) rank; }
+        ks_owner_lists_tail (p, s_qb, b, m, nb, lane, slice, qe, ss, valid, rstar);
         return;
     } else if constexpr (OWNER) {
         if (ss == 0u && valid) p.owner[(size_t) b * m + i] = rstar;
@@ -1032,334 +1444,19 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     else if (nr <= KT) { const uint2 on = s_on[rstar]; o = on.x; n = on.y; asm volatile ("" : "+v"(o), "+v"(n)); }
     else { o = gO[rstar]; n = gN[rstar]; }
 
-    // ---- stage 2: exhaustive scan of that representative's list: the LPQ lanes of a query read LPQ consecutive
-    // candidates (32 contiguous bytes each) per load.  (Staging the block's lists through LDS first was measured and is
-    // slower: enumerating the distinct lists and the extra barrier cost more than the direct gathers.)
+    // ==================================================== STAGE 2 =====================================================
+    // ---- stage 2: the list of that representative (ks_stage2_lanes / ks_stage2_wave)
     float dmin; uint32_t jmin;
     if constexpr (S2W) {
         static_assert (MINW == 4 && LPQ == 8 && !OWNER, "lanes = candidates: the dense search variants");
-        // ---- stage 2, long lists (dense variant, icp_s2_wave): lanes = candidates.  The scan above is bound by the vector-memory
-        // path (every query's lanes load their list for themselves: 24 bytes per candidate and query through the L1); the
-        // wave's 8 queries are neighbours and mostly share ONE list, so here the wave loads a list once — lane l takes the
-        // positions l, l + 64, .. — and every lane evaluates its candidate against each query of the wave that has this list,
-        // the query's six coordinates in SGPRs.  Distinct lists of the wave are served one after the other.  Per lane and
-        // query: best (distance, trip); at the end one butterfly over the 64 lanes that halves the number of queries a lane
-        // holds while it doubles the lanes reduced ((distance bits, position) as one 64-bit key: distances are >= +0, so
-        // the unsigned order of the bits is the order of the values; smallest distance, ties -> lowest position).
-        const uint32_t je = valid ? o + n : o;
-        unsigned long long todo = __ballot (je != o);                // lanes of the queries with a list to scan
-        float sx[8], sy[8], sz[8], sr[8], sg[8], sb[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            sx[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qx), 8 * q));
-            sy[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qy), 8 * q));
-            sz[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qz), 8 * q));
-            sr[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qr), 8 * q));
-            sg[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qg), 8 * q));
-            sb[q] = __uint_as_float ((uint32_t) __builtin_amdgcn_readlane ((int) __float_as_uint (qb), 8 * q));
-        }
-        float bd[8]; uint32_t btr[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { bd[q] = __builtin_inff (); btr[q] = 0xFFFFFFFFu; }
-        // (m8: one bit per query of the wave that has the list; made opaque per trip so that the eight tests stay scalar bit
-        // tests inside the loop instead of eight hoisted lane masks)
-#define KS_WCAND(G, C, TRIP)                                                                                  \
-        asm volatile ("" : "+s"(m8));                                                                         \
-        _Pragma ("unroll") for (int q = 0; q < 8; ++q)                                                        \
-            if (m8 & (1u << q)) {                                                                             \
-                const float2v d1_ = float2v { sx[q], sr[q] } - float2v { (G).x, (G).y },                      \
-                              d2_ = float2v { sy[q], sg[q] } - float2v { (G).z, (G).w },                      \
-                              d3_ = float2v { sz[q], sb[q] } - float2v { (C).x, (C).y };                      \
-                const float2v gp_ = __builtin_elementwise_fma (d3_, d3_, __builtin_elementwise_fma (d2_, d2_, d1_ * d1_)); \
-                const float d_ = __builtin_fmaf (alpha, gp_.y, gp_.x);                                        \
-                if (d_ < bd[q]) { bd[q] = d_; btr[q] = (TRIP); }                                              \
-            }
-        while (todo) {
-            const int l0 = (int) __builtin_ctzll (todo);
-            const uint32_t rL = (uint32_t) __builtin_amdgcn_readlane ((int) rstar, l0);
-            const uint32_t oL = (uint32_t) __builtin_amdgcn_readlane ((int) o, l0), nL = (uint32_t) __builtin_amdgcn_readlane ((int) n, l0);
-            const unsigned long long match = __ballot (rstar == rL) & todo;      // same representative = same list
-            todo &= ~match;
-            uint32_t m8 = 0u;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) m8 |= (uint32_t) ((match >> (8 * q)) & 1ull) << q;
-            m8 = (uint32_t) __builtin_amdgcn_readfirstlane ((int) m8);
-            const uint32_t vlastL = (oL + nL - 1u) << 5, ntr = (nL + 63u) >> 6;
-            uint32_t voff = (oL + lane) << 5;
-            for (uint32_t t = 0; t < ntr; t += 2u, voff += 2u * 64u * 32u) {
-                const char *rec0 = XQb + min (voff, vlastL), *rec1 = XQb + min (voff + 64u * 32u, vlastL);
-                const float4 g0 = *reinterpret_cast<const float4 *> (rec0); const float2 c0 = *reinterpret_cast<const float2 *> (rec0 + 16);
-                const float4 g1 = *reinterpret_cast<const float4 *> (rec1); const float2 c1 = *reinterpret_cast<const float2 *> (rec1 + 16);
-                KS_WCAND (g0, c0, t)
-                if (t + 1u < ntr) { KS_WCAND (g1, c1, t + 1u) }
-            }
-        }
-#undef KS_WCAND
-        // the wave's winner per query: (distance bits, position) as one 64-bit key (distances are >= +0: the unsigned order of
-        // the bits is the order of the values), and a butterfly over the 64 lanes that halves the queries a lane holds while it
-        // doubles the lanes reduced — after three steps lane l holds query l & 7 over its group of 8 lanes, after six over the wave.
-        // (Measured against it and slower, 283 -> 292 us at C: the distances alone through the butterfly and the winner's
-        // position looked up with ballots / readlanes in scalars.)
-        unsigned long long key[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t oq = (uint32_t) __builtin_amdgcn_readlane ((int) o, 8 * q), jeq = (uint32_t) __builtin_amdgcn_readlane ((int) je, 8 * q);
-            const uint32_t pos = (btr[q] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : min (oq + lane + 64u * btr[q], jeq - 1u);
-            key[q] = ((unsigned long long) __float_as_uint (bd[q]) << 32) | pos;
-        }
-        auto xchg_dpp = [] (unsigned long long v, auto ctrl) -> unsigned long long {
-            const uint32_t lo = (uint32_t) __builtin_amdgcn_update_dpp (0, (int) (uint32_t) v, decltype (ctrl)::value, 0xF, 0xF, true);
-            const uint32_t hi = (uint32_t) __builtin_amdgcn_update_dpp (0, (int) (uint32_t) (v >> 32), decltype (ctrl)::value, 0xF, 0xF, true);
-            return ((unsigned long long) hi << 32) | lo;
-        };
-        auto xchg_lane = [] (unsigned long long v, uint32_t src) -> unsigned long long {      // v of lane src
-            const uint32_t lo = (uint32_t) __builtin_amdgcn_ds_bpermute ((int) (src << 2), (int) (uint32_t) v);
-            const uint32_t hi = (uint32_t) __builtin_amdgcn_ds_bpermute ((int) (src << 2), (int) (uint32_t) (v >> 32));
-            return ((unsigned long long) hi << 32) | lo;
-        };
-        auto min64 = [] (unsigned long long a_, unsigned long long b_) { return a_ < b_ ? a_ : b_; };
-        unsigned long long k4[4], k2[2], k1;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                // lane bit 0: keeps the queries 2j + (lane & 1)
-            const bool odd = (lane & 1u) != 0u;
-            const unsigned long long keep = odd ? key[2 * j + 1] : key[2 * j], send = odd ? key[2 * j] : key[2 * j + 1];
-            k4[j] = min64 (keep, xchg_dpp (send, std::integral_constant<int, 0xB1> {}));      // quad_perm [1,0,3,2]
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {                // lane bit 1
-            const bool odd = (lane & 2u) != 0u;
-            const unsigned long long keep = odd ? k4[2 * j + 1] : k4[2 * j], send = odd ? k4[2 * j] : k4[2 * j + 1];
-            k2[j] = min64 (keep, xchg_dpp (send, std::integral_constant<int, 0x4E> {}));      // quad_perm [2,3,0,1]
-        }
-        {                                            // lane bit 2
-            const bool odd = (lane & 4u) != 0u;
-            const unsigned long long keep = odd ? k2[1] : k2[0], send = odd ? k2[0] : k2[1];
-            k1 = min64 (keep, xchg_lane (send, lane ^ 4u));
-        }
-        k1 = min64 (k1, xchg_lane (k1, lane ^ 8u));  // over the wave's 8 groups of 8 lanes
-        k1 = min64 (k1, xchg_lane (k1, lane ^ 16u));
-        k1 = min64 (k1, xchg_lane (k1, lane ^ 32u));
-        k1 = xchg_lane (k1, (lane & 56u) | (lane >> 3));            // to the lanes of query lane >> 3
-        dmin = __uint_as_float ((uint32_t) (k1 >> 32)); jmin = (uint32_t) k1;
-    } else {
-    float best2 = __builtin_inff (); uint32_t bj = 0xFFFFFFFFu;
-    const float2v vq_xr = { qx, qr }, vq_yg = { qy, qg }, vq_zb = { qz, qb };
-    {
-        // a batch = KS_DEPTH candidates per lane, all loads issued before the first distance (clamped addresses, the
-        // tail is masked): one memory round trip per batch, and one batch covers a list of KS_DEPTH * LPQ candidates.
-        // The number of trips the wave needs (its longest list) is a scalar: a trip no lane needs is neither loaded
-        // nor evaluated, at the cost of scalar compares only (the scan is bound by the vector-memory issue rate).
-        constexpr uint32_t KS_DEPTH = (KS_SPLIT == 16) ? ICP_S2_DEPTH16 : 4u;
-        const uint32_t je = valid ? o + n : o;       // (invalid queries: an empty range)
-        // the wave's trip count = its longest list: the lanes of a query hold the same count, so one mirror inside the 16-lane rows
-        // (two queries per row at 8 lanes per query) and the two row broadcasts of a wave reduction leave the maximum in lane 63
-        uint32_t nl = (je - o + KS_SPLIT - 1u) / KS_SPLIT;
-        if (KS_SPLIT == 8) nl = max (nl, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) nl, 0x140, 0xF, 0xF, true));        // row_mirror
-        nl = max (nl, (uint32_t) __builtin_amdgcn_update_dpp ((int) nl, (int) nl, 0x142, 0xA, 0xF, false));                   // row_bcast:15 -> rows 1, 3
-        nl = max (nl, (uint32_t) __builtin_amdgcn_update_dpp ((int) nl, (int) nl, 0x143, 0xC, 0xF, false));                   // row_bcast:31 -> rows 2, 3
-        const uint32_t ntrips = (uint32_t) __builtin_amdgcn_readlane ((int) nl, 63);
-        // byte offsets from the uniform base (m <= 2^20: < 2^25 bytes); a position past the list's end is clamped to its last
-        // element, whose (distance, position) some lane holds anyway — a duplicate changes neither the minimum nor the lowest
-        // position among equals, so there is no tail test.  The lane keeps the TRIP of its best candidate (a scalar + constant per
-        // candidate instead of a recomputed position); trips ascend, so a strict '<' keeps the lane's lowest position.
-        const uint32_t alast = (max (je, 1u) - 1u) << 5;
-        // Lists of up to 2 x ICP_S2_UNCOND positions are scanned as they come (a second batch costs less than the test in front of it:
-        // |F| = 16384 with a list of 135, 9.54 against 8.95 us per iteration); of longer lists the first ICP_S2_UNCOND positions, and what lies
-        // beyond chunk by chunk behind a box test (below).  (The wave's longest list decides: scalar control flow.)
-        constexpr uint32_t KS_UNC = ICP_S2_UNCOND / KS_SPLIT;      // (ICP_S2_UNCOND = 0, A/B builds: no chunk tests, every list scanned as it comes)
-        const uint32_t ntr0 = (ICP_S2_UNCOND == 0u || ntrips <= 2u * KS_UNC) ? ntrips : KS_UNC;
-        for (uint32_t tb = 0; tb < ntr0; tb += KS_DEPTH) {
-            const uint32_t a0 = (o + ss + tb * KS_SPLIT) << 5, nt = min (KS_DEPTH, ntr0 - tb);
-            float4 g[KS_DEPTH], c[KS_DEPTH];
-#pragma unroll
-            for (uint32_t t = 0; t < KS_DEPTH; ++t) {
-                if (t >= nt) break;
-                const char *rec = XQb + min (a0 + t * (KS_SPLIT * 32u), alast);
-                g[t] = *reinterpret_cast<const float4 *> (rec); c[t] = *reinterpret_cast<const float4 *> (rec + 16);
-            }
-#pragma unroll
-            for (uint32_t t = 0; t < KS_DEPTH; ++t) {
-                if (t >= nt) break;
-                KS_CAND (g[t], c[t], tb + t);
-            }
-        }
-        if (ntrips > ntr0) {
-            // ---- long lists: exact pruning over chunks of 16 consecutive positions (boxes: k_list_boxes).  A query tests a chunk with the
-            // metric's own operations applied to the per-axis distances to the chunk's 6-D box — every operation is monotone under
-            // round-to-nearest, so bound <= d of every member (a > 0) — against `lim`: the distance to the representative itself, bumped one
-            // ulp (the representative is a member of its own list: a nearer-or-equal identical point with a lower index would have been
-            // the nearest representative instead; so the list's minimum is <= dr, and a chunk whose bound is above dr holds neither the
-            // minimum nor a tie with it), and the query's best so far (a chunk whose bound is not BELOW it cannot replace a candidate at a
-            // lower position: trips ascend, updates need a strict '<' — the tie rule of the serial scan).  Lane ss tests the chunks
-            // cb + ss, cb + ss + LPQ of a round; the answers of a query's lanes come back through a ballot; the chunks that pass are
-            // scanned in ascending order by all lanes of the query, two chunks per memory round trip.  The bits are those of the
-            // exhaustive scan; a list of identical points (invalid pixels with their colour zeroed) costs a box test per chunk behind
-            // its first 128 candidates instead of the candidates themselves.
-            constexpr uint32_t CPT = 16u / KS_SPLIT, BD = 2u;          // trips per chunk; boxes per lane and round
-            const uint32_t nch = (je - o + 15u) >> 4, nchw = (ntrips + CPT - 1u) / CPT;     // chunks of this query's list / of the wave's longest
-            // (the boxes' base and stride are fetched from the kernel arguments HERE, through an opaque copy of the argument pointer — see the
-            // per-query output pointers of the epilogue: left to the compiler, their scalar loads join the ones at the top of the kernel, in
-            // front of the prologue's vector loads, for a path hardly any launch takes: 8.66 -> 8.71 us per iteration at |F| = 16384)
-            static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
-            unsigned long long lb_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
-            asm volatile ("" : "+s"(lb_));
-            const icp_params *pl = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) lb_;
-            typedef float4 __attribute__ ((address_space (1))) *gf4;
-            const float4 *LBq = (const float4 *) (gf4) pl->LB + (size_t) b * 3u * pl->nlb + 3u * (o >> 4);
-            const float inf_ = __builtin_inff ();
-            float lim = (alpha > 0.f && dr >= 0.f && dr < inf_) ? __uint_as_float (__float_as_uint (dr) + 1u) : inf_;
-            const bool bounds = alpha > 0.f;                            // (a <= 0: d >= bound does not hold; everything is scanned)
-            for (uint32_t cb = ICP_S2_UNCOND / 16u; cb < nchw; cb += BD * KS_SPLIT) {
-                lim = fminf (lim, ks_grp_min_f<KS_SPLIT> (best2));
-                float4 bx[BD][3];
-#pragma unroll
-                for (uint32_t j = 0; j < BD; ++j) {
-                    const uint32_t cc = min (cb + ss + KS_SPLIT * j, max (nch, 1u) - 1u);       // (clamped: inside the buffer; masked below)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) bx[j][k] = LBq[3u * cc + (uint32_t) k];
-                }
-                uint32_t cmask = 0u;
-#pragma unroll
-                for (uint32_t j = 0; j < BD; ++j) {
-                    const float4 b0 = bx[j][0], b1 = bx[j][1], b2 = bx[j][2];                   // [lo.x lo.y lo.z lo.r | lo.g lo.b hi.x hi.y | hi.z hi.r hi.g hi.b]
-                    const float ex = fmaxf (fmaxf (b0.x - qx, qx - b1.z), 0.f), ey = fmaxf (fmaxf (b0.y - qy, qy - b1.w), 0.f);
-                    const float ez = fmaxf (fmaxf (b0.z - qz, qz - b2.x), 0.f), er = fmaxf (fmaxf (b0.w - qr, qr - b2.y), 0.f);
-                    const float eg = fmaxf (fmaxf (b1.x - qg, qg - b2.z), 0.f), eb = fmaxf (fmaxf (b1.y - qb, qb - b2.w), 0.f);
-                    const float geo_ = __builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex)), pho_ = __builtin_fmaf (eb, eb, __builtin_fmaf (eg, eg, er * er));
-                    const bool pass = cb + ss + KS_SPLIT * j < nch && (!bounds || __builtin_fmaf (alpha, pho_, geo_) < lim);
-                    const unsigned long long bal = __ballot (pass);
-                    cmask |= ((uint32_t) (bal >> (lane & (64u - KS_SPLIT))) & ((1u << KS_SPLIT) - 1u)) << (KS_SPLIT * j);      // bit k: chunk cb + k of this query's list
-                }
-                while (__ballot (cmask != 0u)) {
-                    const bool live0 = cmask != 0u;
-                    const uint32_t k0 = live0 ? (uint32_t) __builtin_ctz (cmask) : 0u;
-                    cmask &= cmask - 1u;
-                    const bool live1 = cmask != 0u;
-                    const uint32_t k1 = live1 ? (uint32_t) __builtin_ctz (cmask) : k0;
-                    cmask &= cmask - 1u;
-                    const uint32_t t0 = (cb + k0) * CPT, t1 = (cb + k1) * CPT;
-                    float4 g[2 * CPT], c[2 * CPT];
-#pragma unroll
-                    for (uint32_t h = 0; h < CPT; ++h) {
-                        const char *r0 = XQb + min ((o + ss + (t0 + h) * KS_SPLIT) << 5, alast), *r1 = XQb + min ((o + ss + (t1 + h) * KS_SPLIT) << 5, alast);
-                        g[h] = *reinterpret_cast<const float4 *> (r0); c[h] = *reinterpret_cast<const float4 *> (r0 + 16);
-                        g[CPT + h] = *reinterpret_cast<const float4 *> (r1); c[CPT + h] = *reinterpret_cast<const float4 *> (r1 + 16);
-                    }
-#pragma unroll
-                    for (uint32_t h = 0; h < CPT; ++h) KS_CAND_IF (g[h], c[h], t0 + h, live0);
-#pragma unroll
-                    for (uint32_t h = 0; h < CPT; ++h) KS_CAND_IF (g[CPT + h], c[CPT + h], t1 + h, live1);
-                }
-            }
-        }
-        if (bj != 0xFFFFFFFFu) bj = min (o + ss + bj * KS_SPLIT, max (je, 1u) - 1u);     // trip -> list position
-        if (je == o) { best2 = __builtin_inff (); bj = 0xFFFFFFFFu; }      // empty list / invalid query: nothing above was a candidate
-    }
-    KS_STAMP (4)
-    // the query's winner among its lanes: smallest distance, ties -> lowest list position; that lane finishes
-    // the query (lane ss == 0 when the list is empty or no candidate has a finite distance)
-    dmin = ks_grp_min_f<KS_SPLIT> (best2);
-    jmin = ks_grp_min_u<KS_SPLIT> (best2 == dmin ? bj : 0xFFFFFFFFu);
-    }
+        ks_stage2_wave (XQb, o, n, valid, rstar, qx, qy, qz, qr, qg, qb, alpha, lane, dmin, jmin);
+    } else ks_stage2_lanes<LPQ> (XQb, o, n, valid, qx, qy, qz, qr, qg, qb, alpha, dr, b, lane, ss, dmin, jmin);
     KS_KEEP (dmin, jmin)
     KS_STAMP (5)
-    // Hand-off: lane 0 of every query leaves (q, distance, winner position, representative, flags) in LDS, and ONE wave
-    // finishes all 64 queries of the block with every lane active (lane e = query e): the winner's record, the weight,
-    // the per-query outputs and the 18 moment products are then issued once per block instead of once per wave for a
-    // handful of active lanes (an instruction costs the same whatever its lane count).
-    if (ss == 0u) {
-        const bool empty = (n == 0u);
-        s_qa[qe] = make_float4 (qx, qy, qz, empty ? dr : dmin);
-        s_qb[qe] = make_uint4 (empty ? rstar : ((jmin == 0xFFFFFFFFu) ? o : jmin), rstar, (valid ? 1u : 0u) | (empty ? 2u : 0u), i);
-    }
-    __syncthreads ();
-    if (slice == 0u) {
-        const float4 qa = s_qa[lane]; const uint4 qb = s_qb[lane];
-        const bool v = (qb.z & 1u) != 0u, empty = (qb.z & 2u) != 0u;
-        // the search ran on geo + a pho (a positive common factor changes neither the argmin nor the ties, and the pruning
-        // bound d >= geo stays as it is); the distance reported and fed to the weights carries the metric's absolute scale
-        const float ex = qa.x, ey = qa.y, ez = qa.z, d = p.dist_scale * qa.w;
-        const uint32_t ei = qb.w;
-        float w = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f;
-        if (v) {
-            uint32_t id;
-            if (empty) {             // empty list: fall back to the representative itself
-                const float4 nn = R4[2 * (size_t) qb.x];
-                id = p.rep_src[(size_t) b * nr + qb.x]; f0 = nn.x; f1 = nn.y; f2 = nn.z;
-            } else {                 // the winner's point, or, when every distance is inf / NaN, the first list element as
-                                     // the serial scan would: one reload instead of tracking it per candidate
-                const char *rec = XQb + (qb.x << 5);
-                const float4 wg = *reinterpret_cast<const float4 *> (rec), wc = *reinterpret_cast<const float4 *> (rec + 16);
-                f0 = wg.x; f1 = wg.z; f2 = wc.x; id = __float_as_uint (wc.z);
-            }
-            w = p.weighted ? 100.f / (100.f + d) : 1.f;                // icp_kernels.cl:232
-            // per-query outputs: uniform bases + 32-bit byte offsets (i < 2^20)
-            icp_dist_id di; di.dist = d; di.id = id;
-            // One-block-per-CU variants: the four output pointers are fetched from the kernel arguments HERE — an opaque copy of the
-            // argument pointer keeps the compiler from hoisting their scalar loads to the top of the kernel with all the others, where
-            // eight more live SGPRs make it spill freshly loaded arguments to VGPR lanes, i.e. wait for the argument block in front of
-            // the prologue's first vector loads (the chained kernel of a host-driven run: 9.29 -> 8.97 us per iteration); a run that
-            // stores no per-query outputs on the way never loads them at all.
-            const icp_params *pe = &p;
-            if constexpr (MINW == 2 && !OWNER) {
-                // (the kernel's explicit arguments: four pointers, six dwords, then icp_params — no padding in between; a change of the
-                // signature has to move this offset with it: every test that reads per-query outputs at a latency-bound size would show it)
-                static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
-                unsigned long long la_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
-                asm volatile ("" : "+s"(la_));
-                pe = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) la_;
-            }
-            typedef char __attribute__ ((address_space (1))) *gchar;           // (pointers read through `pe` are generic to the compiler: say that they are global)
-            char *o_nn = (char *) (gchar) reinterpret_cast<char *> (pe->nn_id + (size_t) b * m), *o_pf = (char *) (gchar) reinterpret_cast<char *> (pe->PF + (size_t) b * m);
-            char *o_pm = (char *) (gchar) reinterpret_cast<char *> (pe->PM + (size_t) b * m), *o_rid = (char *) (gchar) reinterpret_cast<char *> (pe->rid + (size_t) b * m);
-            // (fused mode consumes none of these itself: inside a graph of a fixed length only the last iteration
-            // stores them — except the nearest representative where the next search seeds its pruning with it)
-            const bool emit = !FUSED || (check_flags & 8u);
-            if (emit) {
-                *reinterpret_cast<icp_dist_id *> (o_nn + (ei << 3)) = di;
-                *reinterpret_cast<float4 *> (o_pf + (ei << 4)) = make_float4 (f0, f1, f2, w);
-                *reinterpret_cast<float4 *> (o_pm + (ei << 4)) = make_float4 (ex, ey, ez, d);
-            }
-            if (emit || PRUNE) *reinterpret_cast<uint32_t *> (o_rid + (ei << 2)) = qb.y;
-        }
-        if constexpr (FUSED) {
-            // the 18 moments of this pair in double (oracle orc_moments_fused); invalid queries contribute 0
-            double W = (double) w;
-            double g0 = v ? (double) f0 : 0.0, g1 = v ? (double) f1 : 0.0, g2 = v ? (double) f2 : 0.0;
-            double q0 = (double) ex, q1 = (double) ey, q2 = (double) ez;
-            if (!v) { W = 0.0; q0 = q1 = q2 = 0.0; }
-            double wq0 = W * q0, wq1 = W * q1, wq2 = W * q2;
-            s_mom[0][lane] = W;
-            s_mom[1][lane] = W * g0; s_mom[2][lane] = W * g1; s_mom[3][lane] = W * g2;
-            s_mom[4][lane] = wq0; s_mom[5][lane] = wq1; s_mom[6][lane] = wq2;
-            s_mom[7][lane] = wq0 * g0; s_mom[8][lane] = wq0 * g1; s_mom[9][lane] = wq0 * g2;
-            s_mom[10][lane] = wq1 * g0; s_mom[11][lane] = wq1 * g1; s_mom[12][lane] = wq1 * g2;
-            s_mom[13][lane] = wq2 * g0; s_mom[14][lane] = wq2 * g1; s_mom[15][lane] = wq2 * g2;
-            s_mom[16][lane] = W * ((g0 * g0 + g1 * g1) + g2 * g2);
-            s_mom[17][lane] = W * ((q0 * q0 + q1 * q1) + q2 * q2);
-        } else
-            s_w[lane] = w;
-    }
-    KS_STAMP (6)
-    __syncthreads ();
-    if constexpr (FUSED) {
-        // halving tree over the block's 64 pairs, one 16-lane row per moment (rows 0..17 of the 32 rows)
-        if (slice * 4u >= (uint32_t) ICP_NMOM) return;                     // (waves without a row: done)
-        const uint32_t l = lane & 15u, mrow = slice * 4u + (lane >> 4);     // first 18 of the block's 4*KS_SPLIT rows
-        const uint32_t k = min (mrow, (uint32_t) ICP_NMOM - 1u);
-        double c0 = s_mom[k][l] + s_mom[k][l + 32], c1 = s_mom[k][l + 16] + s_mom[k][l + 48];
-        double v = row_tree_tail_d (c0 + c1);
-        const uint32_t obuf = CHAIN ? (p.slot ^ 1u) : 0u;
-        if (l == 0 && mrow < ICP_NMOM) p.mom[(((size_t) b * 2 + obuf) * ICP_NMOM + mrow) * p.nb + tile_id] = v;
-    } else if (slice == 0 && p.weighted) {
-        // tree levels d = 64 .. 2 restricted to this block's parity class (icp_kernels.cl:244-249):
-        // element e of the class is position 2e + parity; levels pair e with e+32, e+16, .., e+1.
-        const uint32_t l = lane & 15u;
-        float a[4] = { s_w[l], s_w[l + 16], s_w[l + 32], s_w[l + 48] };
-        float v = row_tree4 (a);
-        if (lane == 0) p.wpart[(size_t) b * 2 * p.nwp + blockIdx.x] = v;
-    }
-    KS_STAMP (7)
+    // ==================================================== EPILOGUE ====================================================
+    // ---- epilogue (ks_epilogue): hand-off, finishing wave, outputs, block moments
+    ks_epilogue<FUSED, CHAIN, MINW, LPQ, OWNER, PRUNE> (p, s_qa, s_qb, s_mom, s_w, R4, XQb, b, m, nr, check_flags, tid, lane, slice, tile_id, qe, ss, i, valid, o, n, rstar, dr, dmin, jmin,
+                                                        qx, qy, qz);
 }
 
 

@@ -1,6 +1,6 @@
 """Diagnostic (not a test; needs hipcc only): the memory / synchronisation skeleton of a kernel's ISA — every scalar / vector / LDS access, wait,
 barrier and branch target with its instruction index — the view in which round 4 found the chained search waiting for its argument block in
-front of its first loads.  usage: python tests/diag_isa_skeleton.py [SOURCE [NAME-SUBSTRING [FIRST-N-INSTRUCTIONS]]]
+front of its first loads (docs/HISTORY.md §5).  usage: python tests/diag_isa_skeleton.py [SOURCE [NAME-SUBSTRING [FIRST-N-INSTRUCTIONS]]]
     python tests/diag_isa_skeleton.py icp_amd/csrc/icp_kernels.hip k_searchILb1ELb1ELi2ELi16ELb0ELi1ELi1024ELb0ELb0ELb0E 700"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

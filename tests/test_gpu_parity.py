@@ -340,7 +340,7 @@ def test_config5_properties(engine, oracle):
     g.close()
 
 
-# ---- fused reduction mode: bit-exact against the oracle's fused restatement, and within the
+# ---- fused reduction mode (docs/HISTORY.md §3.11): bit-exact against the oracle's fused restatement, and within the
 # ---- north-star tolerance of the reference-order mode
 
 @pytest.mark.parametrize("side,nr,rot,weighted", [(128, 256, 1, 1), (32, 16, 1, 1), (30, 4, 1, 1), (6, 4, 1, 1),
@@ -375,7 +375,7 @@ def test_fused_run_and_cross_mode_tolerance(engine, oracle):
     kr = r.run()
     Tr = r.read(engine.Memory.T)
     assert abs(kr - kg) <= 1
-    # The contract ("final R|t within 1e-5 relative", north star), under a float64 solution: every mode's result against the
+    # The contract ("final R|t within 1e-5 relative", north star; docs/HISTORY.md §3.11), under a float64 solution: every mode's result against the
     # float64 restatement of its own iterations (tests/float64_ref.py, fed the correspondences the ENGINE found in each iteration), each
     # block of [q | t, s] against its own magnitude — |q| = 1, |t| (25 mm here), s.
     import float64_ref as R64
@@ -1065,7 +1065,7 @@ def test_nan_and_inf_points_do_not_break_the_search(engine, oracle, side, nr, fu
     the moving set, infinite ones in both: the RBC structure, the nearest representatives and every correspondence id still equal the
     oracle's (a NaN or infinite distance never wins a '<' on either side; the box pruning skips such coordinates), distances agree
     bit for bit wherever the oracle's is a number; a query without any comparable candidate reports +inf here where the serial
-    scan reports the NaN of its first candidate (DESIGN.md §3.5); T turns NaN on both sides (garbage in, the same garbage out) —
+    scan reports the NaN of its first candidate (DESIGN.md §3 item 4); T turns NaN on both sides (garbage in, the same garbage out) —
     latency variant, dense variant with one and with several representative tiles."""
     m = side * side
     F, M = engine.synth_pair(side)

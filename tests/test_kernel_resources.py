@@ -56,7 +56,7 @@ def test_chained_search_issues_its_first_loads_before_it_waits_for_its_arguments
     the rest of its arguments arrives by scalar loads, and the only wait for those is `s_waitcnt lgkmcnt (0)` — for all of them.  Such a
     wait (or a spill of freshly loaded arguments: v_writelane) in front of the state load and the eight block-moment loads starts every
     wave's first memory round trip an argument fetch late: a scalar-cache miss in a graph replay, a trip to memory in a plain launch
-    ("Where the kernel arguments are waited for": 0.3 - 0.5 us of 9).  Both instantiations, power-method rotation."""
+    (docs/HISTORY.md §5, "Where the kernel arguments are waited for": 0.3 - 0.5 us of 9).  Both instantiations, power-method rotation."""
     isa = kernel_isa("icp_amd/csrc/icp_kernels.hip")
     names = [n for n in isa if n.startswith("_Z8k_searchILb1ELb1ELi2ELi16ELb0ELi1ELi1024ELb0ELb0E")]
     assert len(names) == 2, names                                     # HOSTRUN = false (fixed-length graphs) and true (host-driven runs)

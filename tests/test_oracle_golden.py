@@ -322,7 +322,7 @@ def test_init_rejects(oracle):
 
 
 def test_fused_mode_agrees_with_reference_order(oracle, engine):
-    """the single-pass double-moment formulation gives the reference-order means / S / T to
+    """DESIGN.md §3 item 8; docs/HISTORY.md §3.11: the single-pass double-moment formulation gives the reference-order means / S / T to
     within fp32 rounding of the coordinates, the same iteration count and the same final correspondences."""
     F, M = engine.synth_pair(64)
     res = []

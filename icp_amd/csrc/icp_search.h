@@ -465,12 +465,100 @@ static __device__ __forceinline__ void fin_result_to_state (const icp_fin_result
 }
 
 // ------------------------------------------------------------------------------------------
+// ks_list_tail — stage 2, what lies beyond the unconditionally scanned head of a LONG list (both forms of stage 2 end here; no clean
+// scene has such a list: every branch into this function is a scalar one that is never taken then).
+// Exact pruning over chunks of 16 consecutive positions (boxes: k_list_boxes).  A query tests a chunk with the
+// metric's own operations applied to the per-axis distances to the chunk's 6-D box — every operation is monotone under
+// round-to-nearest, so bound <= d of every member (a > 0) — against `lim`: the distance to the representative itself, bumped one
+// ulp (the representative is a member of its own list: a nearer-or-equal identical point with a lower index would have been
+// the nearest representative instead; so the list's minimum is <= dr, and a chunk whose bound is above dr holds neither the
+// minimum nor a tie with it), and the query's best so far (a chunk whose bound is not BELOW it cannot replace a candidate at a
+// lower position: trips ascend, updates need a strict '<' — the tie rule of the serial scan).  Lane ss tests the chunks
+// cb + ss, cb + ss + LPQ of a round; the answers of a query's lanes come back through a ballot; the chunks that pass are
+// scanned in ascending order by all lanes of the query, two chunks per memory round trip.  The bits are those of the
+// exhaustive scan; a list of identical points (invalid pixels with their colour zeroed) costs a box test per chunk behind
+// its first 128 candidates instead of the candidates themselves.
+//   cb0: first chunk to test; ntrips: trips (of LPQ positions) of the wave's longest list; best2 / bj: the lane's best so far (distance, TRIP
+//   index: position o + ss + trip * LPQ), updated.
+// ------------------------------------------------------------------------------------------
+template <int LPQ>
+static __device__ __forceinline__ void ks_list_tail (const char *XQb, uint32_t o, uint32_t je, uint32_t alast, uint32_t cb0, uint32_t ntrips, float qx, float qy, float qz,
+                                                     float qr, float qg, float qb, float alpha, float dr, uint32_t b, uint32_t lane, uint32_t ss, float &best2, uint32_t &bj)
+{
+    const float2v vq_xr = { qx, qr }, vq_yg = { qy, qg }, vq_zb = { qz, qb };
+    constexpr uint32_t CPT = 16u / KS_SPLIT, BD = KS_SPLIT == 16 ? 2u : 1u;     // trips per chunk; boxes per lane and round (LPQ = 8: the 64-register variants have room for one)
+    const uint32_t nch = (je - o + 15u) >> 4, nchw = (ntrips + CPT - 1u) / CPT;     // chunks of this query's list / of the wave's longest
+    // (the boxes' base and stride are fetched from the kernel arguments HERE, through an opaque copy of the argument pointer — see the
+    // per-query output pointers of the epilogue: left to the compiler, their scalar loads join the ones at the top of the kernel, in
+    // front of the prologue's vector loads, for a path hardly any launch takes: 8.66 -> 8.71 us per iteration at |F| = 16384)
+    static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
+    unsigned long long lb_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
+    asm volatile ("" : "+s"(lb_));
+    const icp_params *pl = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) lb_;
+    typedef float4 __attribute__ ((address_space (1))) *gf4;
+    const float4 *LBq = (const float4 *) (gf4) pl->LB + (size_t) b * 3u * pl->nlb + 3u * (o >> 4);
+    const float inf_ = __builtin_inff ();
+    float lim = (alpha > 0.f && dr >= 0.f && dr < inf_) ? __uint_as_float (__float_as_uint (dr) + 1u) : inf_;
+    const bool bounds = alpha > 0.f;                            // (a <= 0: d >= bound does not hold; everything is scanned)
+    for (uint32_t cb = cb0; cb < nchw; cb += BD * KS_SPLIT) {
+        lim = fminf (lim, ks_grp_min_f<KS_SPLIT> (best2));
+        float4 bx[BD][3];
+#pragma unroll
+        for (uint32_t j = 0; j < BD; ++j) {
+            const uint32_t cc = min (cb + ss + KS_SPLIT * j, max (nch, 1u) - 1u);       // (clamped: inside the buffer; masked below)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) bx[j][k] = LBq[3u * cc + (uint32_t) k];
+        }
+        uint32_t cmask = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < BD; ++j) {
+            const float4 b0 = bx[j][0], b1 = bx[j][1], b2 = bx[j][2];                   // [lo.x lo.y lo.z lo.r | lo.g lo.b hi.x hi.y | hi.z hi.r hi.g hi.b]
+            const float ex = fmaxf (fmaxf (b0.x - qx, qx - b1.z), 0.f), ey = fmaxf (fmaxf (b0.y - qy, qy - b1.w), 0.f);
+            const float ez = fmaxf (fmaxf (b0.z - qz, qz - b2.x), 0.f), er = fmaxf (fmaxf (b0.w - qr, qr - b2.y), 0.f);
+            const float eg = fmaxf (fmaxf (b1.x - qg, qg - b2.z), 0.f), eb = fmaxf (fmaxf (b1.y - qb, qb - b2.w), 0.f);
+            const float geo_ = __builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex)), pho_ = __builtin_fmaf (eb, eb, __builtin_fmaf (eg, eg, er * er));
+            const bool pass = cb + ss + KS_SPLIT * j < nch && (!bounds || __builtin_fmaf (alpha, pho_, geo_) < lim);
+            const unsigned long long bal = __ballot (pass);
+            cmask |= ((uint32_t) (bal >> (lane & (64u - KS_SPLIT))) & ((1u << KS_SPLIT) - 1u)) << (KS_SPLIT * j);      // bit k: chunk cb + k of this query's list
+        }
+        // the chunks that pass, ascending: two per memory round trip where the registers are there (LPQ = 16: the latency variant), one in the
+        // 64-register variants (LPQ = 8: a chunk is two trips)
+        while (__ballot (cmask != 0u)) {
+            constexpr uint32_t NS = KS_SPLIT == 16 ? 2u : 1u;
+            bool live[NS]; uint32_t tr[NS];
+#pragma unroll
+            for (uint32_t u = 0; u < NS; ++u) {
+                live[u] = cmask != 0u;
+                tr[u] = (cb + (live[u] ? (uint32_t) __builtin_ctz (cmask) : 0u)) * CPT;
+                cmask &= cmask - 1u;
+            }
+            float4 g[NS * CPT], c[NS * CPT];
+#pragma unroll
+            for (uint32_t u = 0; u < NS; ++u)
+#pragma unroll
+                for (uint32_t h = 0; h < CPT; ++h) {
+                    const char *r0 = XQb + min ((o + ss + (tr[u] + h) * KS_SPLIT) << 5, alast);
+                    g[u * CPT + h] = *reinterpret_cast<const float4 *> (r0); c[u * CPT + h] = *reinterpret_cast<const float4 *> (r0 + 16);
+                }
+#pragma unroll
+            for (uint32_t u = 0; u < NS; ++u)
+#pragma unroll
+                for (uint32_t h = 0; h < CPT; ++h) KS_CAND_IF (g[u * CPT + h], c[u * CPT + h], tr[u] + h, live[u]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // ks_stage2_wave — stage 2, lanes = candidates (dense variant, long lists: icp_s2_wave_of): called by every lane of the wave.
 //   o, n, valid, rstar, q*: the calling lane's query (LPQ = 8: query lane >> 3); dmin / jmin: that query's winner (distance, list
 //   position; 0xFFFFFFFF: no candidate) in all of its lanes.
 // ------------------------------------------------------------------------------------------
+#ifndef ICP_S2W_UNCOND
+#define ICP_S2W_UNCOND 1024u         // lanes = candidates: positions of a list scanned unconditionally (16 trips of 64); beyond them chunk boxes first
+#endif
 static __device__ __forceinline__ void ks_stage2_wave (const char *XQb, uint32_t o, uint32_t n, bool valid, uint32_t rstar, float qx, float qy, float qz,
-                                                       float qr, float qg, float qb, float alpha, uint32_t lane, float &dmin, uint32_t &jmin)
+                                                       float qr, float qg, float qb, float alpha, float dr, uint32_t b, uint32_t lane, const float4 *s_qa, const float4 *s_qc,
+                                                       uint32_t qe, float &dmin, uint32_t &jmin)
 {
     // ---- stage 2, long lists (dense variant, icp_s2_wave): lanes = candidates.  The scan above is bound by the vector-memory
     // path (every query's lanes load their list for themselves: 24 bytes per candidate and query through the L1); the
@@ -519,13 +607,17 @@ static __device__ __forceinline__ void ks_stage2_wave (const char *XQb, uint32_t
         for (int q = 0; q < 8; ++q) m8 |= (uint32_t) ((match >> (8 * q)) & 1ull) << q;
         m8 = (uint32_t) __builtin_amdgcn_readfirstlane ((int) m8);
         const uint32_t vlastL = (oL + nL - 1u) << 5, ntr = (nL + 63u) >> 6;
+        // (a list's first ICP_S2W_UNCOND positions here; what a LONG list holds beyond them is scanned behind chunk-box tests by the
+        // queries' own lanes afterwards: see the end of this function)
+        constexpr uint32_t TU = ICP_S2W_UNCOND / 64u;
+        const uint32_t ntr0 = min (ntr, TU);
         uint32_t voff = (oL + lane) << 5;
-        for (uint32_t t = 0; t < ntr; t += 2u, voff += 2u * 64u * 32u) {
+        for (uint32_t t = 0; t < ntr0; t += 2u, voff += 2u * 64u * 32u) {
             const char *rec0 = XQb + min (voff, vlastL), *rec1 = XQb + min (voff + 64u * 32u, vlastL);
             const float4 g0 = *reinterpret_cast<const float4 *> (rec0); const float2 c0 = *reinterpret_cast<const float2 *> (rec0 + 16);
             const float4 g1 = *reinterpret_cast<const float4 *> (rec1); const float2 c1 = *reinterpret_cast<const float2 *> (rec1 + 16);
             KS_WCAND (g0, c0, t)
-            if (t + 1u < ntr) { KS_WCAND (g1, c1, t + 1u) }
+            if (t + 1u < ntr0) { KS_WCAND (g1, c1, t + 1u) }
         }
     }
 #undef KS_WCAND
@@ -575,6 +667,29 @@ static __device__ __forceinline__ void ks_stage2_wave (const char *XQb, uint32_t
     k1 = min64 (k1, xchg_lane (k1, lane ^ 32u));
     k1 = xchg_lane (k1, (lane & 56u) | (lane >> 3));            // to the lanes of query lane >> 3
     dmin = __uint_as_float ((uint32_t) (k1 >> 32)); jmin = (uint32_t) k1;
+    // ---- long lists (beyond ICP_S2W_UNCOND positions: no clean scene has one; a frame's invalid points with their colours zeroed are ONE
+    // point, and the list that holds them all is scanned by every query that is such a point — |F| = 65536, |R| = 256, 30 % of them: 377 us
+    // per iteration instead of 23): the rest of such a list is scanned by the query's own 8 lanes behind chunk-box tests (ks_list_tail),
+    // starting from the winner of the head: positions ascend, updates need a strict '<' — the serial scan's tie rule.
+    {
+        uint32_t nl = (je - o + 7u) >> 3;                                // trips of 8 positions; the wave's maximum as in ks_stage2_lanes
+        nl = max (nl, (uint32_t) __builtin_amdgcn_update_dpp (0, (int) nl, 0x140, 0xF, 0xF, true));
+        nl = max (nl, (uint32_t) __builtin_amdgcn_update_dpp ((int) nl, (int) nl, 0x142, 0xA, 0xF, false));
+        nl = max (nl, (uint32_t) __builtin_amdgcn_update_dpp ((int) nl, (int) nl, 0x143, 0xC, 0xF, false));
+        const uint32_t ntrips = (uint32_t) __builtin_amdgcn_readlane ((int) nl, 63);
+        if (__builtin_expect (ntrips > ICP_S2W_UNCOND / 8u, 0)) {
+            const uint32_t ss = lane & 7u;
+            float best2 = dmin; uint32_t bj = 0xFFFFFFFFu;               // (bj: a TRIP of this scan, or none: the head's winner stands)
+            // (the query comes back from LDS, where the query wave left it: held in registers across the scan above and the butterfly, its
+            // colour alone made the 64-register variants spill)
+            const float4 a4 = s_qa[qe], c4 = s_qc[qe];
+            ks_list_tail<8> (XQb, o, je, (max (je, 1u) - 1u) << 5, ICP_S2W_UNCOND / 16u, ntrips, a4.x, a4.y, a4.z, c4.x, c4.y, c4.z, alpha, dr, b, lane, ss, best2, bj);
+            const uint32_t pos = bj != 0xFFFFFFFFu ? min (o + ss + bj * 8u, max (je, 1u) - 1u) : jmin;
+            const float d2 = ks_grp_min_f<8> (best2);
+            jmin = ks_grp_min_u<8> (best2 == d2 ? pos : 0xFFFFFFFFu);
+            dmin = d2;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -627,75 +742,8 @@ static __device__ __forceinline__ void ks_stage2_lanes (const char *XQb, uint32_
                 KS_CAND (g[t], c[t], tb + t);
             }
         }
-        if (__builtin_expect (ntrips > ntr0, 0)) {
-            // ---- long lists: exact pruning over chunks of 16 consecutive positions (boxes: k_list_boxes).  A query tests a chunk with the
-            // metric's own operations applied to the per-axis distances to the chunk's 6-D box — every operation is monotone under
-            // round-to-nearest, so bound <= d of every member (a > 0) — against `lim`: the distance to the representative itself, bumped one
-            // ulp (the representative is a member of its own list: a nearer-or-equal identical point with a lower index would have been
-            // the nearest representative instead; so the list's minimum is <= dr, and a chunk whose bound is above dr holds neither the
-            // minimum nor a tie with it), and the query's best so far (a chunk whose bound is not BELOW it cannot replace a candidate at a
-            // lower position: trips ascend, updates need a strict '<' — the tie rule of the serial scan).  Lane ss tests the chunks
-            // cb + ss, cb + ss + LPQ of a round; the answers of a query's lanes come back through a ballot; the chunks that pass are
-            // scanned in ascending order by all lanes of the query, two chunks per memory round trip.  The bits are those of the
-            // exhaustive scan; a list of identical points (invalid pixels with their colour zeroed) costs a box test per chunk behind
-            // its first 128 candidates instead of the candidates themselves.
-            constexpr uint32_t CPT = 16u / KS_SPLIT, BD = KS_SPLIT == 16 ? 2u : 1u;     // trips per chunk; boxes per lane and round (LPQ = 8: the 64-register variants have room for one)
-            const uint32_t nch = (je - o + 15u) >> 4, nchw = (ntrips + CPT - 1u) / CPT;     // chunks of this query's list / of the wave's longest
-            // (the boxes' base and stride are fetched from the kernel arguments HERE, through an opaque copy of the argument pointer — see the
-            // per-query output pointers of the epilogue: left to the compiler, their scalar loads join the ones at the top of the kernel, in
-            // front of the prologue's vector loads, for a path hardly any launch takes: 8.66 -> 8.71 us per iteration at |F| = 16384)
-            static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
-            unsigned long long lb_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
-            asm volatile ("" : "+s"(lb_));
-            const icp_params *pl = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) lb_;
-            typedef float4 __attribute__ ((address_space (1))) *gf4;
-            const float4 *LBq = (const float4 *) (gf4) pl->LB + (size_t) b * 3u * pl->nlb + 3u * (o >> 4);
-            const float inf_ = __builtin_inff ();
-            float lim = (alpha > 0.f && dr >= 0.f && dr < inf_) ? __uint_as_float (__float_as_uint (dr) + 1u) : inf_;
-            const bool bounds = alpha > 0.f;                            // (a <= 0: d >= bound does not hold; everything is scanned)
-            for (uint32_t cb = ICP_S2_UNCOND / 16u; cb < nchw; cb += BD * KS_SPLIT) {
-                lim = fminf (lim, ks_grp_min_f<KS_SPLIT> (best2));
-                float4 bx[BD][3];
-#pragma unroll
-                for (uint32_t j = 0; j < BD; ++j) {
-                    const uint32_t cc = min (cb + ss + KS_SPLIT * j, max (nch, 1u) - 1u);       // (clamped: inside the buffer; masked below)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) bx[j][k] = LBq[3u * cc + (uint32_t) k];
-                }
-                uint32_t cmask = 0u;
-#pragma unroll
-                for (uint32_t j = 0; j < BD; ++j) {
-                    const float4 b0 = bx[j][0], b1 = bx[j][1], b2 = bx[j][2];                   // [lo.x lo.y lo.z lo.r | lo.g lo.b hi.x hi.y | hi.z hi.r hi.g hi.b]
-                    const float ex = fmaxf (fmaxf (b0.x - qx, qx - b1.z), 0.f), ey = fmaxf (fmaxf (b0.y - qy, qy - b1.w), 0.f);
-                    const float ez = fmaxf (fmaxf (b0.z - qz, qz - b2.x), 0.f), er = fmaxf (fmaxf (b0.w - qr, qr - b2.y), 0.f);
-                    const float eg = fmaxf (fmaxf (b1.x - qg, qg - b2.z), 0.f), eb = fmaxf (fmaxf (b1.y - qb, qb - b2.w), 0.f);
-                    const float geo_ = __builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex)), pho_ = __builtin_fmaf (eb, eb, __builtin_fmaf (eg, eg, er * er));
-                    const bool pass = cb + ss + KS_SPLIT * j < nch && (!bounds || __builtin_fmaf (alpha, pho_, geo_) < lim);
-                    const unsigned long long bal = __ballot (pass);
-                    cmask |= ((uint32_t) (bal >> (lane & (64u - KS_SPLIT))) & ((1u << KS_SPLIT) - 1u)) << (KS_SPLIT * j);      // bit k: chunk cb + k of this query's list
-                }
-                while (__ballot (cmask != 0u)) {
-                    const bool live0 = cmask != 0u;
-                    const uint32_t k0 = live0 ? (uint32_t) __builtin_ctz (cmask) : 0u;
-                    cmask &= cmask - 1u;
-                    const bool live1 = cmask != 0u;
-                    const uint32_t k1 = live1 ? (uint32_t) __builtin_ctz (cmask) : k0;
-                    cmask &= cmask - 1u;
-                    const uint32_t t0 = (cb + k0) * CPT, t1 = (cb + k1) * CPT;
-                    float4 g[2 * CPT], c[2 * CPT];
-#pragma unroll
-                    for (uint32_t h = 0; h < CPT; ++h) {
-                        const char *r0 = XQb + min ((o + ss + (t0 + h) * KS_SPLIT) << 5, alast), *r1 = XQb + min ((o + ss + (t1 + h) * KS_SPLIT) << 5, alast);
-                        g[h] = *reinterpret_cast<const float4 *> (r0); c[h] = *reinterpret_cast<const float4 *> (r0 + 16);
-                        g[CPT + h] = *reinterpret_cast<const float4 *> (r1); c[CPT + h] = *reinterpret_cast<const float4 *> (r1 + 16);
-                    }
-#pragma unroll
-                    for (uint32_t h = 0; h < CPT; ++h) KS_CAND_IF (g[h], c[h], t0 + h, live0);
-#pragma unroll
-                    for (uint32_t h = 0; h < CPT; ++h) KS_CAND_IF (g[CPT + h], c[CPT + h], t1 + h, live1);
-                }
-            }
-        }
+        if (__builtin_expect (ntrips > ntr0, 0))     // ---- long lists: the rest chunk by chunk behind box tests (ks_list_tail)
+            ks_list_tail<LPQ> (XQb, o, je, alast, ICP_S2_UNCOND / 16u, ntrips, qx, qy, qz, qr, qg, qb, alpha, dr, b, lane, ss, best2, bj);
         if (bj != 0xFFFFFFFFu) bj = min (o + ss + bj * KS_SPLIT, max (je, 1u) - 1u);     // trip -> list position
         if (je == o) { best2 = __builtin_inff (); bj = 0xFFFFFFFFu; }      // empty list / invalid query: nothing above was a candidate
     }
@@ -1449,7 +1497,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     float dmin; uint32_t jmin;
     if constexpr (S2W) {
         static_assert (MINW == 4 && LPQ == 8 && !OWNER, "lanes = candidates: the dense search variants");
-        ks_stage2_wave (XQb, o, n, valid, rstar, qx, qy, qz, qr, qg, qb, alpha, lane, dmin, jmin);
+        ks_stage2_wave (XQb, o, n, valid, rstar, qx, qy, qz, qr, qg, qb, alpha, dr, b, lane, s_qa, s_qc, qe, dmin, jmin);
     } else ks_stage2_lanes<LPQ> (XQb, o, n, valid, qx, qy, qz, qr, qg, qb, alpha, dr, b, lane, ss, dmin, jmin);
     KS_KEEP (dmin, jmin)
     KS_STAMP (5)

@@ -7,6 +7,8 @@ import icp_amd
 from icp_amd import workloads as W
 
 side, nr = W.CONFIGS[os.environ.get("CFG", "A")]
+if os.environ.get("SIDE"):                        # any other shape: SIDE=256 NR=256 (long lists: the lanes = candidates form of stage 2)
+    side, nr = int(os.environ["SIDE"]), int(os.environ["NR"])
 m = side * side
 batch = int(os.environ.get("BATCH", "1"))
 names = ["clean"] + list(W.HOLES)

@@ -159,7 +159,9 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
             hi.x = fmaxf (hi.x, v.x); hi.y = fmaxf (hi.y, v.y); hi.z = fmaxf (hi.z, v.z);
         }
         float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n1k);
-        GB[2 * g] = lo; GB[2 * g + 1] = hi;
+        GB[2 * g] = lo;
+        float *hi3 = reinterpret_cast<float *> (GB + 2 * g + 1);          // (hi.w of group box 0 belongs to the block that lists the representatives at the origin)
+        hi3[0] = hi.x; hi3[1] = hi.y; hi3[2] = hi.z;
     } else if (blockIdx.x == gridDim.x - 1u) {
         // the representatives at the origin, ascending: (r, g, b, index) each behind their number (one wave: a ballot and a running offset
         // per 64 representatives)
@@ -177,7 +179,8 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
         if (lane == 0) {
             OL[0] = make_float4 (__uint_as_float (run), 0.f, 0.f, 0.f);
             // the number the search reads: a spare lane of the box array (hi.w of the first tile box: nobody else writes that word)
-            reinterpret_cast<float *> (p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + 1u)[3] = __uint_as_float (run);
+            reinterpret_cast<float *> (p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + 1u)[3] = __uint_as_float (run);      // tile box 0, hi.w
+            reinterpret_cast<float *> (p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 1u)[3] = __uint_as_float (run);                    // group box 0, hi.w
         }
     } else {
         const uint32_t tile = blockIdx.x - nbr - nbg;

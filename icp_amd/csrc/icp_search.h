@@ -1068,17 +1068,6 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         if (!OWNER && !MASKED && k < tn0) ron[u] = make_uint2 (gO[k], gN[k]);
         if (!OWNER && MASKED && u == 0 && tid < tnH) ron[0] = make_uint2 (gO[ht * KT + tid], gN[ht * KT + tid]);
     }
-    // (dense variants: the number of representatives at the origin — a frame's invalid points: ks_origin_list — travels with the prologue's loads)
-    // (a SCALAR load — the address is block-uniform, the word was written by an earlier launch (k_reps_and_boxes): through the constant address
-    // space the compiler emits s_load_dword; as a vector load + readfirstlane it cost 0.8 % at |F| = 16384 x 64 and 0.4 % at |F| = 65536)
-    // The number lives in a spare lane of the box array (hi.w of the first tile box: k_reps_and_boxes), i.e. behind a pointer the prologue holds
-    // anyway: the list's own pointer is fetched where the list is scanned — one more pointer held from the top of the kernel made the compiler spill
-    // scalar registers to vector lanes THERE, each spill behind a wait for the argument loads (|F| = 65536: search 11.88 -> 12.22 us).
-    uint32_t n_origin = 0u;
-    if constexpr (ICP_S1_SEED && ICP_S1_ORIGIN_LIST && MINW == 4) {
-        typedef const uint32_t __attribute__ ((address_space (4))) *cu32;
-        n_origin = ((cu32) (unsigned long long) (p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + 1u))[3];
-    }
     // (HOSTRUN: the flag is read HERE, behind the prologue's vector loads — a scalar load of the flag's address, a second one of the flag and a
     // wait for both: in front of them it would hold every load of the prologue back by two scalar round trips)
     if constexpr (CHAIN && HOSTRUN) { if (p.run_flag) run_over = (p.run_flag[b] == p.epoch) ? 1u : 0u; }
@@ -1456,6 +1445,12 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     }
     if constexpr (PRUNE && ICP_S1_ORIGIN_LIST) {
         // the representatives at the origin (invalid points): kept out of the boxes above, scanned here by the queries that are near the origin
+        // Their number rides in a spare lane of the box array the block has staged in LDS anyway (hi.w of group box 0 / of tile box 0:
+        // k_reps_and_boxes): one LDS read here.  (Loaded from global memory in the prologue — by a vector load, or by a scalar one with its
+        // address arithmetic — it cost 0.8 - 1.3 % at |F| = 16384 x 64; the list's own pointer, held from the top of the kernel, made the
+        // compiler spill scalars in front of the prologue's loads: search at |F| = 65536 11.88 -> 12.22 us.  Both are fetched here.)
+        uint32_t n_origin = 0u;
+        if (prune) n_origin = (uint32_t) __builtin_amdgcn_readfirstlane ((int) __float_as_uint ((MASKED || (!SINGLE && nr > KT)) ? s_tbox[1].w : s_box[1].w));
         if (prune && __builtin_expect (n_origin != 0u, 0)) {
             static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
             unsigned long long ol_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);

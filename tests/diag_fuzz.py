@@ -59,13 +59,17 @@ def run(seconds=None, cases=None, seed=1, verbose=True):
         batch = int(rng.choice([1, 1, 3])) if m <= 16384 else 1
         bsel = int(rng.integers(0, batch)) if batch > 1 else None
         runmode = bool(rng.integers(0, 3) == 0)
-        desc = "side %d nr %d a %g fused %d fast %d rot %d w %d zero %.1f seed %d batch %d/%s %s" % (side, nr, alpha, fused, fast, rot, weighted, zero, seed, batch, bsel, "run" if runmode else "steps")
+        holes = (int(rng.integers(0, 2)), float(rng.choice([0.1, 0.3])), bool(rng.integers(0, 2))) if rng.integers(0, 3) == 0 else None
+        desc = "side %d nr %d a %g fused %d fast %d rot %d w %d zero %.1f holes %s seed %d batch %d/%s %s" % (side, nr, alpha, fused, fast, rot, weighted, zero, holes, seed, batch, bsel, "run" if runmode else "steps")
         try:
             g = E.ICP(0, rot, weighted)
             g.init(m, nr, alpha, 1e-6, batch=batch) if batch > 1 else g.init(m, nr, alpha, 1e-6)
             g.setPowerMode(E.PowerMode.SQUARED if fast else E.PowerMode.LITERAL)
             g.setReduceMode(E.ReduceMode.FUSED if fused else E.ReduceMode.REFERENCE_ORDER)
             pairs = [E.synth_pair(side, seed=seed + 7 * b, zero_fraction=zero) for b in range(batch)]
+            if holes:                                               # a Kinect frame's invalid points (round 5): scattered / contiguous, colour kept / zeroed
+                hp, hf, hk = holes
+                pairs = [(E.punch_holes(F, side, side, hp, hf, hk, seed=seed + 11 * b), E.punch_holes(M, side, side, hp, hf, hk, seed=seed + 13 * b)) for b, (F, M) in enumerate(pairs)]
             for b, (F, M) in enumerate(pairs):
                 if batch > 1: g.write(Mem.F, F, batch_index=b); g.write(Mem.M, M, batch_index=b)
                 else: g.write(Mem.F, F); g.write(Mem.M, M)

@@ -165,7 +165,7 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
     } else if (blockIdx.x == gridDim.x - 1u) {
         // the representatives at the origin, ascending: (r, g, b, index) each behind their number (one wave: a ballot and a running offset
         // per 64 representatives)
-        float4 *OL = p.OL + (size_t) b * (p.nr + 1u);
+        float4 *OL = p.OL + (size_t) b * ICP_OL_STRIDE (p.nr);
         uint32_t run = 0u;
         for (uint32_t r0 = 0; r0 < p.nr; r0 += 64u) {
             const uint32_t r = r0 + lane;
@@ -175,6 +175,22 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
             const unsigned long long bal = __ballot (at0);
             if (at0) OL[1u + run + (uint32_t) __builtin_popcountll (bal & ((1ull << lane) - 1ull))] = make_float4 (c.x, c.y, c.z, __uint_as_float (r));
             run += (uint32_t) __builtin_popcountll (bal);
+        }
+        // colour boxes of the chunks of 8 consecutive entries (ks_origin_list tests a chunk before it scans it — the owner search of THIS
+        // construction already does, so the boxes cannot wait for a later launch): the wave reads its own entries back behind a fence
+        __threadfence ();
+        {
+            float4 *BX = OL + 1u + p.nr;
+            const uint32_t n_oc = (run + 7u) >> 3;
+            for (uint32_t c = lane; c < n_oc; c += 64u) {
+                float4 lo = make_float4 (inf, inf, inf, 0.f), hi = make_float4 (-inf, -inf, -inf, 0.f);
+                for (uint32_t e = 8u * c; e < min (8u * c + 8u, run); ++e) {
+                    const float4 v = OL[1u + e];
+                    lo.x = fminf (lo.x, v.x); lo.y = fminf (lo.y, v.y); lo.z = fminf (lo.z, v.z);
+                    hi.x = fmaxf (hi.x, v.x); hi.y = fmaxf (hi.y, v.y); hi.z = fmaxf (hi.z, v.z);
+                }
+                BX[2u * c] = lo; BX[2u * c + 1u] = hi;
+            }
         }
         if (lane == 0) {
             OL[0] = make_float4 (__uint_as_float (run), 0.f, 0.f, 0.f);

@@ -229,7 +229,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &p.GB, B * 2 * (p.n16 + p.n1k)))) return rc;
     if ((rc = dalloc (h, &p.XP, B * m * 8))) return rc;
     if ((rc = dalloc (h, &p.XQ, B * m * 8))) return rc;
-    if ((rc = dalloc (h, &p.OL, B * (nr + 1u)))) return rc;
+    if ((rc = dalloc (h, &p.OL, B * ICP_OL_STRIDE (nr)))) return rc;
     p.nlb = m / 16u + 2u;
     if ((rc = dalloc (h, &p.LB, B * 3 * p.nlb))) return rc;
     if ((rc = dalloc (h, &p.rep_src, B * nr))) return rc;

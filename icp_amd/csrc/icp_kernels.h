@@ -20,6 +20,7 @@
 #define ICP_BAND_ROW_BYTES (ICP_BAND_COLS * 32u)
 #define ICP_BAND_BYTES ((size_t) ICP_BAND_ROWS * ICP_BAND_ROW_BYTES)
 #define ICP_TBOX 1024u            // representatives per LDS tile box of the 1024-tile dense search (k_reps_and_boxes, k_search)
+#define ICP_OL_STRIDE(nr) ((nr) + 1u + 2u * (((nr) + 7u) / 8u))    // float4 per registration of icp_params::OL
 #define ICP_CHUNK 1024u          // fixed points per block in the stable RBC placement
 
 struct icp_params {
@@ -56,8 +57,9 @@ struct icp_params {
     uint32_t s2wave;             // stage 2 of the dense search with lanes = candidates (lists of >= ICP_S2_WAVE_MIN candidates on average: see k_search)
     float *XP;                   // [batch][m][8]  permuted database (RBCConstruct D_OUT_X_P)
     float *XQ;                   // [batch][m][8]  same, lane 3 = original index bits (search copy)
-    float4 *OL;                  // [batch][nr + 1]  the representatives at the origin (invalid points), ascending: [0].x = their number (bits), then
-                                 // (r, g, b, index bits) each — kept out of the pruning boxes, scanned by the queries near the origin (dense search)
+    float4 *OL;                  // [batch][ICP_OL_STRIDE (nr)]  the representatives at the origin (invalid points), ascending: [0].x = their number (bits),
+                                 // [1 .. nr]: (r, g, b, index bits) each — kept out of the pruning boxes, scanned by the queries near the origin (dense
+                                 // search) —, behind them the colour boxes (lo rgb, hi rgb) of the chunks of 8 consecutive entries (k_list_boxes)
     float4 *LB;                  // [batch][3 * nlb]  6-D bounding boxes of the list chunks (16 consecutive positions of one list, chunk c >= 1 of list r at
                                  // index (O[r] >> 4) + c: k_list_boxes) as [lo.x lo.y lo.z lo.r | lo.g lo.b hi.x hi.y | hi.z hi.r hi.g hi.b]
     uint32_t nlb;                // m / 16 + 2 boxes per registration

@@ -117,26 +117,55 @@ template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint
 // invalid point, moved by T: its nearest representative is the invalid one nearest in colour).  Same bits as the exhaustive scan:
 // the list is visited behind the tiles, out of index order, so its updates carry the tie rule explicitly (equal distance: lower index).
 template <int LPQ>
-static __device__ __forceinline__ void ks_origin_list (const float4 *OL, uint32_t n_o, float qx, float qy, float qz, float qr, float qg, float qb, float alpha,
-                                                       float lim, uint32_t ss, float &best, uint32_t &bid)
+static __device__ __forceinline__ void ks_origin_list (const float4 *OL, uint32_t n_o, uint32_t nr, float qx, float qy, float qz, float qr, float qg, float qb, float alpha,
+                                                       float lim, uint32_t lane, uint32_t ss, float &best, uint32_t &bid)
 {
-    // (n_o = OL[0].x, block-uniform: loaded with the prologue's other loads — asked for here it would be a memory round trip of its own
-    // on every block's path, holes or not: |F| = 16384 x 64 registrations 1.845 -> 1.882 us per registration-iteration)
     if (__builtin_expect (n_o == 0u, 1)) return;
     const float qq = __builtin_fmaf (qz, qz, __builtin_fmaf (qy, qy, qx * qx));
     const bool need = qq <= lim;                     // d >= qq for every member: none can win, or tie at a lower index, beyond that
     if (!__ballot (need)) return;
-    // four entries per lane and memory round trip (clamped addresses: a duplicate of the last entry changes nothing under the explicit tie rule)
-    for (uint32_t e0 = 0; e0 < n_o; e0 += 4u * (uint32_t) LPQ) {
-        float4 v[4];
+    // The members differ in colour only (their geometric term is qq for all of them): chunks of 8 consecutive entries — neighbours on the
+    // representative grid where the invalid points form regions: similar colours — have a colour box each (k_list_boxes), and a chunk whose
+    // bound fma (a, pho (box), qq) is ABOVE the query's bound holds no winner and no tie (<=, not <: the list is visited behind the tiles, a
+    // member may tie with the best so far at a lower index).  Lane ss tests chunk cb + ss; the chunks that pass are evaluated one entry per
+    // lane.  (Every invalid query of a region scanning every invalid representative made a wave of them cost twice a wave of valid queries.)
+    if (n_o <= 128u) {
+        // (a short list as it comes, four entries per lane and memory round trip: up to 128 entries the tests below cost more than the entries
+        // they save — |F| = 16384 x 64 with 10 - 30 % invalid points, 26 - 77 entries: 2.33 - 2.54 against 2.44 - 2.66 us)
+        for (uint32_t e0 = 0; e0 < n_o; e0 += 4u * (uint32_t) LPQ) {
+            float4 v[4];
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) v[k] = OL[1u + min (e0 + ss + k * (uint32_t) LPQ, n_o - 1u)];
+            for (uint32_t k = 0; k < 4u; ++k) v[k] = OL[1u + min (e0 + ss + k * (uint32_t) LPQ, n_o - 1u)];
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const float dr_ = qr - v[k].x, dg_ = qg - v[k].y, db_ = qb - v[k].z;
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const float dr_ = qr - v[k].x, dg_ = qg - v[k].y, db_ = qb - v[k].z;
+                const float d = __builtin_fmaf (alpha, __builtin_fmaf (db_, db_, __builtin_fmaf (dg_, dg_, dr_ * dr_)), qq);
+                const uint32_t idx = __float_as_uint (v[k].w);
+                if (need && (d < best || (d == best && idx < bid))) { best = d; bid = idx; }
+            }
+        }
+        return;
+    }
+    const float4 *BX = OL + 1u + nr;
+    const uint32_t n_oc = (n_o + 7u) >> 3;
+    for (uint32_t cb = 0; cb < n_oc; cb += (uint32_t) LPQ) {
+        const uint32_t c = min (cb + ss, n_oc - 1u);
+        const float4 lo = BX[2u * c], hi = BX[2u * c + 1u];
+        const float er = fmaxf (fmaxf (lo.x - qr, qr - hi.x), 0.f), eg = fmaxf (fmaxf (lo.y - qg, qg - hi.y), 0.f), eb = fmaxf (fmaxf (lo.z - qb, qb - hi.z), 0.f);
+        const float bound = __builtin_fmaf (alpha, __builtin_fmaf (eb, eb, __builtin_fmaf (eg, eg, er * er)), qq);
+        const float lim2 = fminf (lim, ks_grp_min_f<LPQ> (best));
+        const bool pass = need && cb + ss < n_oc && bound <= lim2;
+        const unsigned long long bal = __ballot (pass);
+        uint32_t mask = (uint32_t) (bal >> (lane & (64u - (uint32_t) LPQ))) & ((1u << LPQ) - 1u);      // bit k: chunk cb + k, for this query
+        while (__ballot (mask != 0u)) {
+            const bool live = mask != 0u;
+            const uint32_t e = 8u * (cb + (live ? (uint32_t) __builtin_ctz (mask) : 0u)) + (ss & 7u);
+            mask &= mask - 1u;
+            const float4 v = OL[1u + min (e, n_o - 1u)];              // (clamped: a duplicate of the last entry changes nothing under the explicit tie rule)
+            const float dr_ = qr - v.x, dg_ = qg - v.y, db_ = qb - v.z;
             const float d = __builtin_fmaf (alpha, __builtin_fmaf (db_, db_, __builtin_fmaf (dg_, dg_, dr_ * dr_)), qq);
-            const uint32_t idx = __float_as_uint (v[k].w);
-            if (need && (d < best || (d == best && idx < bid))) { best = d; bid = idx; }
+            const uint32_t idx = __float_as_uint (v.w);
+            if (live && (d < best || (d == best && idx < bid))) { best = d; bid = idx; }
         }
     }
 }
@@ -1457,7 +1486,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             asm volatile ("" : "+s"(ol_));
             const icp_params *po = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) ol_;
             typedef float4 __attribute__ ((address_space (1))) *gf4;
-            ks_origin_list<KS_SPLIT> ((const float4 *) (gf4) po->OL + (size_t) b * (nr + 1u), n_origin, qx, qy, qz, qr, qg, qb, alpha, s1_lim, ss, best, bid);
+            ks_origin_list<KS_SPLIT> ((const float4 *) (gf4) po->OL + (size_t) b * ICP_OL_STRIDE (nr), n_origin, nr, qx, qy, qz, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
         }
     }
     KS_KEEP (best, bid)

@@ -50,7 +50,7 @@ static int track_prepare (icp_context *h)
             return e == hipSuccess ? ICP_OK : fail (h, ICP_ENOMEM, std::string ("tracking (second RBC set): ") + hipGetErrorString (e));
         };
         int rc;
-        if (!b.R && ((rc = al ((void **) &b.R, (size_t) p.nr * 32)) || (rc = al ((void **) &b.GB, (size_t) 2 * (p.n16 + p.n1k) * 16)) || (rc = al ((void **) &b.LB, (size_t) 3 * p.nlb * 16)) || (rc = al ((void **) &b.OL, (size_t) (p.nr + 1u) * 16)) || (rc = al ((void **) &b.XP, (size_t) p.m * 32)) ||
+        if (!b.R && ((rc = al ((void **) &b.R, (size_t) p.nr * 32)) || (rc = al ((void **) &b.GB, (size_t) 2 * (p.n16 + p.n1k) * 16)) || (rc = al ((void **) &b.LB, (size_t) 3 * p.nlb * 16)) || (rc = al ((void **) &b.OL, (size_t) ICP_OL_STRIDE (p.nr) * 16)) || (rc = al ((void **) &b.XP, (size_t) p.m * 32)) ||
             (rc = al ((void **) &b.XQ, (size_t) p.m * 32)) || (rc = al ((void **) &b.rep_src, (size_t) p.nr * 4)) || (rc = al ((void **) &b.owner, (size_t) p.m * 4)) ||
             (rc = al ((void **) &b.N, (size_t) p.nr * 4)) || (rc = al ((void **) &b.O, (size_t) p.nr * 4)) || (rc = al ((void **) &b.perm, (size_t) p.m * 4)) ||
             (rc = al ((void **) &b.chunk_hist, (size_t) p.nchunk * p.nr * 4)) || (rc = al ((void **) &b.blist, (size_t) p.nb * 64 * 8)) ||

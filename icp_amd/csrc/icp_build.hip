@@ -167,14 +167,22 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
         // per 64 representatives)
         float4 *OL = p.OL + (size_t) b * ICP_OL_STRIDE (p.nr);
         uint32_t run = 0u;
-        for (uint32_t r0 = 0; r0 < p.nr; r0 += 64u) {
-            const uint32_t r = r0 + lane;
-            float4 v = make_float4 (1.f, 1.f, 1.f, 0.f), c = v;
-            if (r < p.nr) { const uint32_t src = rep_src_index (p, r); v = F4[2 * (size_t) src]; c = F4[2 * (size_t) src + 1]; }
-            const bool at0 = r < p.nr && v.x == 0.f && v.y == 0.f && v.z == 0.f;
-            const unsigned long long bal = __ballot (at0);
-            if (at0) OL[1u + run + (uint32_t) __builtin_popcountll (bal & ((1ull << lane) - 1ull))] = make_float4 (c.x, c.y, c.z, __uint_as_float (r));
-            run += (uint32_t) __builtin_popcountll (bal);
+        for (uint32_t r0 = 0; r0 < p.nr; r0 += 8u * 64u) {           // eight passes' loads in flight (one wave walks the whole set: 4096 representatives
+            float4 v[8], c[8];                                        // one pass at a time were 64 dependent round trips, 10 -> 29 us for this kernel)
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) {
+                const uint32_t r = r0 + 64u * u + lane;
+                v[u] = make_float4 (1.f, 1.f, 1.f, 0.f); c[u] = v[u];
+                if (r < p.nr) { const uint32_t src = rep_src_index (p, r); v[u] = F4[2 * (size_t) src]; c[u] = F4[2 * (size_t) src + 1]; }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) {
+                const uint32_t r = r0 + 64u * u + lane;
+                const bool at0 = r < p.nr && v[u].x == 0.f && v[u].y == 0.f && v[u].z == 0.f;
+                const unsigned long long bal = __ballot (at0);
+                if (at0) OL[1u + run + (uint32_t) __builtin_popcountll (bal & ((1ull << lane) - 1ull))] = make_float4 (c[u].x, c[u].y, c[u].z, __uint_as_float (r));
+                run += (uint32_t) __builtin_popcountll (bal);
+            }
         }
         // colour boxes of the chunks of 8 consecutive entries (ks_origin_list tests a chunk before it scans it — the owner search of THIS
         // construction already does, so the boxes cannot wait for a later launch): the wave reads its own entries back behind a fence
@@ -496,12 +504,17 @@ __global__ __launch_bounds__ (256) void k_list_boxes (icp_params p)
 {
     const uint32_t r = blockIdx.x, b = blockIdx.y, l = threadIdx.x & 15u, row = threadIdx.x >> 4;
     const uint32_t n = p.N[(size_t) b * p.nr + r];
-    if (n <= 16u) return;
+    // (only what the scans ask for: a list's first ICP_S2_UNCOND = 128 positions are always scanned as they come — ks_stage2_lanes; a wave
+    // whose longest list has more than 256 tests every list of its queries from chunk 8 on: ks_list_tail —; on a clean frame of the
+    // reference's size every block of this kernel leaves here)
+    // (lanes = candidates — p.s2wave: a list's first ICP_S2W_UNCOND = 1024 positions are scanned wave-cooperatively, the tail from chunk 64 on)
+    const uint32_t n_min = p.s2wave ? 1024u : 128u, c_first = p.s2wave ? 64u : 8u;
+    if (n <= n_min) return;
     const uint32_t o = p.O[(size_t) b * p.nr + r], nch = (n + 15u) >> 4;
     const float4 *Q4 = reinterpret_cast<const float4 *> (p.XQ + (size_t) b * p.m * 8);
     float4 *LB = p.LB + (size_t) b * 3 * p.nlb;
     const float inf = __builtin_inff ();
-    for (uint32_t c = 1u + row; c < nch; c += 16u) {
+    for (uint32_t c = c_first + row; c < nch; c += 16u) {
         const uint32_t j = 16u * c + l;
         float lo[6] = { inf, inf, inf, inf, inf, inf }, hi[6] = { -inf, -inf, -inf, -inf, -inf, -inf };
         if (j < n) {

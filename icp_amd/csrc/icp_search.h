@@ -14,10 +14,11 @@
 //   ks_stage2_lanes<LPQ>         stage 2, a query's lanes scan its list; exact chunk-box pruning beyond the first 128 positions of long lists
 //   ks_epilogue<...>             hand-off to the finishing wave, winner record, weights, per-query outputs, block moments / weight tree
 //   ks_owner_lists_tail          RBC construct of the latency-bound sizes: what the owner search leaves for k_place_lists
+//   ks_coarse_pass / ks_fine_pass  stage 1 over one LDS tile of representatives: group-box tests, then the groups some query of the wave needs
+//                                (free functions with plain scalar parameters: with the query passed as a struct the 64-register variants spilled)
 //   k_search<...>                the kernel: PROLOGUE (every independent load issued before the first wait; chained form: the previous
-//                                iteration's finalize), STAGE 1 (nearest representative: the coarse / fine passes over one LDS tile are the
-//                                lambdas coarse_pass / fine_pass, their drivers — MASKED: tile set decided once; else a tile loop — follow
-//                                them; kept inside the kernel: as free functions the 64-register variants spill, measured), then the calls above
+//                                iteration's finalize), the STAGE 1 drivers (MASKED: tile set decided once; else a tile loop; the origin list),
+//                                then the calls above
 //   host side                    icp_tpr_magic, KS_FLAGS, KS_ARGS
 #pragma once
 #include "icp_kernels.h"
@@ -938,6 +939,78 @@ static __device__ __forceinline__ void ks_owner_lists_tail (const icp_params &p,
     return;
 }
 
+// ------------------------------------------------------------------------------------------
+// stage 1 (nearest representative) — the two passes over one tile of representatives in LDS; their drivers (which tiles, in which order,
+// behind which barriers: MASKED / the tile loop) are in k_search.
+// ------------------------------------------------------------------------------------------
+// coarse pass of the pruning over the groups of the tile in LDS (box[box0 ..]: the tile's (lo, hi) pairs): bit t of the result = this lane's
+// t-th group (ss, ss + LPQ, ..) may hold a representative nearer than `lim`.  The lower bound applies the metric's own operations to the
+// per-axis distances to the group's bounding box; every operation is monotone under round-to-nearest, so bound <= geo <= d for every
+// member, and a group whose bound is not below `lim` cannot hold the winner.
+template <int LPQ, int TILE>
+static __device__ __forceinline__ uint32_t ks_coarse_pass (const float4 *s_box, uint32_t box0, float qx, float qy, float qz, uint32_t ss, uint32_t tn_, float lim_)
+{
+    const uint32_t ngt = (((tn_ + 1u) >> 1) + KS_SPLIT - 1u) / KS_SPLIT;
+    uint32_t cm = 0u;
+    auto test = [&] (uint32_t t, uint32_t g) {
+        const float4 lo = s_box[box0 + 2 * g], hi = s_box[box0 + 2 * g + 1];
+        const float ex = fmaxf (fmaxf (lo.x - qx, qx - hi.x), 0.f);
+        const float ey = fmaxf (fmaxf (lo.y - qy, qy - hi.y), 0.f);
+        const float ez = fmaxf (fmaxf (lo.z - qz, qz - hi.z), 0.f);
+        const float bound = __builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex));
+        if (bound < lim_) cm |= 1u << t;
+    };
+    if constexpr (TILE == 256) {                     // at most two trips per lane: not unrolled (the 64-register budget of this variant)
+#pragma unroll 1
+        for (uint32_t t = 0, g = ss; g < ngt; ++t, g += KS_SPLIT) test (t, g);
+    } else
+        for (uint32_t t = 0, g = ss; g < ngt; ++t, g += KS_SPLIT) test (t, g);
+    return cm;
+}
+
+// fine pass of the pruning over the tile in LDS (s_pair[pair0 ..]; first representative t0_, npair_ pairs): the groups whose bit is set in
+// cmask_ for some query of the wave, in ascending order (a lane's pairs must ascend for the tie rule), full evaluation.
+// (scalar control flow: the lane ballot of trip t is folded over the wave's queries into one bit per group and only the set bits are
+// visited — a taken branch costs more than the arithmetic it guards)
+template <int LPQ>
+static __device__ __forceinline__ void ks_fine_pass (const float4 *s_pair, uint32_t pair0, float qx, float qy, float qz, float qr, float qg, float qb, float alpha,
+                                                     uint32_t gt_lg1, uint32_t ss, uint32_t t0_, uint32_t npair_, uint32_t cmask_, float &best, uint32_t &bid)
+{
+    const uint32_t ngt_ = (npair_ + KS_SPLIT - 1u) / KS_SPLIT;
+    const float2v vqx = { qx, qx }, vqy = { qy, qy }, vqz = { qz, qz }, vqr = { qr, qr }, vqg = { qg, qg }, vqb = { qb, qb };
+    const float2v va = { alpha, alpha };
+    for (uint32_t t = 0; t * KS_SPLIT < ngt_; ++t) {
+        unsigned long long bal = __ballot ((cmask_ >> t) & 1u);
+        if (bal == 0ull) continue;
+        bal |= bal >> 32; bal |= bal >> 16;
+        if (KS_SPLIT == 8) bal |= bal >> 8;
+        uint32_t need = (uint32_t) bal & ((1u << KS_SPLIT) - 1u);
+        while (need) {
+            const uint32_t sg = (uint32_t) __builtin_ctz (need);
+            need &= need - 1u;
+            // pair of this lane in group gl of the LDS tile.  Strips: the group's 16 consecutive representatives.
+            // Tiles (LPQ == 8): lane ss holds row ss >> 1, columns 2 (ss & 1) and + 1 of the 4 x 4 tile; groups are
+            // visited in ascending (tile row, tile column) order, so every lane's pairs still ascend in index —
+            // what the tie rule (strict '<' keeps a lane's lowest index) relies on.
+            const uint32_t gl = sg + KS_SPLIT * t;
+            const uint32_t P = (KS_SPLIT == 8 && gt_lg1) ? (((4u * (gl >> (gt_lg1 - 1u)) + (ss >> 1)) << gt_lg1) + 2u * (gl & ((1u << (gt_lg1 - 1u)) - 1u)) + (ss & 1u))
+                                                          : gl * KS_SPLIT + ss;
+            if (P < npair_) {
+                const uint32_t P3 = pair0 + __umul24 (P, 3u);        // (24-bit multiply: full rate; a 32-bit v_mul_lo costs four issue slots)
+                float4 A = s_pair[P3], B = s_pair[P3 + 1], C = s_pair[P3 + 2];
+                float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
+                float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
+                float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
+                float2v pho = __builtin_elementwise_fma (db, db, __builtin_elementwise_fma (dg, dg, dr * dr));
+                float2v d = __builtin_elementwise_fma (va, pho, geo);
+                const uint32_t r0 = t0_ + 2u * P;
+                if (d.x < best) { best = d.x; bid = r0; }
+                if (d.y < best) { best = d.y; bid = r0 + 1u; }
+            }
+        }
+    }
+}
+
 // CHAIN (fused mode only): launch j reads state slot j&1 and the moments buffer j&1, turns the previous
 // iteration's moments into T in its prologue (every block redundantly; block 0 publishes the result in the
 // other slot), searches, and leaves its own moments in the other buffer: ONE launch per ICP iteration.
@@ -1222,69 +1295,6 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // ==================================================== STAGE 1 =====================================================
     // ---- stage 1: nearest representative, two representatives per packed instruction ----
     float best = __builtin_inff (), s1_lim = __builtin_inff (); uint32_t bid = 0xFFFFFFFFu;
-    // coarse pass of the pruning over the groups of the tile in LDS (s_box): bit t of the result = this lane's t-th
-    // group (ss, ss + LPQ, ..) may hold a representative nearer than `lim`.  The lower bound applies the metric's own
-    // operations to the per-axis distances to the group's bounding box; every operation is monotone under
-    // round-to-nearest, so bound <= geo <= d for every member, and a group whose bound is not below `lim` cannot hold the winner.
-    auto coarse_pass = [&] (uint32_t tn_, float lim_, uint32_t hb_ = 0u) -> uint32_t {
-        const uint32_t ngt = (((tn_ + 1u) >> 1) + KS_SPLIT - 1u) / KS_SPLIT;
-        uint32_t cm = 0u;
-        auto test = [&] (uint32_t t, uint32_t g) {
-            const float4 lo = s_box[hb_ * BB + 2 * g], hi = s_box[hb_ * BB + 2 * g + 1];
-            const float ex = fmaxf (fmaxf (lo.x - qx, qx - hi.x), 0.f);
-            const float ey = fmaxf (fmaxf (lo.y - qy, qy - hi.y), 0.f);
-            const float ez = fmaxf (fmaxf (lo.z - qz, qz - hi.z), 0.f);
-            const float bound = __builtin_fmaf (ez, ez, __builtin_fmaf (ey, ey, ex * ex));
-            if (bound < lim_) cm |= 1u << t;
-        };
-        if constexpr (TILE == 256) {                 // at most two trips per lane: not unrolled (the 64-register budget of this variant)
-#pragma unroll 1
-            for (uint32_t t = 0, g = ss; g < ngt; ++t, g += KS_SPLIT) test (t, g);
-        } else
-            for (uint32_t t = 0, g = ss; g < ngt; ++t, g += KS_SPLIT) test (t, g);
-        return cm;
-    };
-    // fine pass of the pruning over the tile in LDS (first representative t0_, npair_ pairs): the groups whose bit is set in
-    // cmask_ for some query of the wave, full evaluation.
-    auto fine_pass = [&] (uint32_t t0_, uint32_t npair_, uint32_t cmask_, uint32_t hb_ = 0u) {
-        const uint32_t ngt_ = (npair_ + KS_SPLIT - 1u) / KS_SPLIT;
-        const float2v vqx = { qx, qx }, vqy = { qy, qy }, vqz = { qz, qz }, vqr = { qr, qr }, vqg = { qg, qg }, vqb = { qb, qb };
-        const float2v va = { alpha, alpha };
-        // fine pass: the groups some query of the wave still needs, in ascending order (a lane's pairs must ascend
-        // for the tie rule), full evaluation
-        // (scalar control flow: the lane ballot of trip t is folded over the wave's queries into one bit per group
-        // and only the set bits are visited — a taken branch costs more than the arithmetic it guards)
-        for (uint32_t t = 0; t * KS_SPLIT < ngt_; ++t) {
-            unsigned long long bal = __ballot ((cmask_ >> t) & 1u);
-            if (bal == 0ull) continue;
-            bal |= bal >> 32; bal |= bal >> 16;
-            if (KS_SPLIT == 8) bal |= bal >> 8;
-            uint32_t need = (uint32_t) bal & ((1u << KS_SPLIT) - 1u);
-            while (need) {
-                const uint32_t sg = (uint32_t) __builtin_ctz (need);
-                need &= need - 1u;
-                // pair of this lane in group gl of the LDS tile.  Strips: the group's 16 consecutive representatives.
-                // Tiles (LPQ == 8): lane ss holds row ss >> 1, columns 2 (ss & 1) and + 1 of the 4 x 4 tile; groups are
-                // visited in ascending (tile row, tile column) order, so every lane's pairs still ascend in index —
-                // what the tie rule (strict '<' keeps a lane's lowest index) relies on.
-                const uint32_t gl = sg + KS_SPLIT * t;
-                const uint32_t P = (KS_SPLIT == 8 && gt_lg1) ? (((4u * (gl >> (gt_lg1 - 1u)) + (ss >> 1)) << gt_lg1) + 2u * (gl & ((1u << (gt_lg1 - 1u)) - 1u)) + (ss & 1u))
-                                                              : gl * KS_SPLIT + ss;
-                if (P < npair_) {
-                    const uint32_t P3 = hb_ * PB + __umul24 (P, 3u);       // (24-bit multiply: full rate; a 32-bit v_mul_lo costs four issue slots)
-                    float4 A = s_pair[P3], B = s_pair[P3 + 1], C = s_pair[P3 + 2];
-                    float2v x = { A.x, A.y }, y = { A.z, A.w }, z = { B.x, B.y }, r = { B.z, B.w }, g = { C.x, C.y }, bb = { C.z, C.w };
-                    float2v dx = vqx - x, dy = vqy - y, dz = vqz - z, dr = vqr - r, dg = vqg - g, db = vqb - bb;
-                    float2v geo = __builtin_elementwise_fma (dz, dz, __builtin_elementwise_fma (dy, dy, dx * dx));
-                    float2v pho = __builtin_elementwise_fma (db, db, __builtin_elementwise_fma (dg, dg, dr * dr));
-                    float2v d = __builtin_elementwise_fma (va, pho, geo);
-                    const uint32_t r0 = t0_ + 2u * P;
-                    if (d.x < best) { best = d.x; bid = r0; }
-                    if (d.y < best) { best = d.y; bid = r0 + 1u; }
-                }
-            }
-        }
-    };
     if constexpr (MASKED) {
         __syncthreads ();                            // the queries (s_qa / s_qc), the tile boxes, s_tmask = 0
         {
@@ -1356,8 +1366,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             if (prune) {
                 const bool mine = ((qmask >> tl) & 1u) != 0u;
                 uint32_t cmask = 0u;
-                if (__ballot (mine)) cmask = coarse_pass (tn, mine ? s1_lim : -__builtin_inff (), hb);
-                fine_pass (t0, npair, cmask, hb);
+                if (__ballot (mine)) cmask = ks_coarse_pass<LPQ, TILE> (s_box, hb * BB, qx, qy, qz, ss, tn, mine ? s1_lim : -__builtin_inff ());
+                ks_fine_pass<LPQ> (s_pair, hb * PB, qx, qy, qz, qr, qg, qb, alpha, gt_lg1, ss, t0, npair, cmask, best, bid);
                 s1_lim = fminf (s1_lim, ks_grp_min_f<KS_SPLIT> (best));
             } else {
                 const float2v vqx = { qx, qx }, vqy = { qy, qy }, vqz = { qz, qz }, vqr = { qr, qr }, vqg = { qg, qg }, vqb = { qb, qb };
@@ -1398,7 +1408,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
                 const uint32_t nbx = 2u * ((tn + 2u * KS_SPLIT - 1u) / (2u * KS_SPLIT));
                 for (uint32_t k = tid; k < nbx; k += 64 * KS_SPLIT) s_box[k] = GBt[2u * (t0 / (2u * KS_SPLIT)) + k];
                 __syncthreads ();
-                if (__ballot (near)) cmask = coarse_pass (tn, s1_lim);
+                if (__ballot (near)) cmask = ks_coarse_pass<LPQ, TILE> (s_box, 0u, qx, qy, qz, ss, tn, s1_lim);
                 if (!__syncthreads_or (cmask != 0u)) continue;
             }
             for (uint32_t k = tid; k < tn; k += 64 * KS_SPLIT) {
@@ -1454,8 +1464,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         if (prune) {
             // coarse pass: a group = the 2 * LPQ representatives of one trip of the query's lanes; lane ss tests the
             // groups ss, ss + LPQ, ..  (further tiles: done above, before the tile was staged)
-            if (t0 == 0 && __ballot (tile_near (lim))) cmask = coarse_pass (tn, lim);
-            fine_pass (t0, npair, cmask);
+            if (t0 == 0 && __ballot (tile_near (lim))) cmask = ks_coarse_pass<LPQ, TILE> (s_box, 0u, qx, qy, qz, ss, tn, lim);
+            ks_fine_pass<LPQ> (s_pair, 0u, qx, qy, qz, qr, qg, qb, alpha, gt_lg1, ss, t0, npair, cmask, best, bid);
             s1_lim = fminf (lim, ks_grp_min_f<KS_SPLIT> (best));
         } else {
 #pragma unroll 8

@@ -61,6 +61,23 @@ int main ()
         orc_exscan_u32 (n.data (), 257, ex.data ());
         if (ex[256] != 768u) ++bad;
     }
+    // round 5's generator entries: invalid points punched into ragged grids (both patterns, ellipses clipped at every border), the wall scene
+    {
+        const float axis[3] = { 0.3f, 0.9f, 0.1f }, t[3] = { 8.f, -4.f, 0.f };
+        for (uint32_t side : { 1u, 7u, 30u, 64u }) {
+            std::vector<float> F ((size_t) side * side * 8), M (F.size ());
+            float Tt[8];
+            for (int scene = 0; scene < 2; ++scene)
+                if (icp_synth_pair_scene (5, side, scene, 2.f, axis, t, 1.f, 0.01f, F.data (), M.data (), scene ? Tt : nullptr)) ++bad;
+            for (int pattern = 0; pattern < 2; ++pattern)
+                for (float fr : { 0.f, 0.3f, 1.f })
+                    if (icp_synth_punch_holes (9 + side, side, side, pattern, fr, pattern, F.data ())) ++bad;
+        }
+        std::vector<float> cloud ((size_t) 640 * 480 * 8);
+        if (icp_synth_cloud_vga (1, 1, cloud.data ()) || icp_synth_punch_holes (3, 640, 480, 1, 0.3f, 1, cloud.data ())) ++bad;
+        if (icp_synth_punch_holes (3, 640, 480, 2, 0.3f, 1, cloud.data ()) == 0) ++bad;          // (unknown pattern: refused)
+        if (icp_synth_pair_scene (5, 8, 3, 2.f, axis, t, 1.f, 0.01f, cloud.data (), cloud.data (), nullptr) == 0) ++bad;
+    }
     // rejected arguments must not touch memory
     {
         orc_icp *o = orc_icp_create (1, 1);

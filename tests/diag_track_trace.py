@@ -11,6 +11,8 @@ frames = [icp_amd.synth_cloud_vga(moved=f) for f in range(5)]
 order = [0, 1, 2, 3, 4, 3, 2, 1]
 seq = [frames[order[i % len(order)]] for i in range(hops + 8)]
 g = icp_amd.ICP(0); g.init(16384, 256, 2e2, 1e-6)
+if int(os.environ.get("REG", "0")):                   # the frame buffers registered as DMA sources (round 5)
+    for fr in frames: g.track_register(fr)
 g.track_pipelined(seq[:8], warm_start=warm); g.sync()
 if pinned:
     g.track_reset()

@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda x: x[0])
 def kind(n):
     if "k_gate" in n: return "gate"
-    if "k_place_lists" in n: return "build"
+    if "k_place_lists" in n or "k_list_boxes" in n: return "build"
     if "k_search" in n and "2, 16, true" in n: return "build"          # the owner search
     if "k_search" in n and "true, true, 2, 16" in n: return "search"
     if "k_get_lms" in n: return "lms"

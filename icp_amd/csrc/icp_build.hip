@@ -117,6 +117,36 @@ __global__ __launch_bounds__ (256) void k_transform_cloud_ex (const float4 *in, 
 // buildRBC
 // ------------------------------------------------------------------------------------------
 
+#define ICP_ORIGIN_SOLO 16u       // k_reps_and_boxes: up to this many blocks of 64 representatives, one wave lists those at the origin by itself
+
+// the end of the list of the representatives at the origin (k_reps_and_boxes): colour boxes of its chunks, its length where the search reads it
+static __device__ __forceinline__ void origin_list_close (const icp_params &p, uint32_t b, uint32_t lane, float4 *OL, uint32_t run)
+{
+    const float inf = __builtin_inff ();
+    // colour boxes of the chunks of 8 consecutive entries (ks_origin_list tests a chunk before it scans it — the owner search of THIS
+    // construction already does, so the boxes cannot wait for a later launch): the wave reads its own entries back behind a fence
+    __threadfence ();
+    {
+        float4 *BX = OL + 1u + p.nr;
+        const uint32_t n_oc = (run + 7u) >> 3;
+        for (uint32_t c = lane; c < n_oc; c += 64u) {
+            float4 lo = make_float4 (inf, inf, inf, 0.f), hi = make_float4 (-inf, -inf, -inf, 0.f);
+            for (uint32_t e = 8u * c; e < min (8u * c + 8u, run); ++e) {
+                const float4 v = OL[1u + e];
+                lo.x = fminf (lo.x, v.x); lo.y = fminf (lo.y, v.y); lo.z = fminf (lo.z, v.z);
+                hi.x = fmaxf (hi.x, v.x); hi.y = fmaxf (hi.y, v.y); hi.z = fmaxf (hi.z, v.z);
+            }
+            BX[2u * c] = lo; BX[2u * c + 1u] = hi;
+        }
+    }
+    if (lane == 0) {
+        OL[0] = make_float4 (__uint_as_float (run), 0.f, 0.f, 0.f);      // (.y: the arrival counter, back at zero for the next construction)
+        // the number the search reads: a spare lane of the box array (hi.w of the first tile box: nobody else writes that word)
+        reinterpret_cast<float *> (p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + 1u)[3] = __uint_as_float (run);      // tile box 0, hi.w
+        reinterpret_cast<float *> (p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 1u)[3] = __uint_as_float (run);                    // group box 0, hi.w
+    }
+}
+
 // a1 + the boxes of the stage-1 pruning, ONE launch of 64-thread blocks with three kinds of duty (buildRBC is a chain of
 // small dependent launches: every launch saved is ~4 us of its ~40 at |F| = 16384):
 //   blocks [0, nbr)            the representatives: R[r] = F[src (r)], rep_src[r] = src (r)                     (getReps)
@@ -126,9 +156,10 @@ __global__ __launch_bounds__ (256) void k_transform_cloud_ex (const float4 *in, 
 //                              bound instead of 3.3 - 8.8 with 16 x 1 strips), else 16 consecutive representatives
 //   blocks [nbr + nbg, ..)     the box of every LDS tile of the dense k_search for multi-tile sets (p.tbox consecutive
 //                              representatives: 256, or 1024 for the largest sets), one wave per box
-//   the last block             the representatives at the origin (a frame's invalid points), colour + index, ascending: they stay out
-//                              of every box above (one such member would stretch a box from the scene to the origin) and are scanned
-//                              as a list of their own by the queries that are near the origin (k_search: ks_origin_list)
+//   (the block of the first kind that finishes last) the representatives at the origin (a frame's invalid points), colour + index,
+//                              ascending: they stay out of every box above (one such member would stretch a box from the scene to the
+//                              origin) and are scanned as a list of their own by the queries that are near the origin (k_search:
+//                              ks_origin_list)
 // The boxes read the representatives' points from F at src (r): they do not wait for R.  fminf / fmaxf skip NaN
 // coordinates: a representative with a NaN coordinate never wins a '<' anyway; min / max are exact in any order.
 __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t nbr, uint32_t nbg)
@@ -136,84 +167,130 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
     const uint32_t b = blockIdx.y, lane = threadIdx.x;
     const float4 *F4 = reinterpret_cast<const float4 *> (p.F + (size_t) b * p.m * 8);
     const float inf = __builtin_inff ();
+    const rep_src_map src_of (p);
     if (blockIdx.x < nbr) {
         const uint32_t r = blockIdx.x * 64u + lane;
-        if (r >= p.nr) return;
-        const uint32_t src = rep_src_index (p, r);
         float4 *R4 = reinterpret_cast<float4 *> (p.R + (size_t) b * p.nr * 8);
-        R4[2 * r] = F4[2 * (size_t) src];
-        R4[2 * r + 1] = F4[2 * (size_t) src + 1];
-        p.rep_src[(size_t) b * p.nr + r] = src;
+        bool at0 = false;
+        if (r < p.nr) {
+            const uint32_t src = src_of (r);
+            const float4 g = F4[2 * (size_t) src];
+            R4[2 * r] = g;
+            R4[2 * r + 1] = F4[2 * (size_t) src + 1];
+            p.rep_src[(size_t) b * p.nr + r] = src;
+            at0 = g.x == 0.f && g.y == 0.f && g.z == 0.f;
+        }
+        // The representatives at the origin (a frame's invalid points), listed in ascending order.  Large sets (more than ICP_ORIGIN_SOLO
+        // blocks of representatives): every block leaves the ballot of its 64, and the block that arrives last (a counter; nobody waits
+        // for anybody) compacts the list from the ballots and from R — one wave that walked all of F's 4096 sampled points by itself took
+        // 21 of this kernel's 27 us at |F| = 2^20.  Small sets: one more block walks them in one round of loads (below) — an arrival costs
+        // every block a release fence, 256 of them at 64 batched registrations of 256 representatives tripled this kernel's time.
+        if (nbr <= ICP_ORIGIN_SOLO) return;
+        float4 *OL = p.OL + (size_t) b * ICP_OL_STRIDE (p.nr);
+        unsigned long long *MK = reinterpret_cast<unsigned long long *> (OL + 1u + p.nr + 2u * ((p.nr + 7u) / 8u));
+        const unsigned long long bal = __ballot (at0);
+        uint32_t last = 0u;
+        if (lane == 0) MK[blockIdx.x] = bal;
+        __threadfence ();                                             // this block's R rows and ballot, before its arrival counts
+        if (lane == 0) last = __hip_atomic_fetch_add (reinterpret_cast<uint32_t *> (OL) + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nbr - 1u ? 1u : 0u;
+        if (!__builtin_amdgcn_readfirstlane (last)) return;
+        __threadfence ();                                             // the others' R rows and ballots
+        uint32_t run = 0u;
+        for (uint32_t i0 = 0; i0 < nbr; i0 += 64u) {                  // 64 ballots at a time: lane l holds ballot i0 + l and the number of entries in front of it
+            const unsigned long long mk = i0 + lane < nbr ? __hip_atomic_load (MK + i0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            const uint32_t cnt = (uint32_t) __builtin_popcountll (mk);
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up (incl, d); if ((int) lane >= d) incl += t; }
+            const uint32_t before = run + incl - cnt, mlo = (uint32_t) mk, mhi = (uint32_t) (mk >> 32);
+            if (__ballot (mk != 0ull)) {
+                for (uint32_t u0 = 0; u0 < 64u; u0 += 8u) {           // eight ballots' colour loads in flight
+                    float4 c[8]; uint32_t pos[8];
+#pragma unroll
+                    for (uint32_t k = 0; k < 8u; ++k) {
+                        const uint32_t lo_ = (uint32_t) __builtin_amdgcn_readlane ((int) mlo, (int) (u0 + k)), hi_ = (uint32_t) __builtin_amdgcn_readlane ((int) mhi, (int) (u0 + k));
+                        const unsigned long long m = ((unsigned long long) hi_ << 32) | lo_;
+                        const uint32_t base = (uint32_t) __builtin_amdgcn_readlane ((int) before, (int) (u0 + k));
+                        pos[k] = 0xffffffffu;
+                        if ((m >> lane) & 1ull) {
+                            pos[k] = base + (uint32_t) __builtin_popcountll (m & ((1ull << lane) - 1ull));
+                            c[k] = R4[2 * ((i0 + u0 + k) * 64u + lane) + 1];
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 8u; ++k)
+                        if (pos[k] != 0xffffffffu) OL[1u + pos[k]] = make_float4 (c[k].x, c[k].y, c[k].z, __uint_as_float ((i0 + u0 + k) * 64u + lane));
+                }
+            }
+            run += (uint32_t) __builtin_amdgcn_readlane ((int) incl, 63);
+        }
+        origin_list_close (p, b, lane, OL, run);
     } else if (blockIdx.x < nbr + nbg) {
         const uint32_t g = (blockIdx.x - nbr) * 64u + lane;
         if (g >= p.n16) return;
         float4 lo = make_float4 (inf, inf, inf, 0.f), hi = make_float4 (-inf, -inf, -inf, 0.f);
         const bool tiled = p.gtile != 0u;
         const uint32_t lg = p.gtile - 1u, ty = tiled ? g >> lg : 0u, tx = tiled ? g & ((1u << lg) - 1u) : 0u;
+        float4 v[16];                                                 // (all sixteen loads in flight, then the selects: a loop with an early
+#pragma unroll                                                        // `continue` is sixteen dependent round trips)
         for (uint32_t e = 0; e < 16u; ++e) {
             const uint32_t r = tiled ? (4u * ty + (e >> 2)) * p.nrx + 4u * tx + (e & 3u) : g * 16u + e;
-            if (r >= p.nr) continue;
-            const float4 v = F4[2 * (size_t) rep_src_index (p, r)];
-            if (v.x == 0.f && v.y == 0.f && v.z == 0.f) continue;     // an invalid point (at the origin): kept out of the box, listed in p.OL (k_search: ks_origin_list)
-            lo.x = fminf (lo.x, v.x); lo.y = fminf (lo.y, v.y); lo.z = fminf (lo.z, v.z);
-            hi.x = fmaxf (hi.x, v.x); hi.y = fmaxf (hi.y, v.y); hi.z = fmaxf (hi.z, v.z);
+            v[e] = make_float4 (0.f, 0.f, 0.f, 0.f);
+            if (r < p.nr) v[e] = F4[2 * (size_t) src_of (r)];
+        }
+#pragma unroll
+        for (uint32_t e = 0; e < 16u; ++e) {
+            // an invalid point (at the origin; so reads a slot beyond the set): kept out of the box, listed in p.OL (k_search: ks_origin_list)
+            const bool in = !(v[e].x == 0.f && v[e].y == 0.f && v[e].z == 0.f);
+            lo.x = fminf (lo.x, in ? v[e].x : inf); lo.y = fminf (lo.y, in ? v[e].y : inf); lo.z = fminf (lo.z, in ? v[e].z : inf);
+            hi.x = fmaxf (hi.x, in ? v[e].x : -inf); hi.y = fmaxf (hi.y, in ? v[e].y : -inf); hi.z = fmaxf (hi.z, in ? v[e].z : -inf);
         }
         float4 *GB = p.GB + (size_t) b * 2 * (p.n16 + p.n1k);
         GB[2 * g] = lo;
         float *hi3 = reinterpret_cast<float *> (GB + 2 * g + 1);          // (hi.w of group box 0 belongs to the block that lists the representatives at the origin)
         hi3[0] = hi.x; hi3[1] = hi.y; hi3[2] = hi.z;
-    } else if (blockIdx.x == gridDim.x - 1u) {
-        // the representatives at the origin, ascending: (r, g, b, index) each behind their number (one wave: a ballot and a running offset
-        // per 64 representatives)
+    } else if (nbr <= ICP_ORIGIN_SOLO && blockIdx.x == gridDim.x - 1u) {
+        // (small sets) the representatives at the origin: one wave, a ballot and a running offset per 64 representatives, all geometry
+        // loads in flight at once; the colour is fetched by the lanes that list an entry
         float4 *OL = p.OL + (size_t) b * ICP_OL_STRIDE (p.nr);
+        float4 v[ICP_ORIGIN_SOLO];
+#pragma unroll
+        for (uint32_t u = 0; u < ICP_ORIGIN_SOLO; ++u) {
+            const uint32_t r = 64u * u + lane;
+            v[u] = make_float4 (1.f, 1.f, 1.f, 0.f);
+            if (r < p.nr) v[u] = F4[2 * (size_t) src_of (r)];
+        }
         uint32_t run = 0u;
-        for (uint32_t r0 = 0; r0 < p.nr; r0 += 8u * 64u) {           // eight passes' loads in flight (one wave walks the whole set: 4096 representatives
-            float4 v[8], c[8];                                        // one pass at a time were 64 dependent round trips, 10 -> 29 us for this kernel)
 #pragma unroll
-            for (uint32_t u = 0; u < 8u; ++u) {
-                const uint32_t r = r0 + 64u * u + lane;
-                v[u] = make_float4 (1.f, 1.f, 1.f, 0.f); c[u] = v[u];
-                if (r < p.nr) { const uint32_t src = rep_src_index (p, r); v[u] = F4[2 * (size_t) src]; c[u] = F4[2 * (size_t) src + 1]; }
+        for (uint32_t u = 0; u < ICP_ORIGIN_SOLO; ++u) {
+            const uint32_t r = 64u * u + lane;
+            const bool at0 = r < p.nr && v[u].x == 0.f && v[u].y == 0.f && v[u].z == 0.f;
+            const unsigned long long bal = __ballot (at0);
+            if (at0) {
+                const float4 c = F4[2 * (size_t) src_of (r) + 1];
+                OL[1u + run + (uint32_t) __builtin_popcountll (bal & ((1ull << lane) - 1ull))] = make_float4 (c.x, c.y, c.z, __uint_as_float (r));
             }
-#pragma unroll
-            for (uint32_t u = 0; u < 8u; ++u) {
-                const uint32_t r = r0 + 64u * u + lane;
-                const bool at0 = r < p.nr && v[u].x == 0.f && v[u].y == 0.f && v[u].z == 0.f;
-                const unsigned long long bal = __ballot (at0);
-                if (at0) OL[1u + run + (uint32_t) __builtin_popcountll (bal & ((1ull << lane) - 1ull))] = make_float4 (c[u].x, c[u].y, c[u].z, __uint_as_float (r));
-                run += (uint32_t) __builtin_popcountll (bal);
-            }
+            run += (uint32_t) __builtin_popcountll (bal);
         }
-        // colour boxes of the chunks of 8 consecutive entries (ks_origin_list tests a chunk before it scans it — the owner search of THIS
-        // construction already does, so the boxes cannot wait for a later launch): the wave reads its own entries back behind a fence
-        __threadfence ();
-        {
-            float4 *BX = OL + 1u + p.nr;
-            const uint32_t n_oc = (run + 7u) >> 3;
-            for (uint32_t c = lane; c < n_oc; c += 64u) {
-                float4 lo = make_float4 (inf, inf, inf, 0.f), hi = make_float4 (-inf, -inf, -inf, 0.f);
-                for (uint32_t e = 8u * c; e < min (8u * c + 8u, run); ++e) {
-                    const float4 v = OL[1u + e];
-                    lo.x = fminf (lo.x, v.x); lo.y = fminf (lo.y, v.y); lo.z = fminf (lo.z, v.z);
-                    hi.x = fmaxf (hi.x, v.x); hi.y = fmaxf (hi.y, v.y); hi.z = fmaxf (hi.z, v.z);
-                }
-                BX[2u * c] = lo; BX[2u * c + 1u] = hi;
-            }
-        }
-        if (lane == 0) {
-            OL[0] = make_float4 (__uint_as_float (run), 0.f, 0.f, 0.f);
-            // the number the search reads: a spare lane of the box array (hi.w of the first tile box: nobody else writes that word)
-            reinterpret_cast<float *> (p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + 1u)[3] = __uint_as_float (run);      // tile box 0, hi.w
-            reinterpret_cast<float *> (p.GB + (size_t) b * 2 * (p.n16 + p.n1k) + 1u)[3] = __uint_as_float (run);                    // group box 0, hi.w
-        }
+        origin_list_close (p, b, lane, OL, run);
     } else {
         const uint32_t tile = blockIdx.x - nbr - nbg;
         float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
-        for (uint32_t r = tile * p.tbox + lane; r < min (p.nr, (tile + 1u) * p.tbox); r += 64u) {
-            const float4 v = F4[2 * (size_t) rep_src_index (p, r)];
-            if (v.x == 0.f && v.y == 0.f && v.z == 0.f) continue;
-            lo[0] = fminf (lo[0], v.x); lo[1] = fminf (lo[1], v.y); lo[2] = fminf (lo[2], v.z);
-            hi[0] = fmaxf (hi[0], v.x); hi[1] = fmaxf (hi[1], v.y); hi[2] = fmaxf (hi[2], v.z);
+        const uint32_t r_end = min (p.nr, (tile + 1u) * p.tbox);
+        for (uint32_t r0 = tile * p.tbox; r0 < r_end; r0 += 16u * 64u) {      // (sixteen passes' loads in flight: p.tbox = 256 or 1024)
+            float4 v[16];
+#pragma unroll
+            for (uint32_t u = 0; u < 16u; ++u) {
+                const uint32_t r = r0 + 64u * u + lane;
+                v[u] = make_float4 (0.f, 0.f, 0.f, 0.f);
+                if (r < r_end) v[u] = F4[2 * (size_t) src_of (r)];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 16u; ++u) {
+                const bool in = !(v[u].x == 0.f && v[u].y == 0.f && v[u].z == 0.f);
+                lo[0] = fminf (lo[0], in ? v[u].x : inf); lo[1] = fminf (lo[1], in ? v[u].y : inf); lo[2] = fminf (lo[2], in ? v[u].z : inf);
+                hi[0] = fmaxf (hi[0], in ? v[u].x : -inf); hi[1] = fmaxf (hi[1], in ? v[u].y : -inf); hi[2] = fmaxf (hi[2], in ? v[u].z : -inf);
+            }
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1)
@@ -659,7 +736,7 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
     }
     {   // the representatives, the boxes of their pruning groups and (several tiles only) of the LDS tiles: one launch
         const uint32_t nbr = (p.nr + 63u) / 64u, nbg = (p.n16 + 63u) / 64u, nbt = p.nr > p.tbox ? p.n1k : 0u;
-        hipLaunchKernelGGL (k_reps_and_boxes, dim3 (nbr + nbg + nbt + 1u, p.batch), dim3 (64), 0, s, p, nbr, nbg);     // (+ 1: the list of the representatives at the origin)
+        hipLaunchKernelGGL (k_reps_and_boxes, dim3 (nbr + nbg + nbt + (nbr <= ICP_ORIGIN_SOLO ? 1u : 0u), p.batch), dim3 (64), 0, s, p, nbr, nbg);    // (+ 1: small sets' origin list)
     }
     icp_launch_owner_search (p, s);                  // step 1, owner(x) = nearest representative (icp_kernels.hip)
     hipLaunchKernelGGL (k_chunk_hist, dim3 (p.nchunk, p.batch), dim3 (256), p.nr * sizeof (uint32_t), s, p);

@@ -103,7 +103,7 @@ def test_holes_dense_batched(engine, oracle, fused):
 
 
 @pytest.mark.parametrize("side,nr,name", [(256, 1024, "scattered10"), (256, 1024, "blobs30_rgb0"), (256, 256, "blobs10"), (256, 256, "scattered10_rgb0"),
-                                          (192, 2048, "blobs30")])
+                                          (192, 2048, "blobs30"), (256, 4096, "scattered10_rgb0")])
 def test_holes_dense_layouts(engine, oracle, side, nr, name):
     """Config B (several 256-tiles, tile masks), a set with long lists (lanes = candidates in stage 2) and one on the 1024-tile variant."""
     m = side * side
@@ -118,6 +118,38 @@ def test_holes_dense_layouts(engine, oracle, side, nr, name):
     for it in range(3):
         g.step(); o.step()
         check_step(engine, g, o)
+    g.close()
+
+
+def test_holes_large_sets_batched_and_rebuilt(engine, oracle):
+    """More than 1024 representatives: their blocks of k_reps_and_boxes leave a ballot each and the one that arrives last lists the
+    representatives at the origin (an arrival counter per registration of the handle, back at zero for the next construction) —
+    three registrations with different hole patterns in one handle, constructed twice with the frames swapped in between."""
+    side, nr = 192, 2048
+    m = side * side
+    names = ["blobs30", "clean", "scattered10_rgb0"]
+    pairs = [engine.synth_pair(side, seed=91 + 5 * b) if n == "clean" else _pair(engine, n, side, seed=91 + 5 * b) for b, n in enumerate(names)]
+    g = engine.ICP(0)
+    g.init(m, nr, A, C_, batch=len(names))
+    orcs_last = []
+    for rnd in range(2):
+        order = list(range(len(names))) if rnd == 0 else [2, 0, 1]
+        for b, j in enumerate(order):
+            g.write(engine.Memory.F, pairs[j][0], batch_index=b); g.write(engine.Memory.M, pairs[j][1], batch_index=b)
+            g.write(engine.Memory.T, [0, 0, 0, 1, 0, 0, 0, 1], batch_index=b)
+        g.buildRBC()
+        for b, j in enumerate(order):
+            o = oracle.OracleICP(m, nr, A, C_, threads=16, power_fast=True, fused=True)
+            o.write_f(pairs[j][0]); o.write_m(pairs[j][1]); o.build_rbc()
+            assert np.array_equal(g.read(engine.Memory.RBC_OWNER, batch_index=b), o.rbc_owner), (rnd, b)
+            assert np.array_equal(g.read(engine.Memory.RBC_N, batch_index=b), o.rbc_N), (rnd, b)
+            assert np.array_equal(g.read(engine.Memory.RBC_PERM, batch_index=b), o.rbc_perm), (rnd, b)
+            o.step()
+            orcs_last = orcs_last + [o] if b else [o]
+        g.step()
+        for b, o in enumerate(orcs_last):
+            assert np.array_equal(g.read(engine.Memory.NN_ID, batch_index=b)["id"], o.nn_id["id"]), (rnd, b)
+            assert_bits(g.read(engine.Memory.T, batch_index=b), o.T, "T")
     g.close()
 
 

@@ -118,25 +118,24 @@ template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint
 // invalid point, moved by T: its nearest representative is the invalid one nearest in colour).  Same bits as the exhaustive scan:
 // the list is visited behind the tiles, out of index order, so its updates carry the tie rule explicitly (equal distance: lower index).
 template <int LPQ>
-static __device__ __forceinline__ void ks_origin_list (const float4 *OL, uint32_t n_o, uint32_t nr, float qx, float qy, float qz, float qr, float qg, float qb, float alpha,
+static __device__ __forceinline__ void ks_origin_list (const float4 *ent, const float4 *box, uint32_t n_e, bool boxed, float qq, bool need, float qr, float qg, float qb, float alpha,
                                                        float lim, uint32_t lane, uint32_t ss, float &best, uint32_t &bid)
 {
-    if (__builtin_expect (n_o == 0u, 1)) return;
-    const float qq = __builtin_fmaf (qz, qz, __builtin_fmaf (qy, qy, qx * qx));
-    const bool need = qq <= lim;                     // d >= qq for every member: none can win, or tie at a lower index, beyond that
-    if (!__ballot (need)) return;
-    // The members differ in colour only (their geometric term is qq for all of them): chunks of 8 consecutive entries — neighbours on the
-    // representative grid where the invalid points form regions: similar colours — have a colour box each (k_list_boxes), and a chunk whose
-    // bound fma (a, pho (box), qq) is ABOVE the query's bound holds no winner and no tie (<=, not <: the list is visited behind the tiles, a
-    // member may tie with the best so far at a lower index).  Lane ss tests chunk cb + ss; the chunks that pass are evaluated one entry per
-    // lane.  (Every invalid query of a region scanning every invalid representative made a wave of them cost twice a wave of valid queries.)
-    if (n_o <= 128u) {
-        // (a short list as it comes, four entries per lane and memory round trip: up to 128 entries the tests below cost more than the entries
-        // they save — |F| = 16384 x 64 with 10 - 30 % invalid points, 26 - 77 entries: 2.33 - 2.54 against 2.44 - 2.66 us)
-        for (uint32_t e0 = 0; e0 < n_o; e0 += 4u * (uint32_t) LPQ) {
+    // One staged segment of the list (LDS: k_search stages it for the whole block, entries `ent[0 .. n_e)`, the colour boxes of their chunks
+    // of 8 behind them) — a wave that fetched the list from memory by itself paid 2 - 4 dependent round trips for a few dozen entries, a
+    // quarter to a half of a dense search's time for every wave with one invalid query in it (|F| = 65536, 10 % invalid points scattered:
+    // 13.0 -> 19.6 us).  qq = |q|^2: every member's geometric term.  need: d >= qq for every member, so none can win, or tie at a lower
+    // index, when qq is above the query's bound.
+    // The members differ in colour only: chunks of 8 consecutive entries — neighbours on the representative grid where the invalid points
+    // form regions: similar colours — have a colour box each (k_reps_and_boxes), and a chunk whose bound fma (a, pho (box), qq) is ABOVE the
+    // query's bound holds no winner and no tie (<=, not <: the list is visited behind the tiles, a member may tie with the best so far at a
+    // lower index).  Lane ss tests chunk cb + ss; the chunks that pass are evaluated one entry per lane.
+    if (!boxed) {
+        // (a short list as it comes, four entries per lane and trip: up to 128 entries the tests below cost more than the entries they save)
+        for (uint32_t e0 = 0; e0 < n_e; e0 += 4u * (uint32_t) LPQ) {
             float4 v[4];
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) v[k] = OL[1u + min (e0 + ss + k * (uint32_t) LPQ, n_o - 1u)];
+            for (uint32_t k = 0; k < 4u; ++k) v[k] = ent[min (e0 + ss + k * (uint32_t) LPQ, n_e - 1u)];
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) {
                 const float dr_ = qr - v[k].x, dg_ = qg - v[k].y, db_ = qb - v[k].z;
@@ -147,11 +146,10 @@ static __device__ __forceinline__ void ks_origin_list (const float4 *OL, uint32_
         }
         return;
     }
-    const float4 *BX = OL + 1u + nr;
-    const uint32_t n_oc = (n_o + 7u) >> 3;
+    const uint32_t n_oc = (n_e + 7u) >> 3;
     for (uint32_t cb = 0; cb < n_oc; cb += (uint32_t) LPQ) {
         const uint32_t c = min (cb + ss, n_oc - 1u);
-        const float4 lo = BX[2u * c], hi = BX[2u * c + 1u];
+        const float4 lo = box[2u * c], hi = box[2u * c + 1u];
         const float er = fmaxf (fmaxf (lo.x - qr, qr - hi.x), 0.f), eg = fmaxf (fmaxf (lo.y - qg, qg - hi.y), 0.f), eb = fmaxf (fmaxf (lo.z - qb, qb - hi.z), 0.f);
         const float bound = __builtin_fmaf (alpha, __builtin_fmaf (eb, eb, __builtin_fmaf (eg, eg, er * er)), qq);
         const float lim2 = fminf (lim, ks_grp_min_f<LPQ> (best));
@@ -162,7 +160,7 @@ static __device__ __forceinline__ void ks_origin_list (const float4 *OL, uint32_
             const bool live = mask != 0u;
             const uint32_t e = 8u * (cb + (live ? (uint32_t) __builtin_ctz (mask) : 0u)) + (ss & 7u);
             mask &= mask - 1u;
-            const float4 v = OL[1u + min (e, n_o - 1u)];              // (clamped: a duplicate of the last entry changes nothing under the explicit tie rule)
+            const float4 v = ent[min (e, n_e - 1u)];                  // (clamped: a duplicate of the last entry changes nothing under the explicit tie rule)
             const float dr_ = qr - v.x, dg_ = qg - v.y, db_ = qb - v.z;
             const float d = __builtin_fmaf (alpha, __builtin_fmaf (db_, db_, __builtin_fmaf (dg_, dg_, dr_ * dr_)), qq);
             const uint32_t idx = __float_as_uint (v.w);
@@ -1067,6 +1065,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     __shared__ float4 s_pair[NBUF * PB];
     __shared__ uint2 s_on[(MASKED && OWNER) ? 1 : KT];            // (offset, size) of the lists of the tile's representatives (MASKED: of the home tile's)
     __shared__ uint32_t s_tmask;                     // MASKED: tiles some query of the block needs
+    __shared__ uint32_t s_ovote;                     // some query of the block is near the origin (the list of the representatives there is staged for it)
     __shared__ float4 s_box[NBUF * BB];              // (lo, hi) of the tile's groups of 2 * LPQ representatives
     __shared__ float4 s_tbox[(MINW == 4 && !SINGLE) ? 2 * 32 : 2];      // (lo, hi) of every tile (multi-tile sets: |R| <= 32768)
     __shared__ float s_w[64];
@@ -1256,6 +1255,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         if constexpr (!OWNER) { if (tid < tnH) s_on[tid] = ron[0]; }
     }
     if (MASKED && tid == 0) s_tmask = 0u;
+    if (PRUNE && ICP_S1_ORIGIN_LIST && tid == 0) s_ovote = 0u;
     if constexpr (MINW == 4 && !SINGLE) {            // the boxes of all tiles: a tile is tested before it is staged (stage 1 below)
         if (prune && nr > KT && tid < 2u * p.n1k) s_tbox[tid] = p.GB[(size_t) b * 2 * (p.n16 + p.n1k) + 2u * p.n16 + tid];
     }
@@ -1332,6 +1332,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             tm |= (uint32_t) __builtin_amdgcn_update_dpp (0, (int) tm, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
             tm |= (uint32_t) __builtin_amdgcn_update_dpp (0, (int) tm, 0x141, 0xF, 0xF, true);     // row_half_mirror
             qmask = tm;
+            // (the query's colour once more from LDS: held across the loop above it is the value the 64-register variants spill)
+            { uint32_t qe2 = qe; asm volatile ("" : "+v"(qe2)); const float4 c4 = s_qc[qe2]; qr = c4.x; qg = c4.y; qb = c4.z; }
         }
         {   // the block's union: OR over the wave (8 queries: one per half row), one LDS atomic per wave
             uint32_t wm = qmask | (uint32_t) __builtin_amdgcn_update_dpp (0, (int) qmask, 0x140, 0xF, 0xF, true);      // row_mirror: both half rows
@@ -1491,12 +1493,39 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         uint32_t n_origin = 0u;
         if (prune) n_origin = (uint32_t) __builtin_amdgcn_readfirstlane ((int) __float_as_uint ((MASKED || (!SINGLE && nr > KT)) ? s_tbox[1].w : s_box[1].w));
         if (prune && __builtin_expect (n_origin != 0u, 0)) {
-            static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
-            unsigned long long ol_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
-            asm volatile ("" : "+s"(ol_));
-            const icp_params *po = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) ol_;
-            typedef float4 __attribute__ ((address_space (1))) *gf4;
-            ks_origin_list<KS_SPLIT> ((const float4 *) (gf4) po->OL + (size_t) b * ICP_OL_STRIDE (nr), n_origin, nr, qx, qy, qz, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
+            const float qq = __builtin_fmaf (qz, qz, __builtin_fmaf (qy, qy, qx * qx));
+            const bool need = qq <= s1_lim;
+            // (block-uniform from here: the list is staged once for the block's queries — through the tile buffer, free behind the barrier.
+            // Fetching the first segment straight into a buffer of its own from the prologue on — global_load_lds, the round trip under
+            // stage 1 — measured the same: |F| = 65536 with 10 - 30 % invalid points 20.9 - 23.4 against 20.6 - 23.4 us, clean 18.2 against 18.15)
+            if (need) s_ovote = 1u;
+            __syncthreads ();
+            if (s_ovote) {
+                static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
+                unsigned long long ol_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
+                asm volatile ("" : "+s"(ol_));
+                const icp_params *po = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) ol_;
+                typedef float4 __attribute__ ((address_space (1))) *gf4;
+                const float4 *OLb = (const float4 *) (gf4) po->OL + (size_t) b * ICP_OL_STRIDE (nr);
+                constexpr uint32_t OE = ((PB * 4u / 5u) / 8u) * 8u;      // entries per staged segment, the boxes of their chunks of 8 behind them: OE + OE / 4 <= PB
+                const bool boxed = n_origin > 128u;
+                for (uint32_t e0 = 0; e0 < n_origin; e0 += OE) {
+                    const uint32_t ne = min (OE, n_origin - e0);
+                    if (e0) __syncthreads ();
+                    if constexpr (OE <= 64u * KS_SPLIT) {                 // (a segment is one load per thread)
+                        // (the thread's number from the wave's and the lane's, not from the register the kernel received it in: held
+                        // until here it costs the 64-register variants a spill in the prologue)
+                        const uint32_t tl = slice * 64u + __builtin_amdgcn_mbcnt_hi (~0u, __builtin_amdgcn_mbcnt_lo (~0u, 0u));
+                        if (tl < ne) s_pair[tl] = OLb[1u + e0 + tl];
+                        if (boxed && tl < 2u * ((ne + 7u) >> 3)) s_pair[OE + tl] = OLb[1u + nr + 2u * (e0 >> 3) + tl];
+                    } else {
+                        for (uint32_t k = tid; k < ne; k += 64u * KS_SPLIT) s_pair[k] = OLb[1u + e0 + k];
+                        if (boxed) for (uint32_t k = tid; k < 2u * ((ne + 7u) >> 3); k += 64u * KS_SPLIT) s_pair[OE + k] = OLb[1u + nr + 2u * (e0 >> 3) + k];
+                    }
+                    __syncthreads ();
+                    if (__ballot (need)) ks_origin_list<KS_SPLIT> (s_pair, s_pair + OE, ne, boxed, qq, need, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
+                }
+            }
         }
     }
     KS_KEEP (best, bid)

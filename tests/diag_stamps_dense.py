@@ -8,7 +8,7 @@ side, nr = int(sys.argv[1]), int(sys.argv[2])
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 g = icp_amd.ICP(0); g.init(side * side, nr, 2e2, 1e-6, batch=batch)
 for b in range(batch):
-    F, M = icp_amd.synth_pair(side, seed=0x1C9D5EED + b)
+    F, M = icp_amd.synth_pair(side, seed=0x1C9D5EED + b) if not os.environ.get("CASE") else __import__("icp_amd.workloads", fromlist=["x"]).holes_pair(icp_amd, os.environ["CASE"], side, seed=0x1C9D5EED + b)      # CASE: a hole case of workloads.HOLES
     g.write(icp_amd.Memory.F, F, batch_index=b); g.write(icp_amd.Memory.M, M, batch_index=b)
 g.buildRBC(); g.run_fixed(int(os.environ.get("ITERS", "5"))); g.sync()
 if os.environ.get("FUSED", "1") == "0":

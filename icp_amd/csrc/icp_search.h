@@ -1484,6 +1484,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             }
         }
     }
+    KS_STAMP (14)
     if constexpr (PRUNE && ICP_S1_ORIGIN_LIST) {
         // the representatives at the origin (invalid points): kept out of the boxes above, scanned here by the queries that are near the origin
         // Their number rides in a spare lane of the box array the block has staged in LDS anyway (hi.w of group box 0 / of tile box 0:

@@ -24,7 +24,7 @@ chained = g.launches_per_iteration() == 1
 seq = ([(13, "chain: prologue loads arrived (state, moments, reps, query)"), (10, "chain: moment trees + barrier"), (11, "chain: finish (means / S from the moments)"),
         (12, "chain: power method"), (9, "chain: compose, hand-over of the queries, barrier"), (0, "to the search proper"), (1, "first barrier (reps + queries in LDS)"),
         (2, "stage 1")] if chained else
-       [(0, "prologue: loads, transform, hand-over"), (10, "seed bound + tile masks (2 barriers)"), (2, "stage 1 (tiles staged + scanned)")]) + [(-1, "")]
+       [(0, "prologue: loads, transform, hand-over"), (10, "seed bound + tile masks (2 barriers)"), (14, "stage 1 (tiles staged + scanned)"), (2, "the representatives at the origin (vote, staged list, scan)")]) + [(-1, "")]
 seq = [x for x in seq if x[0] >= 0] + [
        (3, "nearest representative"), (4, "stage 2 list scan"), (5, "stage 2 reduce"), (6, "hand-off barrier + epilogue wave"), (7, "moment tree + store")]
 prev, total = 8, 0.0

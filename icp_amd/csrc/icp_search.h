@@ -1497,8 +1497,10 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             const float qq = __builtin_fmaf (qz, qz, __builtin_fmaf (qy, qy, qx * qx));
             const bool need = qq <= s1_lim;
             // (block-uniform from here: the list is staged once for the block's queries — through the tile buffer, free behind the barrier.
-            // Fetching the first segment straight into a buffer of its own from the prologue on — global_load_lds, the round trip under
-            // stage 1 — measured the same: |F| = 65536 with 10 - 30 % invalid points 20.9 - 23.4 against 20.6 - 23.4 us, clean 18.2 against 18.15)
+            // Measured and not kept: the first segment fetched straight into a buffer of its own from the prologue on (global_load_lds, by
+            // the builtin and written out), by the block or by every wave for itself (no barrier at all): |F| = 65536 with 10 - 30 %
+            // invalid points 20.6 - 23.8 against 20.6 - 23.4 us, 64 x 16384: 2.28 against 2.35; colour boxes for lists of 16 / 48 entries
+            // and more: slower.  What is left of a wave's 1 - 1.5 us here is the scan itself on a busy SIMD: profiles/r05_stamps_holes_dense.txt)
             if (need) s_ovote = 1u;
             __syncthreads ();
             if (s_ovote) {

@@ -504,8 +504,9 @@ class ICPStep:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.icp_destroy(self._h)
+            self._L.icp_destroy(self._h)           # (unregisters what track_register page-locked)
             self._h = None
+            self.__dict__.pop("_registered", None)
 
     def __del__(self):
         try:
@@ -521,6 +522,7 @@ class ICPStep:
     def init(self, m, nr, a=1e2, c=1e-6, batch=1):
         self._chk(self._L.icp_init_batched(self._h, batch, m, nr, a, c, self._max_it, self._ang, self._tra))
         self.m, self.nr, self.batch = m, nr, batch
+        self.__dict__.pop("_registered", None)     # (icp_init unregisters the frame buffers of an earlier configuration)
 
     def write(self, mem=Memory.D_IN_F, ptr=None, block=False, batch_index=0):
         arr = None
@@ -645,9 +647,13 @@ class ICPStep:
         a = np.asarray(frames)
         assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.nbytes >= 640 * 480 * 32
         self._chk(self._L.icp_track_register_source(self._h, _p(a), a.nbytes))
+        # (the array stays alive while its pages are locked: the engine unregisters what is left at init / close)
+        self.__dict__.setdefault("_registered", {})[a.ctypes.data] = a
 
     def track_unregister(self, frames):
-        self._chk(self._L.icp_track_unregister_source(self._h, _p(np.asarray(frames))))
+        a = np.asarray(frames)
+        self._chk(self._L.icp_track_unregister_source(self._h, _p(a)))
+        self.__dict__.get("_registered", {}).pop(a.ctypes.data, None)
 
     def track_pipelined(self, frames, warm_start=False, depth=2, pinned=False):
         """Feeds a sequence with `depth` frames in flight; returns [None | (k, T)] per frame.  pinned: every frame is first copied

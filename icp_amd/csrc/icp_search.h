@@ -1496,38 +1496,49 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         if (prune && __builtin_expect (n_origin != 0u, 0)) {
             const float qq = __builtin_fmaf (qz, qz, __builtin_fmaf (qy, qy, qx * qx));
             const bool need = qq <= s1_lim;
-            // (block-uniform from here: the list is staged once for the block's queries — through the tile buffer, free behind the barrier.
+            // (a list the tile buffer holds: staged once for the block's queries — the buffer is free behind the barrier.
             // Measured and not kept: the first segment fetched straight into a buffer of its own from the prologue on (global_load_lds, by
             // the builtin and written out), by the block or by every wave for itself (no barrier at all): |F| = 65536 with 10 - 30 %
             // invalid points 20.6 - 23.8 against 20.6 - 23.4 us, 64 x 16384: 2.28 against 2.35; colour boxes for lists of 16 / 48 entries
             // and more: slower.  What is left of a wave's 1 - 1.5 us here is the scan itself on a busy SIMD: profiles/r05_stamps_holes_dense.txt)
-            if (need) s_ovote = 1u;
-            __syncthreads ();
-            if (s_ovote) {
+            constexpr uint32_t OE = ((PB * 4u / 5u) / 8u) * 8u;          // entries the tile buffer holds with the boxes of their chunks of 8 behind them: OE + OE / 4 <= PB
+            const bool boxed = n_origin > 128u;
+            if (n_origin <= OE) {
+                if (need) s_ovote = 1u;
+                __syncthreads ();
+                if (s_ovote) {
+                    static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
+                    unsigned long long ol_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
+                    asm volatile ("" : "+s"(ol_));
+                    const icp_params *po = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) ol_;
+                    typedef float4 __attribute__ ((address_space (1))) *gf4;
+                    const float4 *OLb = (const float4 *) (gf4) po->OL + (size_t) b * ICP_OL_STRIDE (nr);
+                    if constexpr (OE <= 64u * KS_SPLIT) {                 // (one load per thread)
+                        // (the thread's number from the wave's and the lane's, not from the register the kernel received it in: held
+                        // until here it costs the 64-register variants a spill in the prologue)
+                        const uint32_t tl = slice * 64u + __builtin_amdgcn_mbcnt_hi (~0u, __builtin_amdgcn_mbcnt_lo (~0u, 0u));
+                        if (tl < n_origin) s_pair[tl] = OLb[1u + tl];
+                        if (boxed && tl < 2u * ((n_origin + 7u) >> 3)) s_pair[OE + tl] = OLb[1u + nr + tl];
+                    } else {
+                        for (uint32_t k = tid; k < n_origin; k += 64u * KS_SPLIT) s_pair[k] = OLb[1u + k];
+                        if (boxed) for (uint32_t k = tid; k < 2u * ((n_origin + 7u) >> 3); k += 64u * KS_SPLIT) s_pair[OE + k] = OLb[1u + nr + k];
+                    }
+                    __syncthreads ();
+                    if (__ballot (need)) ks_origin_list<KS_SPLIT> (s_pair, s_pair + OE, n_origin, boxed, qq, need, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
+                }
+            } else if (__ballot (need)) {
+                // a list the tile buffer does not hold at once: every wave that needs it reads it from memory by itself, a chunk's box
+                // before the chunk (staged a segment at a time it costs two block-wide barriers per segment: |F| = 2^20 with 10 - 30 %
+                // invalid points, 400 - 1200 entries, 287 - 393 -> 293 - 403 us; through both tile buffers of the small-tile variant,
+                // 608 entries at once: no gain either — at that size the time goes into the lists of stage 2, one more distinct list per
+                // wave with an invalid query in it)
                 static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
                 unsigned long long ol_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
                 asm volatile ("" : "+s"(ol_));
                 const icp_params *po = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) ol_;
                 typedef float4 __attribute__ ((address_space (1))) *gf4;
                 const float4 *OLb = (const float4 *) (gf4) po->OL + (size_t) b * ICP_OL_STRIDE (nr);
-                constexpr uint32_t OE = ((PB * 4u / 5u) / 8u) * 8u;      // entries per staged segment, the boxes of their chunks of 8 behind them: OE + OE / 4 <= PB
-                const bool boxed = n_origin > 128u;
-                for (uint32_t e0 = 0; e0 < n_origin; e0 += OE) {
-                    const uint32_t ne = min (OE, n_origin - e0);
-                    if (e0) __syncthreads ();
-                    if constexpr (OE <= 64u * KS_SPLIT) {                 // (a segment is one load per thread)
-                        // (the thread's number from the wave's and the lane's, not from the register the kernel received it in: held
-                        // until here it costs the 64-register variants a spill in the prologue)
-                        const uint32_t tl = slice * 64u + __builtin_amdgcn_mbcnt_hi (~0u, __builtin_amdgcn_mbcnt_lo (~0u, 0u));
-                        if (tl < ne) s_pair[tl] = OLb[1u + e0 + tl];
-                        if (boxed && tl < 2u * ((ne + 7u) >> 3)) s_pair[OE + tl] = OLb[1u + nr + 2u * (e0 >> 3) + tl];
-                    } else {
-                        for (uint32_t k = tid; k < ne; k += 64u * KS_SPLIT) s_pair[k] = OLb[1u + e0 + k];
-                        if (boxed) for (uint32_t k = tid; k < 2u * ((ne + 7u) >> 3); k += 64u * KS_SPLIT) s_pair[OE + k] = OLb[1u + nr + 2u * (e0 >> 3) + k];
-                    }
-                    __syncthreads ();
-                    if (__ballot (need)) ks_origin_list<KS_SPLIT> (s_pair, s_pair + OE, ne, boxed, qq, need, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
-                }
+                ks_origin_list<KS_SPLIT> (OLb + 1u, OLb + 1u + nr, n_origin, true, qq, need, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
             }
         }
     }

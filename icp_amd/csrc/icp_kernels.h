@@ -114,22 +114,18 @@ static __device__ __forceinline__ uint32_t rep_src_index (const icp_params &p, u
     return yi * p.side + xi;
 }
 
-// The same mapping for a thread that walks many representatives (the boxes and the origin list of k_reps_and_boxes): the two step
-// divisions once, and shifts instead of r / nrx, r % nrx where the grid's width is a power of two (it is for every set the engine's own
-// configurations use) — a wave that maps 4096 representatives one after the other spent 10 of its 29 us in integer division.
+// The same mapping for a thread that walks many representatives (the boxes of k_reps_and_boxes): the two step divisions once, and shifts
+// for r / nrx, r % nrx — the grid's width is a power of two (icp_init accepts no other: icp_capi.hip, "nr must be a power of two").
 struct rep_src_map {
     uint32_t nrx, side, stepX, stepY, offX, offY, lgx;
-    bool pow2;
     __device__ __forceinline__ explicit rep_src_map (const icp_params &p)
-        : nrx (p.nrx), side (p.side), stepX (p.side / p.nrx), stepY (p.side / p.nry), lgx (31u - (uint32_t) __builtin_clz (p.nrx | 1u)), pow2 ((p.nrx & (p.nrx - 1u)) == 0u)
+        : nrx (p.nrx), side (p.side), stepX (p.side / p.nrx), stepY (p.side / p.nry), lgx (31u - (uint32_t) __builtin_clz (p.nrx | 1u))
     {
         offX = (stepX == 1u) ? 0u : (stepX >> 1) - 1u; offY = (stepY == 1u) ? 0u : (stepY >> 1) - 1u;
     }
     __device__ __forceinline__ uint32_t operator() (uint32_t r) const
     {
-        uint32_t gX, gY;
-        if (pow2) { gX = r & (nrx - 1u); gY = r >> lgx; } else { gX = r % nrx; gY = r / nrx; }
-        return (gY * stepY + offY) * side + gX * stepX + offX;
+        return ((r >> lgx) * stepY + offY) * side + (r & (nrx - 1u)) * stepX + offX;
     }
 };
 

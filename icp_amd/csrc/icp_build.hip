@@ -120,12 +120,40 @@ __global__ __launch_bounds__ (256) void k_transform_cloud_ex (const float4 *in, 
 #define ICP_ORIGIN_SOLO 16u       // k_reps_and_boxes: up to this many blocks of 64 representatives, one wave lists those at the origin by itself
 
 // the end of the list of the representatives at the origin (k_reps_and_boxes): colour boxes of its chunks, its length where the search reads it
-static __device__ __forceinline__ void origin_list_close (const icp_params &p, uint32_t b, uint32_t lane, float4 *OL, uint32_t run)
+static __device__ __forceinline__ void origin_list_close (const icp_params &p, uint32_t b, uint32_t lane, float4 *OL, uint32_t run, uint32_t nw)
 {
     const float inf = __builtin_inff ();
     // colour boxes of the chunks of 8 consecutive entries (ks_origin_list tests a chunk before it scans it — the owner search of THIS
     // construction already does, so the boxes cannot wait for a later launch): the wave reads its own entries back behind a fence
     __threadfence ();
+    // For every representative at the origin the nearest one by index that is not (its own index if there is none within four ballot
+    // words): a registration's FIRST search (and the owner search of this construction) seeds a query with the representative of its
+    // grid cell — an invalid point there bounds nothing for a valid query, which then scanned every tile of the set (k_search: the seed bound).
+    if (run) {
+        const unsigned long long *MK = reinterpret_cast<const unsigned long long *> (OL + ICP_OL_MASKS (p.nr));
+        uint32_t *VS = reinterpret_cast<uint32_t *> (OL + ICP_OL_VSEED (p.nr));
+        auto valid_bits = [&] (uint32_t w) -> unsigned long long {       // bit l: representative 64 w + l exists and is not at the origin
+            unsigned long long z = ~__hip_atomic_load (MK + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t left = p.nr - 64u * w;
+            if (left < 64u) z &= (1ull << left) - 1ull;
+            return z;
+        };
+        for (uint32_t w = 0; w < nw; ++w) {
+            const unsigned long long z = valid_bits (w);
+            const uint32_t left = p.nr - 64u * w;
+            const unsigned long long m = ~z & (left < 64u ? (1ull << left) - 1ull : ~0ull);          // this word's representatives at the origin
+            if (m == 0ull) continue;
+            uint32_t best_d = 0xFFFFFFFFu, best_r = 64u * w + lane;
+            const unsigned long long below = z & ((1ull << lane) - 1ull), above = lane < 63u ? z & ~((2ull << lane) - 1ull) : 0ull;
+            if (below) { const uint32_t q = 63u - (uint32_t) __builtin_clzll (below); best_d = lane - q; best_r = 64u * w + q; }
+            if (above) { const uint32_t q = (uint32_t) __builtin_ctzll (above); if (q - lane < best_d) { best_d = q - lane; best_r = 64u * w + q; } }
+            for (uint32_t d = 1; d <= 4u && __ballot (((m >> lane) & 1ull) && best_d == 0xFFFFFFFFu); ++d) {      // a word of nothing but invalid points: the neighbouring words
+                if (w >= d) { const unsigned long long zl = valid_bits (w - d); if (zl && best_d == 0xFFFFFFFFu) { best_d = 0u; best_r = 64u * (w - d) + 63u - (uint32_t) __builtin_clzll (zl); } }
+                if (w + d < nw) { const unsigned long long zr = valid_bits (w + d); if (zr && best_d == 0xFFFFFFFFu) { best_d = 0u; best_r = 64u * (w + d) + (uint32_t) __builtin_ctzll (zr); } }
+            }
+            if ((m >> lane) & 1ull) VS[64u * w + lane] = best_r;
+        }
+    }
     {
         float4 *BX = OL + 1u + p.nr;
         const uint32_t n_oc = (run + 7u) >> 3;
@@ -187,7 +215,7 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
         // every block a release fence, 256 of them at 64 batched registrations of 256 representatives tripled this kernel's time.
         if (nbr <= ICP_ORIGIN_SOLO) return;
         float4 *OL = p.OL + (size_t) b * ICP_OL_STRIDE (p.nr);
-        unsigned long long *MK = reinterpret_cast<unsigned long long *> (OL + 1u + p.nr + 2u * ((p.nr + 7u) / 8u));
+        unsigned long long *MK = reinterpret_cast<unsigned long long *> (OL + ICP_OL_MASKS (p.nr));
         const unsigned long long bal = __ballot (at0);
         uint32_t last = 0u;
         if (lane == 0) MK[blockIdx.x] = bal;
@@ -224,7 +252,7 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
             }
             run += (uint32_t) __builtin_amdgcn_readlane ((int) incl, 63);
         }
-        origin_list_close (p, b, lane, OL, run);
+        origin_list_close (p, b, lane, OL, run, nbr);
     } else if (blockIdx.x < nbr + nbg) {
         const uint32_t g = (blockIdx.x - nbr) * 64u + lane;
         if (g >= p.n16) return;
@@ -270,9 +298,10 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
                 const float4 c = F4[2 * (size_t) src_of (r) + 1];
                 OL[1u + run + (uint32_t) __builtin_popcountll (bal & ((1ull << lane) - 1ull))] = make_float4 (c.x, c.y, c.z, __uint_as_float (r));
             }
+            if (lane == 0 && u < nbr) reinterpret_cast<unsigned long long *> (OL + ICP_OL_MASKS (p.nr))[u] = bal;      // (the ballots: origin_list_close derives the valid seeds from them)
             run += (uint32_t) __builtin_popcountll (bal);
         }
-        origin_list_close (p, b, lane, OL, run);
+        origin_list_close (p, b, lane, OL, run, nbr);
     } else {
         const uint32_t tile = blockIdx.x - nbr - nbg;
         float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };

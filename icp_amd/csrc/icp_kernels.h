@@ -20,7 +20,9 @@
 #define ICP_BAND_ROW_BYTES (ICP_BAND_COLS * 32u)
 #define ICP_BAND_BYTES ((size_t) ICP_BAND_ROWS * ICP_BAND_ROW_BYTES)
 #define ICP_TBOX 1024u            // representatives per LDS tile box of the 1024-tile dense search (k_reps_and_boxes, k_search)
-#define ICP_OL_STRIDE(nr) ((nr) + 1u + 2u * (((nr) + 7u) / 8u) + ((nr) + 127u) / 128u)    // float4 per registration of icp_params::OL
+#define ICP_OL_MASKS(nr) ((nr) + 1u + 2u * (((nr) + 7u) / 8u))                            // float4 offset of the ballots inside a registration's OL
+#define ICP_OL_VSEED(nr) (ICP_OL_MASKS (nr) + ((nr) + 127u) / 128u)                       // ... of the valid seeds (one uint32 per representative)
+#define ICP_OL_STRIDE(nr) (ICP_OL_VSEED (nr) + ((nr) + 3u) / 4u)                          // float4 per registration of icp_params::OL
 #define ICP_CHUNK 1024u          // fixed points per block in the stable RBC placement
 
 struct icp_params {
@@ -60,7 +62,8 @@ struct icp_params {
     float4 *OL;                  // [batch][ICP_OL_STRIDE (nr)]  the representatives at the origin (invalid points), ascending: [0].x = their number (bits),
                                  // [1 .. nr]: (r, g, b, index bits) each — kept out of the pruning boxes, scanned by the queries near the origin (dense
                                  // search) —, behind them the colour boxes (lo rgb, hi rgb) of the chunks of 8 consecutive entries, then one 64-bit ballot per 64
-                                 // representatives ([0].y: the arrival counter of k_reps_and_boxes' blocks, zero between constructions)
+                                 // representatives ([0].y: the arrival counter of k_reps_and_boxes' blocks, zero between constructions), then one uint32 per representative:
+                                 // for a representative at the origin the nearest one (by index) that is not — the seed of a valid query whose own seed is an invalid point
     float4 *LB;                  // [batch][3 * nlb]  6-D bounding boxes of the list chunks (16 consecutive positions of one list, chunk c >= 1 of list r at
                                  // index (O[r] >> 4) + c: k_list_boxes) as [lo.x lo.y lo.z lo.r | lo.g lo.b hi.x hi.y | hi.z hi.r hi.g hi.b]
     uint32_t nlb;                // m / 16 + 2 boxes per registration

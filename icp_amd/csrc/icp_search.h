@@ -117,6 +117,33 @@ template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint
 // a query either needs none of them (qq above its bound: every valid point of a scene) or scans the list (a query that is itself an
 // invalid point, moved by T: its nearest representative is the invalid one nearest in colour).  Same bits as the exhaustive scan:
 // the list is visited behind the tiles, out of index order, so its updates carry the tie rule explicitly (equal distance: lower index).
+// The seed of the stage-1 bound against a frame's invalid points (dense variants).  A registration's first search — and the owner search of
+// buildRBC — seeds a query with the representative sampled from its own grid cell: where that is an invalid point (at the origin) and the
+// query is not, or the other way round, the distance to it bounds nothing, no tile and no group is pruned, and the block stages and scans
+// every tile of the set for that one query (|F| = 2^20 with 10 % invalid points: first search 308 -> 697 us, owner search 127 -> 605).
+// Such a query takes another seed: an invalid query (flagged by the query wave: bit 31 of the seed it hands over) the first representative
+// at the origin, a valid one the nearest representative by index that is not at the origin (k_reps_and_boxes: ICP_OL_VSEED).  Any
+// representative is a legitimate seed — the bound stays exact.  Clean frames: three compares and a scalar branch per search.
+static __device__ __forceinline__ void ks_seed_against_invalid (bool hq, const float4 *s_count, uint32_t nr, uint32_t b, const float4 *R4, uint32_t &seed,
+                                                                float &sx, float &sy, float &sz, float &sr, float &sg, float &sb)
+{
+    const bool s0 = sx == 0.f && sy == 0.f && sz == 0.f;
+    if (__builtin_expect (__ballot (hq != s0) == 0ull, 1)) return;
+    if (__builtin_amdgcn_readfirstlane ((int) __float_as_uint (s_count->w)) == 0) return;      // (no representative at the origin: nothing to choose from — s_count: hi of box 0 in LDS)
+    static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
+    unsigned long long ol_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
+    asm volatile ("" : "+s"(ol_));
+    const icp_params *po = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) ol_;
+    typedef float4 __attribute__ ((address_space (1))) *gf4;
+    const float4 *OLb = (const float4 *) (gf4) po->OL + (size_t) b * ICP_OL_STRIDE (nr);
+    if (hq != s0) {
+        uint32_t s2 = hq ? __float_as_uint (OLb[1].w) : reinterpret_cast<const uint32_t *> (OLb + ICP_OL_VSEED (nr))[seed];
+        s2 = min (s2, nr - 1u);
+        const float4 g = R4[2 * (size_t) s2], c = R4[2 * (size_t) s2 + 1];
+        seed = s2; sx = g.x; sy = g.y; sz = g.z; sr = c.x; sg = c.y; sb = c.z;
+    }
+}
+
 template <int LPQ>
 static __device__ __forceinline__ void ks_origin_list (const float4 *ent, const float4 *box, uint32_t n_e, bool boxed, float qq, bool need, float qr, float qg, float qb, float alpha,
                                                        float lim, uint32_t lane, uint32_t ss, float &best, uint32_t &bid)
@@ -1285,7 +1312,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         float tx = mg.x, ty = mg.y, tz = mg.z;
         if constexpr (!OWNER) icp_transform_point (T, mg.x, mg.y, mg.z, tx, ty, tz);
         s_qa[lane] = make_float4 (tx, ty, tz, __uint_as_float (iq));
-        s_qc[lane] = make_float4 (mc.x, mc.y, mc.z, __uint_as_float (seed));
+        // (dense variants: bit 31 of the seed = the query is an invalid point of its frame — at the origin before the transformation: ks_seed_against_invalid)
+        s_qc[lane] = make_float4 (mc.x, mc.y, mc.z, __uint_as_float ((PRUNE && ICP_S1_ORIGIN_LIST && mg.x == 0.f && mg.y == 0.f && mg.z == 0.f) ? (seed | 0x80000000u) : seed));
     }
     float qx = 0.f, qy = 0.f, qz = 0.f, qr = 0.f, qg = 0.f, qb = 0.f;
     uint32_t i = 0u; bool valid = false;
@@ -1306,7 +1334,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         uint32_t qmask = 0xFFFFFFFFu >> (32u - ntile);
         if (prune) {
             // the seed bound: the seed representative from the home tile in LDS, from global memory where it lies outside
-            seed = min (seed, nr - 1u);
+            const bool hq = (seed >> 31) != 0u;        // (an invalid point of its frame: ks_seed_against_invalid)
+            seed = min (seed & 0x7FFFFFFFu, nr - 1u);
             float sx, sy, sz, sr, sg, sb;
             if (ICP_HOME_MODE == 1 && seed / KT == ht) {
                 const float *sp = s_pairf + PB * 4u + ((seed - ht * KT) >> 1) * 12u + (seed & 1u);
@@ -1317,6 +1346,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
                 const float4 g = R4[2 * (size_t) seed], c = R4[2 * (size_t) seed + 1];
                 sx = g.x; sy = g.y; sz = g.z; sr = c.x; sg = c.y; sb = c.z;
             }
+            if constexpr (ICP_S1_ORIGIN_LIST) ks_seed_against_invalid (hq, s_tbox + 1, nr, b, R4, seed, sx, sy, sz, sr, sg, sb);
             const float b0 = icp_metric8 (qx, qy, qz, qr, qg, qb, sx, sy, sz, sr, sg, sb, alpha);
             if (b0 >= 0.f && b0 < __builtin_inff ()) s1_lim = __uint_as_float (__float_as_uint (b0) + 1u);     // next float up
             // tiles this query can find a nearer representative in: lane ss tests the tiles ss, ss + LPQ, ..; OR over the lanes
@@ -1448,7 +1478,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         // keeps every representative that could tie with it.
         float lim = __builtin_inff ();
         if (t0 == 0 && prune) {
-            seed = min (seed, nr - 1u);
+            const bool hq = (seed >> 31) != 0u;        // (an invalid point of its frame: ks_seed_against_invalid)
+            seed = min (seed & 0x7FFFFFFFu, nr - 1u);
             float sx, sy, sz, sr, sg, sb;
             if (MINW == 2 || nr <= KT) {        // one tile: the seed is in LDS (MINW == 2: always, see icp_launch_search)
                 const float *sp = s_pairf + (seed >> 1) * 12u + (seed & 1u);
@@ -1459,6 +1490,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
                 const float4 g = R4[2 * (size_t) seed], c = R4[2 * (size_t) seed + 1];
                 sx = g.x; sy = g.y; sz = g.z; sr = c.x; sg = c.y; sb = c.z;
             }
+            if constexpr (ICP_S1_ORIGIN_LIST && MINW == 4)
+                ks_seed_against_invalid (hq, (!SINGLE && nr > KT) ? s_tbox + 1 : s_box + 1, nr, b, R4, seed, sx, sy, sz, sr, sg, sb);
             const float b0 = icp_metric8 (qx, qy, qz, qr, qg, qb, sx, sy, sz, sr, sg, sb, alpha);
             if (b0 >= 0.f && b0 < __builtin_inff ()) lim = __uint_as_float (__float_as_uint (b0) + 1u);     // next float up
             s1_lim = lim;

@@ -8,7 +8,9 @@
 //
 // Map of this file (round 5: k_search split into its phases; what a phase needs from the others is in its parameter list):
 //   helpers                      sums, group minima (DPP), KS_CAND / KS_CAND_IF (one list candidate against the lane's query), ks_tile_of_block,
-//                                fused_query_index, cell_rep_of, ks_origin_list (representatives at the origin: a frame's invalid points)
+//                                fused_query_index, cell_rep_of
+//   ks_seed_against_invalid, ks_origin_list, ks_origin_section    a frame's invalid points (representatives at the origin): the seed of a
+//                                query whose cell's representative is of the other kind; their list, scanned behind the tiles
 //   fused_moment_* / fused_finalize_block / fin_result_to_state      the finalize of a block: 18 double moments -> T (shared with icp_kernels.hip)
 //   ks_stage2_wave               stage 2, lanes = candidates (dense variant, long lists)
 //   ks_stage2_lanes<LPQ>         stage 2, a query's lanes scan its list; exact chunk-box pruning beyond the first 128 positions of long lists
@@ -193,6 +195,61 @@ static __device__ __forceinline__ void ks_origin_list (const float4 *ent, const 
             const uint32_t idx = __float_as_uint (v.w);
             if (live && (d < best || (d == best && idx < bid))) { best = d; bid = idx; }
         }
+    }
+}
+
+// STAGE 1, the representatives at the origin (a frame's invalid points; kept out of the pruning boxes): scanned behind the tiles by the queries
+// that are near the origin.  Block-uniform entry (n_origin comes from LDS); s_pair = the tile buffer (PB_ float4), s_ovote = a block-wide flag
+// that is zero on entry.
+template <int LPQ, uint32_t PB_>
+static __device__ __forceinline__ void ks_origin_section (float4 *s_pair, uint32_t *s_ovote, uint32_t n_origin, uint32_t nr, uint32_t b, uint32_t slice, uint32_t tid,
+                                                          float qx, float qy, float qz, float qr, float qg, float qb, float alpha, float s1_lim,
+                                                          uint32_t lane, uint32_t ss, float &best, uint32_t &bid)
+{
+    const float qq = __builtin_fmaf (qz, qz, __builtin_fmaf (qy, qy, qx * qx));
+    const bool need = qq <= s1_lim;
+    // the list's pointer: fetched here, through an opaque copy of the kernarg pointer (held from the top of the kernel it made the compiler
+    // spill scalars in front of the prologue's loads: search at |F| = 65536 11.88 -> 12.22 us)
+    static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
+    auto list_base = [&] () -> const float4 * {
+        unsigned long long ol_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
+        asm volatile ("" : "+s"(ol_));
+        const icp_params *po = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) ol_;
+        typedef float4 __attribute__ ((address_space (1))) *gf4;
+        return (const float4 *) (gf4) po->OL + (size_t) b * ICP_OL_STRIDE (nr);
+    };
+    // (a list the tile buffer holds: staged once for the block's queries — the buffer is free behind the barrier.
+    // Measured and not kept: the first segment fetched straight into a buffer of its own from the prologue on (global_load_lds, by
+    // the builtin and written out), by the block or by every wave for itself (no barrier at all): |F| = 65536 with 10 - 30 %
+    // invalid points 20.6 - 23.8 against 20.6 - 23.4 us, 64 x 16384: 2.28 against 2.35; colour boxes for lists of 16 / 48 entries
+    // and more: slower.  What is left of a wave's 1 - 1.5 us here is the scan itself on a busy SIMD: profiles/r05_stamps_holes_dense.txt)
+    constexpr uint32_t OE = ((PB_ * 4u / 5u) / 8u) * 8u;             // entries the tile buffer holds with the boxes of their chunks of 8 behind them: OE + OE / 4 <= PB_
+    const bool boxed = n_origin > 128u;
+    if (n_origin <= OE) {
+        if (need) *s_ovote = 1u;
+        __syncthreads ();
+        if (*s_ovote) {
+            const float4 *OLb = list_base ();
+            if constexpr (OE <= 64u * LPQ) {                          // (one load per thread)
+                // (the thread's number from the wave's and the lane's, not from the register the kernel received it in: held
+                // until here it costs the 64-register variants a spill in the prologue)
+                const uint32_t tl = slice * 64u + __builtin_amdgcn_mbcnt_hi (~0u, __builtin_amdgcn_mbcnt_lo (~0u, 0u));
+                if (tl < n_origin) s_pair[tl] = OLb[1u + tl];
+                if (boxed && tl < 2u * ((n_origin + 7u) >> 3)) s_pair[OE + tl] = OLb[1u + nr + tl];
+            } else {
+                for (uint32_t k = tid; k < n_origin; k += 64u * LPQ) s_pair[k] = OLb[1u + k];
+                if (boxed) for (uint32_t k = tid; k < 2u * ((n_origin + 7u) >> 3); k += 64u * LPQ) s_pair[OE + k] = OLb[1u + nr + k];
+            }
+            __syncthreads ();
+            if (__ballot (need)) ks_origin_list<LPQ> (s_pair, s_pair + OE, n_origin, boxed, qq, need, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
+        }
+    } else if (__ballot (need)) {
+        // a list the tile buffer does not hold at once: every wave that needs it reads it from memory by itself, a chunk's box
+        // before the chunk (staged a segment at a time it costs two block-wide barriers per segment: |F| = 2^20 with 10 - 30 %
+        // invalid points, 400 - 1200 entries, 287 - 393 -> 293 - 403 us; through both tile buffers of the small-tile variant,
+        // 608 entries at once: no gain either)
+        const float4 *OLb = list_base ();
+        ks_origin_list<LPQ> (OLb + 1u, OLb + 1u + nr, n_origin, true, qq, need, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
     }
 }
 
@@ -1526,54 +1583,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         // compiler spill scalars in front of the prologue's loads: search at |F| = 65536 11.88 -> 12.22 us.  Both are fetched here.)
         uint32_t n_origin = 0u;
         if (prune) n_origin = (uint32_t) __builtin_amdgcn_readfirstlane ((int) __float_as_uint ((MASKED || (!SINGLE && nr > KT)) ? s_tbox[1].w : s_box[1].w));
-        if (prune && __builtin_expect (n_origin != 0u, 0)) {
-            const float qq = __builtin_fmaf (qz, qz, __builtin_fmaf (qy, qy, qx * qx));
-            const bool need = qq <= s1_lim;
-            // (a list the tile buffer holds: staged once for the block's queries — the buffer is free behind the barrier.
-            // Measured and not kept: the first segment fetched straight into a buffer of its own from the prologue on (global_load_lds, by
-            // the builtin and written out), by the block or by every wave for itself (no barrier at all): |F| = 65536 with 10 - 30 %
-            // invalid points 20.6 - 23.8 against 20.6 - 23.4 us, 64 x 16384: 2.28 against 2.35; colour boxes for lists of 16 / 48 entries
-            // and more: slower.  What is left of a wave's 1 - 1.5 us here is the scan itself on a busy SIMD: profiles/r05_stamps_holes_dense.txt)
-            constexpr uint32_t OE = ((PB * 4u / 5u) / 8u) * 8u;          // entries the tile buffer holds with the boxes of their chunks of 8 behind them: OE + OE / 4 <= PB
-            const bool boxed = n_origin > 128u;
-            if (n_origin <= OE) {
-                if (need) s_ovote = 1u;
-                __syncthreads ();
-                if (s_ovote) {
-                    static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
-                    unsigned long long ol_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
-                    asm volatile ("" : "+s"(ol_));
-                    const icp_params *po = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) ol_;
-                    typedef float4 __attribute__ ((address_space (1))) *gf4;
-                    const float4 *OLb = (const float4 *) (gf4) po->OL + (size_t) b * ICP_OL_STRIDE (nr);
-                    if constexpr (OE <= 64u * KS_SPLIT) {                 // (one load per thread)
-                        // (the thread's number from the wave's and the lane's, not from the register the kernel received it in: held
-                        // until here it costs the 64-register variants a spill in the prologue)
-                        const uint32_t tl = slice * 64u + __builtin_amdgcn_mbcnt_hi (~0u, __builtin_amdgcn_mbcnt_lo (~0u, 0u));
-                        if (tl < n_origin) s_pair[tl] = OLb[1u + tl];
-                        if (boxed && tl < 2u * ((n_origin + 7u) >> 3)) s_pair[OE + tl] = OLb[1u + nr + tl];
-                    } else {
-                        for (uint32_t k = tid; k < n_origin; k += 64u * KS_SPLIT) s_pair[k] = OLb[1u + k];
-                        if (boxed) for (uint32_t k = tid; k < 2u * ((n_origin + 7u) >> 3); k += 64u * KS_SPLIT) s_pair[OE + k] = OLb[1u + nr + k];
-                    }
-                    __syncthreads ();
-                    if (__ballot (need)) ks_origin_list<KS_SPLIT> (s_pair, s_pair + OE, n_origin, boxed, qq, need, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
-                }
-            } else if (__ballot (need)) {
-                // a list the tile buffer does not hold at once: every wave that needs it reads it from memory by itself, a chunk's box
-                // before the chunk (staged a segment at a time it costs two block-wide barriers per segment: |F| = 2^20 with 10 - 30 %
-                // invalid points, 400 - 1200 entries, 287 - 393 -> 293 - 403 us; through both tile buffers of the small-tile variant,
-                // 608 entries at once: no gain either — at that size the time goes into the lists of stage 2, one more distinct list per
-                // wave with an invalid query in it)
-                static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
-                unsigned long long ol_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
-                asm volatile ("" : "+s"(ol_));
-                const icp_params *po = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) ol_;
-                typedef float4 __attribute__ ((address_space (1))) *gf4;
-                const float4 *OLb = (const float4 *) (gf4) po->OL + (size_t) b * ICP_OL_STRIDE (nr);
-                ks_origin_list<KS_SPLIT> (OLb + 1u, OLb + 1u + nr, n_origin, true, qq, need, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
-            }
-        }
+        if (prune && __builtin_expect (n_origin != 0u, 0))
+            ks_origin_section<KS_SPLIT, PB> (s_pair, &s_ovote, n_origin, nr, b, slice, tid, qx, qy, qz, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
     }
     KS_KEEP (best, bid)
     KS_STAMP (2)

@@ -871,7 +871,7 @@ static __device__ __forceinline__ void ks_stage2_lanes (const char *XQb, uint32_
 // block calls it (two block barriers inside), and its returns end the kernel.
 // ------------------------------------------------------------------------------------------
 template <bool FUSED, bool CHAIN, int MINW, int LPQ, bool OWNER, bool PRUNE>
-static __device__ __forceinline__ void ks_epilogue (const icp_params &p, float4 *s_qa, uint4 *s_qb, double (*s_mom)[64], float *s_w, const float4 *R4, const char *XQb,
+static __device__ __forceinline__ void ks_epilogue (const icp_params &p, float4 *s_qa, uint4 *s_qb, const uint32_t *s_slot, double (*s_mom)[64], float *s_w, const float4 *R4, const char *XQb,
                                                     uint32_t b, uint32_t m, uint32_t nr, uint32_t check_flags, uint32_t tid, uint32_t lane, uint32_t slice, uint32_t tile_id,
                                                     uint32_t qe, uint32_t ss, uint32_t i, bool valid, uint32_t o, uint32_t n, uint32_t rstar, float dr, float dmin, uint32_t jmin,
                                                     float qx, float qy, float qz)
@@ -888,6 +888,8 @@ static __device__ __forceinline__ void ks_epilogue (const icp_params &p, float4 
     __syncthreads ();
     if (slice == 0u) {
         const float4 qa = s_qa[lane]; const uint4 qb = s_qb[lane];
+        // (dense variants: the queries were handed over with a frame's invalid ones last — s_slot: the place in the tile of the query at this position)
+        const uint32_t eo = (PRUNE && ICP_S1_ORIGIN_LIST) ? s_slot[lane] : lane;
         const bool v = (qb.z & 1u) != 0u, empty = (qb.z & 2u) != 0u;
         // the search ran on geo + a pho (a positive common factor changes neither the argmin nor the ties, and the pruning
         // bound d >= geo stays as it is); the distance reported and fed to the weights carries the metric's absolute scale
@@ -951,16 +953,16 @@ static __device__ __forceinline__ void ks_epilogue (const icp_params &p, float4 
             double q0 = (double) ex, q1 = (double) ey, q2 = (double) ez;
             if (!v) { W = 0.0; q0 = q1 = q2 = 0.0; }
             double wq0 = W * q0, wq1 = W * q1, wq2 = W * q2;
-            s_mom[0][lane] = W;
-            s_mom[1][lane] = W * g0; s_mom[2][lane] = W * g1; s_mom[3][lane] = W * g2;
-            s_mom[4][lane] = wq0; s_mom[5][lane] = wq1; s_mom[6][lane] = wq2;
-            s_mom[7][lane] = wq0 * g0; s_mom[8][lane] = wq0 * g1; s_mom[9][lane] = wq0 * g2;
-            s_mom[10][lane] = wq1 * g0; s_mom[11][lane] = wq1 * g1; s_mom[12][lane] = wq1 * g2;
-            s_mom[13][lane] = wq2 * g0; s_mom[14][lane] = wq2 * g1; s_mom[15][lane] = wq2 * g2;
-            s_mom[16][lane] = W * ((g0 * g0 + g1 * g1) + g2 * g2);
-            s_mom[17][lane] = W * ((q0 * q0 + q1 * q1) + q2 * q2);
+            s_mom[0][eo] = W;
+            s_mom[1][eo] = W * g0; s_mom[2][eo] = W * g1; s_mom[3][eo] = W * g2;
+            s_mom[4][eo] = wq0; s_mom[5][eo] = wq1; s_mom[6][eo] = wq2;
+            s_mom[7][eo] = wq0 * g0; s_mom[8][eo] = wq0 * g1; s_mom[9][eo] = wq0 * g2;
+            s_mom[10][eo] = wq1 * g0; s_mom[11][eo] = wq1 * g1; s_mom[12][eo] = wq1 * g2;
+            s_mom[13][eo] = wq2 * g0; s_mom[14][eo] = wq2 * g1; s_mom[15][eo] = wq2 * g2;
+            s_mom[16][eo] = W * ((g0 * g0 + g1 * g1) + g2 * g2);
+            s_mom[17][eo] = W * ((q0 * q0 + q1 * q1) + q2 * q2);
         } else
-            s_w[lane] = w;
+            s_w[eo] = w;
     }
     KS_STAMP (6)
     __syncthreads ();
@@ -1156,6 +1158,9 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     __shared__ float4 s_qc[64];                      // query hand-in: (r, g, b, pruning seed); s_qa carries (q', index)
     __shared__ float4 s_qa[64];                      // per-query hand-off to the finishing wave: (q', distance)
     __shared__ uint4 s_qb[64];                       //   (winner position or representative, representative, flags, query index)
+    // dense variants: the query wave hands a frame's invalid queries over BEHIND the valid ones (see there); the finishing wave puts a query's
+    // moment products back at the slot of its place in the block's tile: the sums keep their order
+    __shared__ uint32_t s_slot[(ICP_S1_SEED && ICP_S1_ORIGIN_LIST && MINW == 4) ? 64 : 1];      // the tile slot of the query handed over at position p
     __shared__ double s_mom[FUSED ? ICP_NMOM : 1][64];
     __shared__ icp_fin_result s_fin;
     __shared__ double s_l1[CHAIN ? ICP_NMOM : 1][CHAIN ? 32 : 1];
@@ -1368,9 +1373,28 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     if (qwave && !handed) {
         float tx = mg.x, ty = mg.y, tz = mg.z;
         if constexpr (!OWNER) icp_transform_point (T, mg.x, mg.y, mg.z, tx, ty, tz);
-        s_qa[lane] = make_float4 (tx, ty, tz, __uint_as_float (iq));
-        // (dense variants: bit 31 of the seed = the query is an invalid point of its frame — at the origin before the transformation: ks_seed_against_invalid)
-        s_qc[lane] = make_float4 (mc.x, mc.y, mc.z, __uint_as_float ((PRUNE && ICP_S1_ORIGIN_LIST && mg.x == 0.f && mg.y == 0.f && mg.z == 0.f) ? (seed | 0x80000000u) : seed));
+        if constexpr (PRUNE && ICP_S1_ORIGIN_LIST) {
+            // Dense variants.  A query that is an invalid point of its frame (at the origin before the transformation) is flagged — bit 31 of
+            // the seed: ks_seed_against_invalid — and handed over BEHIND the block's valid queries (a stable partition of the 64: the valid
+            // ones stay neighbours).  Scattered over the block's waves such queries made nearly every wave walk the list of the
+            // representatives at the origin behind its tiles, and the block waited for each of them at the hand-over to the finishing wave;
+            // together they cost one wave that walk.  s_slot keeps the slot of a query's place in the tile: the finishing wave puts the
+            // query's moment products there, so the block's sums run in the order of the tile as before.
+            const bool hole = mg.x == 0.f && mg.y == 0.f && mg.z == 0.f;
+            const float4 ha = make_float4 (tx, ty, tz, __uint_as_float (iq)), hc = make_float4 (mc.x, mc.y, mc.z, __uint_as_float (hole ? (seed | 0x80000000u) : seed));
+            // (first in tile order, addresses that do not wait for the point; a block with invalid queries writes all 64 once more, permuted —
+            // one wave's LDS writes land in order.  With the position itself in the address the whole block waited ~0.15 us longer for this wave)
+            s_qa[lane] = ha; s_qc[lane] = hc; s_slot[lane] = lane;
+            const unsigned long long hb = __ballot (hole);
+            if (__builtin_expect (hb != 0ull, 0)) {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const uint32_t pos = hole ? 64u - (uint32_t) __builtin_popcountll (hb) + (uint32_t) __builtin_popcountll (hb & lt) : (uint32_t) __builtin_popcountll (~hb & lt);
+                s_qa[pos] = ha; s_qc[pos] = hc; s_slot[pos] = lane;
+            }
+        } else {
+            s_qa[lane] = make_float4 (tx, ty, tz, __uint_as_float (iq));
+            s_qc[lane] = make_float4 (mc.x, mc.y, mc.z, __uint_as_float (seed));
+        }
     }
     float qx = 0.f, qy = 0.f, qz = 0.f, qr = 0.f, qg = 0.f, qb = 0.f;
     uint32_t i = 0u; bool valid = false;
@@ -1624,7 +1648,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     KS_STAMP (5)
     // ==================================================== EPILOGUE ====================================================
     // ---- epilogue (ks_epilogue): hand-off, finishing wave, outputs, block moments
-    ks_epilogue<FUSED, CHAIN, MINW, LPQ, OWNER, PRUNE> (p, s_qa, s_qb, s_mom, s_w, R4, XQb, b, m, nr, check_flags, tid, lane, slice, tile_id, qe, ss, i, valid, o, n, rstar, dr, dmin, jmin,
+    ks_epilogue<FUSED, CHAIN, MINW, LPQ, OWNER, PRUNE> (p, s_qa, s_qb, s_slot, s_mom, s_w, R4, XQb, b, m, nr, check_flags, tid, lane, slice, tile_id, qe, ss, i, valid, o, n, rstar, dr, dmin, jmin,
                                                         qx, qy, qz);
 }
 

@@ -120,7 +120,9 @@ __global__ __launch_bounds__ (256) void k_transform_cloud_ex (const float4 *in, 
 #define ICP_ORIGIN_SOLO 16u       // k_reps_and_boxes: up to this many blocks of 64 representatives, one wave lists those at the origin by itself
 
 // the end of the list of the representatives at the origin (k_reps_and_boxes): colour boxes of its chunks, its length where the search reads it
-static __device__ __forceinline__ void origin_list_close (const icp_params &p, uint32_t b, uint32_t lane, float4 *OL, uint32_t run, uint32_t nw)
+#define ICP_OL_SORT_MAX 2048u      // k_reps_and_boxes: lists of the representatives at the origin up to this length are ordered by colour (LDS: 24 bytes per entry)
+
+static __device__ __forceinline__ void origin_list_close (const icp_params &p, uint32_t b, uint32_t lane, float4 *OL, uint32_t run, uint32_t nw, float4 *s_ent, uint32_t *s_key, uint32_t sort_cap)
 {
     const float inf = __builtin_inff ();
     // colour boxes of the chunks of 8 consecutive entries (ks_origin_list tests a chunk before it scans it — the owner search of THIS
@@ -153,6 +155,54 @@ static __device__ __forceinline__ void origin_list_close (const icp_params &p, u
             }
             if ((m >> lane) & 1ull) VS[64u * w + lane] = best_r;
         }
+    }
+    // Lists the search prunes by chunk boxes (more than 128 entries): ordered by a Morton key of the colour instead of by index, so that the
+    // 8 entries of a chunk are neighbours in colour whatever the invalid points' pattern in the frame — in index order 10 of 49 / 157
+    // chunks passed a query's test at |F| = 2^20 with 10 % scattered / 30 % contiguous invalid points, ordered by colour 4
+    // (tests/diag_origin_list_sim.py).  The scan's tie rule is explicit (ks_origin_list), so the list's order is free.  One wave: entries and
+    // keys (colour key << 16 | position) in LDS, a bitonic sort of the keys, the entries written back in their order.
+    if (run > 128u && run <= sort_cap) {
+        float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+        for (uint32_t e = lane; e < run; e += 64u) {
+            const float4 v = OL[1u + e];
+            s_ent[e] = v;
+            lo[0] = fminf (lo[0], v.x); lo[1] = fminf (lo[1], v.y); lo[2] = fminf (lo[2], v.z);
+            hi[0] = fmaxf (hi[0], v.x); hi[1] = fmaxf (hi[1], v.y); hi[2] = fmaxf (hi[2], v.z);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf (lo[k], __shfl_xor (lo[k], d)); hi[k] = fmaxf (hi[k], __shfl_xor (hi[k], d)); }
+        float sc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sc[k] = hi[k] > lo[k] ? 32.f / (hi[k] - lo[k]) : 0.f;
+        uint32_t n2 = 256u;
+        while (n2 < run) n2 <<= 1;
+        __syncthreads ();                                             // (the block is this one wave: the entries are in LDS)
+        auto spread5 = [] (uint32_t x) -> uint32_t { return (x & 1u) | ((x & 2u) << 2) | ((x & 4u) << 4) | ((x & 8u) << 6) | ((x & 16u) << 8); };
+        for (uint32_t e = lane; e < n2; e += 64u) {
+            uint32_t key = 0xFFFFFFFFu;
+            if (e < run) {
+                const float4 v = s_ent[e];
+                // (a NaN colour: fmaxf / fminf leave 0 — any key will do, the order only has to be the same every time)
+                const uint32_t q0 = (uint32_t) fminf (fmaxf ((v.x - lo[0]) * sc[0], 0.f), 31.f), q1 = (uint32_t) fminf (fmaxf ((v.y - lo[1]) * sc[1], 0.f), 31.f),
+                               q2 = (uint32_t) fminf (fmaxf ((v.z - lo[2]) * sc[2], 0.f), 31.f);
+                key = ((spread5 (q0) | (spread5 (q1) << 1) | (spread5 (q2) << 2)) << 16) | e;
+            }
+            s_key[e] = key;
+        }
+        for (uint32_t k = 2u; k <= n2; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+                __syncthreads ();
+                for (uint32_t t = lane; t < (n2 >> 1); t += 64u) {
+                    const uint32_t i0 = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), i1 = i0 + j;
+                    const uint32_t a = s_key[i0], c = s_key[i1];
+                    if ((a > c) == ((i0 & k) == 0u)) { s_key[i0] = c; s_key[i1] = a; }
+                }
+            }
+        __syncthreads ();
+        for (uint32_t e = lane; e < run; e += 64u) OL[1u + e] = s_ent[s_key[e] & 0xFFFFu];
+        __threadfence ();                                             // (the boxes below read the entries back)
     }
     {
         float4 *BX = OL + 1u + p.nr;
@@ -190,8 +240,12 @@ static __device__ __forceinline__ void origin_list_close (const icp_params &p, u
 //                              ks_origin_list)
 // The boxes read the representatives' points from F at src (r): they do not wait for R.  fminf / fmaxf skip NaN
 // coordinates: a representative with a NaN coordinate never wins a '<' anyway; min / max are exact in any order.
-__global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t nbr, uint32_t nbg)
+__global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t nbr, uint32_t nbg, uint32_t sort_cap)
 {
+    // (origin_list_close: the one block that orders the list of the representatives at the origin — sort_cap entries of 16 + 4 bytes, dynamic:
+    // a launch of many small registrations goes without, 40 KB per 64-thread block would leave four blocks to a CU)
+    extern __shared__ __attribute__ ((aligned (16))) float4 s_ent[];
+    uint32_t *s_key = reinterpret_cast<uint32_t *> (s_ent + sort_cap);
     const uint32_t b = blockIdx.y, lane = threadIdx.x;
     const float4 *F4 = reinterpret_cast<const float4 *> (p.F + (size_t) b * p.m * 8);
     const float inf = __builtin_inff ();
@@ -252,7 +306,7 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
             }
             run += (uint32_t) __builtin_amdgcn_readlane ((int) incl, 63);
         }
-        origin_list_close (p, b, lane, OL, run, nbr);
+        origin_list_close (p, b, lane, OL, run, nbr, s_ent, s_key, sort_cap);
     } else if (blockIdx.x < nbr + nbg) {
         const uint32_t g = (blockIdx.x - nbr) * 64u + lane;
         if (g >= p.n16) return;
@@ -301,7 +355,7 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
             if (lane == 0 && u < nbr) reinterpret_cast<unsigned long long *> (OL + ICP_OL_MASKS (p.nr))[u] = bal;      // (the ballots: origin_list_close derives the valid seeds from them)
             run += (uint32_t) __builtin_popcountll (bal);
         }
-        origin_list_close (p, b, lane, OL, run, nbr);
+        origin_list_close (p, b, lane, OL, run, nbr, s_ent, s_key, sort_cap);
     } else {
         const uint32_t tile = blockIdx.x - nbr - nbg;
         float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
@@ -765,7 +819,11 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
     }
     {   // the representatives, the boxes of their pruning groups and (several tiles only) of the LDS tiles: one launch
         const uint32_t nbr = (p.nr + 63u) / 64u, nbg = (p.n16 + 63u) / 64u, nbt = p.nr > p.tbox ? p.n1k : 0u;
-        hipLaunchKernelGGL (k_reps_and_boxes, dim3 (nbr + nbg + nbt + (nbr <= ICP_ORIGIN_SOLO ? 1u : 0u), p.batch), dim3 (64), 0, s, p, nbr, nbg);    // (+ 1: small sets' origin list)
+        // (the ordered origin list: sets large enough to hold a list the search prunes by boxes, launches small enough to afford the LDS)
+        const uint32_t nblk = (nbr + nbg + nbt + (nbr <= ICP_ORIGIN_SOLO ? 1u : 0u)) * p.batch;
+        uint32_t sort_cap = 0u;
+        if (p.nr >= 256u && nblk <= 2048u) { sort_cap = 256u; while (sort_cap < p.nr && sort_cap < ICP_OL_SORT_MAX) sort_cap <<= 1; }
+        hipLaunchKernelGGL (k_reps_and_boxes, dim3 (nbr + nbg + nbt + (nbr <= ICP_ORIGIN_SOLO ? 1u : 0u), p.batch), dim3 (64), sort_cap * 20u, s, p, nbr, nbg, sort_cap);    // (+ 1: small sets' origin list)
     }
     icp_launch_owner_search (p, s);                  // step 1, owner(x) = nearest representative (icp_kernels.hip)
     hipLaunchKernelGGL (k_chunk_hist, dim3 (p.nchunk, p.batch), dim3 (256), p.nr * sizeof (uint32_t), s, p);

@@ -1,7 +1,7 @@
 """Diagnostic (not a test, CPU only): the list of the representatives at the origin (a frame's invalid points) — how many of its chunks of 8
 entries pass the colour-box test of a query with a tight bound, in index order (what k_reps_and_boxes writes) and sorted by a Morton key of
-the colour.  Measured: 10 of 49 / 157 chunks at (2^20, 4096) with 10 % scattered / 30 % contiguous invalid points, 4 when sorted — not built:
-behind the sort the scan's fixed cost per 8 chunks dominates (profiles/r05_stamps_holes_dense.txt)."""
+the colour.  Measured: 10 of 49 / 157 chunks at (2^20, 4096) with 10 % scattered / 30 % contiguous invalid points, 4 when sorted — built afterwards
+(k_reps_and_boxes: origin_list_close; profiles/r05_holes_colour_order_ab.txt)."""
 import sys, numpy as np
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

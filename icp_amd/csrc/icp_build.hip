@@ -161,7 +161,7 @@ static __device__ __forceinline__ void origin_list_close (const icp_params &p, u
     // chunks passed a query's test at |F| = 2^20 with 10 % scattered / 30 % contiguous invalid points, ordered by colour 4
     // (tests/diag_origin_list_sim.py).  The scan's tie rule is explicit (ks_origin_list), so the list's order is free.  One wave: entries and
     // keys (colour key << 16 | position) in LDS, a bitonic sort of the keys, the entries written back in their order.
-    if (run > 128u && run <= sort_cap) {
+    if (run > ICP_OL_BOXED_MIN && run <= sort_cap) {
         float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
         for (uint32_t e = lane; e < run; e += 64u) {
             const float4 v = OL[1u + e];

@@ -20,6 +20,9 @@
 #define ICP_BAND_ROW_BYTES (ICP_BAND_COLS * 32u)
 #define ICP_BAND_BYTES ((size_t) ICP_BAND_ROWS * ICP_BAND_ROW_BYTES)
 #define ICP_TBOX 1024u            // representatives per LDS tile box of the 1024-tile dense search (k_reps_and_boxes, k_search)
+#ifndef ICP_OL_BOXED_MIN
+#define ICP_OL_BOXED_MIN 128u        // the list of the representatives at the origin: beyond this length ordered by colour, its chunks of 8 tested by their boxes before they are scanned
+#endif
 #define ICP_OL_MASKS(nr) ((nr) + 1u + 2u * (((nr) + 7u) / 8u))                            // float4 offset of the ballots inside a registration's OL
 #define ICP_OL_VSEED(nr) (ICP_OL_MASKS (nr) + ((nr) + 127u) / 128u)                       // ... of the valid seeds (one uint32 per representative)
 #define ICP_OL_STRIDE(nr) (ICP_OL_VSEED (nr) + ((nr) + 3u) / 4u)                          // float4 per registration of icp_params::OL

@@ -224,7 +224,7 @@ static __device__ __forceinline__ void ks_origin_section (float4 *s_pair, uint32
     // invalid points 20.6 - 23.8 against 20.6 - 23.4 us, 64 x 16384: 2.28 against 2.35; colour boxes for lists of 16 / 48 entries
     // and more: slower.  What is left of a wave's 1 - 1.5 us here is the scan itself on a busy SIMD: profiles/r05_stamps_holes_dense.txt)
     constexpr uint32_t OE = ((PB_ * 4u / 5u) / 8u) * 8u;             // entries the tile buffer holds with the boxes of their chunks of 8 behind them: OE + OE / 4 <= PB_
-    const bool boxed = n_origin > 128u;
+    const bool boxed = n_origin > ICP_OL_BOXED_MIN;
     if (n_origin <= OE) {
         if (need) *s_ovote = 1u;
         __syncthreads ();

@@ -1404,10 +1404,14 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // ==================================================== STAGE 1 =====================================================
     // ---- stage 1: nearest representative, two representatives per packed instruction ----
     float best = __builtin_inff (), s1_lim = __builtin_inff (); uint32_t bid = 0xFFFFFFFFu;
+    // (the number of representatives at the origin — a spare lane of box 0 in LDS: k_reps_and_boxes — is read where the query is read, so that
+    // the wait is the query's; read behind stage 1 its LDS round trip stood alone at the end of every wave's stage 1)
+    uint32_t n_origin = 0u;
     if constexpr (MASKED) {
         __syncthreads ();                            // the queries (s_qa / s_qc), the tile boxes, s_tmask = 0
         {
             const float4 a4 = s_qa[qe], c4 = s_qc[qe];
+            if constexpr (PRUNE && ICP_S1_ORIGIN_LIST) { if (prune) n_origin = (uint32_t) __builtin_amdgcn_readfirstlane ((int) __float_as_uint (s_tbox[1].w)); }
             qx = a4.x; qy = a4.y; qz = a4.z; i = __float_as_uint (a4.w); valid = i < m;
             qr = c4.x; qg = c4.y; qb = c4.z; seed = __float_as_uint (c4.w);
         }
@@ -1541,6 +1545,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         if (!(CHAIN && handed && t0 == 0u && !(tn & 1u))) __syncthreads ();
         if (t0 == 0) {                               // the query prepared by the query wave
             const float4 a4 = s_qa[qe], c4 = s_qc[qe];
+            if constexpr (PRUNE && ICP_S1_ORIGIN_LIST) { if (prune) n_origin = (uint32_t) __builtin_amdgcn_readfirstlane ((int) __float_as_uint ((!SINGLE && nr > KT) ? s_tbox[1].w : s_box[1].w)); }
             qx = a4.x; qy = a4.y; qz = a4.z; i = __float_as_uint (a4.w); valid = i < m;
             qr = c4.x; qg = c4.y; qb = c4.z; seed = __float_as_uint (c4.w);
         }
@@ -1605,8 +1610,6 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         // k_reps_and_boxes): one LDS read here.  (Loaded from global memory in the prologue — by a vector load, or by a scalar one with its
         // address arithmetic — it cost 0.8 - 1.3 % at |F| = 16384 x 64; the list's own pointer, held from the top of the kernel, made the
         // compiler spill scalars in front of the prologue's loads: search at |F| = 65536 11.88 -> 12.22 us.  Both are fetched here.)
-        uint32_t n_origin = 0u;
-        if (prune) n_origin = (uint32_t) __builtin_amdgcn_readfirstlane ((int) __float_as_uint ((MASKED || (!SINGLE && nr > KT)) ? s_tbox[1].w : s_box[1].w));
         if (prune && __builtin_expect (n_origin != 0u, 0))
             ks_origin_section<KS_SPLIT, PB> (s_pair, &s_ovote, n_origin, nr, b, slice, tid, qx, qy, qz, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
     }

@@ -1436,6 +1436,9 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             if (b0 >= 0.f && b0 < __builtin_inff ()) s1_lim = __uint_as_float (__float_as_uint (b0) + 1u);     // next float up
             // tiles this query can find a nearer representative in: lane ss tests the tiles ss, ss + LPQ, ..; OR over the lanes
             uint32_t tm = 0u;
+            // (not unrolled: at most 32 tiles over the query's 8 lanes; unrolled twice the loop held the query's colour in registers the
+            // 64-register variants then spilled — or read again from LDS behind it: |F| = 65536 18.19 -> 18.09 us, 2^20 274.7 -> 273.2)
+#pragma unroll 1
             for (uint32_t t = ss; t < ntile; t += KS_SPLIT) {
                 const float4 lo = s_tbox[2u * t], hi = s_tbox[2u * t + 1u];
                 const float ex = fmaxf (fmaxf (lo.x - qx, qx - hi.x), 0.f);
@@ -1448,7 +1451,6 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
             tm |= (uint32_t) __builtin_amdgcn_update_dpp (0, (int) tm, 0x141, 0xF, 0xF, true);     // row_half_mirror
             qmask = tm;
             // (the query's colour once more from LDS: held across the loop above it is the value the 64-register variants spill)
-            { uint32_t qe2 = qe; asm volatile ("" : "+v"(qe2)); const float4 c4 = s_qc[qe2]; qr = c4.x; qg = c4.y; qb = c4.z; }
         }
         {   // the block's union: OR over the wave (8 queries: one per half row), one LDS atomic per wave
             uint32_t wm = qmask | (uint32_t) __builtin_amdgcn_update_dpp (0, (int) qmask, 0x140, 0xF, 0xF, true);      // row_mirror: both half rows

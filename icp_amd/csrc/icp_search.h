@@ -51,6 +51,9 @@ static __device__ __forceinline__ float sum4 (float4 v) { return ((v.x + v.y) + 
 #ifndef ICP_S1_ORIGIN_LIST
 #define ICP_S1_ORIGIN_LIST 1         // dense variants: the representatives at the origin are scanned as a list of their own (0: A/B builds without it — wrong results on frames with invalid points)
 #endif
+#ifndef ICP_OL_STAGED_MIN
+#define ICP_OL_STAGED_MIN 32u         // the list of the representatives at the origin: up to this length (one trip of a query's lanes) read per wave, not staged per block
+#endif
 #ifndef ICP_S1_SEED
 #define ICP_S1_SEED 1                // stage 1: prune with the distance to the previous search's nearest representative
 #endif
@@ -218,14 +221,16 @@ static __device__ __forceinline__ void ks_origin_section (float4 *s_pair, uint32
         typedef float4 __attribute__ ((address_space (1))) *gf4;
         return (const float4 *) (gf4) po->OL + (size_t) b * ICP_OL_STRIDE (nr);
     };
-    // (a list the tile buffer holds: staged once for the block's queries — the buffer is free behind the barrier.
+    // (a list of up to 32 entries — one trip of a query's lanes — is read per wave: with a block's invalid queries in its last wave(s) only
+    // those pay for it, and nobody stands at the two barriers of the staging: 64 x 16384 with 10 % invalid points 2.30 -> 2.24 us.)
+    // (a longer list the tile buffer holds: staged once for the block's queries — the buffer is free behind the barrier.
     // Measured and not kept: the first segment fetched straight into a buffer of its own from the prologue on (global_load_lds, by
     // the builtin and written out), by the block or by every wave for itself (no barrier at all): |F| = 65536 with 10 - 30 %
     // invalid points 20.6 - 23.8 against 20.6 - 23.4 us, 64 x 16384: 2.28 against 2.35; colour boxes for lists of 16 / 48 entries
     // and more: slower.  What is left of a wave's 1 - 1.5 us here is the scan itself on a busy SIMD: profiles/r05_stamps_holes_dense.txt)
     constexpr uint32_t OE = ((PB_ * 4u / 5u) / 8u) * 8u;             // entries the tile buffer holds with the boxes of their chunks of 8 behind them: OE + OE / 4 <= PB_
     const bool boxed = n_origin > ICP_OL_BOXED_MIN;
-    if (n_origin <= OE) {
+    if (n_origin > ICP_OL_STAGED_MIN && n_origin <= OE) {
         if (need) *s_ovote = 1u;
         __syncthreads ();
         if (*s_ovote) {
@@ -249,7 +254,7 @@ static __device__ __forceinline__ void ks_origin_section (float4 *s_pair, uint32
         // invalid points, 400 - 1200 entries, 287 - 393 -> 293 - 403 us; through both tile buffers of the small-tile variant,
         // 608 entries at once: no gain either)
         const float4 *OLb = list_base ();
-        ks_origin_list<LPQ> (OLb + 1u, OLb + 1u + nr, n_origin, true, qq, need, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
+        ks_origin_list<LPQ> (OLb + 1u, OLb + 1u + nr, n_origin, boxed, qq, need, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
     }
 }
 

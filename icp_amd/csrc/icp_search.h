@@ -249,8 +249,8 @@ static __device__ __forceinline__ void ks_origin_section (float4 *s_pair, uint32
             if (__ballot (need)) ks_origin_list<LPQ> (s_pair, s_pair + OE, n_origin, boxed, qq, need, qr, qg, qb, alpha, s1_lim, lane, ss, best, bid);
         }
     } else if (__ballot (need)) {
-        // a list the tile buffer does not hold at once: every wave that needs it reads it from memory by itself, a chunk's box
-        // before the chunk (staged a segment at a time it costs two block-wide barriers per segment: |F| = 2^20 with 10 - 30 %
+        // a short list, or one the tile buffer does not hold at once: every wave that needs it reads it from memory by itself, a long one's
+        // chunk boxes before the chunks (staged a segment at a time it costs two block-wide barriers per segment: |F| = 2^20 with 10 - 30 %
         // invalid points, 400 - 1200 entries, 287 - 393 -> 293 - 403 us; through both tile buffers of the small-tile variant,
         // 608 entries at once: no gain either)
         const float4 *OLb = list_base ();

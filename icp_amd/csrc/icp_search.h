@@ -227,7 +227,9 @@ static __device__ __forceinline__ void ks_origin_section (float4 *s_pair, uint32
     // Measured and not kept: the first segment fetched straight into a buffer of its own from the prologue on (global_load_lds, by
     // the builtin and written out), by the block or by every wave for itself (no barrier at all): |F| = 65536 with 10 - 30 %
     // invalid points 20.6 - 23.8 against 20.6 - 23.4 us, 64 x 16384: 2.28 against 2.35; colour boxes for lists of 16 / 48 entries
-    // and more: slower.  What is left of a wave's 1 - 1.5 us here is the scan itself on a busy SIMD: profiles/r05_stamps_holes_dense.txt)
+    // and more: slower.  What is left of a wave's 1 - 1.5 us here is the scan itself on a busy SIMD: profiles/r05_stamps_holes_dense.txt.
+    // Again with the invalid queries in a block's last waves: every wave that needs the list fetching it for itself (global_load_lds into a
+    // buffer of the block, no vote, no barrier) — |F| = 65536 21.2 -> 20.9 (10 % scattered), 21.5 -> 21.8 (30 % contiguous): not kept)
     constexpr uint32_t OE = ((PB_ * 4u / 5u) / 8u) * 8u;             // entries the tile buffer holds with the boxes of their chunks of 8 behind them: OE + OE / 4 <= PB_
     const bool boxed = n_origin > ICP_OL_BOXED_MIN;
     if (n_origin > ICP_OL_STAGED_MIN && n_origin <= OE) {

@@ -153,6 +153,59 @@ def test_holes_large_sets_batched_and_rebuilt(engine, oracle):
     g.close()
 
 
+@pytest.mark.parametrize("side,nr,batch,ff,fm", [(128, 256, 4, 1.0, 0.9), (128, 256, 4, 0.9, 1.0), (256, 1024, 1, 1.0, 1.0), (256, 1024, 1, 0.95, 0.5),
+                                                 (192, 2048, 1, 1.0, 0.3)])
+def test_holes_extreme_fractions_dense(engine, oracle, side, nr, batch, ff, fm):
+    """Frames that are (nearly) nothing but invalid points, dense layouts: every representative at the origin (all pruning boxes empty, the
+    origin list as long as the set: sorted, staged or read per wave by its length), no valid representative for the seeds to fall back on,
+    blocks whose 64 queries are all handed over as invalid ones."""
+    m = side * side
+    rng = np.random.default_rng(side * nr + batch)
+
+    def punch(cloud, frac, seed):
+        c = cloud.reshape(-1, 8).copy()
+        if frac >= 1.0:
+            c[:, 0:3] = 0.0
+        else:
+            c[rng.random(m) < frac, 0:3] = 0.0
+        return c
+
+    pairs = []
+    for b in range(batch):
+        F, M = engine.synth_pair(side, seed=4242 + 17 * b)
+        pairs.append((punch(F, ff, b), punch(M, fm, b)))
+    g = engine.ICP(0)
+    g.init(m, nr, A, C_, batch=batch)
+    for b, (F, M) in enumerate(pairs):
+        g.write(engine.Memory.F, F, batch_index=b); g.write(engine.Memory.M, M, batch_index=b)
+    g.buildRBC()
+    orcs = []
+    for F, M in pairs:
+        o = oracle.OracleICP(m, nr, A, C_, threads=16, power_fast=True, fused=True)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        orcs.append(o)
+    for b, o in enumerate(orcs):
+        assert np.array_equal(g.read(engine.Memory.RBC_OWNER, batch_index=b), o.rbc_owner), b
+        assert np.array_equal(g.read(engine.Memory.RBC_PERM, batch_index=b), o.rbc_perm), b
+    for it in range(2):
+        g.step()
+        for b, o in enumerate(orcs):
+            o.step()
+            assert np.array_equal(g.read(engine.Memory.RID, batch_index=b), o.rid), (it, b)
+            gn = g.read(engine.Memory.NN_ID, batch_index=b)
+            assert np.array_equal(gn["id"], o.nn_id["id"]), (it, b)
+            assert_bits(gn["dist"], o.nn_id["dist"], "distances")
+            gT = g.read(engine.Memory.T, batch_index=b)
+            if np.isnan(o.T).any():          # (a fixed set of nothing but invalid points: S = 0, no rotation to find — NaN in the same places; payloads are not compared)
+                assert np.array_equal(np.isnan(gT), np.isnan(o.T)) and np.array_equal(gT[~np.isnan(gT)], o.T[~np.isnan(o.T)]), (it, b)
+                break
+            assert_bits(gT, o.T, "T")
+        else:
+            continue
+        break
+    g.close()
+
+
 @pytest.mark.parametrize("warm", [False, True])
 def test_holes_tracked_sequence(engine, oracle, warm):
     """Frame-to-frame tracking on 640 x 480 frames with contiguous invalid regions (10 - 30 %, another pattern in every frame; one frame with

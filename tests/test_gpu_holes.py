@@ -154,9 +154,9 @@ def test_holes_large_sets_batched_and_rebuilt(engine, oracle):
 
 
 @pytest.mark.parametrize("side,nr,batch,ff,fm", [(128, 256, 4, 1.0, 0.9), (128, 256, 4, 0.9, 1.0), (256, 1024, 1, 1.0, 1.0), (256, 1024, 1, 0.95, 0.5),
-                                                 (192, 2048, 1, 1.0, 0.3)])
+                                                 (192, 2048, 1, 1.0, 0.3), (128, 256, 1, 1.0, 0.9), (128, 256, 1, 0.95, 1.0)])
 def test_holes_extreme_fractions_dense(engine, oracle, side, nr, batch, ff, fm):
-    """Frames that are (nearly) nothing but invalid points, dense layouts: every representative at the origin (all pruning boxes empty, the
+    """Frames that are (nearly) nothing but invalid points, dense layouts (and the latency-bound one: batch 1 at 16384): every representative at the origin (all pruning boxes empty, the
     origin list as long as the set: sorted, staged or read per wave by its length), no valid representative for the seeds to fall back on,
     blocks whose 64 queries are all handed over as invalid ones."""
     m = side * side

@@ -556,11 +556,42 @@ __global__ __launch_bounds__ (1024) void k_place (icp_params p)
 // owner blocks + rank inside the own block: the stable order by original index, the same integers as k_chunk_hist +
 // k_count_offsets + k_place.  Block 0 also writes N and O and resets k / done (ICP::buildRBC, src/ICP/algorithms.cpp:4796).
 // buildRBC at |F| = 16384: 6 launches, 33.6 us -> 2 launches.
+// the boxes of a list (n positions from offset o) of registration b: 16-lane row `row` of `nrows` takes the chunks c_first + row, + nrows, ..
+static __device__ __forceinline__ void list_boxes_of (const icp_params &p, uint32_t b, uint32_t n, uint32_t o, uint32_t c_first, uint32_t l, uint32_t row, uint32_t nrows)
+{
+    const uint32_t nch = (n + 15u) >> 4;
+    const float4 *Q4 = reinterpret_cast<const float4 *> (p.XQ + (size_t) b * p.m * 8);
+    float4 *LB = p.LB + (size_t) b * 3 * p.nlb;
+    const float inf = __builtin_inff ();
+    for (uint32_t c = c_first + row; c < nch; c += nrows) {
+        const uint32_t j = 16u * c + l;
+        float lo[6] = { inf, inf, inf, inf, inf, inf }, hi[6] = { -inf, -inf, -inf, -inf, -inf, -inf };
+        if (j < n) {
+            const float4 g = Q4[2 * (size_t) (o + j)], cc = Q4[2 * (size_t) (o + j) + 1];     // [x r y g | z b id 0]
+            lo[0] = hi[0] = g.x; lo[1] = hi[1] = g.z; lo[2] = hi[2] = cc.x; lo[3] = hi[3] = g.y; lo[4] = hi[4] = g.w; lo[5] = hi[5] = cc.y;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (lo[k] != lo[k]) { lo[k] = inf; hi[k] = -inf; }    // NaN: out of the box
+        }
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { lo[k] = fminf (lo[k], __shfl_xor (lo[k], d, 16)); hi[k] = fmaxf (hi[k], __shfl_xor (hi[k], d, 16)); }
+        if (l == 0) {
+            float4 *dst = LB + 3 * (size_t) ((o >> 4) + c);
+            dst[0] = make_float4 (lo[0], lo[1], lo[2], lo[3]);
+            dst[1] = make_float4 (lo[4], lo[5], hi[0], hi[1]);
+            dst[2] = make_float4 (hi[2], hi[3], hi[4], hi[5]);
+        }
+    }
+}
+
 __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
 {
     __shared__ uint32_t s_total[1024], s_before[1024];
     __shared__ uint2 s_list[4][64];
     __shared__ uint32_t s_n[4], s_wave[4];
+    __shared__ uint32_t s_off[1024], s_cnt;          // (the end: the offsets of the lists, the number of moderately long ones)
+    __shared__ uint32_t s_long, s_last;              // a list beyond the positions a search scans unconditionally exists / this block arrived last (see the end)
     const uint32_t c = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane (t >> 6);
     const uint32_t nb = p.nb, ob0 = c * 4u, i = c * 256u + t;
@@ -594,6 +625,7 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
     for (uint32_t r = t; r < p.nr; r += 256u) { s_total[r] = 0u; s_before[r] = 0u; }
     s_list[wave][lane] = lown;
     if (lane == 0) s_n[wave] = nown;
+    if (t == 0) { s_long = 0u; s_last = 0u; s_cnt = 0u; }
     __syncthreads ();
     {
         const bool earlier = t < ob0;
@@ -631,6 +663,8 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
     for (uint32_t w = 0; w < wave; ++w) run += s_wave[w];
     for (uint32_t r = lo; r < hi; ++r) {
         const uint32_t n = s_total[r];
+        if (n > 128u) s_long = 1u;                   // (ICP_S2_UNCOND: every block sees the same totals, so the same answer)
+        s_off[r] = run;
         if (c == 0u) { p.N[(size_t) b * p.nr + r] = n; p.O[(size_t) b * p.nr + r] = run; }
         s_before[r] += run;                          // position of the chunk's first point of list r
         run += n;
@@ -651,6 +685,28 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
         Q4[2 * (size_t) pos] = make_float4 (g.x, cc.x, g.y, cc.y);                      // search copy: see k_place
         Q4[2 * (size_t) pos + 1] = make_float4 (g.z, cc.z, __uint_as_float (i), 0.f);
     }
+    // The 6-D boxes of the chunks of long lists (k_list_boxes for the other construction): a launch of their own cost every construction of
+    // this size ~2 us of its 15 for lists that are hardly ever there.  Every block holds all totals, so every block knows whether any list is
+    // longer than what a search scans as it comes; only then the blocks count their arrivals (the counter: a word of this registration's OL
+    // header, which this construction does not use otherwise; zero between constructions) and the one that arrives last — behind everybody's
+    // placements — builds the boxes of those lists.  Nobody waits for anybody.
+    if (s_long) {                                    // (block-uniform, and the same in every block of the registration)
+        __threadfence ();                            // this thread's placements
+        __syncthreads ();
+        uint32_t *arrive = reinterpret_cast<uint32_t *> (p.OL + (size_t) b * ICP_OL_STRIDE (p.nr)) + 1;
+        if (t == 0u) s_last = __hip_atomic_fetch_add (arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+        __syncthreads ();
+        if (s_last) {
+            __threadfence ();                        // the others' placements, and N / O of block 0
+            // a very long list (more than 16 chunks behind the first 8): all 16 rows of the block; the others: a row per list, 16 lists at a time
+            // (s_before is free by now: the numbers of those lists)
+            for (uint32_t r = t; r < p.nr; r += 256u) { const uint32_t n = s_total[r]; if (n > 128u && n <= 384u) s_before[atomicAdd (&s_cnt, 1u)] = r; }
+            for (uint32_t r = 0; r < p.nr; ++r) { const uint32_t n = s_total[r]; if (n > 384u) list_boxes_of (p, b, n, s_off[r], 8u, t & 15u, t >> 4, 16u); }
+            __syncthreads ();
+            for (uint32_t k = t >> 4; k < s_cnt; k += 16u) { const uint32_t r = s_before[k]; list_boxes_of (p, b, s_total[r], s_off[r], 8u, t & 15u, 0u, 1u); }
+            if (t == 0u) __hip_atomic_store (arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // 6-D bounding boxes of the list chunks (stage-2 pruning of long lists, k_search): chunk c of list r = its positions 16 c .. 16 c + 15.
@@ -662,7 +718,7 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
 // Chunk 0 is always scanned.  min / max are exact in any order; fminf / fmaxf skip NaN coordinates (such a point never wins a '<').
 __global__ __launch_bounds__ (256) void k_list_boxes (icp_params p)
 {
-    const uint32_t r = blockIdx.x, b = blockIdx.y, l = threadIdx.x & 15u, row = threadIdx.x >> 4;
+    const uint32_t r = blockIdx.x, b = blockIdx.y;
     const uint32_t n = p.N[(size_t) b * p.nr + r];
     // (only what the scans ask for: a list's first ICP_S2_UNCOND = 128 positions are always scanned as they come — ks_stage2_lanes; a wave
     // whose longest list has more than 256 tests every list of its queries from chunk 8 on: ks_list_tail —; on a clean frame of the
@@ -670,30 +726,7 @@ __global__ __launch_bounds__ (256) void k_list_boxes (icp_params p)
     // (lanes = candidates — p.s2wave: a list's first ICP_S2W_UNCOND = 1024 positions are scanned wave-cooperatively, the tail from chunk 64 on)
     const uint32_t n_min = p.s2wave ? 1024u : 128u, c_first = p.s2wave ? 64u : 8u;
     if (n <= n_min) return;
-    const uint32_t o = p.O[(size_t) b * p.nr + r], nch = (n + 15u) >> 4;
-    const float4 *Q4 = reinterpret_cast<const float4 *> (p.XQ + (size_t) b * p.m * 8);
-    float4 *LB = p.LB + (size_t) b * 3 * p.nlb;
-    const float inf = __builtin_inff ();
-    for (uint32_t c = c_first + row; c < nch; c += 16u) {
-        const uint32_t j = 16u * c + l;
-        float lo[6] = { inf, inf, inf, inf, inf, inf }, hi[6] = { -inf, -inf, -inf, -inf, -inf, -inf };
-        if (j < n) {
-            const float4 g = Q4[2 * (size_t) (o + j)], cc = Q4[2 * (size_t) (o + j) + 1];     // [x r y g | z b id 0]
-            lo[0] = hi[0] = g.x; lo[1] = hi[1] = g.z; lo[2] = hi[2] = cc.x; lo[3] = hi[3] = g.y; lo[4] = hi[4] = g.w; lo[5] = hi[5] = cc.y;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) if (lo[k] != lo[k]) { lo[k] = inf; hi[k] = -inf; }    // NaN: out of the box
-        }
-#pragma unroll
-        for (int d = 8; d > 0; d >>= 1)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { lo[k] = fminf (lo[k], __shfl_xor (lo[k], d, 16)); hi[k] = fmaxf (hi[k], __shfl_xor (hi[k], d, 16)); }
-        if (l == 0) {
-            float4 *dst = LB + 3 * (size_t) ((o >> 4) + c);
-            dst[0] = make_float4 (lo[0], lo[1], lo[2], lo[3]);
-            dst[1] = make_float4 (lo[4], lo[5], hi[0], hi[1]);
-            dst[2] = make_float4 (hi[2], hi[3], hi[4], hi[5]);
-        }
-    }
+    list_boxes_of (p, b, n, p.O[(size_t) b * p.nr + r], c_first, threadIdx.x & 15u, threadIdx.x >> 4, 16u);
 }
 
 // ICPPowerMethod as a kernel of its own (reference include/ICP/algorithms.hpp:1451-1537, kernels/icp_kernels.cl:977-1054: an
@@ -813,8 +846,7 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 {
     if (icp_build_lists (p)) {                       // two launches: the owner search (gathers the representatives itself, leaves the lists), the placement
         icp_launch_owner_search (p, s);
-        hipLaunchKernelGGL (k_place_lists, dim3 ((p.nb + 3u) / 4u, p.batch), dim3 (256), 0, s, p);
-        hipLaunchKernelGGL (k_list_boxes, dim3 (p.nr, p.batch), dim3 (256), 0, s, p);
+        hipLaunchKernelGGL (k_place_lists, dim3 ((p.nb + 3u) / 4u, p.batch), dim3 (256), 0, s, p);      // (+ the chunk boxes of long lists, where there are any)
         return;
     }
     {   // the representatives, the boxes of their pruning groups and (several tiles only) of the LDS tiles: one launch

@@ -546,16 +546,6 @@ __global__ __launch_bounds__ (1024) void k_place (icp_params p)
     }
 }
 
-// RBC construct, steps 2 - 5 in ONE launch for the latency-bound sizes (at most 512 blocks of 64 points over the batch, |R| < 1024:
-// the sizes whose owner search is k_search<.., OWNER, MINW = 2>, which leaves owner[], the rank of every point inside its block of
-// 64 and the block's (owner, count) list).  A block places 256 consecutive points = 4 owner blocks.  Nothing here waits for
-// another block: every block re-derives what it needs from the lists of ALL owner blocks (a few KB, L2-resident) —
-//   total[r]  = points owned by r                       (N; its exclusive scan is O: exclusiveScan_i, kernels/scan_kernels.cl:188)
-//   before[r] = points owned by r in earlier chunks
-// with integer LDS atomics (deterministic), then position = O[owner] + before[owner] + counts of the owner in the chunk's earlier
-// owner blocks + rank inside the own block: the stable order by original index (SURVEY Appendix B), the same integers as k_chunk_hist +
-// k_count_offsets + k_place.  Block 0 also writes N and O and resets k / done (ICP::buildRBC, src/ICP/algorithms.cpp:4796).
-// buildRBC at |F| = 16384: 6 launches, 33.6 us -> 2 launches.
 // the boxes of a list (n positions from offset o) of registration b: 16-lane row `row` of `nrows` takes the chunks c_first + row, + nrows, ..
 static __device__ __forceinline__ void list_boxes_of (const icp_params &p, uint32_t b, uint32_t n, uint32_t o, uint32_t c_first, uint32_t l, uint32_t row, uint32_t nrows)
 {
@@ -585,6 +575,16 @@ static __device__ __forceinline__ void list_boxes_of (const icp_params &p, uint3
     }
 }
 
+// RBC construct, steps 2 - 5 in ONE launch for the latency-bound sizes (at most 512 blocks of 64 points over the batch, |R| < 1024:
+// the sizes whose owner search is k_search<.., OWNER, MINW = 2>, which leaves owner[], the rank of every point inside its block of
+// 64 and the block's (owner, count) list).  A block places 256 consecutive points = 4 owner blocks.  Nothing here waits for
+// another block: every block re-derives what it needs from the lists of ALL owner blocks (a few KB, L2-resident) —
+//   total[r]  = points owned by r                       (N; its exclusive scan is O: exclusiveScan_i, kernels/scan_kernels.cl:188)
+//   before[r] = points owned by r in earlier chunks
+// with integer LDS atomics (deterministic), then position = O[owner] + before[owner] + counts of the owner in the chunk's earlier
+// owner blocks + rank inside the own block: the stable order by original index (SURVEY Appendix B), the same integers as k_chunk_hist +
+// k_count_offsets + k_place.  Block 0 also writes N and O and resets k / done (ICP::buildRBC, src/ICP/algorithms.cpp:4796).
+// buildRBC at |F| = 16384: 6 launches, 33.6 us -> 2 launches.
 __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
 {
     __shared__ uint32_t s_total[1024], s_before[1024];

@@ -573,6 +573,32 @@ def test_tracking_on_device_four_frames(engine, oracle, warm):
     g.close()
 
 
+def test_batch_slot_workers_survive_a_failing_call(engine):
+    """A call that fails inside the slot workers (icp_init_batched rejects the configuration on every slot) comes back as the slots'
+    error — code and text — and leaves the workers alive: the next calls on the same batch object work, and so does a call that fails
+    before any worker is asked (a registration index out of range)."""
+    side, nr = 64, 64
+    m = side * side
+    b = engine.ICPBatch([0, 0, 0])
+    with pytest.raises(engine.ICPError) as ei:
+        b.init(5, m, 48, 2e2, 1e-6)                       # (|R| is not a power of two)
+    assert "slot" in str(ei.value) and "power of two" in str(ei.value)
+    with pytest.raises(engine.ICPError):
+        b.buildRBC()                                      # (not initialised)
+    b.init(5, m, nr, 2e2, 1e-6)
+    pairs = [engine.synth_pair(side, seed=70 + i) for i in range(5)]
+    for i, (F, M) in enumerate(pairs):
+        b.write(i, engine.Memory.F, F); b.write(i, engine.Memory.M, M)
+    b.buildRBC(); b.run_fixed(3)
+    assert all(b.state(i).k == 3 for i in range(5))
+    with pytest.raises(engine.ICPError):
+        b.read(5, engine.Memory.T)
+    k_before = [b.state(i).k for i in range(5)]
+    b.run_fixed(2)
+    assert all(b.state(i).k == k_before[i] + 2 or b.state(i).k == 2 for i in range(5)), [b.state(i).k for i in range(5)]
+    b.close()
+
+
 def test_batch_api_across_device_slots(engine, oracle):
     """icp_batch_* with the device list [0, 0] (two slots = two handles, streams and host threads on the one GPU of this
     box): 5 registrations land on slots 0,1,0,1,0; every one equals its own oracle; gather by registration index."""

@@ -128,12 +128,16 @@ template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint
 // every tile of the set for that one query (|F| = 2^20 with 10 % invalid points: first search 308 -> 697 us, owner search 127 -> 605).
 // Such a query takes another seed: an invalid query (flagged by the query wave: bit 31 of the seed it hands over) the first representative
 // at the origin, a valid one the nearest representative by index that is not at the origin (k_reps_and_boxes: ICP_OL_VSEED).  Any
-// representative is a legitimate seed — the bound stays exact.  Clean frames: three compares and a scalar branch per search.
-static __device__ __forceinline__ void ks_seed_against_invalid (bool hq, const float4 *s_count, uint32_t nr, uint32_t b, const float4 *R4, uint32_t &seed,
+// representative is a legitimate seed — the bound stays exact.  Clean frames: one compare and a scalar branch per search behind the first.
+static __device__ __forceinline__ void ks_seed_against_invalid (uint32_t sfl, const float4 *s_count, uint32_t nr, uint32_t b, const float4 *R4, uint32_t &seed,
                                                                 float &sx, float &sy, float &sz, float &sr, float &sg, float &sb)
 {
+    // (sfl: the two flag bits the query wave put on the seed — 2: the query is an invalid point, 1: the seed is its grid cell's representative.
+    // A valid query seeded with its previous winner has neither: a later search of a clean frame leaves at this one test)
+    if (__builtin_expect (__ballot (sfl != 0u) == 0ull, 1)) return;
+    const bool hq = (sfl & 2u) != 0u;
     const bool s0 = sx == 0.f && sy == 0.f && sz == 0.f;
-    if (__builtin_expect (__ballot (hq != s0) == 0ull, 1)) return;
+    if (__ballot (hq != s0) == 0ull) return;
     if (__builtin_amdgcn_readfirstlane ((int) __float_as_uint (s_count->w)) == 0) return;      // (no representative at the origin: nothing to choose from — s_count: hi of box 0 in LDS)
     static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
     unsigned long long ol_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
@@ -1283,7 +1287,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     // check_flags bit 5 (ICP_AMD_WARM_SEED=1, diagnostics): always the previous search's answer.
     uint32_t seed = 0u, seed_cell = 0xFFFFFFFFu;
     if (qwave && prune && p.side_magic) seed_cell = cell_rep_of (p, ic);     // the representative sampled from the point's own cell
-    if constexpr (OWNER) seed = seed_cell == 0xFFFFFFFFu ? 0u : seed_cell;
+    if constexpr (OWNER) seed = (seed_cell == 0xFFFFFFFFu ? 0u : seed_cell) | ((PRUNE && ICP_S1_ORIGIN_LIST) ? 0x40000000u : 0u);      // (bit 30: a seed from the grid cell — ks_seed_against_invalid)
     else if (qwave && prune) {
         seed = p.rid[(size_t) b * m + ic];           // (selected against seed_cell below, once the state has arrived)
         if ((check_flags & 32u) || seed_cell == 0xFFFFFFFFu) seed_cell = 0xFFFFFFFFu;
@@ -1299,7 +1303,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
 #pragma unroll
     for (int k = 0; k < 8; ++k) T[k] = state_lane_f (sv, ICP_ST_DW (T) + k);
     if constexpr (PRUNE && !OWNER) {
-        if (seed_cell != 0xFFFFFFFFu && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (k)) == 0) seed = seed_cell;    // first search of a registration
+        if (seed_cell != 0xFFFFFFFFu && __builtin_amdgcn_readlane ((int) sv, (int) ICP_ST_DW (k)) == 0) seed = seed_cell | (ICP_S1_ORIGIN_LIST ? 0x40000000u : 0u);    // first search of a registration (bit 30: a seed from the grid cell)
     }
     icp_reg_state *sout = CHAIN ? p.cst + (size_t) b * 2 + (p.slot ^ 1u) : st;
     if constexpr (!OWNER && !CHAIN) {
@@ -1426,8 +1430,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         uint32_t qmask = 0xFFFFFFFFu >> (32u - ntile);
         if (prune) {
             // the seed bound: the seed representative from the home tile in LDS, from global memory where it lies outside
-            const bool hq = (seed >> 31) != 0u;        // (an invalid point of its frame: ks_seed_against_invalid)
-            seed = min (seed & 0x7FFFFFFFu, nr - 1u);
+            const uint32_t sfl = seed >> 30;             // (bit 1: an invalid point of its frame, bit 0: a seed from the grid cell — ks_seed_against_invalid)
+            seed = min (seed & 0x3FFFFFFFu, nr - 1u);
             float sx, sy, sz, sr, sg, sb;
             if (ICP_HOME_MODE == 1 && seed / KT == ht) {
                 const float *sp = s_pairf + PB * 4u + ((seed - ht * KT) >> 1) * 12u + (seed & 1u);
@@ -1438,7 +1442,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
                 const float4 g = R4[2 * (size_t) seed], c = R4[2 * (size_t) seed + 1];
                 sx = g.x; sy = g.y; sz = g.z; sr = c.x; sg = c.y; sb = c.z;
             }
-            if constexpr (ICP_S1_ORIGIN_LIST) ks_seed_against_invalid (hq, s_tbox + 1, nr, b, R4, seed, sx, sy, sz, sr, sg, sb);
+            if constexpr (ICP_S1_ORIGIN_LIST) ks_seed_against_invalid (sfl, s_tbox + 1, nr, b, R4, seed, sx, sy, sz, sr, sg, sb);
             const float b0 = icp_metric8 (qx, qy, qz, qr, qg, qb, sx, sy, sz, sr, sg, sb, alpha);
             if (b0 >= 0.f && b0 < __builtin_inff ()) s1_lim = __uint_as_float (__float_as_uint (b0) + 1u);     // next float up
             // tiles this query can find a nearer representative in: lane ss tests the tiles ss, ss + LPQ, ..; OR over the lanes
@@ -1572,8 +1576,8 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
         // keeps every representative that could tie with it.
         float lim = __builtin_inff ();
         if (t0 == 0 && prune) {
-            const bool hq = (seed >> 31) != 0u;        // (an invalid point of its frame: ks_seed_against_invalid)
-            seed = min (seed & 0x7FFFFFFFu, nr - 1u);
+            const uint32_t sfl = seed >> 30;             // (bit 1: an invalid point of its frame, bit 0: a seed from the grid cell — ks_seed_against_invalid)
+            seed = min (seed & 0x3FFFFFFFu, nr - 1u);
             float sx, sy, sz, sr, sg, sb;
             if (MINW == 2 || nr <= KT) {        // one tile: the seed is in LDS (MINW == 2: always, see icp_launch_search)
                 const float *sp = s_pairf + (seed >> 1) * 12u + (seed & 1u);
@@ -1585,7 +1589,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
                 sx = g.x; sy = g.y; sz = g.z; sr = c.x; sg = c.y; sb = c.z;
             }
             if constexpr (ICP_S1_ORIGIN_LIST && MINW == 4)
-                ks_seed_against_invalid (hq, (!SINGLE && nr > KT) ? s_tbox + 1 : s_box + 1, nr, b, R4, seed, sx, sy, sz, sr, sg, sb);
+                ks_seed_against_invalid (sfl, (!SINGLE && nr > KT) ? s_tbox + 1 : s_box + 1, nr, b, R4, seed, sx, sy, sz, sr, sg, sb);
             const float b0 = icp_metric8 (qx, qy, qz, qr, qg, qb, sx, sy, sz, sr, sg, sb, alpha);
             if (b0 >= 0.f && b0 < __builtin_inff ()) lim = __uint_as_float (__float_as_uint (b0) + 1u);     // next float up
             s1_lim = lim;

@@ -128,34 +128,6 @@ static __device__ __forceinline__ void origin_list_close (const icp_params &p, u
     // colour boxes of the chunks of 8 consecutive entries (ks_origin_list tests a chunk before it scans it — the owner search of THIS
     // construction already does, so the boxes cannot wait for a later launch): the wave reads its own entries back behind a fence
     __threadfence ();
-    // For every representative at the origin the nearest one by index that is not (its own index if there is none within four ballot
-    // words): a registration's FIRST search (and the owner search of this construction) seeds a query with the representative of its
-    // grid cell — an invalid point there bounds nothing for a valid query, which then scanned every tile of the set (k_search: the seed bound).
-    if (run) {
-        const unsigned long long *MK = reinterpret_cast<const unsigned long long *> (OL + ICP_OL_MASKS (p.nr));
-        uint32_t *VS = reinterpret_cast<uint32_t *> (OL + ICP_OL_VSEED (p.nr));
-        auto valid_bits = [&] (uint32_t w) -> unsigned long long {       // bit l: representative 64 w + l exists and is not at the origin
-            unsigned long long z = ~__hip_atomic_load (MK + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t left = p.nr - 64u * w;
-            if (left < 64u) z &= (1ull << left) - 1ull;
-            return z;
-        };
-        for (uint32_t w = 0; w < nw; ++w) {
-            const unsigned long long z = valid_bits (w);
-            const uint32_t left = p.nr - 64u * w;
-            const unsigned long long m = ~z & (left < 64u ? (1ull << left) - 1ull : ~0ull);          // this word's representatives at the origin
-            if (m == 0ull) continue;
-            uint32_t best_d = 0xFFFFFFFFu, best_r = 64u * w + lane;
-            const unsigned long long below = z & ((1ull << lane) - 1ull), above = lane < 63u ? z & ~((2ull << lane) - 1ull) : 0ull;
-            if (below) { const uint32_t q = 63u - (uint32_t) __builtin_clzll (below); best_d = lane - q; best_r = 64u * w + q; }
-            if (above) { const uint32_t q = (uint32_t) __builtin_ctzll (above); if (q - lane < best_d) { best_d = q - lane; best_r = 64u * w + q; } }
-            for (uint32_t d = 1; d <= 4u && __ballot (((m >> lane) & 1ull) && best_d == 0xFFFFFFFFu); ++d) {      // a word of nothing but invalid points: the neighbouring words
-                if (w >= d) { const unsigned long long zl = valid_bits (w - d); if (zl && best_d == 0xFFFFFFFFu) { best_d = 0u; best_r = 64u * (w - d) + 63u - (uint32_t) __builtin_clzll (zl); } }
-                if (w + d < nw) { const unsigned long long zr = valid_bits (w + d); if (zr && best_d == 0xFFFFFFFFu) { best_d = 0u; best_r = 64u * (w + d) + (uint32_t) __builtin_ctzll (zr); } }
-            }
-            if ((m >> lane) & 1ull) VS[64u * w + lane] = best_r;
-        }
-    }
     // Lists the search prunes by chunk boxes (more than 128 entries): ordered by a Morton key of the colour instead of by index, so that the
     // 8 entries of a chunk are neighbours in colour whatever the invalid points' pattern in the frame — in index order 10 of 49 / 157
     // chunks passed a query's test at |F| = 2^20 with 10 % scattered / 30 % contiguous invalid points, ordered by colour 4
@@ -194,10 +166,24 @@ static __device__ __forceinline__ void origin_list_close (const icp_params &p, u
         for (uint32_t k = 2u; k <= n2; k <<= 1)
             for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
                 __syncthreads ();
-                for (uint32_t t = lane; t < (n2 >> 1); t += 64u) {
-                    const uint32_t i0 = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), i1 = i0 + j;
-                    const uint32_t a = s_key[i0], c = s_key[i1];
-                    if ((a > c) == ((i0 & k) == 0u)) { s_key[i0] = c; s_key[i1] = a; }
+                // (two or four compare-exchanges per lane in flight — n2 >= 256 —: one at a time every step was a chain of dependent LDS round trips)
+                if (n2 >= 512u) {
+                    for (uint32_t t0 = lane; t0 < (n2 >> 1); t0 += 256u) {
+                        uint32_t i0[4], x[4], y[4];
+#pragma unroll
+                        for (uint32_t u = 0; u < 4u; ++u) { const uint32_t t = t0 + 64u * u; i0[u] = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)); x[u] = s_key[i0[u]]; y[u] = s_key[i0[u] + j]; }
+#pragma unroll
+                        for (uint32_t u = 0; u < 4u; ++u) { const bool sw = (x[u] > y[u]) == ((i0[u] & k) == 0u); s_key[i0[u]] = sw ? y[u] : x[u]; s_key[i0[u] + j] = sw ? x[u] : y[u]; }
+                    }
+                } else {
+                    for (uint32_t t0 = lane; t0 < (n2 >> 1); t0 += 128u) {
+                        const uint32_t ta = t0, tb = t0 + 64u;
+                        const uint32_t a0 = ((ta & ~(j - 1u)) << 1) | (ta & (j - 1u)), a1 = a0 + j, b0 = ((tb & ~(j - 1u)) << 1) | (tb & (j - 1u)), b1 = b0 + j;
+                        const uint32_t xa = s_key[a0], ya = s_key[a1], xb = s_key[b0], yb = s_key[b1];
+                        const bool sa = (xa > ya) == ((a0 & k) == 0u), sb = (xb > yb) == ((b0 & k) == 0u);
+                        s_key[a0] = sa ? ya : xa; s_key[a1] = sa ? xa : ya;
+                        s_key[b0] = sb ? yb : xb; s_key[b1] = sb ? xb : yb;
+                    }
                 }
             }
         __syncthreads ();
@@ -209,10 +195,13 @@ static __device__ __forceinline__ void origin_list_close (const icp_params &p, u
         const uint32_t n_oc = (run + 7u) >> 3;
         for (uint32_t c = lane; c < n_oc; c += 64u) {
             float4 lo = make_float4 (inf, inf, inf, 0.f), hi = make_float4 (-inf, -inf, -inf, 0.f);
-            for (uint32_t e = 8u * c; e < min (8u * c + 8u, run); ++e) {
-                const float4 v = OL[1u + e];
-                lo.x = fminf (lo.x, v.x); lo.y = fminf (lo.y, v.y); lo.z = fminf (lo.z, v.z);
-                hi.x = fmaxf (hi.x, v.x); hi.y = fmaxf (hi.y, v.y); hi.z = fmaxf (hi.z, v.z);
+            float4 v[8];                                                  // (the chunk's eight entries in flight; past the list's end: its last entry once more)
+#pragma unroll
+            for (uint32_t e = 0; e < 8u; ++e) v[e] = OL[1u + min (8u * c + e, run - 1u)];
+#pragma unroll
+            for (uint32_t e = 0; e < 8u; ++e) {
+                lo.x = fminf (lo.x, v[e].x); lo.y = fminf (lo.y, v[e].y); lo.z = fminf (lo.z, v[e].z);
+                hi.x = fmaxf (hi.x, v[e].x); hi.y = fmaxf (hi.y, v[e].y); hi.z = fmaxf (hi.z, v[e].z);
             }
             BX[2u * c] = lo; BX[2u * c + 1u] = hi;
         }
@@ -352,7 +341,7 @@ __global__ __launch_bounds__ (64) void k_reps_and_boxes (icp_params p, uint32_t 
                 const float4 c = F4[2 * (size_t) src_of (r) + 1];
                 OL[1u + run + (uint32_t) __builtin_popcountll (bal & ((1ull << lane) - 1ull))] = make_float4 (c.x, c.y, c.z, __uint_as_float (r));
             }
-            if (lane == 0 && u < nbr) reinterpret_cast<unsigned long long *> (OL + ICP_OL_MASKS (p.nr))[u] = bal;      // (the ballots: origin_list_close derives the valid seeds from them)
+            if (lane == 0 && u < nbr) reinterpret_cast<unsigned long long *> (OL + ICP_OL_MASKS (p.nr))[u] = bal;      // (the ballots: a search looks a seed of the right kind up in them — icp_other_kind_near)
             run += (uint32_t) __builtin_popcountll (bal);
         }
         origin_list_close (p, b, lane, OL, run, nbr, s_ent, s_key, sort_cap);

@@ -24,8 +24,7 @@
 #define ICP_OL_BOXED_MIN 128u        // the list of the representatives at the origin: beyond this length ordered by colour, its chunks of 8 tested by their boxes before they are scanned
 #endif
 #define ICP_OL_MASKS(nr) ((nr) + 1u + 2u * (((nr) + 7u) / 8u))                            // float4 offset of the ballots inside a registration's OL
-#define ICP_OL_VSEED(nr) (ICP_OL_MASKS (nr) + ((nr) + 127u) / 128u)                       // ... of the valid seeds (one uint32 per representative)
-#define ICP_OL_STRIDE(nr) (ICP_OL_VSEED (nr) + ((nr) + 3u) / 4u)                          // float4 per registration of icp_params::OL
+#define ICP_OL_STRIDE(nr) (ICP_OL_MASKS (nr) + ((nr) + 127u) / 128u)                          // float4 per registration of icp_params::OL
 #define ICP_CHUNK 1024u          // fixed points per block in the stable RBC placement
 
 struct icp_params {
@@ -65,8 +64,8 @@ struct icp_params {
     float4 *OL;                  // [batch][ICP_OL_STRIDE (nr)]  the representatives at the origin (invalid points), ascending: [0].x = their number (bits),
                                  // [1 .. nr]: (r, g, b, index bits) each — kept out of the pruning boxes, scanned by the queries near the origin (dense
                                  // search) —, behind them the colour boxes (lo rgb, hi rgb) of the chunks of 8 consecutive entries, then one 64-bit ballot per 64
-                                 // representatives ([0].y: the arrival counter of k_reps_and_boxes' blocks, zero between constructions), then one uint32 per representative:
-                                 // for a representative at the origin the nearest one (by index) that is not — the seed of a valid query whose own seed is an invalid point
+                                 // representatives ([0].y: the arrival counter of k_reps_and_boxes' blocks, zero between constructions; a search looks the seed of a query
+                                 // whose own seed is of the wrong kind up in the ballots: icp_other_kind_near)
     float4 *LB;                  // [batch][3 * nlb]  6-D bounding boxes of the list chunks (16 consecutive positions of one list, chunk c >= 1 of list r at
                                  // index (O[r] >> 4) + c: k_list_boxes) as [lo.x lo.y lo.z lo.r | lo.g lo.b hi.x hi.y | hi.z hi.r hi.g hi.b]
     uint32_t nlb;                // m / 16 + 2 boxes per registration
@@ -135,6 +134,29 @@ struct rep_src_map {
     }
 };
 
+
+// The representative nearest by index to r that is of the OTHER kind — not at the origin when r is, at the origin when r is not —, looked up in
+// the ballots k_reps_and_boxes leaves (bit l of word w: representative 64 w + l is an invalid point of its frame: at the origin); `fallback`
+// where r's word and four words to either side hold none.  (ks_seed_against_invalid: a handful of lanes, a registration's first search.)
+static __device__ __forceinline__ uint32_t icp_other_kind_near (const unsigned long long *MK, uint32_t nr, uint32_t r, bool r_at_origin, uint32_t fallback)
+{
+    const uint32_t nw = (nr + 63u) / 64u, w = r >> 6, l = r & 63u;
+    auto other = [&] (uint32_t ww) -> unsigned long long {
+        const uint32_t left = nr - 64u * ww;
+        const unsigned long long m = MK[ww];
+        return (r_at_origin ? ~m : m) & (left < 64u ? (1ull << left) - 1ull : ~0ull);
+    };
+    const unsigned long long o = other (w), below = o & ((1ull << l) - 1ull), above = l < 63u ? o & ~((2ull << l) - 1ull) : 0ull;
+    uint32_t best_d = 0xFFFFFFFFu, best = fallback;
+    if (below) { const uint32_t q = 63u - (uint32_t) __builtin_clzll (below); best_d = l - q; best = 64u * w + q; }
+    if (above) { const uint32_t q = (uint32_t) __builtin_ctzll (above); if (q - l < best_d) { best_d = q - l; best = 64u * w + q; } }
+    if (best_d != 0xFFFFFFFFu) return best;
+    for (uint32_t d = 1; d <= 4u; ++d) {
+        if (w >= d) { const unsigned long long ol = other (w - d); if (ol) return 64u * (w - d) + 63u - (uint32_t) __builtin_clzll (ol); }
+        if (w + d < nw) { const unsigned long long orr = other (w + d); if (orr) return 64u * (w + d) + (uint32_t) __builtin_ctzll (orr); }
+    }
+    return fallback;
+}
 
 // launchers (icp_kernels.hip, icp_build.hip)
 void icp_launch_build_rbc (const icp_params &p, hipStream_t s);

@@ -126,8 +126,9 @@ template <int LPQ> static __device__ __forceinline__ uint32_t ks_grp_min_u (uint
 // buildRBC — seeds a query with the representative sampled from its own grid cell: where that is an invalid point (at the origin) and the
 // query is not, or the other way round, the distance to it bounds nothing, no tile and no group is pruned, and the block stages and scans
 // every tile of the set for that one query (|F| = 2^20 with 10 % invalid points: first search 308 -> 697 us, owner search 127 -> 605).
-// Such a query takes another seed: an invalid query (flagged by the query wave: bit 31 of the seed it hands over) the first representative
-// at the origin, a valid one the nearest representative by index that is not at the origin (k_reps_and_boxes: ICP_OL_VSEED).  Any
+// Such a query takes another seed: the representative nearest by index to its own seed that is of the query's kind — at the origin for an
+// invalid query (flagged by the query wave: bit 31 of the seed it hands over), not at the origin for a valid one — looked up in the
+// ballots k_reps_and_boxes leaves (icp_other_kind_near): a neighbour on the grid, near the query in space or, neighbouring pixels, in colour.  Any
 // representative is a legitimate seed — the bound stays exact.  Clean frames: one compare and a scalar branch per search behind the first.
 static __device__ __forceinline__ void ks_seed_against_invalid (uint32_t sfl, const float4 *s_count, uint32_t nr, uint32_t b, const float4 *R4, uint32_t &seed,
                                                                 float &sx, float &sy, float &sz, float &sr, float &sg, float &sb)
@@ -146,7 +147,7 @@ static __device__ __forceinline__ void ks_seed_against_invalid (uint32_t sfl, co
     typedef float4 __attribute__ ((address_space (1))) *gf4;
     const float4 *OLb = (const float4 *) (gf4) po->OL + (size_t) b * ICP_OL_STRIDE (nr);
     if (hq != s0) {
-        uint32_t s2 = hq ? __float_as_uint (OLb[1].w) : reinterpret_cast<const uint32_t *> (OLb + ICP_OL_VSEED (nr))[seed];
+        uint32_t s2 = icp_other_kind_near (reinterpret_cast<const unsigned long long *> (OLb + ICP_OL_MASKS (nr)), nr, seed, s0, hq ? __float_as_uint (OLb[1].w) : seed);
         s2 = min (s2, nr - 1u);
         const float4 g = R4[2 * (size_t) s2], c = R4[2 * (size_t) s2 + 1];
         seed = s2; sx = g.x; sy = g.y; sz = g.z; sr = c.x; sg = c.y; sb = c.z;

@@ -579,8 +579,6 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
     __shared__ uint32_t s_total[1024], s_before[1024];
     __shared__ uint2 s_list[4][64];
     __shared__ uint32_t s_n[4], s_wave[4];
-    __shared__ uint32_t s_off[1024], s_cnt;          // (the end: the offsets of the lists, the number of moderately long ones)
-    __shared__ uint32_t s_long, s_last;              // a list beyond the positions a search scans unconditionally exists / this block arrived last (see the end)
     const uint32_t c = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane (t >> 6);
     const uint32_t nb = p.nb, ob0 = c * 4u, i = c * 256u + t;
@@ -614,7 +612,6 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
     for (uint32_t r = t; r < p.nr; r += 256u) { s_total[r] = 0u; s_before[r] = 0u; }
     s_list[wave][lane] = lown;
     if (lane == 0) s_n[wave] = nown;
-    if (t == 0) { s_long = 0u; s_last = 0u; s_cnt = 0u; }
     __syncthreads ();
     {
         const bool earlier = t < ob0;
@@ -623,10 +620,18 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
             const uint32_t o_ = (e & 1) ? e0[e >> 1].z : e0[e >> 1].x, n_ = (e & 1) ? e0[e >> 1].w : e0[e >> 1].y;
             if ((uint32_t) e < n0) { atomicAdd (&s_total[o_], n_); if (earlier) atomicAdd (&s_before[o_], n_); }
         }
-        for (uint32_t e = 2u * KP_UP; e < n0; ++e) {
-            const uint2 v = BL[(size_t) t * 64u + e];
-            atomicAdd (&s_total[v.x], v.y);
-            if (earlier) atomicAdd (&s_before[v.x], v.y);
+        // (the rest of a long list sixteen entries per round trip, not one: a frame's invalid points — each with the representative at the
+        // origin whose colour is nearest — give a block of 64 points 30 - 40 owners: buildRBC at |F| = 16384 with 10 % of them 39 -> 2x us)
+        for (uint32_t e0 = 2u * KP_UP; e0 < n0; e0 += 2u * KP_UP) {
+            const uint4 *q = reinterpret_cast<const uint4 *> (BL + (size_t) t * 64u + e0);
+            uint4 e1[KP_UP];
+#pragma unroll
+            for (int k = 0; k < KP_UP; ++k) e1[k] = q[k];
+#pragma unroll
+            for (int e = 0; e < 2 * KP_UP; ++e) {
+                const uint32_t o_ = (e & 1) ? e1[e >> 1].z : e1[e >> 1].x, n_ = (e & 1) ? e1[e >> 1].w : e1[e >> 1].y;
+                if (e0 + (uint32_t) e < n0) { atomicAdd (&s_total[o_], n_); if (earlier) atomicAdd (&s_before[o_], n_); }
+            }
         }
     }
     for (uint32_t ob = t + 256u; ob < nb; ob += 256u) {
@@ -652,8 +657,6 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
     for (uint32_t w = 0; w < wave; ++w) run += s_wave[w];
     for (uint32_t r = lo; r < hi; ++r) {
         const uint32_t n = s_total[r];
-        if (n > 128u) s_long = 1u;                   // (ICP_S2_UNCOND: every block sees the same totals, so the same answer)
-        s_off[r] = run;
         if (c == 0u) { p.N[(size_t) b * p.nr + r] = n; p.O[(size_t) b * p.nr + r] = run; }
         s_before[r] += run;                          // position of the chunk's first point of list r
         run += n;
@@ -673,28 +676,6 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
         X4[2 * (size_t) pos + 1] = cc;
         Q4[2 * (size_t) pos] = make_float4 (g.x, cc.x, g.y, cc.y);                      // search copy: see k_place
         Q4[2 * (size_t) pos + 1] = make_float4 (g.z, cc.z, __uint_as_float (i), 0.f);
-    }
-    // The 6-D boxes of the chunks of long lists (k_list_boxes for the other construction): a launch of their own cost every construction of
-    // this size ~2 us of its 15 for lists that are hardly ever there.  Every block holds all totals, so every block knows whether any list is
-    // longer than what a search scans as it comes; only then the blocks count their arrivals (the counter: a word of this registration's OL
-    // header, which this construction does not use otherwise; zero between constructions) and the one that arrives last — behind everybody's
-    // placements — builds the boxes of those lists.  Nobody waits for anybody.
-    if (s_long) {                                    // (block-uniform, and the same in every block of the registration)
-        __threadfence ();                            // this thread's placements
-        __syncthreads ();
-        uint32_t *arrive = reinterpret_cast<uint32_t *> (p.OL + (size_t) b * ICP_OL_STRIDE (p.nr)) + 1;
-        if (t == 0u) s_last = __hip_atomic_fetch_add (arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
-        __syncthreads ();
-        if (s_last) {
-            __threadfence ();                        // the others' placements, and N / O of block 0
-            // a very long list (more than 16 chunks behind the first 8): all 16 rows of the block; the others: a row per list, 16 lists at a time
-            // (s_before is free by now: the numbers of those lists)
-            for (uint32_t r = t; r < p.nr; r += 256u) { const uint32_t n = s_total[r]; if (n > 128u && n <= 384u) s_before[atomicAdd (&s_cnt, 1u)] = r; }
-            for (uint32_t r = 0; r < p.nr; ++r) { const uint32_t n = s_total[r]; if (n > 384u) list_boxes_of (p, b, n, s_off[r], 8u, t & 15u, t >> 4, 16u); }
-            __syncthreads ();
-            for (uint32_t k = t >> 4; k < s_cnt; k += 16u) { const uint32_t r = s_before[k]; list_boxes_of (p, b, s_total[r], s_off[r], 8u, t & 15u, 0u, 1u); }
-            if (t == 0u) __hip_atomic_store (arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 
@@ -835,7 +816,12 @@ void icp_launch_build_rbc (const icp_params &p, hipStream_t s)
 {
     if (icp_build_lists (p)) {                       // two launches: the owner search (gathers the representatives itself, leaves the lists), the placement
         icp_launch_owner_search (p, s);
-        hipLaunchKernelGGL (k_place_lists, dim3 ((p.nb + 3u) / 4u, p.batch), dim3 (256), 0, s, p);      // (+ the chunk boxes of long lists, where there are any)
+        hipLaunchKernelGGL (k_place_lists, dim3 ((p.nb + 3u) / 4u, p.batch), dim3 (256), 0, s, p);
+        // (the chunk boxes of long lists: folded into k_place_lists — its blocks count their arrivals where a long list exists, the last one
+        // builds the boxes — the construction of a clean frame took 13.5 instead of 15.2 us, but that of a frame with invalid points, which
+        // always has a few lists beyond 128 positions, 35 instead of 19: every block's release fence writes the XCD's L2 back, megabytes
+        // of fresh placements.  The launch boundary does that once.)
+        hipLaunchKernelGGL (k_list_boxes, dim3 (p.nr, p.batch), dim3 (256), 0, s, p);
         return;
     }
     {   // the representatives, the boxes of their pruning groups and (several tiles only) of the LDS tiles: one launch

@@ -26,7 +26,10 @@ pairs (config 4) unless --batch says otherwise, no data-path collective, no RCCL
 time ("scaling": "weak").  EVERY line carries `config4_per_gpu_value` — iterations/s of one GPU at config 4's per-GPU share
 (64 registrations per launch) — so that N = 1 -> 8 reads off ONE field; the N = 1 `value` itself is the batch-1 headline.
 
-Prints ONE JSON line (rank 0).  Extra objects:
+Prints ONE JSON line (rank 0) as the LAST line of stdout, shorter than 4 KB (`compact_line`): the contract's fields, `roofline`,
+`cpu_baseline` and flat scalars for the other BASELINE configs.  Everything else that is measured (per-kernel times, tracking
+distributions, the invalid-point cases, the mode comparison, the thread sweep) goes to bench_extra.json beside this file and to stderr.
+Objects of the line:
   roofline      dominant kernel (k_search): algorithmic bytes per launch ((72 m + 32 |R| + 64) x registrations per launch,
                 SURVEY.md §8d) / its average launch-to-launch time, measured with HIP events on the engine's own stream.
                 In the default (fused, chained) form an iteration IS one k_search launch (it first turns the previous
@@ -127,8 +130,15 @@ def cpu_share():
     return share
 
 
-def cpu_baseline(F, M, m, nr, fused, budget_s=15.0):
-    """The oracle (CPU port of the same iteration) on this host's cores: a thread sweep {1, 8, 16, 64, all host cores}, each count timed on
+def sweep_counts(share, host):
+    """Thread counts of the CPU baseline's sweep: 1, 8, 16, 64 and the process's CPU share — never more threads than the share (a
+    one-GPU box has 16 of its host's 256 cores: 256 threads on them time-slice and measure nothing but the scheduler)."""
+    cap = max(1, min(int(host), int(share)))
+    return sorted({t for t in (1, 8, 16, 64, cap) if 1 <= t <= cap})
+
+
+def cpu_baseline(F, M, m, nr, fused, budget_s=12.0):
+    """The oracle (CPU port of the same iteration) on this host's cores: a thread sweep {1, 8, 16, 64, share} up to the process's CPU share, each count timed on
     a bounded sample of the same workload (fresh 40-iteration passes of the benchmark pair), the best one reported as `value` with the
     sweep beside it.  OpenMP over the queries (search, transform, weights) and over the 64-pair blocks of the moment reduction —
     deterministic per-thread partials: the same bits as one thread (tests/test_oracle_golden.py)."""
@@ -136,7 +146,7 @@ def cpu_baseline(F, M, m, nr, fused, budget_s=15.0):
     host = os.cpu_count() or 1
     env = os.environ.get("ICP_BASELINE_THREADS")
     share = cpu_share()
-    counts = [int(env)] if env else sorted({t for t in (1, 8, 16, 64, int(round(share)), host) if 1 <= t <= host})
+    counts = [int(env)] if env else sweep_counts(share, host)
     o = O.OracleICP(m, nr, ALPHA, SCALING, threads=counts[0], power_fast=True, fused=fused)
     o.write_f(F)
     o.write_m(M)
@@ -161,6 +171,7 @@ def cpu_baseline(F, M, m, nr, fused, budget_s=15.0):
     best = max(sweep, key=lambda x: x["iterations_per_s"])
     return {"value": best["iterations_per_s"], "unit": "iterations/s", "cores": best["threads"], "threads": best["threads"], "host_cores": host,
             "cpu_share": share, "kind": "port", "sweep": sweep,
+            "sample_short": "%d iterations of the same pair in %.1f s, OpenMP thread sweep %s, best count reported" % (total_n, total_t, [x["threads"] for x in sweep]),
             "sample": "%d iterations of the same pair (|F|=|M|=%d, |R|=%d) in %.1f s over a sweep of %s threads of the host's %d cores (this process's share: %.4g) "
                       "(~%.0f s each); `value` = the best count; search, transform, weights and the block partials of the moment "
                       "reduction in OpenMP, deterministic per-thread partials" % (total_n, m, nr, total_t, [x["threads"] for x in sweep], host, share, per)}
@@ -194,7 +205,7 @@ SETUP_MS = float(os.environ.get("ICP_BENCH_SETUP_MS", "25"))
 def settle(g, iters):
     """Part of the untimed set-up, before the W warm-up steps: the graph of a step is captured and instantiated, and the device is kept
     busy with it for SETUP_MS milliseconds.  An MI355X that has been idle runs its first ~10 ms of work below its steady clocks
-    (20 passes right after 5: 9.3 us per iteration; after another 20: 8.95; tests/diag_overhead.py) — a registration service is
+    (20 passes right after 5: 9.3 us per iteration; after another 20: 8.95; tools/diag/overhead.py) — a registration service is
     never in that state, a freshly started benchmark process always is.  Returns the number of passes run."""
     n, t0 = 0, time.perf_counter()
     while True:
@@ -352,6 +363,20 @@ def measure_modes(icp_amd, device, g_default, power_mode, reduce_mode):
     ref_us = rms * 1e3 / (rst * ITERS_PER_STEP)
     launches = r.launches_per_iteration()
     out = {"reference_order_us_per_iteration": ref_us, "reference_order_launches_per_iteration": launches}
+    # the same reductions with the squared power start: what of the reference-order mode's time is the reduction trees (this figure
+    # minus the benchmarked one) and what the literal power loop (the figure above minus this one)
+    try:
+        q, _, _, _ = setup(icp_amd, device, "A", 1, 0, "squared", "reference")
+        settle(q, ITERS_PER_STEP)
+        for _ in range(5):
+            q.run_fixed_fresh(ITERS_PER_STEP)
+        q.sync()
+        qms, qst = q.time_run_fixed_tail(ITERS_PER_STEP, 50, from_identity=True)
+        out["reference_order_squared_us_per_iteration"] = qms * 1e3 / (qst * ITERS_PER_STEP)
+        q.close()
+    except Exception as e:                           # noqa: BLE001
+        out["reference_order_squared_us_per_iteration"] = None
+        out["reference_order_squared_error"] = "%s: %s" % (type(e).__name__, e)
     Mem = icp_amd.Memory
     res = []
     for h in (g_default, r):
@@ -639,6 +664,116 @@ def measure_holes(icp_amd, device, iters):
     return out
 
 
+LINE_LIMIT = 4096                                # bytes of the ONE stdout line (the driver's record keeps the last 8 KB of stdout)
+EXTRA_FILE = "bench_extra.json"
+
+
+def _r(x, sig=6):
+    """A number with `sig` significant digits (the line is read by people and a parser: 17 digits of a timing are noise)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float("%.*g" % (sig, float(x)))
+    except (TypeError, ValueError):
+        return None
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_line(full):
+    """The ONE stdout line from the full measurement dictionary: the contract's fields, `roofline` and `cpu_baseline` as small objects,
+    flat scalars for the other BASELINE configs — everything else stays in bench_extra.json.  Always shorter than LINE_LIMIT: optional
+    scalars are dropped from the end until it is (the contract's fields never are)."""
+    rl, cb, cfg = full.get("roofline") or {}, full.get("cpu_baseline"), full.get("config") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _r(full.get("value"), 8), _r(full.get("ms_per_step"), 8)
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:200], "parallelism": str(cfg.get("parallelism", ""))[:80],
+                      "registrations_per_gpu": cfg.get("registrations_per_gpu"), "launches_per_iteration": cfg.get("launches_per_iteration"),
+                      "reduce_mode": cfg.get("reduce_mode"), "power_start": cfg.get("power_start")}
+    if full.get("roofline") is not None:
+        line["roofline"] = {"bound": rl.get("bound"), "kernel": str(rl.get("kernel", ""))[:40], "achieved": _r(rl.get("achieved")),
+                            "peak": rl.get("peak"), "unit": rl.get("unit"), "frac": _r(rl.get("frac")), "frac_moved": _r(rl.get("frac_moved")),
+                            "traffic": _r(rl.get("traffic"), 7), "traffic_measured_by_this_run": False,
+                            "algorithmic_bytes_per_launch": rl.get("algorithmic_bytes_per_launch"),
+                            "avg_launch_us": _r(rl.get("avg_launch_us")),
+                            "valu_issue_frac": _r(_get(rl, "valu_beside_it", "executed", "valu_issue_frac"))}
+    if cb is not None:
+        line["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "threads": cb.get("threads"),
+                                "host_cores": cb.get("host_cores"), "cpu_share": _r(cb.get("cpu_share")), "kind": cb.get("kind"),
+                                "sample": str(cb.get("sample_short") or cb.get("sample", ""))[:160]}
+    line["us_per_iteration"] = _r(full.get("us_per_iteration"))
+    line["per_gpu_iterations_per_s"] = [_r(x) for x in (full.get("per_gpu_iterations_per_s") or [])]
+    line["config4_per_gpu_value"] = _r(full.get("config4_per_gpu_value"))
+    line["git_head"] = full.get("git_head")
+    line["extra"] = EXTRA_FILE
+    oc = full.get("other_configs") or {}
+    optional = []                                    # (key, value) in the order they are kept
+    for key in ("A_x64", "B", "C"):
+        c = oc.get(key) or {}
+        optional += [("%s_us_per_iteration" % key, _r(c.get("us_per_iteration"))), ("%s_hbm_frac" % key, _r(c.get("hbm_frac"))),
+                     ("%s_valu_issue_frac" % key, _r(c.get("valu_issue_frac"))), ("%s_k_search_us" % key, _r(c.get("k_search_avg_launch_us"))),
+                     ("%s_build_rbc_ms" % key, _r(c.get("build_rbc_ms")))]
+        if "error" in c:
+            optional.append(("%s_error" % key, str(c["error"])[:80]))
+    optional += [("reference_order_us_per_iteration", _r(full.get("reference_order_us_per_iteration"))),
+                 ("reference_order_squared_us_per_iteration", _r(full.get("reference_order_squared_us_per_iteration"))),
+                 ("value_right_after_start", _r(_get(full, "value_right_after_start", "iterations_per_s"))),
+                 ("build_rbc_ms", _r(_get(full, "registration_latency", "build_rbc_ms"))),
+                 ("identical_ids_frac_vs_reference_order", _r(_get(full, "mode_note", "identical_ids_frac"))),
+                 ("dt_over_t_vs_reference_order", _r(_get(full, "mode_note", "vs_float64", "between_the_modes_fp32", "dt_over_t"))),
+                 ("dt_over_t_vs_float64", _r(_get(full, "mode_note", "vs_float64", "benchmarked", "dt_over_t")))]
+    for name, path in (("track_cold_frames_per_s", ("track", "cold_start", "pipelined_pageable", "frames_per_s")),
+                       ("track_warm_frames_per_s", ("track", "warm_start", "pipelined_registered", "frames_per_s")),
+                       ("track_warm_gap_p99_over_same_hop", ("track", "warm_start", "pipelined_registered", "gap_over_same_hop", "p99")),
+                       ("A_scattered10_us_per_iteration", ("holes", "A_holes", "scattered10", "us_per_iteration")),
+                       ("A_blobs30_us_per_iteration", ("holes", "A_holes", "blobs30", "us_per_iteration")),
+                       ("A_blobs10_rgb0_us_per_iteration", ("holes", "A_holes", "blobs10_rgb0", "us_per_iteration")),
+                       ("A_blobs30_rgb0_us_per_iteration", ("holes", "A_holes", "blobs30_rgb0", "us_per_iteration")),
+                       ("A_wall_us_per_iteration", ("holes", "A_wall", "a_2e2", "us_per_iteration")),
+                       ("B_blobs30_us_per_iteration", ("holes", "B_holes", "blobs30", "us_per_iteration")),
+                       ("B_blobs30_rgb0_us_per_iteration", ("holes", "B_holes", "blobs30_rgb0", "us_per_iteration")),
+                       ("A_x64_blobs30_us_per_iteration", ("holes", "A_x64_holes", "blobs30", "us_per_iteration"))):
+        optional.append((name, _r(_get(oc, *path))))
+    for k, v in optional:
+        if v is not None:
+            line[k] = v
+    text = json.dumps(line, separators=(", ", ": "))
+    keys = [k for k, v in optional if v is not None]
+    while len(text.encode()) >= LINE_LIMIT and keys:
+        line.pop(keys.pop())
+        text = json.dumps(line, separators=(", ", ": "))
+    if len(text.encode()) >= LINE_LIMIT:            # (cannot happen with the bounded strings above: fail loudly rather than print a line nobody parses)
+        raise SystemExit("bench.py: the result line is %d bytes, limit %d" % (len(text.encode()), LINE_LIMIT))
+    return text
+
+
+def emit(full, out=None, err=None, extra_dirs=None):
+    """Everything measured -> bench_extra.json (beside bench.py and, on a GPU box, under gpurun_out/) and one line on stderr;
+    the compact line -> the LAST line of stdout."""
+    out, err = out or sys.stdout, err or sys.stderr
+    text = compact_line(full)
+    blob = json.dumps(full)
+    for d in (extra_dirs if extra_dirs is not None else (ROOT, os.path.join(ROOT, "gpurun_out"))):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, EXTRA_FILE), "w") as f:
+                f.write(blob + "\n")
+        except OSError:
+            pass
+    err.write("bench.py: full measurement record (%d bytes, also in %s):\n%s\n" % (len(blob), EXTRA_FILE, blob))
+    err.flush()
+    out.write(text + "\n")
+    out.flush()
+    return text
+
+
 def run_inprocess(icp_amd, args, n, batch, iters, steps, warmup):
     """--gpus N from a plain `python bench.py`: devices 0..N-1 (or ICP_BENCH_DEVICES, a comma list: self-test on a 1-GPU box)
     driven through icp_batch_*: registration i on slot i mod N, one host thread + stream per slot, no collective."""
@@ -895,7 +1030,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and m <= 65536:
             line["cpu_baseline"] = cpu_baseline(F, M, m, nr, fused)
         line["git_head"] = git_head()
-        print(json.dumps(line))
+        emit(line)
     if dist is not None:
         dist.destroy_process_group()
 

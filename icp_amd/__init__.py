@@ -87,7 +87,7 @@ def lib():
     def sig(name, res, *args):
         f = getattr(L, name, None)
         if f is None:
-            if "ICP_AMD_LIB" in os.environ:          # an A/B build of an older ABI (tests/diag_ab.sh): entry points it lacks stay unbound
+            if "ICP_AMD_LIB" in os.environ:          # an A/B build of an older ABI (tools/diag/ab.sh): entry points it lacks stay unbound
                 return
             raise AttributeError("%s does not export %s" % (_SO, name))
         f.restype = res

@@ -131,7 +131,7 @@ static __device__ __forceinline__ void origin_list_close (const icp_params &p, u
     // Lists the search prunes by chunk boxes (more than 128 entries): ordered by a Morton key of the colour instead of by index, so that the
     // 8 entries of a chunk are neighbours in colour whatever the invalid points' pattern in the frame — in index order 10 of 49 / 157
     // chunks passed a query's test at |F| = 2^20 with 10 % scattered / 30 % contiguous invalid points, ordered by colour 4
-    // (tests/diag_origin_list_sim.py).  The scan's tie rule is explicit (ks_origin_list), so the list's order is free.  One wave: entries and
+    // (tools/diag/origin_list_sim.py).  The scan's tie rule is explicit (ks_origin_list), so the list's order is free.  One wave: entries and
     // keys (colour key << 16 | position) in LDS, a bitonic sort of the keys, the entries written back in their order.
     if (run > ICP_OL_BOXED_MIN && run <= sort_cap) {
         float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };

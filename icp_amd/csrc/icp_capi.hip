@@ -758,7 +758,7 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int fr
     for (uint32_t r = 0; r < reps; ++r) HIPCHK (h, hipGraphLaunch (exec, h->stream));
     h->hstate_fresh = false; h->k_base = -1; note_outputs_stored (h);
     HIPCHK (h, hipEventRecord (h->ev1, h->stream));
-    HIPCHK (h, hipStreamSynchronize (h->stream));                       // (not hipEventSynchronize: its wake-up now and then takes 0.5 ms, tests/diag_overhead.py)
+    HIPCHK (h, hipStreamSynchronize (h->stream));                       // (not hipEventSynchronize: its wake-up now and then takes 0.5 ms, tools/diag/overhead.py)
     HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));
     return ICP_OK;
 }
@@ -772,14 +772,14 @@ int icp_time_run_fixed_tail (icp_handle h, uint32_t iterations, uint32_t reps, i
     if ((rc = get_graph (h, iterations, 0, &exec, from_identity != 0))) return rc;
     // the first event goes in BEHIND the first pass: a marker recorded on an idle stream delays the graph launched right after it by
     // 0.1 - 0.25 ms (7.22 - 7.39 ms for 20 passes of 0.357 ms against 7.17 ms wall-clock for the same launches without events;
-    // with the GPU busy when the marker arrives: 7.14 ms, tests/diag_overhead.py); the events then bracket the passes 2 .. reps
+    // with the GPU busy when the marker arrives: 7.14 ms, tools/diag/overhead.py); the events then bracket the passes 2 .. reps
     const uint32_t lead = reps >= 2u ? 1u : 0u;
     if (lead) HIPCHK (h, hipGraphLaunch (exec, h->stream));
     HIPCHK (h, hipEventRecord (h->ev0, h->stream));
     for (uint32_t r = lead; r < reps; ++r) HIPCHK (h, hipGraphLaunch (exec, h->stream));
     h->hstate_fresh = false; h->k_base = -1; note_outputs_stored (h);
     HIPCHK (h, hipEventRecord (h->ev1, h->stream));
-    HIPCHK (h, hipStreamSynchronize (h->stream));                       // (not hipEventSynchronize: its wake-up now and then takes 0.5 ms, tests/diag_overhead.py)
+    HIPCHK (h, hipStreamSynchronize (h->stream));                       // (not hipEventSynchronize: its wake-up now and then takes 0.5 ms, tools/diag/overhead.py)
     HIPCHK (h, hipEventElapsedTime (ms_timed, h->ev0, h->ev1));
     *reps_timed = reps - lead;
     return ICP_OK;

@@ -321,7 +321,7 @@ __device__ inline int icp_power_method_quad (const float *S, const float *means,
         // removes (N x: 8, two sums of squares: 12, two IEEE square roots: 34, one IEEE division: 12, the rest moves and compares) plus ~20
         // hazard no-ops around the quad broadcasts, and ONE wave issues a vector instruction every 4 cycles at best, a dependent one every
         // ~6.6, a no-op every 4 (MI355X_MICROARCH.md, cycle constants): ~520 cycles = 0.22 us per trip, 118 trips per iteration on the
-        // benchmark pair.  Measured (tests/diag_power_time.py, fused reductions + literal loop): 34.9 -> 33.2 us per iteration with the
+        // benchmark pair.  Measured (tools/diag/power_time.py, fused reductions + literal loop): 34.9 -> 33.2 us per iteration with the
         // look-ahead and the scalar branch; replacing the step length's square root by a comparison of the sums (equal sums have equal
         // roots, sums more than 8 ulps apart have different ones, both roots only in between) was bit-identical and no faster (34.2 us: the
         // band test costs what the root's 17 instructions cost less the hazards) and is not kept.  The squared start (the default) is the

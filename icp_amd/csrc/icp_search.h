@@ -78,7 +78,7 @@ typedef float float2v __attribute__ ((ext_vector_type (2)));
         if (tid == 0 && p.dbg) p.dbg[(size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = t_;    \
     }
 #elif defined (ICP_DBG_EXIT_AFTER)
-// diagnostic builds (tests/diag_phase_insts.sh): the search kernel ends behind phase k — the instruction counters of a PMC run
+// diagnostic builds (tools/diag/phase_insts.sh): the search kernel ends behind phase k — the instruction counters of a PMC run
 // then hold the phases up to k, and differences between builds are the phases themselves (every thread of a block gets here)
 #define KS_STAMP(k) { if ((k) == ICP_DBG_EXIT_AFTER) return; }
 #define KS_KEEP(a, b) asm volatile ("" :: "v"(a), "v"(b));      // (the phase's results count as used: nothing of it is optimised away)

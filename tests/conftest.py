@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+DIAG = os.path.join(ROOT, "tools", "diag")       # diagnostics two tests reuse (the fuzzer's case generator, the kernels' resource table)
+if DIAG not in sys.path:
+    sys.path.append(DIAG)
 
 
 def pytest_configure(config):

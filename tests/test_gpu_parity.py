@@ -1096,10 +1096,10 @@ def test_nan_and_inf_points_do_not_break_the_search(engine, oracle, side, nr, fu
 
 
 def test_random_parity_sweep(engine, oracle):
-    """250 random cases of tests/diag_fuzz.py (fixed seed): landmark grids 6 .. 256 wide (also not multiples of 8), every valid
+    """250 random cases of tools/diag/fuzz.py (fixed seed): landmark grids 6 .. 256 wide (also not multiples of 8), every valid
     representative count, alpha 0.5 / 200 / 10^4, both reduce modes, both power modes, both rotation solvers, REGULAR / WEIGHTED,
     10 % holes, batches of three — RBC structure, then three free-running steps or a checked run, every output bit for bit
     against the oracle.  (A 7-minute run of the same generator: 6926 cases, no difference — profiles/r03_fuzz.txt.)"""
-    import diag_fuzz
+    import fuzz as diag_fuzz
     n, fails = diag_fuzz.run(cases=250, seed=3, verbose=False)
     assert n == 250 and not fails, fails[:3]

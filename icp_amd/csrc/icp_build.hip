@@ -190,6 +190,27 @@ static __device__ __forceinline__ void origin_list_close (const icp_params &p, u
         for (uint32_t e = lane; e < run; e += 64u) OL[1u + e] = s_ent[s_key[e] & 0xFFFFu];
         __threadfence ();                                             // (the boxes below read the entries back)
     }
+    // Round 6 — representatives at the origin that REPEAT their predecessor's colour: identical points (a frame's invalid points whose
+    // colour was zeroed too are ONE point; |F| = 65536 with 30 % of them: 300 of the 1024 representatives), of which only the one with the
+    // lowest index can ever be a query's nearest representative (equal coordinates, equal distance bits, ties -> lowest index) — yet every
+    // invalid query scanned them all: their chunk boxes are one point, and a bound that EQUALS the best so far does not prune (the list is
+    // visited out of index order).  An entry whose colour equals that of the entry in front of it is dropped: in index order and in colour
+    // order alike (equal colours = equal sort keys, ordered by position in the index-ordered list) the entry in front has the lower index.
+    // The ballots keep every representative at the origin (a dropped one is still a legitimate seed of its kind).  One wave, in place:
+    // a round's reads come before its writes, which land at or below the round's own positions.
+    {
+        uint32_t w = 0u;
+        for (uint32_t e0 = 0u; e0 < run; e0 += 64u) {
+            const uint32_t e = e0 + lane;
+            const float4 v = OL[1u + min (e, run - 1u)];
+            const float4 pv = OL[1u + min (max (e, 1u) - 1u, run - 1u)];
+            const bool keep = e < run && (e == 0u || !(v.x == pv.x && v.y == pv.y && v.z == pv.z));
+            const unsigned long long bal = __ballot (keep);
+            if (keep) OL[1u + w + (uint32_t) __builtin_popcountll (bal & ((1ull << lane) - 1ull))] = v;
+            w += (uint32_t) __builtin_popcountll (bal);
+        }
+        if (w != run) { run = w; __threadfence (); }
+    }
     {
         float4 *BX = OL + 1u + p.nr;
         const uint32_t n_oc = (run + 7u) >> 3;
@@ -429,7 +450,7 @@ __global__ __launch_bounds__ (1024) void k_count (icp_params p)
         for (uint32_t k = 0; k < 8u; ++k)
             if (live && c0 + k < c_hi) { h0[(size_t) (c0 + k) * p.nr] = run; run += v[k]; }
     }
-    if (live && cg == 0u) p.N[(size_t) b * p.nr + r] = total;
+    if (live && cg == 0u) { p.N[(size_t) b * p.nr + r] = total; ICP_N_FULL (p, b)[r] = total; }
 }
 
 // step 4: O = exclusive scan of N (exclusiveScan_i semantics, kernels/scan_kernels.cl:188). One block of 1024 threads:
@@ -471,7 +492,7 @@ __global__ __launch_bounds__ (1024) void k_count_offsets (icp_params p)
             for (uint32_t k = 0; k < 8u; ++k)
                 if (c0 + k < p.nchunk) { h0[(size_t) (c0 + k) * p.nr] = run; run += v[k]; }
         }
-        p.N[(size_t) b * p.nr + r] = run;
+        p.N[(size_t) b * p.nr + r] = run; ICP_N_FULL (p, b)[r] = run;
     }
     uint32_t inc = run;                              // exclusive scan over r (exclusiveScan_i, kernels/scan_kernels.cl:188)
 #pragma unroll
@@ -657,7 +678,7 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
     for (uint32_t w = 0; w < wave; ++w) run += s_wave[w];
     for (uint32_t r = lo; r < hi; ++r) {
         const uint32_t n = s_total[r];
-        if (c == 0u) { p.N[(size_t) b * p.nr + r] = n; p.O[(size_t) b * p.nr + r] = run; }
+        if (c == 0u) { p.N[(size_t) b * p.nr + r] = n; ICP_N_FULL (p, b)[r] = n; p.O[(size_t) b * p.nr + r] = run; }
         s_before[r] += run;                          // position of the chunk's first point of list r
         run += n;
     }
@@ -686,17 +707,94 @@ __global__ __launch_bounds__ (256) void k_place_lists (icp_params p)
 // it.  One block per representative, one 16-lane row per chunk; box of chunk c >= 1 at index (O[r] >> 4) + c: unique over all lists
 // (a list's last chunk can share floor (position / 16) only with the NEXT list's chunk 0, which has no box), < m / 16 + 1.
 // Chunk 0 is always scanned.  min / max are exact in any order; fminf / fmaxf skip NaN coordinates (such a point never wins a '<').
+// Round 6 — members of a long list's tail that REPEAT an earlier member.  A frame's invalid points whose colour was zeroed too are ONE
+// point: one representative owns them all (|F| = 16384 with 30 % of them: a list of 4973; |F| = 65536: 19673), and every query that is
+// such a point walked that list's chunk boxes (311 / 1230 box tests per query for nothing: 15.8 / 127 us per iteration).  A member that
+// equals an earlier member of its list in all six coordinates can win neither a strict '<' nor the tie for the lowest position, whatever
+// the query (equal coordinates: the same differences, the same distance bits; +0 and -0 give the same differences too): the scan may
+// skip it.  The block of a long list therefore compacts the list's tail IN PLACE in the search copy XQ (the head — the positions every scan
+// takes unconditionally — stays as it is): a tail member is dropped when it equals its predecessor in the list or the list's first
+// member (sufficient, not necessary: runs of one point and repeats of the first point — both are what invalid points make; any other
+// repeat is merely scanned), the order of the rest is kept, and the search's view of the list's length (p.N) shrinks to head + kept;
+// N, O, perm, XP — the construction's outputs — are untouched, and a record carries its original index, so every output of a search is
+// the one of the exhaustive scan.  The chunk boxes are then those of the compacted tail.
+// One pass = 256 threads x 4 consecutive positions; reads of a pass complete (barrier) before its writes, which land at or below the
+// pass's own positions: later passes read untouched records; the predecessor of a pass's first position travels through LDS.
 __global__ __launch_bounds__ (256) void k_list_boxes (icp_params p)
 {
     const uint32_t r = blockIdx.x, b = blockIdx.y;
-    const uint32_t n = p.N[(size_t) b * p.nr + r];
+    const uint32_t n = ICP_N_FULL (p, b)[r];
     // (only what the scans ask for: a list's first ICP_S2_UNCOND = 128 positions are always scanned as they come — ks_stage2_lanes; a wave
     // whose longest list has more than 256 tests every list of its queries from chunk 8 on: ks_list_tail —; on a clean frame of the
     // reference's size every block of this kernel leaves here)
     // (lanes = candidates — p.s2wave: a list's first ICP_S2W_UNCOND = 1024 positions are scanned wave-cooperatively, the tail from chunk 64 on)
     const uint32_t n_min = p.s2wave ? 1024u : 128u, c_first = p.s2wave ? 64u : 8u;
     if (n <= n_min) return;
-    list_boxes_of (p, b, n, p.O[(size_t) b * p.nr + r], c_first, threadIdx.x & 15u, threadIdx.x >> 4, 16u);
+    const uint32_t o = p.O[(size_t) b * p.nr + r], t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    __shared__ float s_prev[6];
+    __shared__ uint32_t s_cnt[4];
+    float4 *Q4 = reinterpret_cast<float4 *> (p.XQ + (size_t) b * p.m * 8);
+    const float4 fg = Q4[2 * (size_t) o], fc = Q4[2 * (size_t) o + 1];                   // the list's first member [x r y g | z b id 0]
+    if (t == 0) {
+        const float4 g = Q4[2 * (size_t) (o + n_min - 1u)], c = Q4[2 * (size_t) (o + n_min - 1u) + 1];
+        s_prev[0] = g.x; s_prev[1] = g.y; s_prev[2] = g.z; s_prev[3] = g.w; s_prev[4] = c.x; s_prev[5] = c.y;
+    }
+    __syncthreads ();
+    constexpr uint32_t E = 4u;
+    uint32_t kept = 0u;                              // tail members kept so far (the same number in every thread)
+    for (uint32_t s = n_min; s < n; s += 256u * E) {
+        const uint32_t j0 = s + t * E;
+        float4 g[E + 1], c[E + 1];                   // [0]: the predecessor of the thread's first position
+        if (t == 0) { g[0] = make_float4 (s_prev[0], s_prev[1], s_prev[2], s_prev[3]); c[0] = make_float4 (s_prev[4], s_prev[5], 0.f, 0.f); }
+        else if (j0 <= n) { g[0] = Q4[2 * (size_t) (o + j0 - 1u)]; c[0] = Q4[2 * (size_t) (o + j0 - 1u) + 1]; }
+#pragma unroll
+        for (uint32_t e = 0; e < E; ++e)
+            if (j0 + e < n) { g[e + 1] = Q4[2 * (size_t) (o + j0 + e)]; c[e + 1] = Q4[2 * (size_t) (o + j0 + e) + 1]; }
+        uint32_t keep = 0u;
+#pragma unroll
+        for (uint32_t e = 0; e < E; ++e) {
+            if (j0 + e >= n) break;
+            const float4 a = g[e + 1], a2 = c[e + 1], q = g[e], q2 = c[e];
+            const bool as_prev = a.x == q.x && a.y == q.y && a.z == q.z && a.w == q.w && a2.x == q2.x && a2.y == q2.y;
+            const bool as_first = a.x == fg.x && a.y == fg.y && a.z == fg.z && a.w == fg.w && a2.x == fc.x && a2.y == fc.y;
+            if (!as_prev && !as_first) keep |= 1u << e;
+        }
+        const uint32_t cnt = (uint32_t) __builtin_popcount (keep);
+        uint32_t inc = cnt;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t v = __shfl_up (inc, d); if (lane >= d) inc += v; }
+        __syncthreads ();                            // (every read of this pass is done; s_prev / s_cnt of the previous pass have been used)
+        if (lane == 63u) s_cnt[wave] = inc;
+        const uint32_t last = min (s + 256u * E, n) - 1u;       // the pass's last position: the next pass's predecessor
+#pragma unroll
+        for (uint32_t e = 0; e < E; ++e)
+            if (j0 + e == last) { s_prev[0] = g[e + 1].x; s_prev[1] = g[e + 1].y; s_prev[2] = g[e + 1].z; s_prev[3] = g[e + 1].w; s_prev[4] = c[e + 1].x; s_prev[5] = c[e + 1].y; }
+        __syncthreads ();
+        uint32_t base = kept + inc - cnt, total = 0u;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) { const uint32_t v = s_cnt[w]; base += (w < wave) ? v : 0u; total += v; }
+        if (kept + total != min (s + 256u * E, n) - n_min) {          // (else: nothing dropped so far, every record is where it belongs)
+            uint32_t k = 0u;
+#pragma unroll
+            for (uint32_t e = 0; e < E; ++e)
+                if (keep & (1u << e)) {
+                    const size_t dst = (size_t) o + n_min + base + k;
+                    Q4[2 * dst] = g[e + 1]; Q4[2 * dst + 1] = c[e + 1];
+                    ++k;
+                }
+        }
+        kept += total;
+    }
+    const uint32_t ns = n_min + kept;
+    if (ns != n) {
+        if (t == 0) p.N[(size_t) b * p.nr + r] = ns;
+        // (the boxes below read records other threads of the block have just written: write-back + invalidate of this CU's vector cache on both sides of the barrier)
+        __threadfence ();
+        __syncthreads ();
+        __threadfence ();
+    }
+    if (ns <= n_min) return;
+    list_boxes_of (p, b, ns, o, c_first, t & 15u, t >> 4, 16u);
 }
 
 // ICPPowerMethod as a kernel of its own (reference include/ICP/algorithms.hpp:1451-1537, kernels/icp_kernels.cl:977-1054: an

@@ -234,7 +234,7 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     if ((rc = dalloc (h, &p.LB, B * 3 * p.nlb))) return rc;
     if ((rc = dalloc (h, &p.rep_src, B * nr))) return rc;
     if ((rc = dalloc (h, &p.owner, B * m))) return rc;
-    if ((rc = dalloc (h, &p.N, B * nr))) return rc;
+    if ((rc = dalloc (h, &p.N, 2 * B * nr))) return rc;         // (the search's view of the lengths, then the lengths: ICP_N_FULL)
     if ((rc = dalloc (h, &p.O, B * nr))) return rc;
     if ((rc = dalloc (h, &p.perm, B * m))) return rc;
     if ((rc = dalloc (h, &p.chunk_hist, B * p.nchunk * nr))) return rc;
@@ -354,7 +354,7 @@ static int mem_ptr (icp_context *h, uint32_t b, int mem, const void **src)
         case ICP_MEM_RBC_OWNER: *src = p.owner + (size_t) b * p.m; break;
         case ICP_MEM_RID: *src = p.rid + (size_t) b * p.m; break;
         case ICP_MEM_REPS: *src = p.R + (size_t) b * p.nr * 8; break;
-        case ICP_MEM_RBC_N: *src = p.N + (size_t) b * p.nr; break;
+        case ICP_MEM_RBC_N: *src = ICP_N_FULL (p, b); break;
         case ICP_MEM_RBC_O: *src = p.O + (size_t) b * p.nr; break;
         case ICP_MEM_NN: *src = p.PF + (size_t) b * p.m; break;
         case ICP_MEM_QT: *src = p.PM + (size_t) b * p.m; break;

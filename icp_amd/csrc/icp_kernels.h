@@ -69,7 +69,9 @@ struct icp_params {
     float4 *LB;                  // [batch][3 * nlb]  6-D bounding boxes of the list chunks (16 consecutive positions of one list, chunk c >= 1 of list r at
                                  // index (O[r] >> 4) + c: k_list_boxes) as [lo.x lo.y lo.z lo.r | lo.g lo.b hi.x hi.y | hi.z hi.r hi.g hi.b]
     uint32_t nlb;                // m / 16 + 2 boxes per registration
-    uint32_t *rep_src, *owner, *N, *O, *perm, *chunk_hist;   // [batch][...]
+    uint32_t *rep_src, *owner, *N, *O, *perm, *chunk_hist;   // [batch][...]; N: [2][batch][nr] — [0] the length of a list AS THE SEARCH SCANS IT (k_search reads
+                                 // p.N: a long list without the tail members that repeat an earlier member bit for bit, k_list_boxes), [1] = ICP_N_FULL: the list's
+                                 // length N of the construction (RBCConstruct's output, ICP_MEM_RBC_N); the two differ for long lists with duplicates only
     uint2 *blist; uint32_t *bn; uint8_t *brank;   // buildRBC of the latency-bound sizes (k_place_lists): per block of 64 fixed points its (owner, count) list
                                                   // [batch][nb][64] and the list's length [batch][nb]; rank of a point inside its block [batch][m]
     // per-iteration
@@ -101,6 +103,8 @@ struct icp_params {
     uint32_t seq_value;          // this registration's number
     uint32_t no_state_reset;     // buildRBC leaves k / done alone (it runs ahead of the previous frame's end; the run's first launch resets them)
 };
+
+#define ICP_N_FULL(p, b) ((p).N + ((size_t) (p).batch + (b)) * (p).nr)
 
 // progress word of a checked run: bits 0..23 k (iterations whose transform has been published), bit 30 FINAL (the end kernel has
 // left the state in p.hstate), bit 31 done (ICP::check said stop), bits 32..63 the run's epoch

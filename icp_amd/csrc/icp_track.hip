@@ -52,7 +52,7 @@ static int track_prepare (icp_context *h)
         int rc;
         if (!b.R && ((rc = al ((void **) &b.R, (size_t) p.nr * 32)) || (rc = al ((void **) &b.GB, (size_t) 2 * (p.n16 + p.n1k) * 16)) || (rc = al ((void **) &b.LB, (size_t) 3 * p.nlb * 16)) || (rc = al ((void **) &b.OL, (size_t) ICP_OL_STRIDE (p.nr) * 16)) || (rc = al ((void **) &b.XP, (size_t) p.m * 32)) ||
             (rc = al ((void **) &b.XQ, (size_t) p.m * 32)) || (rc = al ((void **) &b.rep_src, (size_t) p.nr * 4)) || (rc = al ((void **) &b.owner, (size_t) p.m * 4)) ||
-            (rc = al ((void **) &b.N, (size_t) p.nr * 4)) || (rc = al ((void **) &b.O, (size_t) p.nr * 4)) || (rc = al ((void **) &b.perm, (size_t) p.m * 4)) ||
+            (rc = al ((void **) &b.N, (size_t) 2 * p.batch * p.nr * 4)) || (rc = al ((void **) &b.O, (size_t) p.nr * 4)) || (rc = al ((void **) &b.perm, (size_t) p.m * 4)) ||
             (rc = al ((void **) &b.chunk_hist, (size_t) p.nchunk * p.nr * 4)) || (rc = al ((void **) &b.blist, (size_t) p.nb * 64 * 8)) ||
             (rc = al ((void **) &b.bn, (size_t) p.nb * 4)) || (rc = al ((void **) &b.brank, (size_t) p.m)))) {
             void *ptrs[] = { b.R, b.GB, b.OL, b.LB, b.XP, b.XQ, b.rep_src, b.owner, b.N, b.O, b.perm, b.chunk_hist, b.blist, b.bn, b.brank };

@@ -72,6 +72,7 @@ def main():
     config4()
     bench_configs()
     round5()
+    round6()
 
 
 def round5():
@@ -104,6 +105,50 @@ def round5():
         out[tag + "_run_T"], out[tag + "_run_ids_digest"] = o.T, W.ids_digest(o.nn_id["id"])
     np.savez_compressed(os.path.join(HERE, "round5_vectors.npz"), **out)
     print("wrote round5_vectors.npz:", {k: (v.tolist() if v.size <= 2 else v.shape) for k, v in out.items() if k.endswith("_run") or k.endswith("N_max")})
+
+
+ROUND6_C_CASES = ("scattered10", "blobs30", "blobs30_rgb0")
+
+
+def round6():
+    """Round 6: invalid points at config C's size (|F|=|M|=2^20, |R|=4096) — the MASKED + lanes-as-candidates
+    search with the origin list read per wave behind colour boxes, the Morton colour sort of `k_reps_and_boxes`, the compaction by the
+    last-arriving block — in the default modes, from the oracle (power_fast=True, fused=True):
+      C_<case>_{N,O} + digests of perm / owner; two free-running steps (T, S, means, sum_w; digests of ALL 2^20 ids, distances and
+      nearest representatives); `sub` = the 4096 query indices the GPU test re-checks against the live oracle.
+    B `blobs30_rgb0` through run () (k, converged, T, ids digest)."""
+    from icp_amd import workloads as W
+    out = {}
+    side, nr = W.CONFIGS["C"]
+    m = side * side
+    out["sub"] = np.sort(np.random.default_rng(60606).choice(m, 4096, replace=False)).astype(np.uint32)
+    for name in ROUND6_C_CASES:
+        F, M = W.holes_pair(icp_amd, name, side)
+        o = O.OracleICP(m, nr, W.A, W.C_, power_fast=True, fused=True, threads=8)
+        o.write_f(F); o.write_m(M); o.build_rbc()
+        tag = "C_" + name
+        out[tag + "_N"], out[tag + "_O"] = o.rbc_N, o.rbc_O
+        out[tag + "_perm_digest"], out[tag + "_owner_digest"] = W.ids_digest(o.rbc_perm), W.ids_digest(o.rbc_owner)
+        out[tag + "_invalid"] = np.array([int(np.count_nonzero((X[:, 0] == 0) & (X[:, 1] == 0) & (X[:, 2] == 0))) for X in (F, M)])
+        Ts, Ss, ms, sws, idd, ridd, dd = [], [], [], [], [], [], []
+        for _ in range(2):
+            o.step()
+            nn = o.nn_id
+            Ts.append(o.T); Ss.append(o.S); ms.append(o.means); sws.append(o.sum_w)
+            idd.append(W.ids_digest(nn["id"])); ridd.append(W.ids_digest(o.rid)); dd.append(W.bits_digest(nn["dist"]))
+        out.update({tag + "_T": np.array(Ts), tag + "_S": np.array(Ss), tag + "_means": np.array(ms), tag + "_sum_w": np.array(sws),
+                    tag + "_ids_digest": np.array(idd), tag + "_rid_digest": np.array(ridd), tag + "_dist_digest": np.array(dd)})
+        print("round6", tag, "N_max", int(o.rbc_N.max()), "invalid", out[tag + "_invalid"].tolist(), flush=True)
+    side, nr = W.CONFIGS["B"]
+    F, M = W.holes_pair(icp_amd, "blobs30_rgb0", side)
+    o = O.OracleICP(side * side, nr, W.A, W.C_, power_fast=True, fused=True, threads=8)
+    o.write_f(F); o.write_m(M); o.build_rbc()
+    k = o.run()
+    out["B_blobs30_rgb0_run"] = np.array([k, int(o.converged)])
+    out["B_blobs30_rgb0_run_T"], out["B_blobs30_rgb0_run_ids_digest"] = o.T, W.ids_digest(o.nn_id["id"])
+    out["B_blobs30_rgb0_N_max"] = np.array([int(o.rbc_N.max())])
+    np.savez_compressed(os.path.join(HERE, "round6_vectors.npz"), **out)
+    print("wrote round6_vectors.npz; B blobs30_rgb0 run k = %d converged = %d N_max = %d" % (k, int(o.converged), int(o.rbc_N.max())))
 
 
 def config4():
@@ -176,4 +221,8 @@ def bench_configs():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:                            # e.g. `make_golden.py round6`: one fixture file only
+        for name in sys.argv[1:]:
+            {"round5": round5, "round6": round6, "config4": config4, "bench_configs": bench_configs}[name]()
+    else:
+        main()

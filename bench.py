@@ -697,12 +697,14 @@ def compact_line(full):
     line["config"] = {"workload": str(cfg.get("workload", ""))[:200], "parallelism": str(cfg.get("parallelism", ""))[:80],
                       "registrations_per_gpu": cfg.get("registrations_per_gpu"), "launches_per_iteration": cfg.get("launches_per_iteration"),
                       "reduce_mode": cfg.get("reduce_mode"), "power_start": cfg.get("power_start")}
+    if cfg.get("devices") is not None:
+        line["config"]["devices"] = cfg["devices"]
     if full.get("roofline") is not None:
         line["roofline"] = {"bound": rl.get("bound"), "kernel": str(rl.get("kernel", ""))[:40], "achieved": _r(rl.get("achieved")),
                             "peak": rl.get("peak"), "unit": rl.get("unit"), "frac": _r(rl.get("frac")), "frac_moved": _r(rl.get("frac_moved")),
                             "traffic": _r(rl.get("traffic"), 7), "traffic_measured_by_this_run": False,
                             "algorithmic_bytes_per_launch": rl.get("algorithmic_bytes_per_launch"),
-                            "avg_launch_us": _r(rl.get("avg_launch_us")),
+                            "avg_launch_us": _r(rl.get("avg_launch_us")), "registrations_per_launch": rl.get("registrations_per_launch"),
                             "valu_issue_frac": _r(_get(rl, "valu_beside_it", "executed", "valu_issue_frac"))}
     if cb is not None:
         line["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "threads": cb.get("threads"),
@@ -710,7 +712,8 @@ def compact_line(full):
                                 "sample": str(cb.get("sample_short") or cb.get("sample", ""))[:160]}
     line["us_per_iteration"] = _r(full.get("us_per_iteration"))
     line["per_gpu_iterations_per_s"] = [_r(x) for x in (full.get("per_gpu_iterations_per_s") or [])]
-    line["config4_per_gpu_value"] = _r(full.get("config4_per_gpu_value"))
+    line["single_gpu_same_work_key"] = "config4_per_gpu_value"
+    line["config4_per_gpu_value"] = _r(full.get("config4_per_gpu_value"), 8)
     line["git_head"] = full.get("git_head")
     line["extra"] = EXTRA_FILE
     oc = full.get("other_configs") or {}

@@ -44,6 +44,27 @@ def compare(g, o, b, weighted, what):
     return bad
 
 
+def plant_repeats(X, rng):
+    """Bit-identical points planted in a point set (round 6: the search's view of a long list drops the members that repeat an earlier one):
+    contiguous runs of one point, a share of the set drawn from a few points, the origin with +0 / -0 coordinates and colours."""
+    X = X.copy(); m = X.shape[0]
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        for _ in range(int(rng.integers(1, 6))):
+            a = int(rng.integers(0, m)); n = int(rng.integers(2, max(3, m // 3)))
+            X[a:a + n] = X[int(rng.integers(0, m))]
+    elif kind == 1:
+        src = X[rng.choice(m, int(rng.integers(1, 6)), replace=True)].copy()
+        idx = rng.choice(m, max(1, int(m * float(rng.choice([0.05, 0.3, 0.6])))), replace=False)
+        X[idx] = src[rng.integers(0, src.shape[0], idx.size)]
+    else:
+        idx = rng.choice(m, max(1, m // 3), replace=False)
+        z = np.where(rng.integers(0, 2, (idx.size, 6)) == 1, np.float32(-0.0), np.float32(0.0)).astype(np.float32)
+        X[idx, 0:3] = z[:, 0:3]
+        if rng.integers(0, 2): X[idx, 4:7] = z[:, 3:6]
+    return X
+
+
 def run(seconds=None, cases=None, seed=1, verbose=True):
     """Random cases until `seconds` have passed or `cases` have run; returns (cases, list of failure descriptions)."""
     rng = np.random.default_rng(seed)
@@ -60,7 +81,9 @@ def run(seconds=None, cases=None, seed=1, verbose=True):
         bsel = int(rng.integers(0, batch)) if batch > 1 else None
         runmode = bool(rng.integers(0, 3) == 0)
         holes = (int(rng.integers(0, 2)), float(rng.choice([0.1, 0.3])), bool(rng.integers(0, 2))) if rng.integers(0, 3) == 0 else None
-        desc = "side %d nr %d a %g fused %d fast %d rot %d w %d zero %.1f holes %s seed %d batch %d/%s %s" % (side, nr, alpha, fused, fast, rot, weighted, zero, holes, seed, batch, bsel, "run" if runmode else "steps")
+        rng2 = np.random.default_rng(seed)                 # (draws of its own: the cases of earlier rounds' seeds stay what they were)
+        repeats = int(rng2.integers(0, 3)) == 0
+        desc = "side %d nr %d a %g fused %d fast %d rot %d w %d zero %.1f holes %s repeats %d seed %d batch %d/%s %s" % (side, nr, alpha, fused, fast, rot, weighted, zero, holes, repeats, seed, batch, bsel, "run" if runmode else "steps")
         try:
             g = E.ICP(0, rot, weighted)
             g.init(m, nr, alpha, 1e-6, batch=batch) if batch > 1 else g.init(m, nr, alpha, 1e-6)
@@ -70,6 +93,8 @@ def run(seconds=None, cases=None, seed=1, verbose=True):
             if holes:                                               # a Kinect frame's invalid points (round 5): scattered / contiguous, colour kept / zeroed
                 hp, hf, hk = holes
                 pairs = [(E.punch_holes(F, side, side, hp, hf, hk, seed=seed + 11 * b), E.punch_holes(M, side, side, hp, hf, hk, seed=seed + 13 * b)) for b, (F, M) in enumerate(pairs)]
+            if repeats:
+                pairs = [(plant_repeats(F, rng2), plant_repeats(M, rng2) if rng2.integers(0, 2) else M) for F, M in pairs]
             for b, (F, M) in enumerate(pairs):
                 if batch > 1: g.write(Mem.F, F, batch_index=b); g.write(Mem.M, M, batch_index=b)
                 else: g.write(Mem.F, F); g.write(Mem.M, M)

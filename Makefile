@@ -32,6 +32,10 @@ examples: $(LIB) examples/registration.cpp examples/step_by_step.cpp include/ocl
 	g++ -O2 -std=c++17 -Wall -Iinclude -o examples/registration examples/registration.cpp -Licp_amd -licp_amd -Wl,-rpath,'$$ORIGIN/../icp_amd'
 	g++ -O2 -std=c++17 -Wall -Iinclude -o examples/step_by_step examples/step_by_step.cpp -Licp_amd -licp_amd -Wl,-rpath,'$$ORIGIN/../icp_amd'
 
+# measurement: SIMD cycles per wave64 vector instruction by class (bench.py prices SQ_INSTS_VALU with the result: profiles/valu_issue.json)
+valu_issue_probe: tests/cpp/valu_issue_probe.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -o tests/cpp/valu_issue_probe tests/cpp/valu_issue_probe.hip
+
 capi_example: $(LIB) tests/cpp/capi_example.c include/icp_amd.h
 	gcc -O2 -std=c99 -Wall -Iinclude -o tests/cpp/capi_example tests/cpp/capi_example.c -Licp_amd -licp_amd -Wl,-rpath,'$$ORIGIN/../../icp_amd'
 

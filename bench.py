@@ -241,12 +241,25 @@ def traffic_of(key):
            "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes around this bench command, corrected per MI355X_MICROARCH.md"}
     issue = None
     if det and det.get("SQ_INSTS_VALU") and det.get("avg_dispatch_us_kernel_trace"):
-        # executed work, not algorithmic: wave-level VALU instructions x 4 cycles / (1024 SIMDs x clock) / the kernel's duration in the
-        # same profile
-        issue = {"valu_issue_frac": det["SQ_INSTS_VALU"] * 4.0 / SIMDS / CLOCK_HZ / (det["avg_dispatch_us_kernel_trace"] * 1e-6),
+        # executed work, not algorithmic: the kernel's wave-level VALU instructions (SQ_INSTS_VALU) x the MEASURED issue cost of its instruction
+        # mix (profiles/valu_issue.json: tests/cpp/valu_issue_probe.hip's SIMD cycles per wave64 instruction by class — 2.2 for plain f32 / int
+        # add, mul, fma, mov at 8 waves per SIMD, 4.1 - 4.3 for packed f32, min / max, compares, DPP, shifts, f64 — weighted by the classes'
+        # shares in the loops of the kernel's ISA, tools/diag/valu_mix.py) / (1024 SIMDs x the cycles of the dispatch: SQ_BUSY_CYCLES / 32
+        # shader engines of the same profile where it holds them, else its duration x 2.4 GHz)
+        cyc, mix_src = 4.0, "assumed 4 cycles per instruction (profiles/valu_issue.json not found)"
+        try:
+            km = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))["_kernel_mix"][cfgkey[len("detail_"):]]
+            cyc, mix_src = float(km["cycles_per_valu_instruction_from_the_mix"]), "profiles/valu_issue.json (_kernel_mix, %d waves per SIMD)" % km["waves_per_simd"]
+        except Exception:
+            pass
+        cycles = det["SQ_BUSY_CYCLES"] / 32.0 if det.get("SQ_BUSY_CYCLES") else det["avg_dispatch_us_kernel_trace"] * 1e-6 * CLOCK_HZ
+        issue = {"valu_issue_frac": det["SQ_INSTS_VALU"] * cyc / SIMDS / cycles,
+                 "valu_issue_frac_if_every_instruction_cost_4_cycles": det["SQ_INSTS_VALU"] * 4.0 / SIMDS / cycles,
+                 "valu_issue_frac_if_every_instruction_were_full_rate": det["SQ_INSTS_VALU"] * 2.24 / SIMDS / cycles,
+                 "cycles_per_valu_instruction": cyc, "cycles_source": mix_src, "dispatch_cycles_per_simd": cycles,
+                 "dispatch_cycles_source": "SQ_BUSY_CYCLES / 32" if det.get("SQ_BUSY_CYCLES") else "duration x 2.4 GHz",
                  "SQ_INSTS_VALU_per_launch": det["SQ_INSTS_VALU"], "kernel_us_in_that_profile": det["avg_dispatch_us_kernel_trace"],
-                 "source": src["file"], "measured_at_commit": src["measured_at_commit"], "measured_by_this_run": False,
-                 "how": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz) / kernel duration"}
+                 "source": src["file"], "measured_at_commit": src["measured_at_commit"], "measured_by_this_run": False}
     return t.get(key), src, issue
 
 

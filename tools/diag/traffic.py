@@ -35,7 +35,8 @@ for cfg, key, kname, batch in (("A", "k_search_hbm_bytes_per_launch", "k_search<
         "algorithmic_bytes_per_launch": algo, "traffic_over_algorithmic": c["hbm_bytes_per_launch"] / algo,
         "l2_hit_rate": c.get("l2_hit_rate"), "wait_fraction_of_wave_cycles": c.get("wait_fraction_of_wave_cycles"),
         "SQ_INSTS_VALU": c.get("SQ_INSTS_VALU"), "SQ_INSTS_VMEM_RD": c.get("SQ_INSTS_VMEM_RD"), "SQ_INSTS_LDS": c.get("SQ_INSTS_LDS"),
-        "SQ_WAVE_CYCLES_quad": c.get("SQ_WAVE_CYCLES"), "SQ_WAIT_ANY_quad": c.get("SQ_WAIT_ANY"), "SQ_ACTIVE_INST_VALU_quad": c.get("SQ_ACTIVE_INST_VALU")}
+        "SQ_WAVE_CYCLES_quad": c.get("SQ_WAVE_CYCLES"), "SQ_WAIT_ANY_quad": c.get("SQ_WAIT_ANY"), "SQ_ACTIVE_INST_VALU_quad": c.get("SQ_ACTIVE_INST_VALU"),
+        "SQ_BUSY_CYCLES": c.get("SQ_BUSY_CYCLES"), "SQ_WAIT_INST_ANY_quad": c.get("SQ_WAIT_INST_ANY")}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(ROOT, "gpurun_out", "%s_profile_summary.json" % tag), os.path.join(ROOT, "profiles", "%s_profile_summary.json" % tag))
 for cfg in ("A", "B", "C", "Ax64", "REF"):

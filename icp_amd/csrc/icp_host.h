@@ -164,7 +164,7 @@ void run_enqueue_end (icp_context *h, run_ctl &r);
 bool run_pump (icp_context *h, run_ctl &r);
 int run_finish (icp_context *h, run_ctl &r, run_ctl *other);
 inline int run_finish (icp_context *h) { return run_finish (h, h->run, h->run2.active ? &h->run2 : nullptr); }   // the run on the handle's own stream
-int run_wait_final (icp_context *h, volatile unsigned long long *mirror, uint32_t n, uint32_t epoch);
+int run_wait_final (icp_context *h, volatile unsigned long long *mirror, uint32_t n, uint32_t epoch, bool tracked = false);
 int run_close_all (icp_context *h);
 int launch_run (icp_context *h, uint32_t iterations, int check, bool fresh = false, bool with_build = false);
 int settle (icp_context *h);

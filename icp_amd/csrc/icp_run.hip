@@ -166,7 +166,7 @@ int run_finish (icp_context *h, run_ctl &r, run_ctl *other)
             const auto now = std::chrono::steady_clock::now ();
             if (r.k_seen != k_last) { k_last = r.k_seen; t_last = now; }
             else if (r.k0 && std::chrono::duration<double> (now - t_last).count () > 0.05) { r.k0 = 0u; t_last = now; }      // (a stale idea of where the count began: pace on k itself)
-            else if (h->hGateFlag && *h->hGateFlag) {
+            else if (r.track_slot >= 0 && h->hGateFlag && *h->hGateFlag) {      // (a tracked frame only: a plain run on the handle does not depend on any gate)
                 r.active = false;
                 return fail (h, ICP_EHIP, "tracking: the device made no progress for ~0.5 s (a frame's gate gave up; the frames behind it were skipped): icp_track_reset starts a new sequence");
             }
@@ -192,7 +192,7 @@ int run_finish (icp_context *h, run_ctl &r, run_ctl *other)
 }
 
 // Waits for the FINAL bit of `n` words of epoch `epoch` (the end kernel's last store: the final states are in host memory).
-int run_wait_final (icp_context *h, volatile unsigned long long *mirror, uint32_t n, uint32_t epoch)
+int run_wait_final (icp_context *h, volatile unsigned long long *mirror, uint32_t n, uint32_t epoch, bool tracked)
 {
     uint32_t spins = 0;
     const auto t0 = std::chrono::steady_clock::now ();
@@ -201,7 +201,7 @@ int run_wait_final (icp_context *h, volatile unsigned long long *mirror, uint32_
             const unsigned long long w = mirror[b];
             if ((uint32_t) (w >> 32) == epoch && (w & ICP_MIRROR_FINAL)) break;
             _mm_pause ();
-            if ((++spins & 0x3FFFu) == 0u && h->hGateFlag && *h->hGateFlag)
+            if ((++spins & 0x3FFFu) == 0u && tracked && h->hGateFlag && *h->hGateFlag)
                 return fail (h, ICP_EHIP, "tracking: the device made no progress for ~0.5 s (a frame's gate gave up; the frames behind it were skipped): icp_track_reset starts a new sequence");
             if ((spins & 0x3FFFu) == 0u && std::chrono::duration<double> (std::chrono::steady_clock::now () - t0).count () > 60.0) {
                 // (is the stream in error?  hipStreamQuery reports a faulted queue)

@@ -98,6 +98,17 @@ static void track_note_k (icp_context *h, const run_ctl &r) { if (r.done_seen) t
 static struct track_prof_t { bool on; double t[8]; uint64_t n; } g_tp = { std::getenv ("ICP_AMD_TRACK_PROF") != nullptr, { 0, 0, 0, 0, 0, 0, 0, 0 }, 0 };
 #define TP(k) do { if (g_tp.on) { const double now_ = now_s (); g_tp.t[k] += now_ - tp_last; tp_last = now_; } } while (0)
 
+// How long a frame's gate waits for its predecessor before it gives up (rounds of ~0.25 us): ~0.5 s, and longer where the predecessor may
+// legitimately run longer — it is launch-complete by then, with up to max_iterations iterations still to execute; 2^14 rounds (~4 ms) are
+// allowed per iteration (a registration of the largest configuration on a GPU shared with other work), at most 2^28 rounds (~1 min).
+// ICP_AMD_GATE_SPINS (diagnostics, tests: read at every call) overrides it.
+static uint32_t gate_spins (const icp_context *h)
+{
+    if (const char *e = std::getenv ("ICP_AMD_GATE_SPINS")) { const long v = std::atol (e); if (v > 0) return (uint32_t) std::min<long> (v, 1l << 28); }
+    const uint64_t per_run = (uint64_t) std::max<uint32_t> (h->max_iterations, 1u) << 14;
+    return (uint32_t) std::min<uint64_t> (std::max<uint64_t> (per_run, 1ull << 21), 1ull << 28);
+}
+
 int icp_track_reset (icp_handle h)
 {
     if (!h) return ICP_EINVAL;
@@ -109,11 +120,19 @@ int icp_track_reset (icp_handle h)
         for (double &v : g_tp.t) v = 0.0;
         g_tp.n = 0;
     }
-    if ((rc = run_close_all (h))) return rc;
+    if (h->hGateFlag && *h->hGateFlag) {
+        // A gate gave up: the frames behind it were turned into no-ops (their run flag = their epoch: every launch leaves at its first
+        // load, the end kernel too), so their runs can never publish a decision and run_finish on them can only fail.  Recovery = what
+        // the error text promises: the open runs are dropped, everything queued drains (no-ops and whatever the stalled predecessor
+        // still does), and the sequence words start over.
+        h->run.active = h->run2.active = false;
+        h->stream2_dirty = false;
+    } else if ((rc = run_close_all (h))) return rc;
     if (h->copy_stream) HIPCHK (h, hipStreamSynchronize (h->copy_stream));
     if (h->stream2) HIPCHK (h, hipStreamSynchronize (h->stream2));
     if (h->stream) HIPCHK (h, hipStreamSynchronize (h->stream));
     if (h->dSeq) HIPCHK (h, hipMemset (h->dSeq, 0, sizeof (uint32_t)));
+    if (h->dRunFlag) HIPCHK (h, hipMemset (h->dRunFlag, 0, 2 * sizeof (uint32_t)));
     if (h->hGateFlag) *h->hGateFlag = 0u;
     h->track_submitted = h->track_collected = 0;
     h->track_k_hist[0] = h->track_k_hist[1] = 0; h->track_hist_frame = 0;
@@ -221,7 +240,7 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
         if (h->track_epoch[r2]) {
             // (its end kernel, if it needs one, is enqueued: run_finish above / at the previous submit)
             if (!gated && h->run.active && h->run.track_slot == (int) r2) { if ((rc = run_finish (h))) return rc; track_note_k (h, h->run); }
-            if ((rc = run_wait_final (h, h->hTrackMirror + r2, 1u, h->track_epoch[r2]))) return rc;
+            if ((rc = run_wait_final (h, h->hTrackMirror + r2, 1u, h->track_epoch[r2], true))) return rc;
         } else HIPCHK (h, hipStreamWaitEvent (h->copy_stream, h->evDone[r2], 0));
     }
     tend ();
@@ -296,7 +315,7 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
                 if ((rc2 = wait_upload (s))) return rc2;
                 // (a warm-started frame behind a gate: the gate kernel writes the state as k_set_T would, once it is open)
                 const bool in_gate = gated && f >= 2u && warm;
-                if (gated && f >= 2u) { icp_launch_gate (h->dSeq, (uint32_t) (f - 1u), h->hGateFlag, st, 1u << 21, in_gate ? p.st : nullptr, R.p.run_flag, R.p.epoch); HIPCHK (h, hipGetLastError ()); }
+                if (gated && f >= 2u) { icp_launch_gate (h->dSeq, (uint32_t) (f - 1u), h->hGateFlag, st, gate_spins (h), in_gate ? p.st : nullptr, R.p.run_flag, R.p.epoch); HIPCHK (h, hipGetLastError ()); }
                 if (warm && !in_gate) { icp_launch_set_T (p, 0, p.st->T, st, gated ? 1 : 0); HIPCHK (h, hipGetLastError ()); }
                 return ICP_OK;
             };
@@ -335,7 +354,14 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     // have waited for the same decision.  Frame f's launches went out above, while the predecessor was still running.)
     TP (4);
     if (gated && P->active) {
-        if ((rc = run_finish (h, *P, R.active ? &R : nullptr))) return rc;
+        if ((rc = run_finish (h, *P, R.active ? &R : nullptr))) {
+            // (frame f's launches are queued, its bookkeeping is not committed: a retry would reuse its ring slot and landmark buffer under
+            // them.  Drop the run and let the queues drain before the error leaves; icp_track_reset starts over.)
+            R.active = false;
+            if (h->stream2) (void) hipStreamSynchronize (h->stream2);
+            if (h->stream) (void) hipStreamSynchronize (h->stream);
+            return rc;
+        }
         track_note_k (h, *P);
     }
     TP (5);
@@ -376,7 +402,7 @@ int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered)
             track_note_k (h, R);
         }
     }
-    if (f > 0u && h->track_epoch[ring]) { if ((rc = run_wait_final (h, h->hTrackMirror + ring, 1u, h->track_epoch[ring]))) return rc; }
+    if (f > 0u && h->track_epoch[ring]) { if ((rc = run_wait_final (h, h->hTrackMirror + ring, 1u, h->track_epoch[ring], true))) return rc; }
     else HIPCHK (h, hipEventSynchronize (h->evDone[ring]));
     if (h->hGateFlag && *h->hGateFlag)
         return fail (h, ICP_EHIP, "tracking: the device made no progress for ~0.5 s (a frame's gate gave up waiting for its launch-complete predecessor; the frames behind it "

@@ -1371,3 +1371,44 @@ def test_random_api_sequences_against_the_oracle(engine, oracle, side, nr, ref_o
             assert np.array_equal(g.read(engine.Memory.W).view(np.uint32), o.W.view(np.uint32)), (step, log[-10:])
     assert np.array_equal(g.read(engine.Memory.T).view(np.uint32), o.T.view(np.uint32))
     g.close()
+
+
+def test_tracking_gate_give_up_and_recovery(engine, monkeypatch):
+    """ADVICE round 5 (icp_run.hip:169): a gate that gives up turns the frames behind it into no-ops and the calls report ICP_EHIP — and then ONE
+    icp_track_reset must start a new sequence (it used to fail on the skipped frame's run, which can never publish, and leave the flag).
+    Forced here with a gate that gives up after one look (ICP_AMD_GATE_SPINS=1: the predecessor is still running); after the reset the
+    same handle tracks a sequence to the bits of a fresh handle, and a plain run on it works."""
+    clouds = [engine.synth_cloud_vga(moved=f) for f in range(5)]
+    seq = [clouds[i] for i in (0, 1, 2, 3, 4, 3, 2, 1)]
+    ref = engine.ICP(0); ref.init(16384, 256, 2e2, 1e-6)
+    want = ref.track_pipelined(seq, warm_start=False, depth=2)
+    g = engine.ICP(0); g.init(16384, 256, 2e2, 1e-6)
+    assert g.track_form() == 1
+    for rnd in range(2):
+        monkeypatch.setenv("ICP_AMD_GATE_SPINS", "1")
+        raised = None
+        try:
+            inflight = 0
+            for c in seq:
+                if inflight >= 3:
+                    g.track_collect(); inflight -= 1
+                g.track_submit(c, False); inflight += 1
+            while inflight:
+                g.track_collect(); inflight -= 1
+        except engine.ICPError as e:
+            raised = e
+        assert raised is not None and "icp_track_reset" in str(raised), raised
+        monkeypatch.delenv("ICP_AMD_GATE_SPINS")
+        g.track_reset()                                      # the FIRST reset recovers
+        got = g.track_pipelined(seq, warm_start=False, depth=2)
+        assert got[0] is None and len(got) == len(want)
+        for a, b in zip(got[1:], want[1:]):
+            assert a[0] == b[0] and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    # a plain registration on the handle that went through all this
+    F, M = engine.synth_pair(128)
+    g.track_reset()
+    g.write(engine.Memory.F, F); g.write(engine.Memory.M, M); g.reset_transform(); g.buildRBC()
+    ref.track_reset()
+    ref.write(engine.Memory.F, F); ref.write(engine.Memory.M, M); ref.reset_transform(); ref.buildRBC()
+    assert g.run() == ref.run() and np.array_equal(g.read(engine.Memory.T).view(np.uint32), ref.read(engine.Memory.T).view(np.uint32))
+    g.close(); ref.close()

@@ -877,6 +877,23 @@ def main():
 
     import icp_amd
     device = int(os.environ.get("ICP_BENCH_DEVICE", local_rank))   # override: self-test of the N>1 path on a 1-GPU box
+    host_cpus = None
+    if launch == "ranks" and os.environ.get("ICP_AMD_SLOT_NUMA", "1") != "0":
+        # a rank drives one GPU from this thread: keep it on that GPU's NUMA node (what icp_batch_create does for its slot threads; a two-socket
+        # 8-GPU node has four GPUs per socket).  Silently skipped where sysfs says nothing or none of those CPUs is ours.
+        try:
+            cl = icp_amd.numa_cpulist(icp_amd.device_pci_bus_id(device))
+            want = set()
+            for part in cl.split(","):
+                if part:
+                    a, _, b = part.partition("-")
+                    want.update(range(int(a), int(b or a) + 1))
+            mine = want & set(os.sched_getaffinity(0))
+            if mine:
+                os.sched_setaffinity(0, mine)
+                host_cpus = cl
+        except Exception:                            # noqa: BLE001 — placement is an optimisation, never a reason to fail
+            host_cpus = None
     fused = args.reduce_mode == "fused"
 
     per_gpu = None
@@ -1012,6 +1029,8 @@ def main():
         line["per_gpu_iterations_per_s"] = per_gpu
         if devices_used is not None:
             line["config"]["devices"] = devices_used
+        if host_cpus:
+            line["config"]["rank0_host_cpus"] = host_cpus
         # the same-work field of every line: one GPU at config 4's per-GPU share (64 registrations of A per launch)
         line["single_gpu_same_work_key"] = "config4_per_gpu_value"
         line["config4_per_gpu_value"] = None

@@ -194,6 +194,9 @@ def lib():
     sig("icp_last_error", C.c_char_p, vp)
     sig("icp_version", C.c_char_p)
     sig("icp_device_count", i32, C.POINTER(i32))
+    sig("icp_device_pci_bus_id", i32, i32, C.c_char_p, C.c_size_t)
+    sig("icp_numa_cpulist", i32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t)
+    sig("icp_batch_slot_cpus", i32, vp, u32, C.c_char_p, C.c_size_t)
     sig("icp_synth_pair", i32, C.c_uint64, u32, f32, vp, vp, f32, f32, f32, vp, vp)
     sig("icp_synth_cloud_vga", i32, C.c_uint64, i32, vp)
     sig("icp_track_register_source", i32, vp, vp, C.c_size_t)
@@ -408,6 +411,25 @@ def device_count():
     n = C.c_int(0)
     lib().icp_device_count(C.byref(n))
     return n.value
+
+
+def device_pci_bus_id(device):
+    """PCI bus id of a device ("0000:c1:00.0")."""
+    buf = C.create_string_buffer(64)
+    rc = lib().icp_device_pci_bus_id(device, buf, len(buf))
+    if rc:
+        raise ICPError(rc, "icp_device_pci_bus_id (%d)" % device)
+    return buf.value.decode()
+
+
+def numa_cpulist(pci_bus_id, sysfs_root=None):
+    """cpulist of the NUMA node a PCI device hangs on, from a sysfs tree ("" when the tree has no answer): where icp_batch_create pins
+    the host thread of a device slot by default (host code only: works without a GPU)."""
+    buf = C.create_string_buffer(4096)
+    rc = lib().icp_numa_cpulist(sysfs_root.encode() if sysfs_root else None, pci_bus_id.encode(), buf, len(buf))
+    if rc:
+        raise ICPError(rc, "icp_numa_cpulist")
+    return buf.value.decode()
 
 
 def _p(a):
@@ -869,6 +891,12 @@ class ICPBatch:
     def _chk(self, rc):
         if rc:
             raise ICPError(rc, self._L.icp_batch_last_error(self._b).decode())
+
+    def slot_cpus(self, slot):
+        """The CPUs the host thread of a device slot was pinned to ([] = not pinned)."""
+        buf = C.create_string_buffer(16384)
+        self._chk(self._L.icp_batch_slot_cpus(self._b, slot, buf, len(buf)))
+        return [int(x) for x in buf.value.decode().split(",") if x]
 
     def close(self):
         if getattr(self, "_b", None):

@@ -7,11 +7,14 @@
 // counterpart (single context, single in-order queue: src/ICP/algorithms.cpp:4351-4352).
 // Host code only: everything goes through the C-ABI of include/icp_amd.h.
 #include "../../include/icp_amd.h"
+#include "icp_cguard.h"
 
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -46,6 +49,8 @@ struct icp_batch_context {
     std::atomic<bool> stop { false };
     std::function<int (size_t)> job;
     std::vector<int> rc;
+    std::mutex call_mx;                          // one caller at a time (job / pending / generation are single slots): a second thread waits
+    std::vector<std::string> slot_cpus;          // what every worker was pinned to ("" = nowhere), icp_batch_slot_cpus
 };
 
 namespace {
@@ -72,7 +77,8 @@ void worker_main (icp_batch_context *b, size_t s)
         }
         if (b->stop.load (std::memory_order_acquire)) return;
         seen = b->generation.load (std::memory_order_acquire);
-        b->rc[s] = b->count[s] ? b->job (s) : (int) ICP_OK;
+        try { b->rc[s] = b->count[s] ? b->job (s) : (int) ICP_OK; }
+        catch (...) { b->rc[s] = icp_host::on_exception (); }          // (a throwing job must not take the process down: std::terminate on a worker)
         if (b->pending.fetch_sub (1, std::memory_order_acq_rel) == 1) {
             std::lock_guard<std::mutex> lk (b->mx);       // (the caller may be on its way to sleep: the lock orders this notify behind its wait)
             b->cv_done.notify_one ();
@@ -80,22 +86,85 @@ void worker_main (icp_batch_context *b, size_t s)
     }
 }
 
+// "0-3,8,10-11" -> CPU numbers (a malformed tail ends the list)
+void parse_cpulist (const char *q, std::vector<int> &out)
+{
+    while (q && *q) {
+        char *end = nullptr;
+        const long a = std::strtol (q, &end, 10);
+        if (end == q || a < 0) break;
+        long z = a;
+        if (*end == '-') { const char *r = end + 1; z = std::strtol (r, &end, 10); if (end == r || z < a) break; }
+        for (long v = a; v <= z && out.size () < 4096; ++v) out.push_back ((int) v);
+        if (*end != ',') break;
+        q = end + 1;
+    }
+}
+
+bool read_line (const std::string &path, std::string &line)
+{
+    FILE *f = std::fopen (path.c_str (), "r");
+    if (!f) return false;
+    char buf[4096];
+    const bool ok = std::fgets (buf, sizeof (buf), f) != nullptr;
+    std::fclose (f);
+    if (!ok) return false;
+    line = buf;
+    while (!line.empty () && (line.back () == '\n' || line.back () == '\r' || line.back () == ' ')) line.pop_back ();
+    return true;
+}
+
+// The CPUs next to a PCI device: <root>/bus/pci/devices/<id>/local_cpulist, else the cpulist of the node <id>/numa_node names
+// (<root>/devices/system/node/node<N>/cpulist); "" when the tree says nothing (a container without it, numa_node = -1).
+std::string numa_cpulist_of (const std::string &root, const std::string &pci)
+{
+    std::string id = pci, line;
+    for (char &ch : id) if (ch >= 'A' && ch <= 'F') ch = (char) (ch - 'A' + 'a');      // (sysfs spells bus ids in lower case)
+    const std::string dev = root + "/bus/pci/devices/" + id;
+    if (read_line (dev + "/local_cpulist", line) && !line.empty ()) return line;
+    if (read_line (dev + "/numa_node", line)) {
+        const long node = std::strtol (line.c_str (), nullptr, 10);
+        if (node >= 0 && read_line (root + "/devices/system/node/node" + std::to_string (node) + "/cpulist", line)) return line;
+    }
+    return std::string ();
+}
+
+// One worker per slot.  Where it runs: ICP_AMD_SLOT_CPUS (a comma-separated list of CPU numbers or ranges; slot s takes entry s mod
+// length) if set; else the CPUs of the NUMA node its GPU hangs on (sysfs through the device's PCI bus id: on a two-socket 8-GPU node the
+// thread that drives a GPU belongs on that GPU's socket — its launches and the polled host words then stay off the inter-socket link),
+// intersected with what the process may use; else, silently, wherever the scheduler puts it.  ICP_AMD_SLOT_NUMA=0 switches the default off.
 int start_workers (icp_batch_context *b)
 {
     const size_t n = b->slots.size ();
     b->rc.assign (n, ICP_OK);
-    std::vector<int> cpus;
+    b->slot_cpus.assign (n, std::string ());
+    std::vector<std::vector<int>> want (n);
     if (const char *e = std::getenv ("ICP_AMD_SLOT_CPUS")) {
-        const char *q = e;
-        while (*q) { char *end = nullptr; const long v = std::strtol (q, &end, 10); if (end == q) break; if (v >= 0) cpus.push_back ((int) v); q = (*end == ',') ? end + 1 : end; if (*end && *end != ',') break; }
+        std::vector<std::string> items;
+        std::string cur;
+        for (const char *q = e;; ++q) { if (*q == ',' || !*q) { if (!cur.empty ()) items.push_back (cur); cur.clear (); if (!*q) break; } else cur.push_back (*q); }
+        for (size_t s = 0; s < n && !items.empty (); ++s) parse_cpulist (items[s % items.size ()].c_str (), want[s]);
+    } else {
+        const char *off = std::getenv ("ICP_AMD_SLOT_NUMA");
+        const char *root = std::getenv ("ICP_AMD_SYSFS_ROOT");
+        if (!(off && off[0] == '0'))
+            for (size_t s = 0; s < n; ++s) {
+                char id[64] = { 0 };
+                if (icp_device_pci_bus_id (b->devices[s], id, sizeof (id)) != ICP_OK) continue;
+                parse_cpulist (numa_cpulist_of (root ? root : "/sys", id).c_str (), want[s]);
+            }
     }
+    cpu_set_t allowed; CPU_ZERO (&allowed);
+    const bool have_allowed = sched_getaffinity (0, sizeof (allowed), &allowed) == 0;
     try {
         for (size_t s = 0; s < n; ++s) {
             b->workers.emplace_back (worker_main, b, s);
-            if (!cpus.empty ()) {
-                cpu_set_t set; CPU_ZERO (&set); CPU_SET (cpus[s % cpus.size ()], &set);
-                (void) pthread_setaffinity_np (b->workers.back ().native_handle (), sizeof (set), &set);      // (a CPU that is not there: the thread stays where it is)
-            }
+            cpu_set_t set; CPU_ZERO (&set);
+            std::string text;
+            for (int c : want[s])
+                if (c < CPU_SETSIZE && (!have_allowed || CPU_ISSET (c, &allowed))) { CPU_SET (c, &set); text += (text.empty () ? "" : ",") + std::to_string (c); }
+            if (!text.empty () && pthread_setaffinity_np (b->workers.back ().native_handle (), sizeof (set), &set) == 0) b->slot_cpus[s] = text;
+            // (no usable CPU in the list, or the call refused: the thread stays where the scheduler puts it, and slot_cpus says so)
         }
     } catch (const std::system_error &) { return ICP_ENOMEM; }
     return ICP_OK;
@@ -113,6 +182,7 @@ void stop_workers (icp_batch_context *b)
 template <typename Fn>
 int for_each_slot (icp_batch_context *b, Fn &&fn)
 {
+    std::lock_guard<std::mutex> call (b->call_mx);
     const size_t n = b->slots.size ();
     b->job = std::forward<Fn> (fn);
     b->pending.store ((int) n, std::memory_order_release);
@@ -134,7 +204,7 @@ int for_each_slot (icp_batch_context *b, Fn &&fn)
 
 extern "C" {
 
-int icp_batch_partition (uint32_t registrations, uint32_t n_slots, uint32_t i, uint32_t *slot, uint32_t *index, uint32_t *slot_count)
+int icp_batch_partition (uint32_t registrations, uint32_t n_slots, uint32_t i, uint32_t *slot, uint32_t *index, uint32_t *slot_count) try
 {
     if (n_slots == 0 || i >= registrations) return ICP_EINVAL;
     const uint32_t s = i % n_slots;
@@ -143,39 +213,61 @@ int icp_batch_partition (uint32_t registrations, uint32_t n_slots, uint32_t i, u
     if (slot_count) *slot_count = (registrations - s + n_slots - 1u) / n_slots;    // registrations s, s + n, s + 2n, ..
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
 const char *icp_batch_last_error (icp_batch_handle b) { return b ? b->err.c_str () : g_batch_create_error.c_str (); }
 
-int icp_batch_create (icp_batch_handle *out, const int *devices, int n_devices, int rot, int weighted)
+int icp_batch_create (icp_batch_handle *out, const int *devices, int n_devices, int rot, int weighted) try
 {
     if (!out) return ICP_EINVAL;
     *out = nullptr;
     if (!devices || n_devices <= 0) return bfail (nullptr, ICP_EINVAL, "icp_batch_create: empty device list");
-    icp_batch_context *b = new icp_batch_context ();
+    struct guard {                                   // whatever leaves this function early — a status or an exception — takes the half-built object with it
+        icp_batch_context *b;
+        ~guard () { if (b) { stop_workers (b); for (icp_handle q : b->slots) icp_destroy (q); delete b; } }
+    } g { new icp_batch_context () };
+    icp_batch_context *b = g.b;
     b->rot = rot; b->weighted = weighted;
+    b->devices.reserve ((size_t) n_devices); b->slots.reserve ((size_t) n_devices);
     for (int d = 0; d < n_devices; ++d) {
         icp_handle h = nullptr;
         int rc = icp_create (&h, devices[d], rot, weighted);
-        if (rc != ICP_OK) {
-            std::string m = icp_last_error (nullptr);
-            for (icp_handle q : b->slots) icp_destroy (q);
-            delete b;
-            return bfail (nullptr, rc, "icp_batch_create: device " + std::to_string (devices[d]) + ": " + m);
-        }
-        b->devices.push_back (devices[d]); b->slots.push_back (h);
+        if (rc != ICP_OK) return bfail (nullptr, rc, "icp_batch_create: device " + std::to_string (devices[d]) + ": " + icp_last_error (nullptr));
+        b->devices.push_back (devices[d]); b->slots.push_back (h);          // (reserved above: cannot throw between icp_create and here)
     }
     b->count.assign (b->slots.size (), 0u);
-    if (start_workers (b) != ICP_OK) {
-        stop_workers (b);
-        for (icp_handle q : b->slots) icp_destroy (q);
-        delete b;
-        return bfail (nullptr, ICP_ENOMEM, "icp_batch_create: a host thread per device slot could not be started");
-    }
+    if (start_workers (b) != ICP_OK) return bfail (nullptr, ICP_ENOMEM, "icp_batch_create: a host thread per device slot could not be started");
+    g.b = nullptr;
     *out = b;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_batch_destroy (icp_batch_handle b)
+// The CPUs the worker of a slot was pinned to, as a comma-separated list ("" = not pinned: no ICP_AMD_SLOT_CPUS entry, no NUMA
+// information for its device, or none of the CPUs is available to the process).
+int icp_batch_slot_cpus (icp_batch_handle b, uint32_t slot, char *out, size_t cap) try
+{
+    if (!b || !out || cap == 0 || slot >= b->slots.size ()) return ICP_EINVAL;
+    const std::string &t = b->slot_cpus[slot];
+    if (t.size () + 1 > cap) return bfail (b, ICP_EINVAL, "icp_batch_slot_cpus: the buffer is too small");
+    std::memcpy (out, t.c_str (), t.size () + 1);
+    return ICP_OK;
+}
+ICP_CATCH_ALL
+
+// The cpulist of the NUMA node a PCI device hangs on, read from a sysfs tree (sysfs_root NULL = "/sys"): what icp_batch_create pins a
+// slot's worker to by default.  out = "" when the tree has no answer.
+int icp_numa_cpulist (const char *sysfs_root, const char *pci_bus_id, char *out, size_t cap) try
+{
+    if (!pci_bus_id || !out || cap == 0) return ICP_EINVAL;
+    const std::string t = numa_cpulist_of (sysfs_root ? sysfs_root : "/sys", pci_bus_id);
+    if (t.size () + 1 > cap) return ICP_EINVAL;
+    std::memcpy (out, t.c_str (), t.size () + 1);
+    return ICP_OK;
+}
+ICP_CATCH_ALL
+
+int icp_batch_destroy (icp_batch_handle b) try
 {
     if (!b) return ICP_EINVAL;
     stop_workers (b);
@@ -183,17 +275,19 @@ int icp_batch_destroy (icp_batch_handle b)
     delete b;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_batch_size (icp_batch_handle b, uint32_t *registrations, uint32_t *n_slots)
+int icp_batch_size (icp_batch_handle b, uint32_t *registrations, uint32_t *n_slots) try
 {
     if (!b) return ICP_EINVAL;
     if (registrations) *registrations = b->registrations;
     if (n_slots) *n_slots = (uint32_t) b->slots.size ();
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
 int icp_batch_init (icp_batch_handle b, uint32_t registrations, uint32_t m, uint32_t nr, float a, float c,
-                    uint32_t max_iterations, double angle_threshold, double translation_threshold)
+                    uint32_t max_iterations, double angle_threshold, double translation_threshold) try
 {
     if (!b) return ICP_EINVAL;
     if (registrations == 0) return bfail (b, ICP_EINVAL, "icp_batch_init: no registrations");
@@ -207,6 +301,7 @@ int icp_batch_init (icp_batch_handle b, uint32_t registrations, uint32_t m, uint
     if (rc == ICP_OK) b->inited = true;
     return rc;
 }
+ICP_CATCH_ALL
 
 #define BATCH_SLOT(b, i)                                                                              \
     if (!(b)) return ICP_EINVAL;                                                                      \
@@ -218,28 +313,31 @@ int icp_batch_init (icp_batch_handle b, uint32_t registrations, uint32_t m, uint
 #define BATCH_CALL(b, expr)                                                                           \
     do { int rc_ = (expr); if (rc_ != ICP_OK) return bfail ((b), rc_, icp_last_error (h_)); } while (0)
 
-int icp_batch_write (icp_batch_handle b, uint32_t i, int mem, const void *host_ptr)
+int icp_batch_write (icp_batch_handle b, uint32_t i, int mem, const void *host_ptr) try
 {
     BATCH_SLOT (b, i)
     BATCH_CALL (b, icp_write_b (h_, idx_, mem, host_ptr, 0));
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_batch_read (icp_batch_handle b, uint32_t i, int mem, void *host_dst, size_t bytes)
+int icp_batch_read (icp_batch_handle b, uint32_t i, int mem, void *host_dst, size_t bytes) try
 {
     BATCH_SLOT (b, i)
     BATCH_CALL (b, icp_read_b (h_, idx_, mem, host_dst, bytes));
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_batch_state (icp_batch_handle b, uint32_t i, icp_state_t *out)
+int icp_batch_state (icp_batch_handle b, uint32_t i, icp_state_t *out) try
 {
     BATCH_SLOT (b, i)
     BATCH_CALL (b, icp_state_b (h_, idx_, out));
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_batch_set_modes (icp_batch_handle b, int reduce_mode, int power_mode)
+int icp_batch_set_modes (icp_batch_handle b, int reduce_mode, int power_mode) try
 {
     if (!b) return ICP_EINVAL;
     for (icp_handle h : b->slots) {
@@ -248,20 +346,23 @@ int icp_batch_set_modes (icp_batch_handle b, int reduce_mode, int power_mode)
     }
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_batch_build_rbc (icp_batch_handle b)
+int icp_batch_build_rbc (icp_batch_handle b) try
 {
     if (!b || !b->inited) return b ? bfail (b, ICP_ESTATE, "icp_batch_init has not been called") : ICP_EINVAL;
     return for_each_slot (b, [&] (size_t s) { int rc = icp_build_rbc (b->slots[s]); return rc ? rc : icp_sync (b->slots[s]); });
 }
+ICP_CATCH_ALL
 
-int icp_batch_run (icp_batch_handle b)
+int icp_batch_run (icp_batch_handle b) try
 {
     if (!b || !b->inited) return b ? bfail (b, ICP_ESTATE, "icp_batch_init has not been called") : ICP_EINVAL;
     return for_each_slot (b, [&] (size_t s) { return icp_run (b->slots[s], nullptr); });
 }
+ICP_CATCH_ALL
 
-int icp_batch_run_fixed (icp_batch_handle b, uint32_t iterations, int from_identity)
+int icp_batch_run_fixed (icp_batch_handle b, uint32_t iterations, int from_identity) try
 {
     if (!b || !b->inited) return b ? bfail (b, ICP_ESTATE, "icp_batch_init has not been called") : ICP_EINVAL;
     return for_each_slot (b, [&] (size_t s) {
@@ -270,8 +371,9 @@ int icp_batch_run_fixed (icp_batch_handle b, uint32_t iterations, int from_ident
         return rc ? rc : icp_sync (b->slots[s]);
     });
 }
+ICP_CATCH_ALL
 
-int icp_batch_time_run_fixed_slots (icp_batch_handle b, uint32_t iterations, uint32_t reps, uint32_t warmup, double *seconds, float *slot_ms)
+int icp_batch_time_run_fixed_slots (icp_batch_handle b, uint32_t iterations, uint32_t reps, uint32_t warmup, double *seconds, float *slot_ms) try
 {
     if (!b || !b->inited) return b ? bfail (b, ICP_ESTATE, "icp_batch_init has not been called") : ICP_EINVAL;
     if (!seconds || iterations == 0 || reps == 0) return bfail (b, ICP_EINVAL, "bad arguments");
@@ -306,10 +408,12 @@ int icp_batch_time_run_fixed_slots (icp_batch_handle b, uint32_t iterations, uin
     if (slot_ms) for (size_t s = 0; s < n; ++s) slot_ms[s] = ms[s];
     return rc;
 }
+ICP_CATCH_ALL
 
-int icp_batch_time_run_fixed (icp_batch_handle b, uint32_t iterations, uint32_t reps, double *seconds)
+int icp_batch_time_run_fixed (icp_batch_handle b, uint32_t iterations, uint32_t reps, double *seconds) try
 {
     return icp_batch_time_run_fixed_slots (b, iterations, reps, 1u, seconds, nullptr);
 }
+ICP_CATCH_ALL
 
 }  // extern "C"

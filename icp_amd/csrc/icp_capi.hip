@@ -90,7 +90,18 @@ const char *icp_version (void) { return "icp_amd 0.1 (gfx950)"; }
 
 const char *icp_last_error (icp_handle h) { return h ? h->err.c_str () : g_create_error.c_str (); }
 
-int icp_device_count (int *n)
+// PCI bus id of a device ("0000:c1:00.0"): icp_batch_create looks the device's NUMA node up with it.
+int icp_device_pci_bus_id (int device, char *out, size_t cap) try
+{
+    if (!out || cap < 16) return ICP_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount (&n) != hipSuccess || device < 0 || device >= n) { (void) hipGetLastError (); return ICP_ENODEVICE; }
+    if (hipDeviceGetPCIBusId (out, (int) cap, device) != hipSuccess) { (void) hipGetLastError (); out[0] = 0; return ICP_EHIP; }
+    return ICP_OK;
+}
+ICP_CATCH_ALL
+
+int icp_device_count (int *n) try
 {
     if (!n) return fail (nullptr, ICP_EINVAL, "icp_device_count: null output");
     int c = 0;
@@ -99,8 +110,9 @@ int icp_device_count (int *n)
     *n = c;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_create (icp_handle *out, int device, int rot, int weighted)
+int icp_create (icp_handle *out, int device, int rot, int weighted) try
 {
     if (!out) return ICP_EINVAL;
     *out = nullptr;
@@ -142,8 +154,9 @@ int icp_create (icp_handle *out, int device, int rot, int weighted)
     *out = h;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_destroy (icp_handle h)
+int icp_destroy (icp_handle h) try
 {
     if (!h) return ICP_EINVAL;
     (void) hipSetDevice (h->device);
@@ -165,9 +178,10 @@ int icp_destroy (icp_handle h)
     delete h;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
 int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, float a, float c,
-                      uint32_t max_iterations, double angle_threshold, double translation_threshold)
+                      uint32_t max_iterations, double angle_threshold, double translation_threshold) try
 {
     if (!h) return ICP_EINVAL;
     // argument checks of the reference: src/ICP/algorithms.cpp:4413-4420, :1573, :842-854
@@ -268,14 +282,16 @@ int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, flo
     h->inited = true; h->built = false;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
 int icp_init (icp_handle h, uint32_t m, uint32_t nr, float a, float c, uint32_t max_iterations,
-              double angle_threshold, double translation_threshold)
+              double angle_threshold, double translation_threshold) try
 {
     return icp_init_batched (h, 1, m, nr, a, c, max_iterations, angle_threshold, translation_threshold);
 }
+ICP_CATCH_ALL
 
-int icp_write_b (icp_handle h, uint32_t b, int mem, const void *host_ptr, int block)
+int icp_write_b (icp_handle h, uint32_t b, int mem, const void *host_ptr, int block) try
 {
     int rc = need (h, false); if (rc) return rc;
     if (b >= h->p.batch) return fail (h, ICP_EINVAL, "batch index out of range");
@@ -312,8 +328,9 @@ int icp_write_b (icp_handle h, uint32_t b, int mem, const void *host_ptr, int bl
     if (block) HIPCHK (h, hipStreamSynchronize (h->stream));
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_write (icp_handle h, int mem, const void *host_ptr, int block) { return icp_write_b (h, 0, mem, host_ptr, block); }
+int icp_write (icp_handle h, int mem, const void *host_ptr, int block) try { return icp_write_b (h, 0, mem, host_ptr, block); } ICP_CATCH_ALL
 
 size_t icp_mem_size (icp_handle h, int mem)
 {
@@ -364,7 +381,7 @@ static int mem_ptr (icp_context *h, uint32_t b, int mem, const void **src)
     return ICP_OK;
 }
 
-int icp_read_b (icp_handle h, uint32_t b, int mem, void *host_dst, size_t bytes)
+int icp_read_b (icp_handle h, uint32_t b, int mem, void *host_dst, size_t bytes) try
 {
     int rc = need (h, false); if (rc) return rc;
     if (!host_dst) return fail (h, ICP_EINVAL, "icp_read: null destination");
@@ -384,10 +401,11 @@ int icp_read_b (icp_handle h, uint32_t b, int mem, void *host_dst, size_t bytes)
     HIPCHK (h, hipStreamSynchronize (h->stream));
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_read (icp_handle h, int mem, void *host_dst, size_t bytes) { return icp_read_b (h, 0, mem, host_dst, bytes); }
+int icp_read (icp_handle h, int mem, void *host_dst, size_t bytes) try { return icp_read_b (h, 0, mem, host_dst, bytes); } ICP_CATCH_ALL
 
-int icp_device_ptr (icp_handle h, int mem, void **dptr)
+int icp_device_ptr (icp_handle h, int mem, void **dptr) try
 {
     int rc = need (h, false); if (rc) return rc;
     if (!dptr) return fail (h, ICP_EINVAL, "null pointer");
@@ -398,8 +416,9 @@ int icp_device_ptr (icp_handle h, int mem, void **dptr)
     *dptr = const_cast<void *> (src);
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_adopt_device_buffer (icp_handle h, int mem, void *dptr)
+int icp_adopt_device_buffer (icp_handle h, int mem, void *dptr) try
 {
     int rc = need (h, false); if (rc) return rc;
     if (!dptr) return fail (h, ICP_EINVAL, "null pointer");
@@ -410,8 +429,9 @@ int icp_adopt_device_buffer (icp_handle h, int mem, void *dptr)
     drop_graphs (h);
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_build_rbc (icp_handle h)
+int icp_build_rbc (icp_handle h) try
 {
     int rc = need (h, false); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
@@ -444,8 +464,9 @@ int icp_build_rbc (icp_handle h)
     h->built = true; h->k_base = 0;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_step (icp_handle h, int config)
+int icp_step (icp_handle h, int config) try
 {
     (void) config;   // the reference sizes the list-scan launch from a host read when config is set; nothing to configure here
     int rc = need (h, true); if (rc) return rc;
@@ -457,24 +478,27 @@ int icp_step (icp_handle h, int config)
     HIPCHK (h, hipGetLastError ());
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_run_fixed (icp_handle h, uint32_t iterations)
+int icp_run_fixed (icp_handle h, uint32_t iterations) try
 {
     int rc = need (h, true); if (rc) return rc;
     if (iterations == 0) return ICP_OK;
     if ((rc = set_device (h))) return rc;
     return launch_run (h, iterations, 0);
 }
+ICP_CATCH_ALL
 
-int icp_run_fixed_fresh (icp_handle h, uint32_t iterations)
+int icp_run_fixed_fresh (icp_handle h, uint32_t iterations) try
 {
     int rc = need (h, true); if (rc) return rc;
     if (iterations == 0) return icp_reset_transform (h);
     if ((rc = set_device (h))) return rc;
     return launch_run (h, iterations, 0, true);
 }
+ICP_CATCH_ALL
 
-int icp_run (icp_handle h, uint32_t *k)
+int icp_run (icp_handle h, uint32_t *k) try
 {
     int rc = need (h, true); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
@@ -509,8 +533,9 @@ int icp_run (icp_handle h, uint32_t *k)
     }
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_run_stats (icp_handle h, uint32_t *launches, uint32_t *k, uint32_t *dead)
+int icp_run_stats (icp_handle h, uint32_t *launches, uint32_t *k, uint32_t *dead) try
 {
     if (!h) return ICP_EINVAL;
     if (launches) *launches = h->stat_launches;
@@ -518,8 +543,9 @@ int icp_run_stats (icp_handle h, uint32_t *launches, uint32_t *k, uint32_t *dead
     if (dead) *dead = h->stat_dead;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_launch_stats (icp_handle h, double *max_us, uint64_t *slower_than_10us, uint64_t *total, int reset)
+int icp_launch_stats (icp_handle h, double *max_us, uint64_t *slower_than_10us, uint64_t *total, int reset) try
 {
     if (!h) return ICP_EINVAL;
     if (max_us) *max_us = h->stat_launch_max_us;
@@ -528,23 +554,26 @@ int icp_launch_stats (icp_handle h, double *max_us, uint64_t *slower_than_10us, 
     if (reset) { h->stat_launch_max_us = 0.0; h->stat_launch_slow = h->stat_launch_total = 0; }
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_set_output_mode (icp_handle h, int mode)
+int icp_set_output_mode (icp_handle h, int mode) try
 {
     if (!h) return ICP_EINVAL;
     if (mode != ICP_OUTPUTS_LAZY && mode != ICP_OUTPUTS_EVERY_ITERATION) return fail (h, ICP_EINVAL, "unknown output mode");
     h->outputs_lazy = mode == ICP_OUTPUTS_LAZY;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_run_timeline (icp_handle h, double *us6)
+int icp_run_timeline (icp_handle h, double *us6) try
 {
     if (!h || !us6) return ICP_EINVAL;
     for (int i = 0; i < 6; ++i) us6[i] = (h->stat_t[i] - h->stat_t[0]) * 1e6;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_set_run_depth (icp_handle h, uint32_t depth, int adaptive)
+int icp_set_run_depth (icp_handle h, uint32_t depth, int adaptive) try
 {
     if (!h) return ICP_EINVAL;
     if (depth == 0 || depth > 64u) return fail (h, ICP_EINVAL, "icp_set_run_depth: depth must be in [1, 64]");
@@ -552,69 +581,78 @@ int icp_set_run_depth (icp_handle h, uint32_t depth, int adaptive)
     h->run_depth = depth; h->run_adaptive = adaptive ? 1 : 0;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_sync (icp_handle h)
+int icp_sync (icp_handle h) try
 {
     if (!h) return ICP_EINVAL;
     int rc = set_device (h); if (rc) return rc;
     return settle (h);
 }
+ICP_CATCH_ALL
 
-int icp_get_alpha (icp_handle h, float *a) { if (!h || !a) return ICP_EINVAL; *a = h->p.a; return ICP_OK; }
+int icp_get_alpha (icp_handle h, float *a) try { if (!h || !a) return ICP_EINVAL; *a = h->p.a; return ICP_OK; } ICP_CATCH_ALL
 // The setters change a number in the handle's parameters and nothing else: checked runs are plain launches that read the parameters as they
 // are, and a cached fixed-length graph of an older parameter generation is updated in place when it is next used (get_graph).
-int icp_set_alpha (icp_handle h, float a)
+int icp_set_alpha (icp_handle h, float a) try
 {   // setAlpha updates construct and search (src/ICP/algorithms.cpp:4712-4717); lists must be rebuilt by the caller
     if (!h) return ICP_EINVAL;
     if (a == 0.f) return fail (h, ICP_EINVAL, "The alpha parameter cannot be equal to zero");
     { int rc = outputs_before_change (h); if (rc) return rc; }
     h->p.a = a; ++h->param_gen; return ICP_OK;
 }
-int icp_set_metric_scale (icp_handle h, float f_g)
+ICP_CATCH_ALL
+int icp_set_metric_scale (icp_handle h, float f_g) try
 {
     if (!h) return ICP_EINVAL;
     if (!(f_g > 0.f) || !std::isfinite (f_g)) return fail (h, ICP_EINVAL, "the metric scale must be positive and finite");
     { int rc = outputs_before_change (h); if (rc) return rc; }
     h->p.dist_scale = f_g; ++h->param_gen; return ICP_OK;
 }
-int icp_get_metric_scale (icp_handle h, float *f_g) { if (!h || !f_g) return ICP_EINVAL; *f_g = h->p.dist_scale; return ICP_OK; }
-int icp_get_scaling (icp_handle h, float *c) { if (!h || !c) return ICP_EINVAL; *c = h->p.c; return ICP_OK; }
-int icp_set_scaling (icp_handle h, float c) { if (!h) return ICP_EINVAL; h->p.c = c; ++h->param_gen; return ICP_OK; }
-int icp_get_max_iterations (icp_handle h, uint32_t *n) { if (!h || !n) return ICP_EINVAL; *n = h->max_iterations; return ICP_OK; }
-int icp_set_max_iterations (icp_handle h, uint32_t n)
+ICP_CATCH_ALL
+int icp_get_metric_scale (icp_handle h, float *f_g) try { if (!h || !f_g) return ICP_EINVAL; *f_g = h->p.dist_scale; return ICP_OK; } ICP_CATCH_ALL
+int icp_get_scaling (icp_handle h, float *c) try { if (!h || !c) return ICP_EINVAL; *c = h->p.c; return ICP_OK; } ICP_CATCH_ALL
+int icp_set_scaling (icp_handle h, float c) try { if (!h) return ICP_EINVAL; h->p.c = c; ++h->param_gen; return ICP_OK; } ICP_CATCH_ALL
+int icp_get_max_iterations (icp_handle h, uint32_t *n) try { if (!h || !n) return ICP_EINVAL; *n = h->max_iterations; return ICP_OK; } ICP_CATCH_ALL
+int icp_set_max_iterations (icp_handle h, uint32_t n) try
 {
     if (!h) return ICP_EINVAL;
     if (n == 0) return fail (h, ICP_EINVAL, "max_iterations must be positive");
     h->max_iterations = n; return ICP_OK;
 }
-int icp_get_angle_threshold (icp_handle h, double *d) { if (!h || !d) return ICP_EINVAL; *d = h->angle_threshold; return ICP_OK; }
-int icp_set_angle_threshold (icp_handle h, double d)
+ICP_CATCH_ALL
+int icp_get_angle_threshold (icp_handle h, double *d) try { if (!h || !d) return ICP_EINVAL; *d = h->angle_threshold; return ICP_OK; } ICP_CATCH_ALL
+int icp_set_angle_threshold (icp_handle h, double d) try
 {
     if (!h) return ICP_EINVAL;
     h->angle_threshold = d; h->p.tan_half_thr = std::tan (d * M_PI / 360.0); ++h->param_gen; return ICP_OK;
 }
-int icp_get_translation_threshold (icp_handle h, double *d) { if (!h || !d) return ICP_EINVAL; *d = h->translation_threshold; return ICP_OK; }
-int icp_set_translation_threshold (icp_handle h, double d)
+ICP_CATCH_ALL
+int icp_get_translation_threshold (icp_handle h, double *d) try { if (!h || !d) return ICP_EINVAL; *d = h->translation_threshold; return ICP_OK; } ICP_CATCH_ALL
+int icp_set_translation_threshold (icp_handle h, double d) try
 {
     if (!h) return ICP_EINVAL;
     h->translation_threshold = d; h->p.trans_thr = d; ++h->param_gen; return ICP_OK;
 }
-int icp_set_power_mode (icp_handle h, int mode)
+ICP_CATCH_ALL
+int icp_set_power_mode (icp_handle h, int mode) try
 {
     if (!h) return ICP_EINVAL;
     if (mode != ICP_POWER_LITERAL && mode != ICP_POWER_SQUARED) return fail (h, ICP_EINVAL, "unknown power mode");
     h->p.power_mode = mode; ++h->param_gen; return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_set_reduce_mode (icp_handle h, int mode)
+int icp_set_reduce_mode (icp_handle h, int mode) try
 {
     if (!h) return ICP_EINVAL;
     if (mode != ICP_REDUCE_REFERENCE_ORDER && mode != ICP_REDUCE_FUSED) return fail (h, ICP_EINVAL, "unknown reduce mode");
     { int rc = outputs_before_change (h); if (rc) return rc; }
     h->p.fused = mode; drop_graphs (h); return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_state_b (icp_handle h, uint32_t b, icp_state_t *out)
+int icp_state_b (icp_handle h, uint32_t b, icp_state_t *out) try
 {
     int rc = need (h, false); if (rc) return rc;
     if (!out) return fail (h, ICP_EINVAL, "null pointer");
@@ -634,10 +672,11 @@ int icp_state_b (icp_handle h, uint32_t b, icp_state_t *out)
     out->k = st.k; out->converged = st.done; out->power_iterations = st.pm_iters; out->reserved = 0;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_state (icp_handle h, icp_state_t *out) { return icp_state_b (h, 0, out); }
+int icp_state (icp_handle h, icp_state_t *out) try { return icp_state_b (h, 0, out); } ICP_CATCH_ALL
 
-int icp_write_cloud (icp_handle h, int which, const void *cloud, int block)
+int icp_write_cloud (icp_handle h, int which, const void *cloud, int block) try
 {
     int rc = need (h, false); if (rc) return rc;
     if (h->p.m != 16384u) return fail (h, ICP_EINVAL, "getLMs produces 128 x 128 landmarks: m must be 16384");
@@ -661,8 +700,9 @@ int icp_write_cloud (icp_handle h, int which, const void *cloud, int block)
     (void) block;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint32_t n)
+int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint32_t n) try
 {
     int rc = need (h, false); if (rc) return rc;
     if (!host_in || !host_out || n == 0) return fail (h, ICP_EINVAL, "bad arguments");
@@ -682,9 +722,10 @@ int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint
     HIPCHK (h, hipStreamSynchronize (h->stream));
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
 
-int icp_transform_cloud_ex (icp_handle h, int kind, const float *T, const void *host_in, void *host_out, uint32_t n)
+int icp_transform_cloud_ex (icp_handle h, int kind, const float *T, const void *host_in, void *host_out, uint32_t n) try
 {
     if (!h) return ICP_EINVAL;
     if (kind != ICP_TRANSFORM_QUATERNION && kind != ICP_TRANSFORM_QUATERNION_2 && kind != ICP_TRANSFORM_MATRIX)
@@ -706,8 +747,9 @@ int icp_transform_cloud_ex (icp_handle h, int kind, const float *T, const void *
     HIPCHK (h, hipStreamSynchronize (h->stream));
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_power_method (int device, int rot, int power_mode, const float *S11, const float *means8, float *Tk8, float *Rk9, uint32_t *iters)
+int icp_power_method (int device, int rot, int power_mode, const float *S11, const float *means8, float *Tk8, float *Rk9, uint32_t *iters) try
 {
     if (!S11 || !means8 || !Tk8) return fail (nullptr, ICP_EINVAL, "icp_power_method: null pointer");
     if ((rot != ICP_ROT_EIGEN && rot != ICP_ROT_POWER_METHOD) || (power_mode != ICP_POWER_LITERAL && power_mode != ICP_POWER_SQUARED))
@@ -735,8 +777,9 @@ int icp_power_method (int device, int rot, int power_mode, const float *S11, con
     if (iters) std::memcpy (iters, out + 17, sizeof (uint32_t));
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_reset_transform (icp_handle h)
+int icp_reset_transform (icp_handle h) try
 {   // T <- identity, k <- 0 (what ICPStep::init uploads, src/ICP/algorithms.cpp:4486-4493); enqueue only
     int rc = need (h, false); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
@@ -746,8 +789,9 @@ int icp_reset_transform (icp_handle h)
     h->k_base = 0;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int from_identity, float *ms_total)
+int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int from_identity, float *ms_total) try
 {
     int rc = need (h, true); if (rc) return rc;
     if (!ms_total || iterations == 0 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
@@ -762,8 +806,9 @@ int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int fr
     HIPCHK (h, hipEventElapsedTime (ms_total, h->ev0, h->ev1));
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_time_run_fixed_tail (icp_handle h, uint32_t iterations, uint32_t reps, int from_identity, float *ms_timed, uint32_t *reps_timed)
+int icp_time_run_fixed_tail (icp_handle h, uint32_t iterations, uint32_t reps, int from_identity, float *ms_timed, uint32_t *reps_timed) try
 {
     int rc = need (h, true); if (rc) return rc;
     if (!ms_timed || !reps_timed || iterations == 0 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
@@ -784,8 +829,9 @@ int icp_time_run_fixed_tail (icp_handle h, uint32_t iterations, uint32_t reps, i
     *reps_timed = reps - lead;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_run_form (icp_handle h, int *form)
+int icp_run_form (icp_handle h, int *form) try
 {
     int rc = need (h, false); if (rc) return rc;
     if (!form) return fail (h, ICP_EINVAL, "null output");
@@ -793,15 +839,17 @@ int icp_run_form (icp_handle h, int *form)
     else *form = ICP_FORM_SEPARATE;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_search_layout (icp_handle h, int *dense, int *tile, int *stage2)
+int icp_search_layout (icp_handle h, int *dense, int *tile, int *stage2) try
 {
     int rc = need (h, false); if (rc) return rc;
     icp_search_layout_of (h->p, dense, tile, stage2);
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_launches_per_iteration (icp_handle h, uint32_t *n)
+int icp_launches_per_iteration (icp_handle h, uint32_t *n) try
 {
     int rc = need (h, false); if (rc) return rc;
     if (!n) return fail (h, ICP_EINVAL, "null output");
@@ -811,8 +859,9 @@ int icp_launches_per_iteration (icp_handle h, uint32_t *n)
     *n = form != ICP_FORM_SEPARATE ? 1u : h->p.fused ? ((h->p.nb + 127u) / 128u > ICP_L1_MIN_GROUPS ? 3u : 2u) : 4u;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t reps, float *ms_total)
+int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t reps, float *ms_total) try
 {
     int rc = need (h, true); if (rc) return rc;
     if (!ms_total || iterations == 0 || reps == 0 || mask == 0) return fail (h, ICP_EINVAL, "bad arguments");
@@ -834,8 +883,9 @@ int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t 
     if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("icp_time_masked: ") + hipGetErrorString (e));
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_debug_stamps (icp_handle h, unsigned long long *out, uint32_t nblocks)
+int icp_debug_stamps (icp_handle h, unsigned long long *out, uint32_t nblocks) try
 {   // diagnostic builds (ICP_DBG_STAMPS): one k_search launch, per-block s_memtime stamps
     int rc = need (h, true); if (rc) return rc;
     if (!out || nblocks == 0) return fail (h, ICP_EINVAL, "bad arguments");
@@ -856,8 +906,9 @@ int icp_debug_stamps (icp_handle h, unsigned long long *out, uint32_t nblocks)
     if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("icp_debug_stamps: ") + hipGetErrorString (e));
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_profile_run (icp_handle h, uint32_t iterations, float *out_ms, float *total_ms)
+int icp_profile_run (icp_handle h, uint32_t iterations, float *out_ms, float *total_ms) try
 {
     int rc = need (h, true); if (rc) return rc;
     if (!out_ms || iterations == 0) return fail (h, ICP_EINVAL, "bad arguments");
@@ -889,8 +940,9 @@ int icp_profile_run (icp_handle h, uint32_t iterations, float *out_ms, float *to
     if (e != hipSuccess) return fail (h, ICP_EHIP, std::string ("icp_profile_run: ") + hipGetErrorString (e));
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4)
+int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4) try
 {
     if (!h) return ICP_EINVAL;
     if (!out_ms4 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
@@ -904,5 +956,6 @@ int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4)
     }
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
 }  // extern "C"

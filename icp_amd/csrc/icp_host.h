@@ -6,6 +6,7 @@
 
 #include "../../include/icp_amd.h"
 #include "icp_kernels.h"
+#include "icp_cguard.h"
 
 #include <atomic>
 #include <chrono>

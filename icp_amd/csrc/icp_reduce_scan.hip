@@ -5,6 +5,7 @@
 // SUM follows reduce_sum_f's tree exactly (oracle orc_reduce_sum_f): bit-identical sums; MIN/MAX and the
 // integer scans are exact in any order.
 #include "../../include/icp_amd.h"
+#include "icp_cguard.h"
 #include "icp_device.h"
 
 #include <string>
@@ -93,7 +94,7 @@ extern "C" {
 
 const char *icp_reduce_scan_last_error (void) { return g_rs_error.c_str (); }
 
-int icp_rs_destroy (icp_rs_handle r)
+int icp_rs_destroy (icp_rs_handle r) try
 {
     if (!r) return ICP_EINVAL;
     (void) hipSetDevice (r->device);
@@ -107,8 +108,9 @@ int icp_rs_destroy (icp_rs_handle r)
     delete r;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_rs_create (icp_rs_handle *out, int device, int kind, uint32_t cols, uint32_t rows)
+int icp_rs_create (icp_rs_handle *out, int device, int kind, uint32_t cols, uint32_t rows) try
 {
     if (!out) return ICP_EINVAL;
     *out = nullptr;
@@ -140,8 +142,9 @@ int icp_rs_create (icp_rs_handle *out, int device, int kind, uint32_t cols, uint
     *out = r;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_rs_write (icp_rs_handle r, const void *host_in)
+int icp_rs_write (icp_rs_handle r, const void *host_in) try
 {
     if (!r || !host_in) return ICP_EINVAL;
     bool ok = true; std::string err;
@@ -150,6 +153,7 @@ int icp_rs_write (icp_rs_handle r, const void *host_in)
     if (ok) RSCHK (hipStreamSynchronize (r->stream));            // (pageable source)
     return ok ? ICP_OK : rs_fail (ICP_EHIP, err);
 }
+ICP_CATCH_ALL
 
 // enqueue only: the kernels of one run on the object's stream, device buffers resident
 static int rs_enqueue (icp_rs_context *r)
@@ -177,14 +181,15 @@ static int rs_enqueue (icp_rs_context *r)
     return e == hipSuccess ? ICP_OK : rs_fail (ICP_EHIP, std::string ("kernel launch: ") + hipGetErrorString (e));
 }
 
-int icp_rs_run (icp_rs_handle r)
+int icp_rs_run (icp_rs_handle r) try
 {
     if (!r) return ICP_EINVAL;
     if (hipSetDevice (r->device) != hipSuccess) return rs_fail (ICP_EHIP, "hipSetDevice");
     return rs_enqueue (r);
 }
+ICP_CATCH_ALL
 
-int icp_rs_read (icp_rs_handle r, void *host_out)
+int icp_rs_read (icp_rs_handle r, void *host_out) try
 {
     if (!r || !host_out) return ICP_EINVAL;
     bool ok = true; std::string err;
@@ -193,15 +198,17 @@ int icp_rs_read (icp_rs_handle r, void *host_out)
     if (ok) RSCHK (hipStreamSynchronize (r->stream));
     return ok ? ICP_OK : rs_fail (ICP_EHIP, err);
 }
+ICP_CATCH_ALL
 
-int icp_rs_device_ptr (icp_rs_handle r, int output, void **dptr)
+int icp_rs_device_ptr (icp_rs_handle r, int output, void **dptr) try
 {
     if (!r || !dptr) return ICP_EINVAL;
     *dptr = output ? const_cast<void *> (r->result) : r->din;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_rs_time (icp_rs_handle r, uint32_t reps, float *us_per_run)
+int icp_rs_time (icp_rs_handle r, uint32_t reps, float *us_per_run) try
 {
     if (!r || !us_per_run || reps == 0) return ICP_EINVAL;
     bool ok = true; std::string err;
@@ -218,6 +225,7 @@ int icp_rs_time (icp_rs_handle r, uint32_t reps, float *us_per_run)
     *us_per_run = ms * 1e3f / (float) reps;
     return ok ? ICP_OK : rs_fail (ICP_EHIP, err);
 }
+ICP_CATCH_ALL
 
 // one-shot forms: create, write, run, read, destroy
 static int rs_oneshot (int device, int kind, const void *host_in, uint32_t cols, uint32_t rows, void *host_out)
@@ -233,15 +241,17 @@ static int rs_oneshot (int device, int kind, const void *host_in, uint32_t cols,
     return rc;
 }
 
-int icp_reduce (int device, int op, const void *host_in, uint32_t cols, uint32_t rows, void *host_out)
+int icp_reduce (int device, int op, const void *host_in, uint32_t cols, uint32_t rows, void *host_out) try
 {
     if (op < 0 || op > 2) return rs_fail (ICP_EINVAL, "op must be ICP_REDUCE_MIN_F, ICP_REDUCE_MAX_UI or ICP_REDUCE_SUM_F");
     return rs_oneshot (device, op, host_in, cols, rows, host_out);
 }
+ICP_CATCH_ALL
 
-int icp_scan (int device, int inclusive, const int32_t *host_in, uint32_t cols, uint32_t rows, int32_t *host_out)
+int icp_scan (int device, int inclusive, const int32_t *host_in, uint32_t cols, uint32_t rows, int32_t *host_out) try
 {
     return rs_oneshot (device, inclusive ? ICP_RS_SCAN_INCLUSIVE : ICP_RS_SCAN_EXCLUSIVE, host_in, cols, rows, host_out);
 }
+ICP_CATCH_ALL
 
 }  // extern "C"

@@ -8,6 +8,7 @@
 // reduction trees of DESIGN.md §3 (one 16-lane DPP row = one 128-position work-group tree): bit-identical to the oracle's twins
 // (orc_get_lms, orc_get_reps, orc_weights, orc_mean, orc_mean_weighted, orc_devs, orc_sij).
 #include "../../include/icp_amd.h"
+#include "icp_cguard.h"
 #include "icp_kernels.h"
 
 #include <cmath>
@@ -236,7 +237,7 @@ extern "C" {
 
 const char *icp_kernel_last_error (void) { return g_sa_error.c_str (); }
 
-int icp_ko_create (icp_ko_handle *out, int device, int kind, uint32_t n, uint32_t aux, float c)
+int icp_ko_create (icp_ko_handle *out, int device, int kind, uint32_t n, uint32_t aux, float c) try
 {
     if (!out) return sa_fail (ICP_EINVAL, "null pointer");
     *out = nullptr;
@@ -296,8 +297,9 @@ int icp_ko_create (icp_ko_handle *out, int device, int kind, uint32_t n, uint32_
     *out = k;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_ko_destroy (icp_ko_handle k)
+int icp_ko_destroy (icp_ko_handle k) try
 {
     if (!k) return ICP_EINVAL;
     (void) hipSetDevice (k->device);
@@ -307,6 +309,7 @@ int icp_ko_destroy (icp_ko_handle k)
     delete k;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
 // A slot's buffer comes into being at its first use (write, device_ptr, run): until then another object's device pointer can take its
 // place (icp_ko_adopt — the reference: `get (Memory)` assigned before `init`, include/ICP/algorithms.hpp:2214-2220).
@@ -318,7 +321,7 @@ static int ko_ensure (icp_ko *k, int s)
     return rc;
 }
 
-int icp_ko_adopt (icp_ko_handle k, int s, void *dptr)
+int icp_ko_adopt (icp_ko_handle k, int s, void *dptr) try
 {
     if (!k || !dptr || s < 0 || s >= k->nslots) return sa_fail (ICP_EINVAL, "icp_ko_adopt: bad arguments");
     if (hipSetDevice (k->device) != hipSuccess) return sa_fail (ICP_EHIP, "hipSetDevice failed");
@@ -326,8 +329,9 @@ int icp_ko_adopt (icp_ko_handle k, int s, void *dptr)
     k->slot[s] = dptr; k->owned[s] = false;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_ko_device_ptr (icp_ko_handle k, int s, void **dptr)
+int icp_ko_device_ptr (icp_ko_handle k, int s, void **dptr) try
 {
     if (!k || !dptr || s < 0 || s >= k->nslots) return sa_fail (ICP_EINVAL, "icp_ko_device_ptr: bad arguments");
     if (hipSetDevice (k->device) != hipSuccess) return sa_fail (ICP_EHIP, "hipSetDevice failed");
@@ -335,10 +339,11 @@ int icp_ko_device_ptr (icp_ko_handle k, int s, void **dptr)
     *dptr = k->slot[s];
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
 size_t icp_ko_slot_bytes (icp_ko_handle k, int s) { return (k && s >= 0 && s < k->nslots) ? k->bytes[s] : 0; }
 
-int icp_ko_write (icp_ko_handle k, int s, const void *host)
+int icp_ko_write (icp_ko_handle k, int s, const void *host) try
 {
     if (!k || !host || s < 0 || s >= k->nslots) return sa_fail (ICP_EINVAL, "icp_ko_write: bad arguments");
     if (hipSetDevice (k->device) != hipSuccess) return sa_fail (ICP_EHIP, "hipSetDevice failed");
@@ -346,8 +351,9 @@ int icp_ko_write (icp_ko_handle k, int s, const void *host)
     hipError_t e = hipMemcpy (k->slot[s], host, k->bytes[s], hipMemcpyHostToDevice);
     return e == hipSuccess ? ICP_OK : sa_fail (ICP_EHIP, std::string ("hipMemcpy: ") + hipGetErrorString (e));
 }
+ICP_CATCH_ALL
 
-int icp_ko_read (icp_ko_handle k, int s, void *host)
+int icp_ko_read (icp_ko_handle k, int s, void *host) try
 {
     if (!k || !host || s < 0 || s >= k->nslots) return sa_fail (ICP_EINVAL, "icp_ko_read: bad arguments");
     if (hipSetDevice (k->device) != hipSuccess) return sa_fail (ICP_EHIP, "hipSetDevice failed");
@@ -355,10 +361,11 @@ int icp_ko_read (icp_ko_handle k, int s, void *host)
     hipError_t e = hipMemcpy (host, k->slot[s], k->bytes[s], hipMemcpyDeviceToHost);       // (blocking: behind the kernels on the null stream)
     return e == hipSuccess ? ICP_OK : sa_fail (ICP_EHIP, std::string ("hipMemcpy: ") + hipGetErrorString (e));
 }
+ICP_CATCH_ALL
 
-int icp_ko_set_scaling (icp_ko_handle k, float c) { if (!k) return ICP_EINVAL; k->c = c; return ICP_OK; }
+int icp_ko_set_scaling (icp_ko_handle k, float c) try { if (!k) return ICP_EINVAL; k->c = c; return ICP_OK; } ICP_CATCH_ALL
 
-int icp_ko_run (icp_ko_handle k)
+int icp_ko_run (icp_ko_handle k) try
 {
     if (!k) return sa_fail (ICP_EINVAL, "null handle");
     if (hipSetDevice (k->device) != hipSuccess) return sa_fail (ICP_EHIP, "hipSetDevice failed");
@@ -419,6 +426,7 @@ int icp_ko_run (icp_ko_handle k)
     hipError_t e = hipGetLastError ();
     return e == hipSuccess ? ICP_OK : sa_fail (ICP_EHIP, std::string ("icp_ko_run: ") + hipGetErrorString (e));
 }
+ICP_CATCH_ALL
 
 // ---- the one-call forms: create, upload, run, download, destroy ----------------------------------------------------------------------
 
@@ -426,23 +434,25 @@ namespace {
 struct ko_guard { icp_ko_handle k = nullptr; ~ko_guard () { if (k) (void) icp_ko_destroy (k); } };
 }
 
-int icp_kernel_lms (int device, const void *cloud, void *lms)
+int icp_kernel_lms (int device, const void *cloud, void *lms) try
 {
     if (!cloud || !lms) return sa_fail (ICP_EINVAL, "null pointer");
     ko_guard g; int rc;
     if ((rc = icp_ko_create (&g.k, device, ICP_KO_LMS, 0, 0, 0.f)) || (rc = icp_ko_write (g.k, 0, cloud)) || (rc = icp_ko_run (g.k))) return rc;
     return icp_ko_read (g.k, 1, lms);
 }
+ICP_CATCH_ALL
 
-int icp_kernel_reps (int device, const void *F, uint32_t m, uint32_t nr, void *R)
+int icp_kernel_reps (int device, const void *F, uint32_t m, uint32_t nr, void *R) try
 {
     if (!F || !R) return sa_fail (ICP_EINVAL, "null pointer");
     ko_guard g; int rc;
     if ((rc = icp_ko_create (&g.k, device, ICP_KO_REPS, m, nr, 0.f)) || (rc = icp_ko_write (g.k, 0, F)) || (rc = icp_ko_run (g.k))) return rc;
     return icp_ko_read (g.k, 1, R);
 }
+ICP_CATCH_ALL
 
-int icp_kernel_weights (int device, const void *nn_id, uint32_t n, float *W, double *sum_w)
+int icp_kernel_weights (int device, const void *nn_id, uint32_t n, float *W, double *sum_w) try
 {
     if (!nn_id || !W || !sum_w) return sa_fail (ICP_EINVAL, "null pointer");
     ko_guard g; int rc;
@@ -450,8 +460,9 @@ int icp_kernel_weights (int device, const void *nn_id, uint32_t n, float *W, dou
     if ((rc = icp_ko_read (g.k, 1, W))) return rc;
     return icp_ko_read (g.k, 2, sum_w);
 }
+ICP_CATCH_ALL
 
-int icp_kernel_mean (int device, int weighted, const void *F, const void *M, const float *W, double sum_w, uint32_t n, float *mean8)
+int icp_kernel_mean (int device, int weighted, const void *F, const void *M, const float *W, double sum_w, uint32_t n, float *mean8) try
 {
     if (!F || !M || !mean8 || (weighted && !W)) return sa_fail (ICP_EINVAL, "null pointer");
     ko_guard g; int rc;
@@ -460,8 +471,9 @@ int icp_kernel_mean (int device, int weighted, const void *F, const void *M, con
     if ((rc = icp_ko_run (g.k))) return rc;
     return icp_ko_read (g.k, 4, mean8);
 }
+ICP_CATCH_ALL
 
-int icp_kernel_devs (int device, const void *F, const void *M, const float *mean8, uint32_t n, float *DF, float *DM)
+int icp_kernel_devs (int device, const void *F, const void *M, const float *mean8, uint32_t n, float *DF, float *DM) try
 {
     if (!F || !M || !mean8 || !DF || !DM) return sa_fail (ICP_EINVAL, "null pointer");
     ko_guard g; int rc;
@@ -470,8 +482,9 @@ int icp_kernel_devs (int device, const void *F, const void *M, const float *mean
     if ((rc = icp_ko_read (g.k, 3, DF))) return rc;
     return icp_ko_read (g.k, 4, DM);
 }
+ICP_CATCH_ALL
 
-int icp_kernel_s (int device, int weighted, const float *DM, const float *DF, const float *W, uint32_t m, float c, float *S11)
+int icp_kernel_s (int device, int weighted, const float *DM, const float *DF, const float *W, uint32_t m, float c, float *S11) try
 {
     if (!DM || !DF || !S11 || (weighted && !W)) return sa_fail (ICP_EINVAL, "null pointer");
     ko_guard g; int rc;
@@ -479,5 +492,6 @@ int icp_kernel_s (int device, int weighted, const float *DM, const float *DF, co
     if ((rc = icp_ko_write (g.k, 0, DM)) || (rc = icp_ko_write (g.k, 1, DF)) || (weighted && (rc = icp_ko_write (g.k, 2, W))) || (rc = icp_ko_run (g.k))) return rc;
     return icp_ko_read (g.k, 3, S11);
 }
+ICP_CATCH_ALL
 
 }  // extern "C"

@@ -9,6 +9,7 @@
 //     (rotation about `axis`, translation `t`), plus Gaussian geometric / colour noise.
 // RNG: splitmix64 -> xoshiro256**.  Deterministic in (seed, side, parameters) on one libm.
 #include "../../include/icp_amd.h"
+#include "icp_cguard.h"
 
 #include <algorithm>
 #include <cmath>
@@ -100,7 +101,7 @@ void rotation (double deg, const float *axis, double R[9])
 }  // namespace
 
 extern "C" int icp_synth_pair (uint64_t seed, uint32_t side, float rot_deg, const float *axis3, const float *t3,
-                               float noise_mm, float noise_rgb, float zero_fraction, float *F, float *M)
+                               float noise_mm, float noise_rgb, float zero_fraction, float *F, float *M) try
 {
     if (!F || !M || side == 0 || !axis3 || !t3) return ICP_EINVAL;
     rng g (seed);
@@ -132,6 +133,7 @@ extern "C" int icp_synth_pair (uint64_t seed, uint32_t side, float rot_deg, cons
         }
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
 // Invalid pixels as the Kinect grabber leaves them (src/kinect_frame_grabber.cpp:246-262: depth 0 -> x = y = z = 0, the colour is
 // written regardless) and as getLMs picks them (kernels/icp_kernels.cl:49-50), punched into a width x height float8 grid in place.
@@ -145,7 +147,7 @@ extern "C" int icp_synth_pair (uint64_t seed, uint32_t side, float rot_deg, cons
 //          ignored) and the in-plane part of t3; *T_true (may be NULL) receives the ground truth [q | t, 1] that maps the moving frame
 //          onto the fixed one, in the engine's convention.
 extern "C" int icp_synth_pair_scene (uint64_t seed, uint32_t side, int scene_kind, float rot_deg, const float *axis3, const float *t3,
-                                     float noise_mm, float noise_rgb, float *F, float *M, float *T_true)
+                                     float noise_mm, float noise_rgb, float *F, float *M, float *T_true) try
 {
     if (!F || !M || side == 0 || !t3 || (scene_kind == 0 && !axis3) || (scene_kind != 0 && scene_kind != 1)) return ICP_EINVAL;
     rng g (seed);
@@ -186,8 +188,9 @@ extern "C" int icp_synth_pair_scene (uint64_t seed, uint32_t side, int scene_kin
     }
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-extern "C" int icp_synth_punch_holes (uint64_t seed, uint32_t width, uint32_t height, int pattern, float fraction, int keep_rgb, float *cloud)
+extern "C" int icp_synth_punch_holes (uint64_t seed, uint32_t width, uint32_t height, int pattern, float fraction, int keep_rgb, float *cloud) try
 {
     if (!cloud || width == 0 || height == 0 || !(fraction >= 0.f) || fraction > 1.f || (pattern != 0 && pattern != 1)) return ICP_EINVAL;
     rng g (seed ^ 0x401E5ull);
@@ -203,7 +206,8 @@ extern "C" int icp_synth_punch_holes (uint64_t seed, uint32_t width, uint32_t he
         return ICP_OK;
     }
     // contiguous: a bitmap first (ellipses overlap), then the punch
-    uint8_t *mask = new uint8_t[n];
+    uint8_t *mask = new (std::nothrow) uint8_t[n];
+    if (!mask) return ICP_ENOMEM;
     std::memset (mask, 0, n);
     size_t covered = 0;
     const size_t want = (size_t) ((double) fraction * (double) n);
@@ -227,8 +231,9 @@ extern "C" int icp_synth_punch_holes (uint64_t seed, uint32_t width, uint32_t he
     delete[] mask;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-extern "C" int icp_synth_cloud_vga (uint64_t seed, int moved, float *cloud)
+extern "C" int icp_synth_cloud_vga (uint64_t seed, int moved, float *cloud) try
 {
     // `moved` = frame number of a synthetic sequence: frame 0 is the scene itself, frame f > 0 the scene moved rigidly by
     // f times the step (3 degrees about (0.3, 0.9, 0.1), t = (25, -10, 15) mm), sampled at a half-pixel offset, with
@@ -251,3 +256,4 @@ extern "C" int icp_synth_cloud_vga (uint64_t seed, int moved, float *cloud)
         }
     return ICP_OK;
 }
+ICP_CATCH_ALL

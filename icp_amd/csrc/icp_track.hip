@@ -109,7 +109,7 @@ static uint32_t gate_spins (const icp_context *h)
     return (uint32_t) std::min<uint64_t> (std::max<uint64_t> (per_run, 1ull << 21), 1ull << 28);
 }
 
-int icp_track_reset (icp_handle h)
+int icp_track_reset (icp_handle h) try
 {
     if (!h) return ICP_EINVAL;
     int rc = set_device (h); if (rc) return rc;
@@ -139,12 +139,13 @@ int icp_track_reset (icp_handle h)
     h->track_last_gated = false;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
 // The caller's own frame buffers as DMA sources: a capture loop that fills the same few buffers over and over
 // registers them once (hipHostRegister: the pages are locked, the runtime maps them for the device), and a frame submitted from inside a
 // registered range goes the way of the engine's pinned frame buffers — the band getLMs reads by one 2-D DMA, no host copy: the
 // calling thread's 60 us per frame (the 128 row segments into pinned staging) were the largest fixed part of a warm-started frame's host time.
-int icp_track_register_source (icp_handle h, void *frames, size_t bytes)
+int icp_track_register_source (icp_handle h, void *frames, size_t bytes) try
 {
     int rc = need (h, false, true); if (rc) return rc;
     if (!frames || bytes < (size_t) 640 * 480 * 32) return fail (h, ICP_EINVAL, "icp_track_register_source: a range of at least one 640 x 480 float8 frame");
@@ -157,8 +158,9 @@ int icp_track_register_source (icp_handle h, void *frames, size_t bytes)
     h->sources.push_back ({ static_cast<const char *> (frames), bytes });
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_track_unregister_source (icp_handle h, void *frames)
+int icp_track_unregister_source (icp_handle h, void *frames) try
 {
     int rc = need (h, false, true); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
@@ -171,8 +173,9 @@ int icp_track_unregister_source (icp_handle h, void *frames)
         }
     return fail (h, ICP_EINVAL, "icp_track_unregister_source: not the start of a registered range");
 }
+ICP_CATCH_ALL
 
-int icp_track_staging (icp_handle h, uint32_t slot, void **host_ptr)
+int icp_track_staging (icp_handle h, uint32_t slot, void **host_ptr) try
 {
     int rc = need (h, false, true); if (rc) return rc;
     if (slot > 1u || !host_ptr) return fail (h, ICP_EINVAL, "icp_track_staging: slot must be 0 or 1");
@@ -185,6 +188,7 @@ int icp_track_staging (icp_handle h, uint32_t slot, void **host_ptr)
     *host_ptr = h->hFrame[slot];
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
 // Tracking: blind launches of a frame's registration — what is enqueued before icp_track_submit returns (the caller is away until its
 // next call: copying the next frame, typically).  The smaller of the last two registrations' k + the launch that finds out; a first
@@ -375,9 +379,9 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     return ICP_OK;
 }
 
-int icp_track_submit (icp_handle h, const void *cloud, int warm_start) { return track_submit (h, cloud, warm_start, false); }
+int icp_track_submit (icp_handle h, const void *cloud, int warm_start) try { return track_submit (h, cloud, warm_start, false); } ICP_CATCH_ALL
 
-int icp_track_form (icp_handle h, int *gated)
+int icp_track_form (icp_handle h, int *gated) try
 {
     int rc = need (h, false, true); if (rc) return rc;
     if (!gated) return fail (h, ICP_EINVAL, "null output");
@@ -386,8 +390,9 @@ int icp_track_form (icp_handle h, int *gated)
     *gated = (h->run_adaptive && h->track_gate && h->rbc2_ready && icp_chain_supported (h->p)) ? 1 : 0;
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered)
+int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered) try
 {
     int rc = need (h, false, true); if (rc) return rc;
     if (h->track_collected >= h->track_submitted) return fail (h, ICP_ESTATE, "icp_track_collect: no frame in flight");
@@ -422,8 +427,9 @@ int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered)
     } else if (T8) { const float T0[8] = { 0, 0, 0, 1, 0, 0, 0, 1 }; std::memcpy (T8, T0, sizeof T0); }
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
-int icp_track_next (icp_handle h, const void *cloud, int warm_start, uint32_t *k, int *registered)
+int icp_track_next (icp_handle h, const void *cloud, int warm_start, uint32_t *k, int *registered) try
 {
     if (k) *k = 0;
     if (registered) *registered = 0;
@@ -435,5 +441,6 @@ int icp_track_next (icp_handle h, const void *cloud, int warm_start, uint32_t *k
     if (!h->run_adaptive) return settle (h);
     return ICP_OK;
 }
+ICP_CATCH_ALL
 
 }  // extern "C"

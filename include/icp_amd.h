@@ -412,6 +412,8 @@ int icp_batch_time_run_fixed (icp_batch_handle b, uint32_t iterations, uint32_t 
 int icp_batch_time_run_fixed_slots (icp_batch_handle b, uint32_t iterations, uint32_t reps, uint32_t warmup, double *seconds, float *slot_ms);
 /* the partition rule as a pure function (no device needed): slot, index inside the slot, registrations of that slot */
 int icp_batch_partition (uint32_t registrations, uint32_t n_slots, uint32_t i, uint32_t *slot, uint32_t *index, uint32_t *slot_count);
+/* The CPUs the host thread of `slot` was pinned to, comma-separated ("" = not pinned).             */
+int icp_batch_slot_cpus (icp_batch_handle b, uint32_t slot, char *out, size_t cap);
 const char *icp_batch_last_error (icp_batch_handle b);   /* b may be NULL: error of the last failed create */
 
 /* ---- measurement (bench.py, HIP events on the handle's stream) --------------------------------- */
@@ -470,6 +472,14 @@ int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t 
 const char *icp_last_error (icp_handle h);      /* h may be NULL: error of the last failed create */
 const char *icp_version (void);
 int icp_device_count (int *n);
+/* PCI bus id of device `device` ("0000:c1:00.0"; cap >= 16).                                        */
+int icp_device_pci_bus_id (int device, char *out, size_t cap);
+/* The cpulist ("0-47,96-143") of the NUMA node a PCI device hangs on, from a sysfs tree (sysfs_root NULL = "/sys"):
+ * <root>/bus/pci/devices/<id>/local_cpulist, else node<numa_node>/cpulist; out = "" when the tree has no answer.
+ * icp_batch_create pins the host thread of every device slot there unless ICP_AMD_SLOT_CPUS says otherwise
+ * (ICP_AMD_SLOT_NUMA=0: no default placement).  No reference counterpart: one device, one queue
+ * (src/ICP/algorithms.cpp:4351-4352).                                                                */
+int icp_numa_cpulist (const char *sysfs_root, const char *pci_bus_id, char *out, size_t cap);
 
 /* Synthetic RGB-D landmark pair: side x side grid, fixed and moving frame.
  * Host only; deterministic in (seed, side). */

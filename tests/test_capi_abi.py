@@ -121,3 +121,68 @@ def test_hole_generator_makes_kinect_like_invalid_points(engine):
     Fh, Mh = W.holes_pair(engine, "blobs30", 64)
     hf, hm_ = (Fh[:, 2] == 0), (Mh[:, 2] == 0)
     assert 0.25 < hf.mean() < 0.4 and 0.25 < hm_.mean() < 0.4 and not np.array_equal(hf, hm_)
+
+
+def test_numa_cpulist_from_a_fake_sysfs_tree(tmp_path):
+    """the host thread of a device slot goes to the CPUs of its GPU's NUMA node by default (icp_batch_create; the
+    8-GPU node has two sockets).  The lookup is host code: checked here on a fake sysfs tree — local_cpulist first, else numa_node ->
+    node<N>/cpulist, upper-case bus ids as HIP spells them, "" where the tree has no answer (numa_node = -1, no such device)."""
+    import icp_amd
+    root = tmp_path / "sys"
+    for bus, local, node in (("0000:c1:00.0", "0-47,96-143", None), ("0000:05:00.0", None, 1), ("0000:06:00.0", None, -1)):
+        d = root / "bus" / "pci" / "devices" / bus
+        d.mkdir(parents=True)
+        if local is not None:
+            (d / "local_cpulist").write_text(local + "\n")
+        if node is not None:
+            (d / "numa_node").write_text("%d\n" % node)
+    n1 = root / "devices" / "system" / "node" / "node1"
+    n1.mkdir(parents=True)
+    (n1 / "cpulist").write_text("48-95,144-191\n")
+    assert icp_amd.numa_cpulist("0000:C1:00.0", str(root)) == "0-47,96-143"
+    assert icp_amd.numa_cpulist("0000:05:00.0", str(root)) == "48-95,144-191"
+    assert icp_amd.numa_cpulist("0000:06:00.0", str(root)) == ""
+    assert icp_amd.numa_cpulist("0000:ff:00.0", str(root)) == ""
+    L = icp_amd.lib()
+    import ctypes as C
+    buf = C.create_string_buffer(4)
+    assert L.icp_numa_cpulist(str(root).encode(), b"0000:c1:00.0", buf, 4) == 1          # ICP_EINVAL: the buffer is too small
+    assert L.icp_numa_cpulist(None, None, buf, 4) == 1
+
+
+def test_out_of_host_memory_comes_back_as_a_status():
+    """VERDICT round 5, item 8 / SURVEY §8b "Errors": nothing C++ crosses the C boundary.  Every status-returning export is a
+    function-try-block (icp_cguard.h: std::bad_alloc -> ICP_ENOMEM, anything else -> ICP_EHIP) — checked on the sources — and a host
+    allocation that fails under RLIMIT_AS (a child process: the library loaded first, then the limit) returns ICP_ENOMEM instead of
+    throwing through ctypes."""
+    import re
+    import subprocess
+    import sys
+    n_guarded = 0
+    for f in ("icp_capi.hip", "icp_track.hip", "icp_batch.cpp", "icp_standalone.hip", "icp_reduce_scan.hip", "icp_synth.cpp"):
+        src = open(os.path.join(ROOT, "icp_amd", "csrc", f)).read()
+        body = src if f == "icp_synth.cpp" else src[src.index('extern "C" {'):]
+        for m in re.finditer(r'^(?:extern "C" )?int (icp_\w+) \([^;{]*?\)( try)?\s*(\{.*)?$', body, re.M):
+            if f == "icp_synth.cpp" and not m.group(0).startswith('extern "C"'):
+                continue
+            assert m.group(2), "%s: %s is not a function-try-block" % (f, m.group(1))
+            n_guarded += 1
+        assert body.count(" try") >= body.count("ICP_CATCH_ALL") > 0
+    assert n_guarded >= 100, n_guarded
+    code = r'''
+import ctypes as C, resource, sys
+sys.path.insert(0, %r)
+import icp_amd
+L = icp_amd.lib()
+import numpy as np
+cloud = np.zeros((16, 8), np.float32)
+soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+used = int(open("/proc/self/statm").read().split()[0]) * resource.getpagesize()
+resource.setrlimit(resource.RLIMIT_AS, (used + (256 << 20), hard))
+L.icp_synth_punch_holes.restype = C.c_int
+L.icp_synth_punch_holes.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_float, C.c_int, C.c_void_p]
+rc = L.icp_synth_punch_holes(1, 60000, 60000, 1, 0.0, 1, cloud.ctypes.data)      # a 3.6 GB bitmap
+print("rc", rc)
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "rc 3" in out.stdout, (out.stdout, out.stderr[-2000:])

@@ -1412,3 +1412,46 @@ def test_tracking_gate_give_up_and_recovery(engine, monkeypatch):
     ref.write(engine.Memory.F, F); ref.write(engine.Memory.M, M); ref.reset_transform(); ref.buildRBC()
     assert g.run() == ref.run() and np.array_equal(g.read(engine.Memory.T).view(np.uint32), ref.read(engine.Memory.T).view(np.uint32))
     g.close(); ref.close()
+
+
+def test_batch_slot_threads_go_to_their_gpus_numa_node(engine, tmp_path, monkeypatch):
+    """with ICP_AMD_SLOT_CPUS unset the host thread of a device slot is pinned to the CPUs of its GPU's NUMA node
+    (sysfs through the PCI bus id; here a fake tree — ICP_AMD_SYSFS_ROOT — that names two of the CPUs this process may use), silently
+    nowhere when the tree has no answer; ICP_AMD_SLOT_CPUS overrides, ICP_AMD_SLOT_NUMA=0 switches the default off.  The work of a
+    pinned batch is the work of an unpinned one."""
+    allowed = sorted(os.sched_getaffinity(0))
+    bus = engine.device_pci_bus_id(0)
+    assert len(bus.split(":")) == 3
+    d = tmp_path / "sys" / "bus" / "pci" / "devices" / bus.lower()
+    d.mkdir(parents=True)
+    pick = allowed[:2]
+    (d / "local_cpulist").write_text(",".join(str(c) for c in pick + [100000]) + "\n")      # (a CPU that is not there is left out)
+    monkeypatch.delenv("ICP_AMD_SLOT_CPUS", raising=False)
+    monkeypatch.setenv("ICP_AMD_SYSFS_ROOT", str(tmp_path / "sys"))
+    B = engine.ICPBatch([0, 0])
+    assert B.slot_cpus(0) == pick and B.slot_cpus(1) == pick
+    side, nr = 64, 64
+    F, M = engine.synth_pair(side)
+    B.init(2, side * side, nr, 2e2, 1e-6)
+    for i in range(2):
+        B.write(i, engine.Memory.F, F); B.write(i, engine.Memory.M, M)
+    B.buildRBC(); B.run()
+    T = B.read(0, engine.Memory.T)
+    B.close()
+    monkeypatch.setenv("ICP_AMD_SYSFS_ROOT", str(tmp_path / "nothing_here"))
+    B = engine.ICPBatch([0]); assert B.slot_cpus(0) == []; B.close()
+    monkeypatch.setenv("ICP_AMD_SYSFS_ROOT", str(tmp_path / "sys"))
+    monkeypatch.setenv("ICP_AMD_SLOT_NUMA", "0")
+    B = engine.ICPBatch([0]); assert B.slot_cpus(0) == []; B.close()
+    monkeypatch.delenv("ICP_AMD_SLOT_NUMA")
+    monkeypatch.setenv("ICP_AMD_SLOT_CPUS", "%d,%d-%d" % (allowed[-1], allowed[0], allowed[1] if len(allowed) > 1 else allowed[0]))
+    B = engine.ICPBatch([0, 0, 0])
+    assert B.slot_cpus(0) == [allowed[-1]] and B.slot_cpus(1) == sorted(set(allowed[:2])) and B.slot_cpus(2) == [allowed[-1]]
+    B.init(1, side * side, nr, 2e2, 1e-6)
+    B.write(0, engine.Memory.F, F); B.write(0, engine.Memory.M, M)
+    B.buildRBC(); B.run()
+    assert np.array_equal(B.read(0, engine.Memory.T).view(np.uint32), T.view(np.uint32))
+    B.close()
+    # the real tree, whatever it says: creation never fails over it
+    monkeypatch.delenv("ICP_AMD_SLOT_CPUS"); monkeypatch.delenv("ICP_AMD_SYSFS_ROOT")
+    B = engine.ICPBatch([0]); print("slot 0 of the real tree:", engine.numa_cpulist(bus), "->", B.slot_cpus(0)); B.close()

@@ -2,17 +2,20 @@
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 # -ffp-contract=off: the canonical arithmetic has no fused multiply-add
-HIPFLAGS ?= -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -pthread -mllvm -amdgpu-kernarg-preload-count=14
+# EXTRA: -D switches of an A/B build; BUILD: its object directory — e.g. `make BUILD=build/ol32 LIB=build/libicp_ol32.so EXTRA=-DICP_OL_BOXED_MIN=32 build/libicp_ol32.so`
+EXTRA    ?=
+BUILD    ?= build
+HIPFLAGS ?= $(EXTRA) -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -pthread -mllvm -amdgpu-kernarg-preload-count=14
 SRC      := icp_amd/csrc/icp_kernels.hip icp_amd/csrc/icp_search_dense.hip icp_amd/csrc/icp_build.hip icp_amd/csrc/icp_capi.hip icp_amd/csrc/icp_run.hip icp_amd/csrc/icp_track.hip icp_amd/csrc/icp_reduce_scan.hip icp_amd/csrc/icp_standalone.hip icp_amd/csrc/icp_synth.cpp icp_amd/csrc/icp_batch.cpp
 HDR      := icp_amd/csrc/icp_device.h icp_amd/csrc/icp_kernels.h icp_amd/csrc/icp_search.h icp_amd/csrc/icp_host.h icp_amd/csrc/icp_cguard.h include/icp_amd.h
-LIB      := icp_amd/libicp_amd.so
-OBJ      := $(patsubst icp_amd/csrc/%,build/%.o,$(SRC))
+LIB      ?= icp_amd/libicp_amd.so
+OBJ      := $(patsubst icp_amd/csrc/%,$(BUILD)/%.o,$(SRC))
 
 all: $(LIB) oracle
 
 # one object per source (the two k_search translation units are the long ones: `make` builds them side by side)
-build/%.o: icp_amd/csrc/% $(HDR)
-	@mkdir -p build
+$(BUILD)/%.o: icp_amd/csrc/% $(HDR)
+	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 $(LIB): $(OBJ)

@@ -252,12 +252,16 @@ def traffic_of(key):
             cyc, mix_src = float(km["cycles_per_valu_instruction_from_the_mix"]), "profiles/valu_issue.json (_kernel_mix, %d waves per SIMD)" % km["waves_per_simd"]
         except Exception:
             pass
-        cycles = det["SQ_BUSY_CYCLES"] / 32.0 if det.get("SQ_BUSY_CYCLES") else det["avg_dispatch_us_kernel_trace"] * 1e-6 * CLOCK_HZ
+        # (the dispatch's cycles: SQ_BUSY_CYCLES / 32 shader engines — at |F| = 2^20 it says 2.15 GHz, the clock a saturated vector unit runs at —
+        # but never more than the duration at 2.4 GHz: for a 9 us dispatch the counter's window is wider than the kernel)
+        cycles = det["avg_dispatch_us_kernel_trace"] * 1e-6 * CLOCK_HZ
+        if det.get("SQ_BUSY_CYCLES"):
+            cycles = min(cycles, det["SQ_BUSY_CYCLES"] / 32.0)
         issue = {"valu_issue_frac": det["SQ_INSTS_VALU"] * cyc / SIMDS / cycles,
                  "valu_issue_frac_if_every_instruction_cost_4_cycles": det["SQ_INSTS_VALU"] * 4.0 / SIMDS / cycles,
                  "valu_issue_frac_if_every_instruction_were_full_rate": det["SQ_INSTS_VALU"] * 2.24 / SIMDS / cycles,
                  "cycles_per_valu_instruction": cyc, "cycles_source": mix_src, "dispatch_cycles_per_simd": cycles,
-                 "dispatch_cycles_source": "SQ_BUSY_CYCLES / 32" if det.get("SQ_BUSY_CYCLES") else "duration x 2.4 GHz",
+                 "dispatch_cycles_source": "min (SQ_BUSY_CYCLES / 32, duration x 2.4 GHz)" if det.get("SQ_BUSY_CYCLES") else "duration x 2.4 GHz",
                  "SQ_INSTS_VALU_per_launch": det["SQ_INSTS_VALU"], "kernel_us_in_that_profile": det["avg_dispatch_us_kernel_trace"],
                  "source": src["file"], "measured_at_commit": src["measured_at_commit"], "measured_by_this_run": False}
     return t.get(key), src, issue

@@ -62,6 +62,25 @@ static __device__ __forceinline__ float sum4 (float4 v) { return ((v.x + v.y) + 
 #endif
 
 typedef float float2v __attribute__ ((ext_vector_type (2)));
+
+// The kernel's explicit arguments as the kernarg segment lays them out (k_search's parameter list, in order): phases that hardly any launch
+// takes fetch their arguments WHERE THEY ARE USED through an opaque copy of the segment pointer (held from the top of the kernel they make
+// the compiler spill scalars in front of the prologue's loads).  One place knows where icp_params sits in the segment: a
+// change of k_search's signature has to change this mirror with it (the launcher's KS_ARGS / KS_CHAIN_ARGS pass exactly these, in order).
+struct k_search_args {
+    const float *gM, *gR; icp_reg_state *gst; const double *gmom;
+    uint32_t m, nr, side, tpr_magic, nb, check_flags;
+    icp_params p;
+};
+#define KS_PARAMS_OFFSET offsetof (k_search_args, p)
+static_assert (KS_PARAMS_OFFSET == 4 * 8 + 6 * 4, "k_search: four pointers and six dwords in front of icp_params");
+static_assert (KS_PARAMS_OFFSET % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
+static __device__ __forceinline__ const icp_params *ks_params_from_kernarg ()
+{
+    unsigned long long a_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + KS_PARAMS_OFFSET;
+    asm volatile ("" : "+s"(a_));                // (opaque: the scalar loads through it stay where the caller is, they do not join the ones at the kernel's top)
+    return (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) a_;
+}
 // MASKED search, home tile (see k_search): 1 = staged into LDS in the prologue (seed from LDS); 2 = loads issued in the prologue, LDS
 // write after the tile masks (seed from global: the tile's round trip overlaps the seed's); 3 = no home tile (only its list offsets).
 // Same box, alternating, us per iteration of fresh 40-iteration runs at |F| = 65536 / 10-iteration runs at 2^20 (profiles/
@@ -140,10 +159,7 @@ static __device__ __forceinline__ void ks_seed_against_invalid (uint32_t sfl, co
     const bool s0 = sx == 0.f && sy == 0.f && sz == 0.f;
     if (__ballot (hq != s0) == 0ull) return;
     if (__builtin_amdgcn_readfirstlane ((int) __float_as_uint (s_count->w)) == 0) return;      // (no representative at the origin: nothing to choose from — s_count: hi of box 0 in LDS)
-    static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
-    unsigned long long ol_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
-    asm volatile ("" : "+s"(ol_));
-    const icp_params *po = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) ol_;
+    const icp_params *po = ks_params_from_kernarg ();
     typedef float4 __attribute__ ((address_space (1))) *gf4;
     const float4 *OLb = (const float4 *) (gf4) po->OL + (size_t) b * ICP_OL_STRIDE (nr);
     if (hq != s0) {
@@ -218,11 +234,8 @@ static __device__ __forceinline__ void ks_origin_section (float4 *s_pair, uint32
     const bool need = qq <= s1_lim;
     // the list's pointer: fetched here, through an opaque copy of the kernarg pointer (held from the top of the kernel it made the compiler
     // spill scalars in front of the prologue's loads: search at |F| = 65536 11.88 -> 12.22 us)
-    static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
     auto list_base = [&] () -> const float4 * {
-        unsigned long long ol_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
-        asm volatile ("" : "+s"(ol_));
-        const icp_params *po = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) ol_;
+        const icp_params *po = ks_params_from_kernarg ();
         typedef float4 __attribute__ ((address_space (1))) *gf4;
         return (const float4 *) (gf4) po->OL + (size_t) b * ICP_OL_STRIDE (nr);
     };
@@ -615,10 +628,7 @@ static __device__ __forceinline__ void ks_list_tail (const char *XQb, uint32_t o
     // (the boxes' base and stride are fetched from the kernel arguments HERE, through an opaque copy of the argument pointer — see the
     // per-query output pointers of the epilogue: left to the compiler, their scalar loads join the ones at the top of the kernel, in
     // front of the prologue's vector loads, for a path hardly any launch takes: 8.66 -> 8.71 us per iteration at |F| = 16384)
-    static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
-    unsigned long long lb_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
-    asm volatile ("" : "+s"(lb_));
-    const icp_params *pl = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) lb_;
+    const icp_params *pl = ks_params_from_kernarg ();
     typedef float4 __attribute__ ((address_space (1))) *gf4;
     const float4 *LBq = (const float4 *) (gf4) pl->LB + (size_t) b * 3u * pl->nlb + 3u * (o >> 4);
     const float inf_ = __builtin_inff ();
@@ -916,10 +926,8 @@ static __device__ __forceinline__ void ks_epilogue (const icp_params &p, float4 
                 // from the top of the kernel they were the scalar registers the compiler spilled in front of the prologue's loads)
                 const uint32_t *rsrc = p.rep_src;
                 if constexpr (MINW == 4) {
-                    unsigned long long lr_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
-                    asm volatile ("" : "+s"(lr_));
                     typedef uint32_t __attribute__ ((address_space (1))) *gu32;
-                    rsrc = (const uint32_t *) (gu32) ((const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) lr_)->rep_src;
+                    rsrc = (const uint32_t *) (gu32) ks_params_from_kernarg ()->rep_src;
                 }
                 id = rsrc[(size_t) b * nr + qb.x]; f0 = nn.x; f1 = nn.y; f2 = nn.z;
             } else {                 // the winner's point, or, when every distance is inf / NaN, the first list element as
@@ -940,10 +948,7 @@ static __device__ __forceinline__ void ks_epilogue (const icp_params &p, float4 
             if constexpr (MINW == 2 && !OWNER) {
                 // (the kernel's explicit arguments: four pointers, six dwords, then icp_params — no padding in between; a change of the
                 // signature has to move this offset with it: every test that reads per-query outputs at a latency-bound size would show it)
-                static_assert ((4 * 8 + 6 * 4) % alignof (icp_params) == 0, "kernel-argument layout: icp_params follows the scalars without padding");
-                unsigned long long la_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
-                asm volatile ("" : "+s"(la_));
-                pe = (const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) la_;
+                            pe = ks_params_from_kernarg ();
             }
             typedef char __attribute__ ((address_space (1))) *gchar;           // (pointers read through `pe` are generic to the compiler: say that they are global)
             char *o_nn = (char *) (gchar) reinterpret_cast<char *> (pe->nn_id + (size_t) b * m), *o_pf = (char *) (gchar) reinterpret_cast<char *> (pe->PF + (size_t) b * m);
@@ -988,10 +993,8 @@ static __device__ __forceinline__ void ks_epilogue (const icp_params &p, float4 
         const uint32_t obuf = CHAIN ? (p.slot ^ 1u) : 0u;
         double *momw = p.mom;
         if constexpr (MINW == 4) {
-            unsigned long long lm_ = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr () + (4 * 8 + 6 * 4);
-            asm volatile ("" : "+s"(lm_));
             typedef double __attribute__ ((address_space (1))) *gf64;
-            momw = (double *) (gf64) ((const icp_params *) (const icp_params __attribute__ ((address_space (4))) *) lm_)->mom;
+            momw = (double *) (gf64) ks_params_from_kernarg ()->mom;
         }
         if (l == 0 && mrow < ICP_NMOM) momw[(((size_t) b * 2 + obuf) * ICP_NMOM + mrow) * p.nb + tile_id] = v;
     } else if (slice == 0 && p.weighted) {

@@ -528,17 +528,19 @@ def measure_tracking(icp_amd, device, hops=256):
 
         def pipelined(submit_of, n):
             """Two frames in flight: submit frame i, then collect frame i - 1."""
-            sub, stamps, ks = [], [], []
+            sub, stamps, ks, call = [], [], [], []
             gc.collect(); gc.disable()
             t0 = pc()
             for i in range(n):
                 sub.append(pc())
                 submit_of(i)
+                call.append((pc() - sub[-1]) * 1e6)
                 if i >= 1:
                     ks.append(g.track_collect()[0]); stamps.append(pc())
             ks.append(g.track_collect()[0]); stamps.append(pc())
             el = pc() - t0
             gc.enable()
+            pipelined.submit_call_us = _dist(call)       # how long icp_track_submit holds the calling thread
             return el, np.diff(np.array([t0] + stamps)) * 1e6, (np.array(stamps) - np.array(sub)) * 1e6, ks
 
         g.track_reset()
@@ -549,6 +551,7 @@ def measure_tracking(icp_amd, device, hops=256):
         tail = seq[8:]
         el, gaps, lats, ks = pipelined(lambda i: g.track_submit(tail[i], warm), hops)
         res["pipelined_pageable"] = _track_report(hops, el, gaps, lats, ks, period=len(order))
+        res["pipelined_pageable"]["submit_call_us"] = pipelined.submit_call_us
         res["pipelined_pageable"]["host_launch_calls"] = dict(zip(("longest_us", "slower_than_10us", "calls"), g.launch_stats(reset=True)))
         # the same pass with the sequence's five frame buffers registered as DMA sources (icp_track_register_source: what a capture loop that
         # reuses its buffers does once): the band goes by DMA from the caller's own memory, the calling thread copies nothing
@@ -561,6 +564,7 @@ def measure_tracking(icp_amd, device, hops=256):
             g.launch_stats(reset=True)
             el, gaps, lats, ks = pipelined(lambda i: g.track_submit(tail[i], warm), hops)
             res["pipelined_registered"] = _track_report(hops, el, gaps, lats, ks, period=len(order))
+            res["pipelined_registered"]["submit_call_us"] = pipelined.submit_call_us
             res["pipelined_registered"]["host_launch_calls"] = dict(zip(("longest_us", "slower_than_10us", "calls"), g.launch_stats(reset=True)))
             res["pipelined_registered"]["note"] = "the caller's own frame buffers, page-locked once (icp_track_register_source): band by 2-D DMA, no host copy"
             for fr in frames:
@@ -577,6 +581,7 @@ def measure_tracking(icp_amd, device, hops=256):
             g.sync()
             el, gaps, lats, ks = pipelined(lambda i: g.track_submit(i & 1, warm), hops)
             res["pipelined_pinned"] = _track_report(hops, el, gaps, lats, ks, period=2)
+            res["pipelined_pinned"]["submit_call_us"] = pipelined.submit_call_us
             res["pipelined_pinned"]["host_launch_calls"] = dict(zip(("longest_us", "slower_than_10us", "calls"), g.launch_stats(reset=True)))
             res["pipelined_pinned"]["note"] = ("two frames one step apart alternate in the engine's pinned frame buffers (icp_track_staging): what a capture "
                                                "loop that writes its frames there would see")

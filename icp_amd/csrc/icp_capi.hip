@@ -159,6 +159,7 @@ ICP_CATCH_ALL
 int icp_destroy (icp_handle h) try
 {
     if (!h) return ICP_EINVAL;
+    keeper_stop (h);                                 // (the tracking keeper, if this handle ever started one: joined before anything is freed)
     (void) hipSetDevice (h->device);
     if (h->run.active || h->run2.active) (void) run_close_all (h);
     if (h->stream2) (void) hipStreamSynchronize (h->stream2);
@@ -183,6 +184,7 @@ ICP_CATCH_ALL
 int icp_init_batched (icp_handle h, uint32_t batch, uint32_t m, uint32_t nr, float a, float c,
                       uint32_t max_iterations, double angle_threshold, double translation_threshold) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     // argument checks of the reference: src/ICP/algorithms.cpp:4413-4420, :1573, :842-854
     if (m == 0) return fail (h, ICP_EINVAL, "The sets of landmarks cannot have zero points");
@@ -287,12 +289,14 @@ ICP_CATCH_ALL
 int icp_init (icp_handle h, uint32_t m, uint32_t nr, float a, float c, uint32_t max_iterations,
               double angle_threshold, double translation_threshold) try
 {
+    api_guard guard_ (h);
     return icp_init_batched (h, 1, m, nr, a, c, max_iterations, angle_threshold, translation_threshold);
 }
 ICP_CATCH_ALL
 
 int icp_write_b (icp_handle h, uint32_t b, int mem, const void *host_ptr, int block) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false); if (rc) return rc;
     if (b >= h->p.batch) return fail (h, ICP_EINVAL, "batch index out of range");
     if ((rc = set_device (h))) return rc;
@@ -330,7 +334,7 @@ int icp_write_b (icp_handle h, uint32_t b, int mem, const void *host_ptr, int bl
 }
 ICP_CATCH_ALL
 
-int icp_write (icp_handle h, int mem, const void *host_ptr, int block) try { return icp_write_b (h, 0, mem, host_ptr, block); } ICP_CATCH_ALL
+int icp_write (icp_handle h, int mem, const void *host_ptr, int block) try { api_guard guard_ (h); return icp_write_b (h, 0, mem, host_ptr, block); } ICP_CATCH_ALL
 
 size_t icp_mem_size (icp_handle h, int mem)
 {
@@ -383,6 +387,7 @@ static int mem_ptr (icp_context *h, uint32_t b, int mem, const void **src)
 
 int icp_read_b (icp_handle h, uint32_t b, int mem, void *host_dst, size_t bytes) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false); if (rc) return rc;
     if (!host_dst) return fail (h, ICP_EINVAL, "icp_read: null destination");
     if (b >= h->p.batch) return fail (h, ICP_EINVAL, "batch index out of range");
@@ -403,10 +408,11 @@ int icp_read_b (icp_handle h, uint32_t b, int mem, void *host_dst, size_t bytes)
 }
 ICP_CATCH_ALL
 
-int icp_read (icp_handle h, int mem, void *host_dst, size_t bytes) try { return icp_read_b (h, 0, mem, host_dst, bytes); } ICP_CATCH_ALL
+int icp_read (icp_handle h, int mem, void *host_dst, size_t bytes) try { api_guard guard_ (h); return icp_read_b (h, 0, mem, host_dst, bytes); } ICP_CATCH_ALL
 
 int icp_device_ptr (icp_handle h, int mem, void **dptr) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false); if (rc) return rc;
     if (!dptr) return fail (h, ICP_EINVAL, "null pointer");
     const void *src = nullptr;
@@ -420,6 +426,7 @@ ICP_CATCH_ALL
 
 int icp_adopt_device_buffer (icp_handle h, int mem, void *dptr) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false); if (rc) return rc;
     if (!dptr) return fail (h, ICP_EINVAL, "null pointer");
     if (mem == ICP_MEM_F) { h->dF = static_cast<float *> (dptr); h->p.F = h->dF; h->ownF = false; h->built = false; }
@@ -433,6 +440,7 @@ ICP_CATCH_ALL
 
 int icp_build_rbc (icp_handle h) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
     note_inputs_change (h);
@@ -468,6 +476,7 @@ ICP_CATCH_ALL
 
 int icp_step (icp_handle h, int config) try
 {
+    api_guard guard_ (h);
     (void) config;   // the reference sizes the list-scan launch from a host read when config is set; nothing to configure here
     int rc = need (h, true); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
@@ -482,6 +491,7 @@ ICP_CATCH_ALL
 
 int icp_run_fixed (icp_handle h, uint32_t iterations) try
 {
+    api_guard guard_ (h);
     int rc = need (h, true); if (rc) return rc;
     if (iterations == 0) return ICP_OK;
     if ((rc = set_device (h))) return rc;
@@ -491,6 +501,7 @@ ICP_CATCH_ALL
 
 int icp_run_fixed_fresh (icp_handle h, uint32_t iterations) try
 {
+    api_guard guard_ (h);
     int rc = need (h, true); if (rc) return rc;
     if (iterations == 0) return icp_reset_transform (h);
     if ((rc = set_device (h))) return rc;
@@ -500,6 +511,7 @@ ICP_CATCH_ALL
 
 int icp_run (icp_handle h, uint32_t *k) try
 {
+    api_guard guard_ (h);
     int rc = need (h, true); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
     if (!h->run_adaptive) {                                              // rounds 1 - 3: one graph of max_iterations launches
@@ -537,6 +549,7 @@ ICP_CATCH_ALL
 
 int icp_run_stats (icp_handle h, uint32_t *launches, uint32_t *k, uint32_t *dead) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     if (launches) *launches = h->stat_launches;
     if (k) *k = h->stat_k;
@@ -547,6 +560,7 @@ ICP_CATCH_ALL
 
 int icp_launch_stats (icp_handle h, double *max_us, uint64_t *slower_than_10us, uint64_t *total, int reset) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     if (max_us) *max_us = h->stat_launch_max_us;
     if (slower_than_10us) *slower_than_10us = h->stat_launch_slow;
@@ -558,6 +572,7 @@ ICP_CATCH_ALL
 
 int icp_set_output_mode (icp_handle h, int mode) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     if (mode != ICP_OUTPUTS_LAZY && mode != ICP_OUTPUTS_EVERY_ITERATION) return fail (h, ICP_EINVAL, "unknown output mode");
     h->outputs_lazy = mode == ICP_OUTPUTS_LAZY;
@@ -567,6 +582,7 @@ ICP_CATCH_ALL
 
 int icp_run_timeline (icp_handle h, double *us6) try
 {
+    api_guard guard_ (h);
     if (!h || !us6) return ICP_EINVAL;
     for (int i = 0; i < 6; ++i) us6[i] = (h->stat_t[i] - h->stat_t[0]) * 1e6;
     return ICP_OK;
@@ -575,6 +591,7 @@ ICP_CATCH_ALL
 
 int icp_set_run_depth (icp_handle h, uint32_t depth, int adaptive) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     if (depth == 0 || depth > 64u) return fail (h, ICP_EINVAL, "icp_set_run_depth: depth must be in [1, 64]");
     { int rc = set_device (h); if (rc) return rc; if ((rc = run_close_all (h))) return rc; }
@@ -585,17 +602,19 @@ ICP_CATCH_ALL
 
 int icp_sync (icp_handle h) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     int rc = set_device (h); if (rc) return rc;
     return settle (h);
 }
 ICP_CATCH_ALL
 
-int icp_get_alpha (icp_handle h, float *a) try { if (!h || !a) return ICP_EINVAL; *a = h->p.a; return ICP_OK; } ICP_CATCH_ALL
+int icp_get_alpha (icp_handle h, float *a) try { api_guard guard_ (h); if (!h || !a) return ICP_EINVAL; *a = h->p.a; return ICP_OK; } ICP_CATCH_ALL
 // The setters change a number in the handle's parameters and nothing else: checked runs are plain launches that read the parameters as they
 // are, and a cached fixed-length graph of an older parameter generation is updated in place when it is next used (get_graph).
 int icp_set_alpha (icp_handle h, float a) try
 {   // setAlpha updates construct and search (src/ICP/algorithms.cpp:4712-4717); lists must be rebuilt by the caller
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     if (a == 0.f) return fail (h, ICP_EINVAL, "The alpha parameter cannot be equal to zero");
     { int rc = outputs_before_change (h); if (rc) return rc; }
@@ -604,39 +623,44 @@ int icp_set_alpha (icp_handle h, float a) try
 ICP_CATCH_ALL
 int icp_set_metric_scale (icp_handle h, float f_g) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     if (!(f_g > 0.f) || !std::isfinite (f_g)) return fail (h, ICP_EINVAL, "the metric scale must be positive and finite");
     { int rc = outputs_before_change (h); if (rc) return rc; }
     h->p.dist_scale = f_g; ++h->param_gen; return ICP_OK;
 }
 ICP_CATCH_ALL
-int icp_get_metric_scale (icp_handle h, float *f_g) try { if (!h || !f_g) return ICP_EINVAL; *f_g = h->p.dist_scale; return ICP_OK; } ICP_CATCH_ALL
-int icp_get_scaling (icp_handle h, float *c) try { if (!h || !c) return ICP_EINVAL; *c = h->p.c; return ICP_OK; } ICP_CATCH_ALL
-int icp_set_scaling (icp_handle h, float c) try { if (!h) return ICP_EINVAL; h->p.c = c; ++h->param_gen; return ICP_OK; } ICP_CATCH_ALL
-int icp_get_max_iterations (icp_handle h, uint32_t *n) try { if (!h || !n) return ICP_EINVAL; *n = h->max_iterations; return ICP_OK; } ICP_CATCH_ALL
+int icp_get_metric_scale (icp_handle h, float *f_g) try { api_guard guard_ (h); if (!h || !f_g) return ICP_EINVAL; *f_g = h->p.dist_scale; return ICP_OK; } ICP_CATCH_ALL
+int icp_get_scaling (icp_handle h, float *c) try { api_guard guard_ (h); if (!h || !c) return ICP_EINVAL; *c = h->p.c; return ICP_OK; } ICP_CATCH_ALL
+int icp_set_scaling (icp_handle h, float c) try { api_guard guard_ (h); if (!h) return ICP_EINVAL; h->p.c = c; ++h->param_gen; return ICP_OK; } ICP_CATCH_ALL
+int icp_get_max_iterations (icp_handle h, uint32_t *n) try { api_guard guard_ (h); if (!h || !n) return ICP_EINVAL; *n = h->max_iterations; return ICP_OK; } ICP_CATCH_ALL
 int icp_set_max_iterations (icp_handle h, uint32_t n) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     if (n == 0) return fail (h, ICP_EINVAL, "max_iterations must be positive");
     h->max_iterations = n; return ICP_OK;
 }
 ICP_CATCH_ALL
-int icp_get_angle_threshold (icp_handle h, double *d) try { if (!h || !d) return ICP_EINVAL; *d = h->angle_threshold; return ICP_OK; } ICP_CATCH_ALL
+int icp_get_angle_threshold (icp_handle h, double *d) try { api_guard guard_ (h); if (!h || !d) return ICP_EINVAL; *d = h->angle_threshold; return ICP_OK; } ICP_CATCH_ALL
 int icp_set_angle_threshold (icp_handle h, double d) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     h->angle_threshold = d; h->p.tan_half_thr = std::tan (d * M_PI / 360.0); ++h->param_gen; return ICP_OK;
 }
 ICP_CATCH_ALL
-int icp_get_translation_threshold (icp_handle h, double *d) try { if (!h || !d) return ICP_EINVAL; *d = h->translation_threshold; return ICP_OK; } ICP_CATCH_ALL
+int icp_get_translation_threshold (icp_handle h, double *d) try { api_guard guard_ (h); if (!h || !d) return ICP_EINVAL; *d = h->translation_threshold; return ICP_OK; } ICP_CATCH_ALL
 int icp_set_translation_threshold (icp_handle h, double d) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     h->translation_threshold = d; h->p.trans_thr = d; ++h->param_gen; return ICP_OK;
 }
 ICP_CATCH_ALL
 int icp_set_power_mode (icp_handle h, int mode) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     if (mode != ICP_POWER_LITERAL && mode != ICP_POWER_SQUARED) return fail (h, ICP_EINVAL, "unknown power mode");
     h->p.power_mode = mode; ++h->param_gen; return ICP_OK;
@@ -645,6 +669,7 @@ ICP_CATCH_ALL
 
 int icp_set_reduce_mode (icp_handle h, int mode) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     if (mode != ICP_REDUCE_REFERENCE_ORDER && mode != ICP_REDUCE_FUSED) return fail (h, ICP_EINVAL, "unknown reduce mode");
     { int rc = outputs_before_change (h); if (rc) return rc; }
@@ -654,6 +679,7 @@ ICP_CATCH_ALL
 
 int icp_state_b (icp_handle h, uint32_t b, icp_state_t *out) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false); if (rc) return rc;
     if (!out) return fail (h, ICP_EINVAL, "null pointer");
     if (b >= h->p.batch) return fail (h, ICP_EINVAL, "batch index out of range");
@@ -674,10 +700,11 @@ int icp_state_b (icp_handle h, uint32_t b, icp_state_t *out) try
 }
 ICP_CATCH_ALL
 
-int icp_state (icp_handle h, icp_state_t *out) try { return icp_state_b (h, 0, out); } ICP_CATCH_ALL
+int icp_state (icp_handle h, icp_state_t *out) try { api_guard guard_ (h); return icp_state_b (h, 0, out); } ICP_CATCH_ALL
 
 int icp_write_cloud (icp_handle h, int which, const void *cloud, int block) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false); if (rc) return rc;
     if (h->p.m != 16384u) return fail (h, ICP_EINVAL, "getLMs produces 128 x 128 landmarks: m must be 16384");
     if (which != ICP_MEM_F && which != ICP_MEM_M) return fail (h, ICP_EINVAL, "which must be ICP_MEM_F or ICP_MEM_M");
@@ -704,6 +731,7 @@ ICP_CATCH_ALL
 
 int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint32_t n) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false); if (rc) return rc;
     if (!host_in || !host_out || n == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
@@ -727,6 +755,7 @@ ICP_CATCH_ALL
 
 int icp_transform_cloud_ex (icp_handle h, int kind, const float *T, const void *host_in, void *host_out, uint32_t n) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     if (kind != ICP_TRANSFORM_QUATERNION && kind != ICP_TRANSFORM_QUATERNION_2 && kind != ICP_TRANSFORM_MATRIX)
         return fail (h, ICP_EINVAL, "icp_transform_cloud_ex: unknown transformation kind");
@@ -781,6 +810,7 @@ ICP_CATCH_ALL
 
 int icp_reset_transform (icp_handle h) try
 {   // T <- identity, k <- 0 (what ICPStep::init uploads, src/ICP/algorithms.cpp:4486-4493); enqueue only
+    api_guard guard_ (h);
     int rc = need (h, false); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
     note_enqueue (h);
@@ -793,6 +823,7 @@ ICP_CATCH_ALL
 
 int icp_time_run_fixed (icp_handle h, uint32_t iterations, uint32_t reps, int from_identity, float *ms_total) try
 {
+    api_guard guard_ (h);
     int rc = need (h, true); if (rc) return rc;
     if (!ms_total || iterations == 0 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
@@ -810,6 +841,7 @@ ICP_CATCH_ALL
 
 int icp_time_run_fixed_tail (icp_handle h, uint32_t iterations, uint32_t reps, int from_identity, float *ms_timed, uint32_t *reps_timed) try
 {
+    api_guard guard_ (h);
     int rc = need (h, true); if (rc) return rc;
     if (!ms_timed || !reps_timed || iterations == 0 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
@@ -833,6 +865,7 @@ ICP_CATCH_ALL
 
 int icp_run_form (icp_handle h, int *form) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false); if (rc) return rc;
     if (!form) return fail (h, ICP_EINVAL, "null output");
     if (icp_chain_supported (h->p)) *form = ICP_FORM_CHAINED;
@@ -843,6 +876,7 @@ ICP_CATCH_ALL
 
 int icp_search_layout (icp_handle h, int *dense, int *tile, int *stage2) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false); if (rc) return rc;
     icp_search_layout_of (h->p, dense, tile, stage2);
     return ICP_OK;
@@ -851,6 +885,7 @@ ICP_CATCH_ALL
 
 int icp_launches_per_iteration (icp_handle h, uint32_t *n) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false); if (rc) return rc;
     if (!n) return fail (h, ICP_EINVAL, "null output");
     int form = ICP_FORM_SEPARATE;
@@ -863,6 +898,7 @@ ICP_CATCH_ALL
 
 int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t reps, float *ms_total) try
 {
+    api_guard guard_ (h);
     int rc = need (h, true); if (rc) return rc;
     if (!ms_total || iterations == 0 || reps == 0 || mask == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
@@ -887,6 +923,7 @@ ICP_CATCH_ALL
 
 int icp_debug_stamps (icp_handle h, unsigned long long *out, uint32_t nblocks) try
 {   // diagnostic builds (ICP_DBG_STAMPS): one k_search launch, per-block s_memtime stamps
+    api_guard guard_ (h);
     int rc = need (h, true); if (rc) return rc;
     if (!out || nblocks == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
@@ -910,6 +947,7 @@ ICP_CATCH_ALL
 
 int icp_profile_run (icp_handle h, uint32_t iterations, float *out_ms, float *total_ms) try
 {
+    api_guard guard_ (h);
     int rc = need (h, true); if (rc) return rc;
     if (!out_ms || iterations == 0) return fail (h, ICP_EINVAL, "bad arguments");
     if ((rc = set_device (h))) return rc;
@@ -944,6 +982,7 @@ ICP_CATCH_ALL
 
 int icp_time_kernels (icp_handle h, uint32_t reps, float *out_ms4) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     if (!out_ms4 || reps == 0) return fail (h, ICP_EINVAL, "bad arguments");
     std::vector<float> t ((size_t) reps * 4);

@@ -9,6 +9,9 @@
 #include "icp_cguard.h"
 
 #include <atomic>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -49,6 +52,24 @@ struct run_ctl {
     double launch_max_us = 0.0; uint32_t launch_slow = 0;   // the host's own launch calls: the longest, and how many took more than 10 us
 };
 
+// Tracking, gated form: the thread that looks after the open runs while the application is outside the library.
+// A host-driven checked run gets its launches from whoever polls its progress word; icp_track_submit used to stay in the library until
+// the PREVIOUS frame was decided (the liveness rule of round 5: 87 of the 123 us the call held the caller) and the newest frame's queue
+// ran dry whenever the caller stayed away.  Now the call returns once its own launches are out and the keeper pumps both open runs to
+// their decision and enqueues their end kernels.  Mutual exclusion by construction: the keeper works only while no API call is inside the
+// library on this handle — every entry point pauses it first (api_guard) and hands the runs back when it leaves.
+struct track_keeper {
+    std::thread th;
+    std::mutex mx;
+    std::condition_variable cv;
+    std::atomic<int> state { 0 };                // 0 idle, 1 asked to look after the open runs, 2 doing it
+    std::atomic<bool> pause { false }, quit { false };
+    bool started = false;
+    std::thread::id tid;                         // the keeper's own thread (run_finish asks: am I the keeper?)
+    int rc = 0; std::string err;                 // what it ran into (a device that stopped answering): reported by the next tracking call
+};
+constexpr int ICP_KEEPER_ABORTED = -77;          // internal: run_finish on the keeper's thread was asked to stop (never leaves the library)
+
 inline double now_s () { return std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count (); }
 
 }  // namespace icp_host
@@ -79,6 +100,8 @@ struct icp_context {
     int run_adaptive = 1;                        // 0 (ICP_AMD_RUN_ADAPTIVE=0): checked runs as one graph of max_iterations launches (rounds 1 - 3)
     icp_host::run_ctl run;                                 // the open checked run (tracking: of the frames on the handle's own stream)
     icp_host::run_ctl run2;                                // tracking with device-side gates: the open run of the frames on stream2
+    int api_depth = 0;                                     // entry points on the stack (api_guard)
+    icp_host::track_keeper *keeper = nullptr;             // tracking, gated form: the thread that pumps the open runs between API calls (icp_track.hip)
     // Per-query outputs (NN_ID, W, NN, QT, RID) of checked runs: fused kernels consume none of them, and a checked run cannot know which
     // iteration is its last — storing them every iteration costs 0.4 us of every 9 at |F| = 16384.  lazy: the run stores none; every finalize
     // leaves the transform its search used in p.st_prev, and the first read of such an output re-runs that one search (same T, same
@@ -167,6 +190,19 @@ int run_finish (icp_context *h, run_ctl &r, run_ctl *other);
 inline int run_finish (icp_context *h) { return run_finish (h, h->run, h->run2.active ? &h->run2 : nullptr); }   // the run on the handle's own stream
 int run_wait_final (icp_context *h, volatile unsigned long long *mirror, uint32_t n, uint32_t epoch, bool tracked = false);
 int run_close_all (icp_context *h);
+inline bool on_keeper_thread (const icp_context *h) { return h->keeper && h->keeper->started && std::this_thread::get_id () == h->keeper->tid; }
+// the keeper (icp_track.hip): pause it and take the runs back (returns at once when there is none) / let it look after the open tracked runs
+void keeper_quiesce (icp_context *h);
+void keeper_kick (icp_context *h);
+void keeper_stop (icp_context *h);
+// first statement of every entry point that takes a handle (not icp_destroy, which ends the thread itself)
+struct api_guard {
+    icp_context *h;
+    // (entry points call one another — icp_track_next -> icp_track_collect —: only the outermost call hands the runs back)
+    explicit api_guard (icp_context *h_) : h (h_) { if (h && h->api_depth++ == 0 && h->keeper) keeper_quiesce (h); }
+    ~api_guard () { if (h && --h->api_depth == 0 && h->keeper) keeper_kick (h); }
+    api_guard (const api_guard &) = delete; api_guard &operator= (const api_guard &) = delete;
+};
 int launch_run (icp_context *h, uint32_t iterations, int check, bool fresh = false, bool with_build = false);
 int settle (icp_context *h);
 void note_enqueue (icp_context *h);

@@ -160,6 +160,7 @@ int run_finish (icp_context *h, run_ctl &r, run_ctl *other)
     uint32_t spins = 0, k_last = 0xFFFFFFFFu;
     auto t_last = std::chrono::steady_clock::now ();
     while (!run_pump (h, r)) {
+        if (on_keeper_thread (h) && h->keeper->pause.load (std::memory_order_relaxed)) return ICP_KEEPER_ABORTED;      // (an API call wants the runs back: they stay open)
         if (other && other->active) { const uint32_t ko = other->k_seen; (void) run_pump (h, *other); if (other->k_seen != ko || other->decided) t_last = std::chrono::steady_clock::now (); }
         _mm_pause ();
         if ((++spins & 0x3FFu) == 0u) {

@@ -92,6 +92,124 @@ static void track_note_k (icp_context *h, uint64_t frame, uint32_t k)
 }
 static void track_note_k (icp_context *h, const run_ctl &r) { if (r.done_seen) track_note_k (h, r.p.seq_value, r.k_final); }
 
+// ---- the keeper (icp_host.h: track_keeper) ----------------------------------------------------------------------------------------------
+static bool keeper_enabled ()
+{
+    const char *e = std::getenv ("ICP_AMD_TRACK_KEEPER");
+    return !(e && e[0] == '0');
+}
+
+// what the keeper does when asked: both open tracked runs, the older first, to their decision and their end kernel
+static int keeper_work (icp_context *h)
+{
+    run_ctl *a = &h->run, *b = &h->run2;
+    if (a->active && b->active && b->p.seq_value < a->p.seq_value) std::swap (a, b);
+    for (int i = 0; i < 2; ++i) {
+        run_ctl *r = i ? b : a, *o = i ? a : b;
+        if (!r->active || r->track_slot < 0) continue;
+        const int rc = run_finish (h, *r, (o->active && o->track_slot >= 0) ? o : nullptr);
+        if (rc) return rc;
+        track_note_k (h, *r);
+    }
+    return ICP_OK;
+}
+
+static void keeper_main (icp_context *h)
+{
+    track_keeper *K = h->keeper;
+    K->tid = std::this_thread::get_id ();
+    (void) hipSetDevice (h->device);
+    for (;;) {
+        // idle: a short spin (a tracking loop comes back within a frame's time), then asleep
+        int spins = 0;
+        while (K->state.load (std::memory_order_acquire) != 1 && !K->quit.load (std::memory_order_acquire)) {
+            if (++spins < 20000) { _mm_pause (); continue; }
+            std::unique_lock<std::mutex> lk (K->mx);
+            K->cv.wait (lk, [&] { return K->state.load (std::memory_order_acquire) == 1 || K->quit.load (std::memory_order_acquire); });
+        }
+        if (K->quit.load (std::memory_order_acquire)) return;
+        int one = 1;
+        if (!K->state.compare_exchange_strong (one, 2, std::memory_order_acq_rel)) continue;      // (taken back before it began)
+        int rc = ICP_OK;
+        if (!K->pause.load (std::memory_order_acquire)) {
+            try { rc = keeper_work (h); } catch (...) { rc = on_exception (); }
+        }
+        if (rc != ICP_OK && rc != ICP_KEEPER_ABORTED && K->rc == ICP_OK) {
+            K->rc = rc;
+            try { K->err = h->err; } catch (...) { }
+        }
+        K->state.store (0, std::memory_order_release);
+    }
+}
+
+}  // extern "C" (the keeper's entry points have C++ linkage)
+namespace icp_host {
+
+void keeper_quiesce (icp_context *h)
+{
+    track_keeper *K = h->keeper;
+    if (!K || !K->started || on_keeper_thread (h)) return;
+    int s = K->state.load (std::memory_order_acquire);
+    if (s == 0) return;
+    K->pause.store (true, std::memory_order_release);
+    int one = 1;
+    if (s == 1 && K->state.compare_exchange_strong (one, 0, std::memory_order_acq_rel)) { K->pause.store (false, std::memory_order_release); return; }
+    while (K->state.load (std::memory_order_acquire) != 0) _mm_pause ();      // (at most one launch call of the keeper: microseconds)
+    K->pause.store (false, std::memory_order_release);
+}
+
+void keeper_kick (icp_context *h)
+{
+    track_keeper *K = h->keeper;
+    if (!K || !K->started || on_keeper_thread (h)) return;
+    const bool open = (h->run.active && h->run.track_slot >= 0) || (h->run2.active && h->run2.track_slot >= 0);
+    if (!open || !h->track_last_gated || K->rc != ICP_OK) return;
+    int zero = 0;
+    if (K->state.compare_exchange_strong (zero, 1, std::memory_order_acq_rel)) {
+        // (the keeper spins for a while after its last job: the notify is for the one that went to sleep)
+        std::lock_guard<std::mutex> lk (K->mx);
+        K->cv.notify_one ();
+    }
+}
+
+void keeper_stop (icp_context *h)
+{
+    track_keeper *K = h->keeper;
+    if (!K) return;
+    if (K->started) {
+        keeper_quiesce (h);
+        { std::lock_guard<std::mutex> lk (K->mx); K->quit.store (true, std::memory_order_release); }
+        K->cv.notify_all ();
+        if (K->th.joinable ()) K->th.join ();
+    }
+    delete K;
+    h->keeper = nullptr;
+}
+
+}  // namespace icp_host
+extern "C" {
+
+// started with the first gated frame of a handle (ICP_AMD_TRACK_KEEPER=0: never — the calling thread looks after the runs as in round 5)
+static void keeper_start (icp_context *h)
+{
+    if (h->keeper || !keeper_enabled ()) return;
+    track_keeper *K = new (std::nothrow) track_keeper ();
+    if (!K) return;
+    h->keeper = K;
+    try { K->started = true; K->th = std::thread (keeper_main, h); }
+    catch (...) { K->started = false; h->keeper = nullptr; delete K; }
+}
+
+// an error the keeper ran into while the caller was away: reported by the next tracking call
+static int keeper_error (icp_context *h)
+{
+    track_keeper *K = h->keeper;
+    if (!K || K->rc == ICP_OK) return ICP_OK;
+    const int rc = K->rc;
+    K->rc = ICP_OK;
+    return fail (h, rc, K->err.empty () ? std::string ("tracking: the engine's thread failed") : K->err);
+}
+
 // Diagnostic (ICP_AMD_TRACK_PROF=1): where the calling thread's time goes inside icp_track_submit — accumulated per step, printed to stderr
 // by icp_track_reset.  Steps: 0 bookkeeping + the slot's old run, 1 wait for frame f - 2, 2 band copy / DMA enqueue, 3 getLMs + event,
 // 4 run_begin (RBC construction, gate, blind launches), 5 the predecessor brought to its decision, 6 everything.
@@ -111,6 +229,7 @@ static uint32_t gate_spins (const icp_context *h)
 
 int icp_track_reset (icp_handle h) try
 {
+    api_guard guard_ (h);
     if (!h) return ICP_EINVAL;
     int rc = set_device (h); if (rc) return rc;
     if (g_tp.on && g_tp.n) {
@@ -120,6 +239,7 @@ int icp_track_reset (icp_handle h) try
         for (double &v : g_tp.t) v = 0.0;
         g_tp.n = 0;
     }
+    if (h->keeper) { h->keeper->rc = ICP_OK; h->keeper->err.clear (); }      // (whatever the keeper ran into belongs to the sequence that ends here)
     if (h->hGateFlag && *h->hGateFlag) {
         // A gate gave up: the frames behind it were turned into no-ops (their run flag = their epoch: every launch leaves at its first
         // load, the end kernel too), so their runs can never publish a decision and run_finish on them can only fail.  Recovery = what
@@ -147,6 +267,7 @@ ICP_CATCH_ALL
 // calling thread's 60 us per frame (the 128 row segments into pinned staging) were the largest fixed part of a warm-started frame's host time.
 int icp_track_register_source (icp_handle h, void *frames, size_t bytes) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false, true); if (rc) return rc;
     if (!frames || bytes < (size_t) 640 * 480 * 32) return fail (h, ICP_EINVAL, "icp_track_register_source: a range of at least one 640 x 480 float8 frame");
     if ((rc = set_device (h))) return rc;
@@ -162,6 +283,7 @@ ICP_CATCH_ALL
 
 int icp_track_unregister_source (icp_handle h, void *frames) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false, true); if (rc) return rc;
     if ((rc = set_device (h))) return rc;
     for (size_t i = 0; i < h->sources.size (); ++i)
@@ -177,6 +299,7 @@ ICP_CATCH_ALL
 
 int icp_track_staging (icp_handle h, uint32_t slot, void **host_ptr) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false, true); if (rc) return rc;
     if (slot > 1u || !host_ptr) return fail (h, ICP_EINVAL, "icp_track_staging: slot must be 0 or 1");
     if ((rc = set_device (h))) return rc;
@@ -205,6 +328,7 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
 {
     double tp_last = g_tp.on ? now_s () : 0.0; const double tp_first = tp_last;
     int rc = need (h, false, true); if (rc) return rc;
+    if ((rc = keeper_error (h))) return rc;
     if (!cloud) return fail (h, ICP_EINVAL, "null pointer");
     if ((rc = set_device (h))) return rc;
     if ((rc = track_prepare (h))) return rc;                            // (everything that can fail for lack of memory comes first)
@@ -357,7 +481,8 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     // (The caller's cadence is unchanged where it matters: icp_track_collect of frame f - 1, the next call of a pipelined loop, would
     // have waited for the same decision.  Frame f's launches went out above, while the predecessor was still running.)
     TP (4);
-    if (gated && P->active) {
+    if (gated && !h->keeper) keeper_start (h);
+    if (gated && P->active && !h->keeper) {              // (no keeper — ICP_AMD_TRACK_KEEPER=0, or no thread to be had: round 5's rule, the caller brings the predecessor to its decision)
         if ((rc = run_finish (h, *P, R.active ? &R : nullptr))) {
             // (frame f's launches are queued, its bookkeeping is not committed: a retry would reuse its ring slot and landmark buffer under
             // them.  Drop the run and let the queues drain before the error leaves; icp_track_reset starts over.)
@@ -379,10 +504,11 @@ static int track_submit (icp_context *h, const void *cloud, int warm_start, bool
     return ICP_OK;
 }
 
-int icp_track_submit (icp_handle h, const void *cloud, int warm_start) try { return track_submit (h, cloud, warm_start, false); } ICP_CATCH_ALL
+int icp_track_submit (icp_handle h, const void *cloud, int warm_start) try { api_guard guard_ (h); return track_submit (h, cloud, warm_start, false); } ICP_CATCH_ALL
 
 int icp_track_form (icp_handle h, int *gated) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false, true); if (rc) return rc;
     if (!gated) return fail (h, ICP_EINVAL, "null output");
     if ((rc = set_device (h))) return rc;
@@ -394,7 +520,9 @@ ICP_CATCH_ALL
 
 int icp_track_collect (icp_handle h, uint32_t *k, float *T8, int *registered) try
 {
+    api_guard guard_ (h);
     int rc = need (h, false, true); if (rc) return rc;
+    if ((rc = keeper_error (h))) return rc;
     if (h->track_collected >= h->track_submitted) return fail (h, ICP_ESTATE, "icp_track_collect: no frame in flight");
     if ((rc = set_device (h))) return rc;
     const uint64_t f = h->track_collected;
@@ -431,6 +559,7 @@ ICP_CATCH_ALL
 
 int icp_track_next (icp_handle h, const void *cloud, int warm_start, uint32_t *k, int *registered) try
 {
+    api_guard guard_ (h);
     if (k) *k = 0;
     if (registered) *registered = 0;
     int rc = need (h, false, true); if (rc) return rc;

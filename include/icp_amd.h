@@ -257,12 +257,17 @@ int icp_transform_cloud (icp_handle h, const void *host_in, void *host_out, uint
  *                    (into its own set of RBC buffers) and its launches are enqueued at once, behind a one-wave gate kernel that holds
  *                    its stream until the previous registration has released the sequence word — the device goes from one frame to
  *                    the next without the host.  (Host-ordered form: the call first brings the previous frame's run to its end.)
- *                    No deadline for the caller: in the gated form the call returns once the PREVIOUS frame's registration is decided —
- *                    converged, or all its max_iterations launches and its end kernel enqueued —, i.e. what this frame's gate waits
- *                    for never depends on a later call; the frame submitted last may find its queue empty while the caller is away
- *                    (nothing waits behind it) and is topped up by the next icp_track_* call.  A caller that stays away for a second
- *                    or an hour loses that time and nothing else.  (The gate's own bound, ~0.5 s, is a guard against a device that
- *                    has stopped: the frames behind it are then skipped without a store and the next call returns ICP_EHIP.)
+ *                    No deadline for the caller, and (round 6) no waiting for the device either: in the gated form the call returns
+ *                    once this frame's own launches are out, and a thread of the engine (the keeper, one per tracking handle,
+ *                    started with the first gated frame) looks after the open runs while the application is outside the library:
+ *                    it polls their progress words, keeps their queues topped up, enqueues their end kernels.  Every entry point
+ *                    pauses the keeper on its way in and hands the runs back on its way out — the two never touch the handle at the
+ *                    same time.  So what a frame's gate waits for never depends on a later call, and neither does the frame submitted
+ *                    last: a caller that stays away for a second or an hour finds its results waiting.  An error the keeper runs into
+ *                    (below) is reported by the next icp_track_* call.  ICP_AMD_TRACK_KEEPER=0: no thread — the call itself brings
+ *                    the previous frame's registration to its decision before it returns (round 5's rule), later calls top up the rest.
+ *                    (The gate's own bound — ~0.5 s, more for large max_iterations — is a guard against a device that has stopped:
+ *                    the frames behind it are then skipped without a store, the next call returns ICP_EHIP, icp_track_reset recovers.)
  *                    warm_start != 0: the registration starts from the previous hop's transform (written back as by
  *                    icp_write (ICP_MEM_T): the rotation state is re-derived from it) instead of the identity; the first
  *                    registration of a sequence (after icp_init / icp_track_reset) has no previous hop and starts from the

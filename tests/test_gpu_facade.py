@@ -1455,3 +1455,51 @@ def test_batch_slot_threads_go_to_their_gpus_numa_node(engine, tmp_path, monkeyp
     # the real tree, whatever it says: creation never fails over it
     monkeypatch.delenv("ICP_AMD_SLOT_CPUS"); monkeypatch.delenv("ICP_AMD_SYSFS_ROOT")
     B = engine.ICPBatch([0]); print("slot 0 of the real tree:", engine.numa_cpulist(bus), "->", B.slot_cpus(0)); B.close()
+
+
+@pytest.mark.parametrize("keeper", ["1", "0"])
+def test_tracking_keeper_looks_after_the_runs_between_calls(engine, oracle, keeper, monkeypatch):
+    """in the gated form the engine's own thread (the keeper) pumps the open runs while the application is outside
+    the library — icp_track_submit no longer stays in the library until the previous frame is decided, and a frame whose queue ran dry is
+    not left waiting for the caller's next call.  (a) Warm-started frames, two in flight: the time a submit holds the caller is well below
+    the time of the registration it starts (keeper on), every k and T the oracle's (both settings).  (b) After a submit the caller sleeps:
+    with the keeper the frame is FINAL in host memory when it comes back (collect returns in microseconds); ICP_AMD_TRACK_KEEPER=0 is round
+    5's rule (the caller looks after the runs) and gives the same bits."""
+    import time
+    monkeypatch.setenv("ICP_AMD_TRACK_KEEPER", keeper)
+    clouds = [engine.synth_cloud_vga(moved=f) for f in range(5)]
+    lms = [oracle.get_lms(c) for c in clouds]
+    order = [0, 1, 2, 3, 4, 3, 2, 1, 0, 1, 2, 3]
+    g = engine.ICP(0); g.init(16384, 256, 2e2, 1e-6)
+    assert g.track_form() == 1
+    for c in clouds:
+        g.track_register(c)
+    res, held = [], []
+    for i, fi in enumerate(order):
+        t0 = time.perf_counter()
+        g.track_submit(clouds[fi], True)
+        held.append((time.perf_counter() - t0) * 1e6)
+        if i >= 1:
+            res.append(g.track_collect())
+    # (b) the last frame: nobody calls the library for 50 ms
+    time.sleep(0.05)
+    t0 = time.perf_counter()
+    res.append(g.track_collect())
+    collect_us = (time.perf_counter() - t0) * 1e6
+    o = oracle.OracleICP(16384, 256, 2e2, 1e-6, threads=8, power_fast=True, fused=True)
+    ks = []
+    for i in range(1, len(order)):
+        o.write_f(lms[order[i - 1]]); o.write_m(lms[order[i]])
+        o.write_t(o.T if i > 1 else [0, 0, 0, 1, 0, 0, 0, 1])
+        o.build_rbc()
+        ks.append(o.run())
+        assert res[i][0] == ks[-1], (i, res[i][0], ks[-1])
+        assert np.array_equal(res[i][1].view(np.uint32), o.T.view(np.uint32)), i
+    print("keeper %s: submit holds the caller %s us (k of the frame before: %s); collect after 50 ms away: %.0f us" % (keeper, [round(x) for x in held[2:]], ks[:-1][1:] if False else ks[1:], collect_us))
+    if keeper == "1":
+        long_pred = [held[i] for i in range(3, len(order)) if ks[i - 2] >= 30]      # submits whose predecessor ran 30 + iterations (>= 270 us on the device)
+        assert long_pred and max(long_pred) < 200.0, long_pred                         # round 5: the call waited for that decision
+        assert collect_us < 150.0, collect_us                                           # the frame was finished while the caller slept
+    for c in clouds:
+        g.track_unregister(c)
+    g.close()

@@ -1632,7 +1632,11 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     KS_KEEP (best, bid)
     KS_STAMP (2)
     const float dr = ks_grp_min_f<KS_SPLIT> (best);           // the query's nearest representative: smallest distance,
-    uint32_t rstar = ks_grp_min_u<KS_SPLIT> (best == dr ? bid : 0xFFFFFFFFu);     // ties -> lowest index
+    // (the pruning variants start from a seed's distance and the origin list carries an explicit tie rule: with every distance +inf — a
+    // query with an infinite coordinate — their (best, bid) is the seed or a tie among infinities, where the serial scan, which starts from
+    // +inf and updates on a strict '<' only, has found nothing: a nearest distance that is not below +inf names no representative)
+    const bool named = PRUNE ? (best == dr && dr < __builtin_inff ()) : (best == dr);
+    uint32_t rstar = ks_grp_min_u<KS_SPLIT> (named ? bid : 0xFFFFFFFFu);     // ties -> lowest index
     if (rstar == 0xFFFFFFFFu) rstar = 0u;            // every distance inf / NaN: representative 0, as the serial scan would
     if constexpr (OWNER_LISTS) {
         ks_owner_lists_tail (p, s_qb, b, m, nb, lane, slice, qe, ss, valid, rstar);

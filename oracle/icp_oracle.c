@@ -193,8 +193,10 @@ float orc_metric8 (const float *x, const float *y, float a)
 /* owner(x) = argmin_r d(x, R[r]), ties -> lowest r */
 static uint32_t nearest_rep (const float *x, const float *R, uint32_t nr, float a, float *dist)
 {
-    float best = orc_metric8 (x, R, a); uint32_t bid = 0;
-    for (uint32_t r = 1; r < nr; ++r) {
+    /* NaN / +inf distances never win a '<' (DESIGN.md §3 item 4), the first representative's included: the scan starts from +inf, not from
+     * the first distance — with finite data the same bits (a first distance of +inf left best = +inf, bid = 0 before as well) */
+    float best = INFINITY; uint32_t bid = 0;
+    for (uint32_t r = 0; r < nr; ++r) {
         float d = orc_metric8 (x, R + (size_t) r * 8, a);
         if (d < best) { best = d; bid = r; }
     }
@@ -248,8 +250,8 @@ void orc_rbc_search (const float *Q, uint32_t nq, const float *R, uint32_t nr,
             if (NN) memcpy (NN + (size_t) i * 8, R + (size_t) r * 8, 8 * sizeof (float));
             continue;
         }
-        float best = orc_metric8 (q, XP + (size_t) o * 8, a); uint32_t bj = o;
-        for (uint32_t j = o + 1; j < o + n; ++j) {
+        float best = INFINITY; uint32_t bj = o;                     /* (as nearest_rep: no candidate that compares -> +inf and the list's first member) */
+        for (uint32_t j = o; j < o + n; ++j) {
             float d = orc_metric8 (q, XP + (size_t) j * 8, a);
             if (d < best) { best = d; bj = j; }
         }

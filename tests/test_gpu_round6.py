@@ -113,9 +113,9 @@ def test_config_B_degenerate_list_run(engine, oracle):
 def _with_repeats(F, rng, pattern, side):
     """A fixed set with bit-identical points planted in it (a copy): `runs` = contiguous index ranges filled with one point each, `scatter` =
     a third of the set drawn from five points, `alternate` = two points alternating over half of the set, `zeros` = the origin with +0 / -0
-    coordinates and a colour of +0 / -0 (equal as numbers, different bits), `inf` = repeats of a point with an infinite coordinate (equal to one another, at distance +inf from every query:
-    never a winner, legitimately dropped) beside repeats of an ordinary point.  (NaN coordinates in the FIXED set are outside the defined
-    domain: a NaN first candidate is never replaced in the serial scan)"""
+    coordinates and a colour of +0 / -0 (equal as numbers, different bits), `inf` / `nan` = repeats of a point with an infinite / a NaN coordinate (at distance +inf / NaN from every query:
+    never a winner; the infinite ones equal one another and are legitimately dropped, NaN equals nothing and stays) beside repeats of an
+    ordinary point — a quarter of the fixed set each, representatives among them."""
     F = F.copy()
     m = F.shape[0]
     if pattern == "runs":
@@ -134,6 +134,11 @@ def _with_repeats(F, rng, pattern, side):
         idx = rng.choice(m, m // 3, replace=False)
         z = np.where(rng.integers(0, 2, (idx.size, 6)) == 1, np.float32(-0.0), np.float32(0.0)).astype(np.float32)
         F[idx, 0:3] = z[:, 0:3]; F[idx, 4:7] = z[:, 3:6]
+    elif pattern == "nan":
+        p = F[int(rng.integers(0, m))].copy(); p[1] = np.nan
+        F[rng.choice(m, m // 4, replace=False)] = p
+        q = F[int(rng.integers(0, m))].copy()
+        F[rng.choice(m, m // 4, replace=False)] = q
     elif pattern == "inf":
         p = F[int(rng.integers(0, m))].copy(); p[1] = np.inf
         F[rng.choice(m, m // 4, replace=False)] = p
@@ -143,7 +148,7 @@ def _with_repeats(F, rng, pattern, side):
 
 
 @pytest.mark.parametrize("side,nr,batch", [(128, 256, 1), (128, 256, 3), (256, 1024, 1), (256, 256, 1), (192, 2048, 1), (64, 4, 1), (96, 16, 2)])
-@pytest.mark.parametrize("pattern", ["runs", "scatter", "alternate", "zeros", "inf"])
+@pytest.mark.parametrize("pattern", ["runs", "scatter", "alternate", "zeros", "inf", "nan"])
 def test_repeated_points_in_long_lists(engine, oracle, side, nr, batch, pattern):
     """Bit-identical points planted in the fixed set (and some in the moving set): long lists whose tails the search's view drops.  Latency
     variant, dense variants (256-tiles, 1024-tile, batched), lanes = candidates; N / O / perm / owner / XP = the construction's; three steps
@@ -178,7 +183,7 @@ def test_repeated_points_in_long_lists(engine, oracle, side, nr, batch, pattern)
             assert np.array_equal(perm, o.rbc_perm) and np.array_equal(g.read(Mem.RBC_OWNER, batch_index=b), o.rbc_owner)
             assert_bits(g.read(Mem.RBC_XP, batch_index=b), F[perm], "XP")
             longest = max(longest, int(o.rbc_N.max()))
-        if rnd == 0:
+        if rnd == 0 and pattern != "nan":
             assert longest > (1024 if g.search_layout()[2] else 256), longest          # (the case has a list with a tail)
         for it in range(3):
             g.step()
@@ -188,16 +193,12 @@ def test_repeated_points_in_long_lists(engine, oracle, side, nr, batch, pattern)
                 assert np.array_equal(g.read(Mem.RID, batch_index=b), o.rid), (rnd, it, b)
                 assert np.array_equal(gn["id"], o.nn_id["id"]), (rnd, it, b, int(np.count_nonzero(gn["id"] != o.nn_id["id"])))
                 assert_bits(g.read(Mem.NN, batch_index=b)[:, :3], F[gn["id"]][:, :3], "matched points (the winner's own record)")
-                if pattern == "inf":
-                    # (an infinite query coordinate against an infinite candidate coordinate is a NaN distance: a query without any comparable
-                    # candidate reports +inf here where the serial scan reports the NaN of its first candidate — DESIGN.md §3 item 4,
-                    # test_nan_and_inf_points_do_not_break_the_search; T is then NaN on both sides)
-                    num = ~np.isnan(o.nn_id["dist"])
-                    assert np.array_equal(gn["dist"][num].view(np.uint32), o.nn_id["dist"][num].view(np.uint32)) and not np.isfinite(gn["dist"][~num]).any()
+                assert_bits(gn["dist"], o.nn_id["dist"], "distances")
+                if pattern in ("inf", "nan"):
+                    # (non-finite coordinates — also in the FIXED set, representatives included: such a distance never wins a '<', a query
+                    # without any comparable candidate reports +inf and its list's first member on both sides; T is then NaN on both sides)
                     assert np.array_equal(np.isnan(g.read(Mem.T, batch_index=b)), np.isnan(o.T))
                     if np.isnan(o.T).any():
                         continue
-                else:
-                    assert_bits(gn["dist"], o.nn_id["dist"], "distances")
                 assert_bits(g.read(Mem.T, batch_index=b), o.T, "T")
     g.close()

@@ -27,8 +27,12 @@ def bits(a):
 
 
 def same(a, b):
+    """bit for bit; NaN against NaN counts as equal whatever the payload (garbage in: the same garbage kind out)"""
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
-    return a.shape == b.shape and np.array_equal(bits(a).reshape(-1), bits(b).reshape(-1))
+    if a.shape != b.shape:
+        return False
+    na, nb = np.isnan(a), np.isnan(b)
+    return np.array_equal(na, nb) and np.array_equal(bits(a).reshape(-1)[~na.reshape(-1)], bits(b).reshape(-1)[~nb.reshape(-1)])
 
 
 def compare(g, o, b, weighted, what):
@@ -48,7 +52,7 @@ def plant_repeats(X, rng):
     """Bit-identical points planted in a point set (round 6: the search's view of a long list drops the members that repeat an earlier one):
     contiguous runs of one point, a share of the set drawn from a few points, the origin with +0 / -0 coordinates and colours."""
     X = X.copy(); m = X.shape[0]
-    kind = int(rng.integers(0, 3))
+    kind = int(rng.integers(0, 4))
     if kind == 0:
         for _ in range(int(rng.integers(1, 6))):
             a = int(rng.integers(0, m)); n = int(rng.integers(2, max(3, m // 3)))
@@ -57,6 +61,10 @@ def plant_repeats(X, rng):
         src = X[rng.choice(m, int(rng.integers(1, 6)), replace=True)].copy()
         idx = rng.choice(m, max(1, int(m * float(rng.choice([0.05, 0.3, 0.6])))), replace=False)
         X[idx] = src[rng.integers(0, src.shape[0], idx.size)]
+    elif kind == 3:                                # non-finite coordinates (round 6: such a distance never wins, first candidates included)
+        for bad in (np.nan, np.inf):
+            p = X[int(rng.integers(0, m))].copy(); p[int(rng.integers(0, 7))] = bad
+            X[rng.choice(m, max(1, m // int(rng.choice([4, 50, 500]))), replace=False)] = p
     else:
         idx = rng.choice(m, max(1, m // 3), replace=False)
         z = np.where(rng.integers(0, 2, (idx.size, 6)) == 1, np.float32(-0.0), np.float32(0.0)).astype(np.float32)

@@ -1503,3 +1503,51 @@ def test_tracking_keeper_looks_after_the_runs_between_calls(engine, oracle, keep
     for c in clouds:
         g.track_unregister(c)
     g.close()
+
+
+def test_tracking_keeper_survives_rude_callers(engine):
+    """The keeper thread against everything a caller may do in the middle of a sequence: frames left in flight at icp_track_reset, at a
+    re-init, at icp_destroy; other entry points (state, setters, a plain run) between a submit and its collect; two handles tracking at
+    once.  No hang, no crash, and a sequence after any of it gives the bits of a fresh handle."""
+    rng = np.random.default_rng(606)
+    clouds = [engine.synth_cloud_vga(moved=f) for f in range(4)]
+    seq = [clouds[i] for i in (0, 1, 2, 3, 2, 1)]
+    ref = engine.ICP(0); ref.init(16384, 256, 2e2, 1e-6)
+    want = ref.track_pipelined(seq, warm_start=True, depth=2)
+    ref.close()
+
+    def check(g):
+        g.track_reset()
+        got = g.track_pipelined(seq, warm_start=True, depth=2)
+        for a, b in zip(got[1:], want[1:]):
+            assert a[0] == b[0] and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+    F, M = engine.synth_pair(128)
+    for rnd in range(12):
+        g = engine.ICP(0); g.init(16384, 256, 2e2, 1e-6)
+        h = engine.ICP(0); h.init(16384, 256, 2e2, 1e-6)
+        n = int(rng.integers(2, 5))
+        for i in range(n):
+            g.track_submit(seq[i], True)
+            if i < 3:
+                h.track_submit(seq[i + 1], False)
+            if rng.random() < 0.5:
+                g.state(); g.setAlpha(2e2); g.track_form()                 # (entry points in the middle of a sequence: each pauses the keeper)
+            if i >= 3:
+                g.track_collect()
+        what = int(rng.integers(0, 5))
+        if what == 0:
+            g.track_reset(); check(g)
+        elif what == 1:
+            g.init(16384, 256, 2e2, 1e-6); check(g)                        # re-init with frames in flight
+        elif what == 2:
+            g.write(engine.Memory.F, F); g.write(engine.Memory.M, M); g.reset_transform(); g.buildRBC(); assert g.run() > 0; check(g)
+        elif what == 3:
+            while True:
+                try:
+                    g.track_collect()
+                except engine.ICPError:
+                    break                                                  # ("no frame in flight")
+            check(g)
+        g.close()                                                          # (what == 4: destroyed with frames in flight)
+        h.close()

@@ -921,6 +921,9 @@ int icp_time_masked (icp_handle h, uint32_t mask, uint32_t iterations, uint32_t 
 }
 ICP_CATCH_ALL
 
+#ifdef ICP_DBG_STAMPS
+__attribute__ ((visibility ("default")))          // (diagnostic builds only: not part of the ABI)
+#endif
 int icp_debug_stamps (icp_handle h, unsigned long long *out, uint32_t nblocks) try
 {   // diagnostic builds (ICP_DBG_STAMPS): one k_search launch, per-block s_memtime stamps
     api_guard guard_ (h);

@@ -94,8 +94,13 @@ static __device__ __forceinline__ const icp_params *ks_params_from_kernarg ()
     {                                                                                                     \
         unsigned long long t_;                                                                            \
         asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-        if (tid == 0 && p.dbg) p.dbg[(size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = t_;    \
+        KS_STAMP_STORE (k)                                                                                \
     }
+#ifdef ICP_DBG_STAMPS_WAVES     /* every wave's own timeline (row = block x waves per block + wave): which wave a block waits for, and where it was */
+#define KS_STAMP_STORE(k) if ((threadIdx.x & 63u) == 0u && p.dbg) p.dbg[((size_t) (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = t_;
+#else
+#define KS_STAMP_STORE(k) if (tid == 0 && p.dbg) p.dbg[(size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = t_;
+#endif
 #elif defined (ICP_DBG_EXIT_AFTER)
 // diagnostic builds (tools/diag/phase_insts.sh): the search kernel ends behind phase k — the instruction counters of a PMC run
 // then hold the phases up to k, and differences between builds are the phases themselves (every thread of a block gets here)
@@ -1151,7 +1156,7 @@ __global__ __launch_bounds__ (64 * LPQ, TILE == 256 ? 8 : MINW) void k_search (c
     icp_reg_state *st = (CHAIN && !(check_flags & 2u)) ? gst + (size_t) b * 2 : gst + b;
 #ifdef ICP_DBG_STAMPS
     { const uint32_t tid = threadIdx.x; unsigned long long t_; asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
-      if (tid == 0 && p.dbg) p.dbg[(size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 16 + 8] = t_; }
+      KS_STAMP_STORE (8) }
 #endif
 
     // representatives of the current tile, pair-interleaved for packed fp32 math:

@@ -28,7 +28,8 @@ time ("scaling": "weak").  EVERY line carries `config4_per_gpu_value` — iterat
 
 Prints ONE JSON line (rank 0) as the LAST line of stdout, shorter than 4 KB (`compact_line`): the contract's fields, `roofline`,
 `cpu_baseline` and flat scalars for the other BASELINE configs.  Everything else that is measured (per-kernel times, tracking
-distributions, the invalid-point cases, the mode comparison, the thread sweep) goes to bench_extra.json beside this file and to stderr.
+distributions, the invalid-point cases, the mode comparison, the thread sweep) goes to bench_extra.json beside this file (stderr gets one
+line that says so; ICP_BENCH_STDERR_RECORD=1: the whole record).
 Objects of the line:
   roofline      dominant kernel (k_search): algorithmic bytes per launch ((72 m + 32 |R| + 64) x registrations per launch,
                 SURVEY.md §8d) / its average launch-to-launch time, measured with HIP events on the engine's own stream.
@@ -780,7 +781,7 @@ def compact_line(full):
 
 
 def emit(full, out=None, err=None, extra_dirs=None):
-    """Everything measured -> bench_extra.json (beside bench.py and, on a GPU box, under gpurun_out/) and one line on stderr;
+    """Everything measured -> bench_extra.json (beside bench.py and, on a GPU box, under gpurun_out/), a one-line pointer on stderr;
     the compact line -> the LAST line of stdout."""
     out, err = out or sys.stdout, err or sys.stderr
     text = compact_line(full)
@@ -792,7 +793,12 @@ def emit(full, out=None, err=None, extra_dirs=None):
                 f.write(blob + "\n")
         except OSError:
             pass
-    err.write("bench.py: full measurement record (%d bytes, also in %s):\n%s\n" % (len(blob), EXTRA_FILE, blob))
+    # stderr gets a pointer, not the record: whoever keeps only the tail of the two streams together must still find the line in it
+    # (ICP_BENCH_STDERR_RECORD=1: the whole record on stderr as well)
+    if os.environ.get("ICP_BENCH_STDERR_RECORD") == "1":
+        err.write("bench.py: full measurement record (%d bytes, also in %s):\n%s\n" % (len(blob), EXTRA_FILE, blob))
+    else:
+        err.write("bench.py: full measurement record (%d bytes) in %s; the result line (%d bytes) is the last line of stdout\n" % (len(blob), EXTRA_FILE, len(text)))
     err.flush()
     out.write(text + "\n")
     out.flush()

@@ -99,7 +99,8 @@ def test_result_line_is_short_and_last_on_stdout(tmp_path):
         else:
             assert "cpu_baseline" not in line
         assert json.load(open(tmp_path / bench.EXTRA_FILE)) == full
-        assert json.dumps(full) in err.getvalue() and "other_configs" not in line and "mode_note" not in line
+        assert len(err.getvalue()) < 300 and bench.EXTRA_FILE in err.getvalue()      # (a pointer: the two streams' tails together still hold the line)
+        assert "other_configs" not in line and "mode_note" not in line
 
 
 def test_result_line_drops_optional_scalars_before_it_grows(monkeypatch):
